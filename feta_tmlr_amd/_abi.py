@@ -1,0 +1,173 @@
+"""ctypes binding of the C ABI declared in include/feta_hip.h.
+
+``bind(cdll)`` attaches argtypes/restype for every exported symbol and returns a
+thin ``Abi`` wrapper whose methods take torch tensors (device pointers are taken
+with ``data_ptr()``; nothing is copied).  ``feta_tmlr_amd._lib`` opens
+``libfeta_hip.so`` with it; the test-suite also binds the host SIMT-emulation build
+of the same sources (tools/simt) to run the kernel code without a GPU.
+"""
+import ctypes as C
+
+import torch
+
+_F = C.c_void_p  # const float* / float*
+_I = C.c_void_p  # const int32_t* / int64_t*
+_S = C.c_void_p  # feta_stream_t
+
+SIGNATURES = {
+    'feta_version': ([], C.c_int),
+    'feta_last_error': ([], C.c_char_p),
+    'feta_attn_fwd': ([_F, _F, _F, C.c_int64, C.c_int64, _F, _I, _F, C.c_int64, C.c_int64,
+                       _F, _F, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, _S], C.c_int),
+    'feta_attn_bwd': ([_F, _F, _F, C.c_int64, C.c_int64, _F, _I, _F, _F, C.c_int64, C.c_int64,
+                       _F, _F, _F, _F, _F, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, _S],
+                      C.c_int),
+    'feta_coeff_fwd': ([_F, _I, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, _S], C.c_int),
+    'feta_coeff_bwd_groups': ([C.c_int, C.c_int], C.c_int),
+    'feta_coeff_bwd': ([_F, _I, _F, _F, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, _S],
+                       C.c_int),
+    'feta_colsum': ([_F, _F, C.c_int, C.c_int, _S], C.c_int),
+    'feta_cheb_filter_fwd': ([_F, C.c_int64, C.c_int64, _F, _F, _F, _I, _F, C.c_int64, C.c_int64,
+                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _S], C.c_int),
+    'feta_cheb_filter_bwd': ([_F, C.c_int64, C.c_int64, _F, _F, _I, _F, C.c_int64, C.c_int64,
+                              _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _S],
+                             C.c_int),
+    'feta_spec_filter_fwd': ([_F, C.c_int64, C.c_int64, _F, _F, _F, _F, _I, _F, C.c_int64, C.c_int64,
+                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _S],
+                             C.c_int),
+    'feta_spec_filter_bwd': ([_F, C.c_int64, C.c_int64, _F, _F, _F, _I, _F, C.c_int64, C.c_int64,
+                              _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                              C.c_int, _S], C.c_int),
+    'feta_lhat_from_edges': ([_I, C.c_int64, _I, _I, _F, _F, C.c_int, C.c_int, C.c_int64, _S],
+                             C.c_int),
+}
+
+ABI_VERSION = 1
+
+
+class FetaError(RuntimeError):
+    pass
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def tok_strides(t):
+    """(sb, sn) element strides of a token tensor given as a [B, N, H, dh] view whose
+    last two dims are dense (stride dh, 1)."""
+    assert t.dim() == 4 and t.stride(3) == 1 and t.stride(2) == t.shape[3], \
+        'token tensor must be a [B,N,H,dh] view with dense (H,dh)'
+    return t.stride(0), t.stride(1)
+
+
+class Abi:
+    def __init__(self, cdll):
+        self.lib = cdll
+        for name, (argtypes, restype) in SIGNATURES.items():
+            fn = getattr(cdll, name)  # AttributeError if a declared symbol is missing
+            fn.argtypes = argtypes
+            fn.restype = restype
+        v = cdll.feta_version()
+        if v != ABI_VERSION:
+            raise FetaError('libfeta ABI version %d, binding expects %d' % (v, ABI_VERSION))
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.feta_last_error().decode('utf-8', 'replace')
+            if rc == -1:
+                raise ValueError('%s: %s' % (what, msg))
+            raise FetaError('%s failed (%d): %s' % (what, rc, msg))
+
+    # q,k,v,out,...: [B,N,H,dh] views (any B/N strides)
+    def attn_fwd(self, q, k, v, pe, n_real, out, attn, stats, scale, stream):
+        b, n, h, dh = q.shape
+        sb, sn = tok_strides(q)
+        assert tok_strides(k) == (sb, sn) and tok_strides(v) == (sb, sn)
+        osb, osn = tok_strides(out)
+        self._check(self.lib.feta_attn_fwd(_p(q), _p(k), _p(v), sb, sn, _p(pe), _p(n_real),
+                                           _p(out), osb, osn, _p(attn), _p(stats), scale,
+                                           b, n, h, dh, stream), 'feta_attn_fwd')
+
+    def attn_bwd(self, q, k, v, pe, n_real, out, dout, stats, delta, dq, dk, dv, scale, stream):
+        b, n, h, dh = q.shape
+        sb, sn = tok_strides(q)
+        for t in (k, v, dq, dk, dv):
+            assert tok_strides(t) == (sb, sn)
+        osb, osn = tok_strides(out)
+        assert tok_strides(dout) == (osb, osn)
+        self._check(self.lib.feta_attn_bwd(_p(q), _p(k), _p(v), sb, sn, _p(pe), _p(n_real),
+                                           _p(out), _p(dout), osb, osn, _p(stats), _p(delta),
+                                           _p(dq), _p(dk), _p(dv), scale, b, n, h, dh, stream),
+                    'feta_attn_bwd')
+
+    def coeff_fwd(self, attn, n_real, s, gcn_bias, cj, pooled, stream):
+        b, h, n, _ = attn.shape
+        c = s.shape[0]
+        self._check(self.lib.feta_coeff_fwd(_p(attn), _p(n_real), _p(s), _p(gcn_bias), _p(cj),
+                                            _p(pooled), b, n, h, c, stream), 'feta_coeff_fwd')
+
+    def coeff_bwd_groups(self, b, h):
+        return self.lib.feta_coeff_bwd_groups(b, h)
+
+    def coeff_bwd(self, cj, n_real, s, gcn_bias, dpooled, partial, ds, dbias, b, n, h, stream):
+        c = s.shape[0]
+        self._check(self.lib.feta_coeff_bwd(_p(cj), _p(n_real), _p(s), _p(gcn_bias), _p(dpooled),
+                                            _p(partial), _p(ds), _p(dbias), b, n, h, c, stream),
+                    'feta_coeff_bwd')
+
+    def colsum(self, x, out, stream):
+        r, c = x.shape
+        self._check(self.lib.feta_colsum(_p(x), _p(out), r, c, stream), 'feta_colsum')
+
+    def cheb_filter_fwd(self, x, lhat, coeff, bias, n_real, y, order, share, stream):
+        b, n, h, dh = x.shape
+        xsb, xsn = tok_strides(x)
+        ysb, ysn = tok_strides(y)
+        self._check(self.lib.feta_cheb_filter_fwd(_p(x), xsb, xsn, _p(lhat), _p(coeff), _p(bias),
+                                                  _p(n_real), _p(y), ysb, ysn, b, n, h, dh, order,
+                                                  int(share), stream), 'feta_cheb_filter_fwd')
+
+    def cheb_filter_bwd(self, x, lhat, coeff, n_real, dy, dx, dcoeff, dbias_part, order, share,
+                        stream):
+        b, n, h, dh = x.shape
+        xsb, xsn = tok_strides(x)
+        assert tok_strides(dx) == (xsb, xsn)
+        ysb, ysn = tok_strides(dy)
+        self._check(self.lib.feta_cheb_filter_bwd(_p(x), xsb, xsn, _p(lhat), _p(coeff), _p(n_real),
+                                                  _p(dy), ysb, ysn, _p(dx), _p(dcoeff),
+                                                  _p(dbias_part), b, n, h, dh, order, int(share),
+                                                  stream), 'feta_cheb_filter_bwd')
+
+    def spec_filter_fwd(self, x, u, lam, coeff, bias, n_real, y, order, share, stream):
+        b, n, h, dh = x.shape
+        k = u.shape[2]
+        xsb, xsn = tok_strides(x)
+        ysb, ysn = tok_strides(y)
+        self._check(self.lib.feta_spec_filter_fwd(_p(x), xsb, xsn, _p(u), _p(lam), _p(coeff),
+                                                  _p(bias), _p(n_real), _p(y), ysb, ysn, b, n, h, dh,
+                                                  order, k, int(share), stream),
+                    'feta_spec_filter_fwd')
+
+    def spec_filter_bwd(self, x, u, lam, coeff, n_real, dy, dx, dcoeff, dbias_part, order, share,
+                        stream):
+        b, n, h, dh = x.shape
+        k = u.shape[2]
+        xsb, xsn = tok_strides(x)
+        assert tok_strides(dx) == (xsb, xsn)
+        ysb, ysn = tok_strides(dy)
+        self._check(self.lib.feta_spec_filter_bwd(_p(x), xsb, xsn, _p(u), _p(lam), _p(coeff),
+                                                  _p(n_real), _p(dy), ysb, ysn, _p(dx), _p(dcoeff),
+                                                  _p(dbias_part), b, n, h, dh, order, k, int(share),
+                                                  stream), 'feta_spec_filter_bwd')
+
+    def lhat_from_edges(self, edge_index, node_graph, node_off, deg, lhat, stream):
+        b, n, _ = lhat.shape
+        self._check(self.lib.feta_lhat_from_edges(_p(edge_index), edge_index.shape[1],
+                                                  _p(node_graph), _p(node_off), _p(deg), _p(lhat),
+                                                  b, n, node_graph.shape[0], stream),
+                    'feta_lhat_from_edges')
+
+
+def bind(cdll):
+    return Abi(cdll)

@@ -1,0 +1,424 @@
+// A1 attention core for gfx950: scores, masked exp, multiplicative positional kernel,
+// clamped normalisation and the weighted sum, forward and backward, one wave per
+// 16-row block.  Replaces the body of the (absent) DiffTransformerEncoderLayer.self_attn
+// of the reference - contract: transformer/models.py:166-167,179,244,275; form
+// witnesses: LSPE/layers/graphit_gt_layer.py:39-43,120-131,164.
+//
+// Work decomposition (graphs are small: N <= 256, dh <= 64):
+//   forward / dq : one wave per (graph b, head h, 16-query block); the score tile is
+//                  held TRANSPOSED (rows = keys on registers, column = query on the
+//                  lane) so that softmax statistics are lane-local + two shuffles and
+//                  the probabilities feed the P.V / dS.K MFMAs straight from the
+//                  accumulator registers (contraction over keys = accumulator rows);
+//   dk, dv       : one wave per (b, h, 16-key block) holding the tile un-transposed
+//                  (rows = queries) so that dV = P^T dO and dK = dS^T Q contract over
+//                  accumulator rows as well.  No atomics, no cross-wave reduction:
+//                  results are bitwise reproducible.
+#include <cmath>
+
+#include "feta_abi_common.h"
+#include "feta_tiles.h"
+
+namespace feta {
+
+struct AttnArgs {
+  const float* q;
+  const float* k;
+  const float* v;
+  const float* pe;
+  const int32_t* n_real;
+  const float* out;   // forward output (backward input)
+  const float* dout;  // backward input
+  const float* stats_in;
+  float* out_w;
+  float* attn;
+  float* stats;
+  float* delta;
+  float* dq;
+  float* dk;
+  float* dv;
+  int64_t qsb, qsn, osb, osn;
+  float scale;
+  int B, N, H, NB;  // NB = ceil(N / 16) row blocks
+  int total;        // B * H * NB work items
+};
+
+constexpr int kWaves = 4;
+
+template <int DH, int KT_MAX>
+__global__ __launch_bounds__(64 * kWaves) void attn_fwd_kernel(AttnArgs a) {
+  constexpr int CT = Feat<DH>::CT;
+  constexpr int KP = 16 * KT_MAX + 1;  // LDS row pitch of the staged probability block
+  const int lane = lane_id(), lq = lane & 15, g = lane >> 4;
+  const int item = blockIdx.x * kWaves + wave_id();
+  if (item >= a.total) return;
+  const int qb = item % a.NB;
+  const int bh = item / a.NB;
+  const int h = bh % a.H, b = bh / a.H;
+  const int n = a.n_real[b];
+  const int q0 = 16 * qb;
+  const int KT = (n + 15) >> 4;
+  const int q = q0 + lq;  // this lane's query (column of the transposed tile)
+
+  Feat<DH> qf;
+  load_row<DH>(qf, q < a.N ? tok_row(a.q, a.qsb, a.qsn, b, q, h, DH) : nullptr, g, a.scale);
+
+  // S^T tiles: acc[kt][r] <-> key 16kt + 4g + r, query q
+  f32x4 acc[KT_MAX];
+#pragma unroll
+  for (int kt = 0; kt < KT_MAX; ++kt) {
+    if (kt < KT) {
+      const int key = 16 * kt + lq;
+      Feat<DH> kf;
+      load_row<DH>(kf, key < n ? tok_row(a.k, a.qsb, a.qsn, b, key, h, DH) : nullptr, g);
+      acc[kt] = dot_rows<DH>(kf, qf, zero4());
+    }
+  }
+
+  float m = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < KT_MAX; ++kt) {
+    if (kt < KT) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (16 * kt + 4 * g + r < n) m = fmaxf(m, acc[kt][r]);
+    }
+  }
+  m = fmaxf(m, shfl_xor(m, 16));
+  m = fmaxf(m, shfl_xor(m, 32));
+
+  const float* pe_row = (a.pe != nullptr && q < a.N) ? a.pe + ((int64_t)b * a.N + q) * a.N : nullptr;
+  float z = 0.0f;
+#pragma unroll
+  for (int kt = 0; kt < KT_MAX; ++kt) {
+    if (kt < KT) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = 16 * kt + 4 * g + r;
+        float e = 0.0f;
+        if (key < n) {
+          e = fast_exp(acc[kt][r] - m);
+          if (pe_row != nullptr) e *= pe_row[key];
+        }
+        acc[kt][r] = e;
+        z += e;
+      }
+    }
+  }
+  z += shfl_xor(z, 16);
+  z += shfl_xor(z, 32);
+  const float rinv = 1.0f / fmaxf(z, 1e-6f);
+  if (g == 0 && q < a.N) {
+    float* st = a.stats + ((int64_t)bh * a.N + q) * 2;
+    st[0] = m;
+    st[1] = z;
+  }
+
+  // out = P . V : contraction over keys = accumulator rows
+  f32x4 o[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) o[ct] = zero4();
+#pragma unroll
+  for (int kt = 0; kt < KT_MAX; ++kt) {
+    if (kt < KT) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc[kt][r] *= rinv;
+        const int key = 16 * kt + 4 * g + r;
+        const float* vrow = key < n ? tok_row(a.v, a.qsb, a.qsn, b, key, h, DH) : nullptr;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const int c = 16 * ct + lq;
+          const float vb = (vrow != nullptr && c < DH) ? vrow[c] : 0.0f;
+          o[ct] = mfma16(acc[kt][r], vb, o[ct]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const int c = 16 * ct + lq;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qq = q0 + 4 * g + r;
+      if (qq < a.N && c < DH) tok_row(a.out_w, a.osb, a.osn, b, qq, h, DH)[c] = o[ct][r];
+    }
+  }
+
+  // attn[b,h,q0:q0+16,:] is one contiguous run: stage the block in LDS, store coalesced
+  if (a.attn != nullptr) {
+    float* st = feta_lds + wave_id() * 16 * KP;
+#pragma unroll
+    for (int kt = 0; kt < KT_MAX; ++kt) {
+      if (kt < KT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[lq * KP + 16 * kt + 4 * g + r] = acc[kt][r];
+      }
+    }
+    wave_lds_sync();
+    const int rows = min(16, a.N - q0);
+    const int cols = 16 * KT;
+    float* dst = a.attn + ((int64_t)bh * a.N + q0) * a.N;
+    int qq = 0, kk = lane;
+    while (kk >= a.N) {
+      kk -= a.N;
+      ++qq;
+    }
+    for (int idx = lane; idx < rows * a.N; idx += 64) {
+      dst[idx] = kk < cols ? st[qq * KP + kk] : 0.0f;
+      kk += 64;
+      while (kk >= a.N) {
+        kk -= a.N;
+        ++qq;
+      }
+    }
+  }
+}
+
+// dq for one 16-query block (transposed tile, as the forward) + delta = rowsum(dout*out)
+template <int DH>
+__global__ __launch_bounds__(64 * kWaves) void attn_bwd_dq_kernel(AttnArgs a) {
+  constexpr int CT = Feat<DH>::CT;
+  const int lane = lane_id(), lq = lane & 15, g = lane >> 4;
+  const int item = blockIdx.x * kWaves + wave_id();
+  if (item >= a.total) return;
+  const int qb = item % a.NB;
+  const int bh = item / a.NB;
+  const int h = bh % a.H, b = bh / a.H;
+  const int n = a.n_real[b];
+  const int q0 = 16 * qb;
+  const int KT = (n + 15) >> 4;
+  const int q = q0 + lq;
+  const bool qok = q < a.N;
+
+  Feat<DH> qf, dof, of;
+  load_row<DH>(qf, qok ? tok_row(a.q, a.qsb, a.qsn, b, q, h, DH) : nullptr, g, a.scale);
+  load_row<DH>(dof, qok ? tok_row(a.dout, a.osb, a.osn, b, q, h, DH) : nullptr, g);
+  load_row<DH>(of, qok ? tok_row(a.out, a.osb, a.osn, b, q, h, DH) : nullptr, g);
+  float delta = 0.0f;
+#pragma unroll
+  for (int j = 0; j < Feat<DH>::NJ; ++j)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) delta += dof.f[j][s] * of.f[j][s];
+  delta += shfl_xor(delta, 16);
+  delta += shfl_xor(delta, 32);
+  if (g == 0 && qok) a.delta[(int64_t)bh * a.N + q] = delta;
+
+  float m = 0.0f, z = 1.0f;
+  if (qok) {
+    const float* st = a.stats_in + ((int64_t)bh * a.N + q) * 2;
+    m = st[0];
+    z = st[1];
+  }
+  const float rinv = 1.0f / fmaxf(z, 1e-6f);
+  if (z < 1e-6f) delta = 0.0f;  // clamp active: the normaliser is a constant
+  const float* pe_row = (a.pe != nullptr && qok) ? a.pe + ((int64_t)b * a.N + q) * a.N : nullptr;
+
+  f32x4 dq[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) dq[ct] = zero4();
+
+  for (int kt = 0; kt < KT; ++kt) {
+    const int krow = 16 * kt + lq;
+    Feat<DH> kf, vf;
+    load_row<DH>(kf, krow < n ? tok_row(a.k, a.qsb, a.qsn, b, krow, h, DH) : nullptr, g);
+    load_row<DH>(vf, krow < n ? tok_row(a.v, a.qsb, a.qsn, b, krow, h, DH) : nullptr, g);
+    f32x4 s = dot_rows<DH>(kf, qf, zero4());    // scores^T
+    f32x4 da = dot_rows<DH>(vf, dof, zero4());  // (dout . v^T)^T
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = 16 * kt + 4 * g + r;
+      float p = 0.0f;
+      if (key < n) {
+        p = fast_exp(s[r] - m);
+        if (pe_row != nullptr) p *= pe_row[key];
+        p *= rinv;
+      }
+      const float ds = p * (da[r] - delta);
+      const float* krow_p = key < n ? tok_row(a.k, a.qsb, a.qsn, b, key, h, DH) : nullptr;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const int c = 16 * ct + lq;
+        const float kb = (krow_p != nullptr && c < DH) ? krow_p[c] : 0.0f;
+        dq[ct] = mfma16(ds, kb, dq[ct]);
+      }
+    }
+  }
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const int c = 16 * ct + lq;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qq = q0 + 4 * g + r;
+      if (qq < a.N && c < DH) tok_row(a.dq, a.qsb, a.qsn, b, qq, h, DH)[c] = dq[ct][r] * a.scale;
+    }
+  }
+}
+
+// dk, dv for one 16-key block (un-transposed tile: rows = queries, column = key)
+template <int DH>
+__global__ __launch_bounds__(64 * kWaves) void attn_bwd_dkdv_kernel(AttnArgs a) {
+  constexpr int CT = Feat<DH>::CT;
+  const int lane = lane_id(), lq = lane & 15, g = lane >> 4;
+  const int item = blockIdx.x * kWaves + wave_id();
+  if (item >= a.total) return;
+  const int kb = item % a.NB;
+  const int bh = item / a.NB;
+  const int h = bh % a.H, b = bh / a.H;
+  const int n = a.n_real[b];
+  const int key = 16 * kb + lq;  // this lane's key (column)
+  const bool kok = key < n;
+
+  f32x4 dk[CT], dv[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    dk[ct] = zero4();
+    dv[ct] = zero4();
+  }
+
+  if (16 * kb < n) {
+    Feat<DH> kf, vf;
+    load_row<DH>(kf, kok ? tok_row(a.k, a.qsb, a.qsn, b, key, h, DH) : nullptr, g);
+    load_row<DH>(vf, kok ? tok_row(a.v, a.qsb, a.qsn, b, key, h, DH) : nullptr, g);
+    for (int qb = 0; qb < a.NB; ++qb) {
+      const int q0 = 16 * qb;
+      const int qrow = q0 + lq;
+      Feat<DH> qf, dof;
+      load_row<DH>(qf, qrow < a.N ? tok_row(a.q, a.qsb, a.qsn, b, qrow, h, DH) : nullptr, g, a.scale);
+      load_row<DH>(dof, qrow < a.N ? tok_row(a.dout, a.osb, a.osn, b, qrow, h, DH) : nullptr, g);
+      f32x4 s = dot_rows<DH>(qf, kf, zero4());    // scores: row = query 4g+r, col = key
+      f32x4 da = dot_rows<DH>(dof, vf, zero4());  // dout . v^T
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qq = q0 + 4 * g + r;
+        float p = 0.0f, ds = 0.0f;
+        if (qq < a.N && kok) {
+          const float* st = a.stats_in + ((int64_t)bh * a.N + qq) * 2;
+          const float m = st[0], z = st[1];
+          p = fast_exp(s[r] - m);
+          if (a.pe != nullptr) p *= a.pe[((int64_t)b * a.N + qq) * a.N + key];
+          p *= 1.0f / fmaxf(z, 1e-6f);
+          const float delta = z < 1e-6f ? 0.0f : a.delta[(int64_t)bh * a.N + qq];
+          ds = p * (da[r] - delta);
+        }
+        const float* dorow = qq < a.N ? tok_row(a.dout, a.osb, a.osn, b, qq, h, DH) : nullptr;
+        const float* qrow_p = qq < a.N ? tok_row(a.q, a.qsb, a.qsn, b, qq, h, DH) : nullptr;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const int c = 16 * ct + lq;
+          const bool ok = dorow != nullptr && c < DH;
+          dv[ct] = mfma16(p, ok ? dorow[c] : 0.0f, dv[ct]);
+          dk[ct] = mfma16(ds, ok ? qrow_p[c] * a.scale : 0.0f, dk[ct]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const int c = 16 * ct + lq;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int kk = 16 * kb + 4 * g + r;
+      if (kk < a.N && c < DH) {
+        tok_row(a.dk, a.qsb, a.qsn, b, kk, h, DH)[c] = dk[ct][r];
+        tok_row(a.dv, a.qsb, a.qsn, b, kk, h, DH)[c] = dv[ct][r];
+      }
+    }
+  }
+}
+
+template <int DH>
+int launch_fwd(const AttnArgs& a, int kt_max, hipStream_t stream) {
+  const dim3 grid((a.total + kWaves - 1) / kWaves), block(64 * kWaves);
+  const size_t lds = a.attn != nullptr ? sizeof(float) * kWaves * 16 * (16 * kt_max + 1) : 0;
+  if (kt_max <= 3) {
+    auto kern = attn_fwd_kernel<DH, 3>;
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
+  } else if (kt_max <= 4) {
+    auto kern = attn_fwd_kernel<DH, 4>;
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
+  } else if (kt_max <= 8) {
+    auto kern = attn_fwd_kernel<DH, 8>;
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
+  } else {
+    auto kern = attn_fwd_kernel<DH, 16>;
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
+  }
+  return check_launch("feta_attn_fwd");
+}
+
+template <int DH>
+int launch_bwd(const AttnArgs& a, hipStream_t stream) {
+  const dim3 grid((a.total + kWaves - 1) / kWaves), block(64 * kWaves);
+  auto k1 = attn_bwd_dq_kernel<DH>;
+  hipLaunchKernelGGL(k1, grid, block, 0, stream, a);
+  auto k2 = attn_bwd_dkdv_kernel<DH>;
+  hipLaunchKernelGGL(k2, grid, block, 0, stream, a);
+  return check_launch("feta_attn_bwd");
+}
+
+int check_common(const void* q, const void* k, const void* v, int64_t sb, int64_t sn, int64_t osb,
+                 int64_t osn, int B, int N, int H, int dh) {
+  FETA_REQUIRE(B > 0 && N > 0 && H > 0, "attn: empty shape B=%d N=%d H=%d", B, N, H);
+  FETA_REQUIRE(N <= FETA_MAX_NODES, "attn: N=%d exceeds FETA_MAX_NODES", N);
+  FETA_REQUIRE(dh == 4 || dh == 8 || dh == 16 || dh == 32 || dh == 64,
+               "attn: head dim %d not in {4,8,16,32,64}", dh);
+  FETA_REQUIRE((sb % 4) == 0 && (sn % 4) == 0 && (osb % 4) == 0 && (osn % 4) == 0,
+               "attn: strides must be multiples of 4 elements");
+  FETA_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v), "attn: q/k/v must be 16-byte aligned");
+  return FETA_OK;
+}
+
+}  // namespace feta
+
+using namespace feta;
+
+#define FETA_DISPATCH_DH(dh, CALL) \
+  switch (dh) {                    \
+    case 4: return CALL(4);        \
+    case 8: return CALL(8);        \
+    case 16: return CALL(16);      \
+    case 32: return CALL(32);      \
+    default: return CALL(64);      \
+  }
+
+extern "C" int feta_attn_fwd(const float* q, const float* k, const float* v, int64_t qkv_sb,
+                             int64_t qkv_sn, const float* pe, const int32_t* n_real, float* out,
+                             int64_t o_sb, int64_t o_sn, float* attn, float* stats, float scale,
+                             int B, int N, int H, int dh, feta_stream_t stream) {
+  int rc = check_common(q, k, v, qkv_sb, qkv_sn, o_sb, o_sn, B, N, H, dh);
+  if (rc != FETA_OK) return rc;
+  FETA_REQUIRE(out != nullptr && stats != nullptr && n_real != nullptr, "attn_fwd: null output");
+  AttnArgs a{};
+  a.q = q; a.k = k; a.v = v; a.pe = pe; a.n_real = n_real;
+  a.out_w = out; a.attn = attn; a.stats = stats;
+  a.qsb = qkv_sb; a.qsn = qkv_sn; a.osb = o_sb; a.osn = o_sn;
+  a.scale = scale; a.B = B; a.N = N; a.H = H; a.NB = (N + 15) / 16;
+  a.total = B * H * a.NB;
+  const int kt_max = a.NB;
+#define CALL(D) launch_fwd<D>(a, kt_max, (hipStream_t)stream)
+  FETA_DISPATCH_DH(dh, CALL)
+#undef CALL
+}
+
+extern "C" int feta_attn_bwd(const float* q, const float* k, const float* v, int64_t qkv_sb,
+                             int64_t qkv_sn, const float* pe, const int32_t* n_real,
+                             const float* out, const float* dout, int64_t o_sb, int64_t o_sn,
+                             const float* stats, float* delta, float* dq, float* dk, float* dv,
+                             float scale, int B, int N, int H, int dh, feta_stream_t stream) {
+  int rc = check_common(q, k, v, qkv_sb, qkv_sn, o_sb, o_sn, B, N, H, dh);
+  if (rc != FETA_OK) return rc;
+  FETA_REQUIRE(out && dout && stats && delta && dq && dk && dv && n_real, "attn_bwd: null pointer");
+  FETA_REQUIRE(aligned16(out) && aligned16(dout) && aligned16(dq) && aligned16(dk) && aligned16(dv),
+               "attn_bwd: pointers must be 16-byte aligned");
+  AttnArgs a{};
+  a.q = q; a.k = k; a.v = v; a.pe = pe; a.n_real = n_real;
+  a.out = out; a.dout = dout; a.stats_in = stats; a.delta = delta;
+  a.dq = dq; a.dk = dk; a.dv = dv;
+  a.qsb = qkv_sb; a.qsn = qkv_sn; a.osb = o_sb; a.osn = o_sn;
+  a.scale = scale; a.B = B; a.N = N; a.H = H; a.NB = (N + 15) / 16;
+  a.total = B * H * a.NB;
+#define CALL(D) launch_bwd<D>(a, (hipStream_t)stream)
+  FETA_DISPATCH_DH(dh, CALL)
+#undef CALL
+}

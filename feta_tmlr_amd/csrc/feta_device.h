@@ -1,0 +1,38 @@
+// gfx950 device primitives used by every kernel in this directory: the f32 MFMA
+// tile, wave shuffles and the single dynamic-LDS array.  Kernels are written
+// against this header only (tools/simt swaps in a host emulation of the same API
+// so tests can run the kernel source on a CPU).
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// All LDS lives in ONE dynamic array (cdna_hip_programming.md: a second
+// __shared__ object can serialise LDS-DMA waits); kernels carve it by hand.
+extern __shared__ __attribute__((aligned(16))) float feta_lds[];
+
+namespace feta {
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// v_mfma_f32_16x16x4_f32 (exact fp32, k-ordered fma chain): lane l supplies
+// A[l&15][l>>4] and B[l>>4][l&15]; register r of the result is D[4*(l>>4)+r][l&15].
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }
+
+// A wave's DS operations execute in order; this only stops the compiler from
+// moving a wave-private LDS read above the write that another lane made.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+
+}  // namespace feta

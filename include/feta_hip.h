@@ -1,0 +1,173 @@
+/* feta_hip.h - C ABI of libfeta_hip.so: the MI355X (gfx950) kernels behind the FeTA
+ * spectral-attention block (dense per-graph attention with a multiplicative
+ * positional kernel -> attention-conditioned filter coefficients -> dynamic
+ * Chebyshev / eigenbasis spectral filter), forward and backward.
+ *
+ * The reference (ansonb/FeTA_TMLR) has no FFI for this path - it is ~40 PyTorch /
+ * torch-geometric ops per layer - so each entry point below cites the reference
+ * Python text whose arithmetic it replaces (paths relative to the reference root).
+ * The Python side (feta_tmlr_amd/_abi.py) binds exactly these symbols with ctypes.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller and valid until the
+ *    given stream reaches the enqueue point; nothing is allocated or synchronised
+ *    inside; kernels are stream-ordered and graph-capturable;
+ *  - all floating-point data is fp32, row-major; `stream` is a hipStream_t;
+ *  - "token tensors" (q/k/v, per-head outputs, filter input/output) are addressed
+ *    as ptr[b*sb + i*sn + h*dh + c] with element strides sb (graph) and sn (node),
+ *    so seq-first [N,B,d] and batch-first [B,N,d] storage both work without copies;
+ *    base pointers and strides must be multiples of 4 elements (16 bytes);
+ *  - n_real[b] (int32) is the number of real nodes of graph b, 1 <= n_real[b] <= N;
+ *    padding is the suffix i >= n_real[b] (reference collate: transformer/data.py:210);
+ *  - return 0 on success, a negative FETA_E_* code otherwise; feta_last_error()
+ *    gives the message for the calling thread.
+ */
+#ifndef FETA_HIP_H_
+#define FETA_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FETA_ABI_VERSION 1
+
+#define FETA_OK 0
+#define FETA_E_ARG (-1)     /* bad shape / stride / alignment / unsupported size */
+#define FETA_E_LAUNCH (-2)  /* the HIP runtime rejected a launch */
+
+typedef void* feta_stream_t;
+
+int feta_version(void);
+const char* feta_last_error(void);
+
+/* Largest padded node count and head dim the tile templates are instantiated for. */
+#define FETA_MAX_NODES 256
+#define FETA_MAX_HEAD_DIM 64
+
+/* ---- A1: attention core ---------------------------------------------------------
+ * Replaces the score/softmax/weighted-sum of DiffTransformerEncoderLayer.self_attn
+ * (source absent from the reference; contract from transformer/models.py:166-167,179,
+ * 244,275; form witnesses LSPE/layers/graphit_gt_layer.py:39-43,120-131,164):
+ *   s = scale * q.k^T ; keys >= n_real masked ; e = exp(s - rowmax) ; e *= pe (if pe) ;
+ *   attn = e / max(rowsum(e), 1e-6) ; out = attn . v
+ * q,k,v   token tensors (strides qkv_sb, qkv_sn), all N query rows are computed
+ * pe      [B,N,N] or NULL (broadcast over heads)
+ * out     token tensor (strides o_sb, o_sn): out_each_head[b,i,h,:]
+ * attn    [B,H,N,N] or NULL (skip the write; backward recomputes from stats)
+ * stats   [B,H,N,2]: (rowmax, un-clamped rowsum) per query row
+ */
+int feta_attn_fwd(const float* q, const float* k, const float* v,
+                  int64_t qkv_sb, int64_t qkv_sn,
+                  const float* pe, const int32_t* n_real,
+                  float* out, int64_t o_sb, int64_t o_sn,
+                  float* attn, float* stats, float scale,
+                  int B, int N, int H, int dh, feta_stream_t stream);
+
+/* Backward of feta_attn_fwd w.r.t. q,k,v given dout (same strides as out).
+ * delta [B,H,N] is caller-provided scratch (rowsum(dout*out)).
+ * dq,dk,dv use the q/k/v strides and are fully written (zeros on padded keys).
+ * The gradient through the rowmax subtraction is dropped (it is exactly zero
+ * unless the 1e-6 clamp is active). */
+int feta_attn_bwd(const float* q, const float* k, const float* v,
+                  int64_t qkv_sb, int64_t qkv_sn,
+                  const float* pe, const int32_t* n_real,
+                  const float* out, const float* dout, int64_t o_sb, int64_t o_sn,
+                  const float* stats, float* delta,
+                  float* dq, float* dk, float* dv, float scale,
+                  int B, int N, int H, int dh, feta_stream_t stream);
+
+/* ---- A2: filter-coefficient generator ---------------------------------------------
+ * Replaces DiffTransformerEncoderGenGCN.get_filter_coefficients up to (not including)
+ * self.linear: transformer/models.py:240-283 with GCNConv semantics of
+ * transformer/GenGCN.py:55-102,393-402, using the exact collapse
+ * GCNConv(ones)[j] = c_j * colsum(W) + b   (SURVEY F7).
+ *   block (h,b): w = attn[b,h,:n,:n] ; w_jj = 1 where attn_jj == 0 ;
+ *   deg_j = sum_i w_ij ; c_j = sum_i deg_i^-1/2 w_ij deg_j^-1/2 ;
+ *   pooled[h*B+b, :] = mean_j tanh(c_j * s + gcn_bias)
+ * cj      [H*B, N] out (saved for backward; rows >= n are zero)
+ * pooled  [H*B, C] out
+ */
+int feta_coeff_fwd(const float* attn, const int32_t* n_real,
+                   const float* s, const float* gcn_bias,
+                   float* cj, float* pooled,
+                   int B, int N, int H, int C, feta_stream_t stream);
+
+/* ds[c] = sum_{blk,j} dpooled*(1-z^2)*c_j/n ; dbias[c] likewise without c_j.
+ * partial [2, G, C] scratch with G = feta_coeff_bwd_groups(B,H). */
+int feta_coeff_bwd_groups(int B, int H);
+int feta_coeff_bwd(const float* cj, const int32_t* n_real,
+                   const float* s, const float* gcn_bias, const float* dpooled,
+                   float* partial, float* ds, float* dbias,
+                   int B, int N, int H, int C, feta_stream_t stream);
+
+/* out[c] = sum_r in[r, c]  (s = colsum(gcn.weight); also reduces per-block partials) */
+int feta_colsum(const float* in, float* out, int R, int C, feta_stream_t stream);
+
+/* ---- A3: dynamic Chebyshev filter, direct recursion on a dense scaled Laplacian ----
+ * Replaces ChebConvDynamic.forward + __norm__ (transformer/ChebNetDynamic.py:108-189)
+ * and its head-stacking / gather / scatter glue (transformer/models.py:178-186,
+ * 200-202,346-360):
+ *   y[b,i,h,:] = sum_k (T_k(Lhat_b) x_bh)[i,:] . W_k^(h,b) + bias   for i < n_real[b],
+ *   y = 0 on padded rows; W^(h,b) = coeff[h*B+b].reshape(P, dh, dh).
+ * lhat   [B,N,N] dense operator of one propagate(): out = Lhat @ x
+ * heads_share_graph  0 = reference-literal (only head 0 sees the graph, heads >= 1
+ *                    use Lhat = 0: models.py:186); 1 = every head filtered
+ * x, y   token tensors (x strides x_sb,x_sn ; y strides y_sb,y_sn)
+ */
+int feta_cheb_filter_fwd(const float* x, int64_t x_sb, int64_t x_sn,
+                         const float* lhat, const float* coeff, const float* bias,
+                         const int32_t* n_real,
+                         float* y, int64_t y_sb, int64_t y_sn,
+                         int B, int N, int H, int dh, int P, int heads_share_graph,
+                         feta_stream_t stream);
+
+/* dx (x strides), dcoeff [H*B, P*dh*dh], dbias_part [B*H, dh] (reduce with feta_colsum) */
+int feta_cheb_filter_bwd(const float* x, int64_t x_sb, int64_t x_sn,
+                         const float* lhat, const float* coeff, const int32_t* n_real,
+                         const float* dy, int64_t y_sb, int64_t y_sn,
+                         float* dx, float* dcoeff, float* dbias_part,
+                         int B, int N, int H, int dh, int P, int heads_share_graph,
+                         feta_stream_t stream);
+
+/* ---- A3 (eigenbasis form): U^T.X -> g(Lambda) -> U.(.) ------------------------------
+ * Same operator in the Laplacian eigenbasis:
+ *   y = U [ sum_k diag(t_k(lam)) (U^T x) W_k ] + bias ,  t_0=1, t_1=lam, t_k=2 lam t_{k-1}-t_{k-2}
+ * exact w.r.t. feta_cheb_filter_* iff K spans the graph (K >= n_real); K < n is the
+ * truncated benchmark operator (BASELINE configs K=8/16/32).
+ * u [B,N,K] (rows >= n_real zero), lam [B,K].
+ */
+int feta_spec_filter_fwd(const float* x, int64_t x_sb, int64_t x_sn,
+                         const float* u, const float* lam,
+                         const float* coeff, const float* bias, const int32_t* n_real,
+                         float* y, int64_t y_sb, int64_t y_sn,
+                         int B, int N, int H, int dh, int P, int K, int heads_share_graph,
+                         feta_stream_t stream);
+
+int feta_spec_filter_bwd(const float* x, int64_t x_sb, int64_t x_sn,
+                         const float* u, const float* lam,
+                         const float* coeff, const int32_t* n_real,
+                         const float* dy, int64_t y_sb, int64_t y_sn,
+                         float* dx, float* dcoeff, float* dbias_part,
+                         int B, int N, int H, int dh, int P, int K, int heads_share_graph,
+                         feta_stream_t stream);
+
+/* ---- graph preprocessing -------------------------------------------------------------
+ * Dense Lhat = -D^-1/2 A D^-1/2 per graph from the batched edge list, with the exact
+ * edge-list semantics of ChebConvDynamic.__norm__ (transformer/ChebNetDynamic.py:108-130):
+ * self loops removed, degree scattered on the source row, duplicates summed, flow
+ * source -> target (Lhat[b, t, s] += w).  lhat [B,N,N] must be zeroed by the caller;
+ * deg [n_tot] is zero-initialised scratch.
+ * edge_index [2,E] int64 (global node ids), node_graph [n_tot] int64, node_off [B] int32
+ * (first global node id of graph b).
+ */
+int feta_lhat_from_edges(const int64_t* edge_index, int64_t E,
+                         const int64_t* node_graph, const int32_t* node_off,
+                         float* deg, float* lhat, int B, int N, int64_t n_tot,
+                         feta_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FETA_HIP_H_ */

@@ -1,0 +1,416 @@
+"""CPU oracle for the FeTA spectral-attention hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import this module, and only as the checker / the timed CPU
+baseline.  The product (``feta_tmlr_amd``) never imports it and has no CPU
+fallback: it raises when ``libfeta_hip.so`` is missing.
+
+PARITY UNPINNED.  The reference (ansonb/FeTA_TMLR) ships no tests, golden
+vectors or benchmarks for this path, cannot be imported (``transformer/layers.py``
+is the wrong file; ``torch_geometric`` is absent) and the arithmetic lives in
+un-vendored third-party code (torch-geometric 1.7, pytorch 1.6, upstream
+GraphiT).  This file restates the algorithm from the reference text; every
+function cites the file:line it follows (paths relative to the reference root).
+What pins it instead (tests/test_oracle.py): three independent formulations of
+the filter agree to 1e-12 in fp64, the collapsed and the un-collapsed coefficient
+generator agree, and closed-form known answers (empty graph, P=1, uniform
+attention, path-graph spectrum).
+
+Everything is dtype-generic PyTorch on the CPU (fp64 master, fp32 copy) so that
+``torch.autograd`` provides the backward oracle too.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# ---------------------------------------------------------------------------
+# torch-geometric 1.7 semantics used on the path.  The
+# library is not in the reference tree; the only in-tree text is the vendored
+# gcn_norm at transformer/GenGCN.py:55-102.
+# ---------------------------------------------------------------------------
+
+
+def scatter_add_rows(src, index, dim_size):
+    """torch_scatter.scatter_add(src, index, dim=0, dim_size=...)."""
+    out = torch.zeros((dim_size,) + tuple(src.shape[1:]), dtype=src.dtype)
+    return out.index_add(0, index, src)
+
+
+def remove_self_loops(edge_index, edge_weight=None):
+    """PyG remove_self_loops; call site transformer/ChebNetDynamic.py:113."""
+    keep = edge_index[0] != edge_index[1]
+    ew = None if edge_weight is None else edge_weight[keep]
+    return edge_index[:, keep], ew
+
+
+def add_self_loops(edge_index, edge_weight, fill_value, num_nodes):
+    """PyG add_self_loops: appends one (i,i) edge per node, never coalesces.
+    Call site transformer/ChebNetDynamic.py:125-127."""
+    loop = torch.arange(num_nodes, dtype=edge_index.dtype)
+    ei = torch.cat([edge_index, torch.stack([loop, loop])], dim=1)
+    ew = torch.cat([edge_weight,
+                    torch.full((num_nodes,), fill_value, dtype=edge_weight.dtype)])
+    return ei, ew
+
+
+def add_remaining_self_loops(edge_index, edge_weight, fill_value, num_nodes):
+    """PyG add_remaining_self_loops (used by gcn_norm, transformer/GenGCN.py:89-93):
+    non-loop edges kept, one loop per node, existing loop weights kept."""
+    row, col = edge_index[0], edge_index[1]
+    mask = row != col
+    loop = torch.arange(num_nodes, dtype=edge_index.dtype)
+    ei = torch.cat([edge_index[:, mask], torch.stack([loop, loop])], dim=1)
+    loop_w = torch.full((num_nodes,), fill_value, dtype=edge_weight.dtype)
+    inv = ~mask
+    if int(inv.sum()) > 0:
+        loop_w = loop_w.index_put((row[inv],), edge_weight[inv])
+    ew = torch.cat([edge_weight[mask], loop_w])
+    return ei, ew
+
+
+def get_laplacian_sym(edge_index, edge_weight, num_nodes, dtype):
+    """PyG get_laplacian(normalization='sym'): L = I - D^-1/2 A D^-1/2 as an
+    edge list (off-diagonal weights -w', +1 loop on every node).
+    Call sites transformer/ChebNetDynamic.py:115-117, position_encoding.py:130."""
+    edge_index, edge_weight = remove_self_loops(edge_index, edge_weight)
+    if edge_weight is None:
+        edge_weight = torch.ones(edge_index.shape[1], dtype=dtype)
+    row, col = edge_index[0], edge_index[1]
+    deg = scatter_add_rows(edge_weight, row, num_nodes)
+    dis = deg.pow(-0.5)
+    dis = dis.masked_fill(dis == float('inf'), 0.0)
+    w = dis[row] * edge_weight * dis[col]
+    return add_self_loops(edge_index, -w, 1.0, num_nodes)
+
+
+def cheb_norm(edge_index, num_nodes, dtype, lambda_max=2.0):
+    """ChebConvDynamic.__norm__, transformer/ChebNetDynamic.py:108-130
+    (normalization='sym', scalar lambda_max): L_hat = 2L/lmax - I as an edge list
+    with un-coalesced +1 and -1 loops."""
+    edge_index, edge_weight = remove_self_loops(edge_index, None)
+    edge_index, edge_weight = get_laplacian_sym(edge_index, edge_weight, num_nodes, dtype)
+    edge_weight = (2.0 * edge_weight) / lambda_max
+    edge_weight = edge_weight.masked_fill(edge_weight == float('inf'), 0.0)
+    return add_self_loops(edge_index, edge_weight, -1.0, num_nodes)
+
+
+def propagate(edge_index, x, norm):
+    """MessagePassing.propagate with aggr='add', flow source->target and
+    message = norm * x_j  (transformer/ChebNetDynamic.py:82-83,171,192-193)."""
+    msg = norm.view(-1, 1) * x[edge_index[0]]
+    return scatter_add_rows(msg, edge_index[1], x.shape[0])
+
+
+# ---------------------------------------------------------------------------
+# A3: the dynamic Chebyshev filter, three formulations
+# ---------------------------------------------------------------------------
+
+
+def cheb_conv_dynamic_edges(x, edge_index, filter_coeff, batch, bias):
+    """Formulation (i): line-by-line restatement of ChebConvDynamic.forward,
+    transformer/ChebNetDynamic.py:146-189 (non-scalar mode).
+
+    x [M, din]; filter_coeff [P, G, din, dout]; batch [M] sorted group ids."""
+    _, counts = torch.unique(batch, sorted=True, return_counts=True)        # :148
+    weight = torch.repeat_interleave(filter_coeff, counts, dim=1)           # :149
+    ei, norm = cheb_norm(edge_index, x.shape[0], x.dtype)                   # :157-160
+    tx0 = x
+    out = torch.bmm(tx0.unsqueeze(1), weight[0]).squeeze(1)                 # :167
+    tx1 = x
+    if weight.shape[0] > 1:
+        tx1 = propagate(ei, x, norm)                                        # :171
+        out = out + torch.bmm(tx1.unsqueeze(1), weight[1]).squeeze(1)       # :175
+    for k in range(2, weight.shape[0]):
+        tx2 = 2.0 * propagate(ei, tx1, norm) - tx0                          # :178-179
+        out = out + torch.bmm(tx2.unsqueeze(1), weight[k]).squeeze(1)       # :183
+        tx0, tx1 = tx1, tx2
+    if bias is not None:
+        out = out + bias                                                    # :186-187
+    return out
+
+
+def lhat_dense(edge_index, n, dtype):
+    """Dense operator applied by one propagate() of cheb_norm's edge list:
+    M[t, s] = sum of norm over edges s->t (so propagate(x) == M @ x)."""
+    ei, norm = cheb_norm(edge_index, n, dtype)
+    m = torch.zeros(n, n, dtype=dtype)
+    return m.index_put((ei[1], ei[0]), norm, accumulate=True)
+
+
+def cheb_filter_dense(x, lhat, w, bias):
+    """Formulation (ii) for ONE (head, graph) block: dense L_hat recursion.
+    x [n, din], lhat [n, n], w [P, din, dout]."""
+    tx0 = x
+    out = tx0 @ w[0]
+    tx1 = x
+    if w.shape[0] > 1:
+        tx1 = lhat @ x
+        out = out + tx1 @ w[1]
+    for k in range(2, w.shape[0]):
+        tx2 = 2.0 * (lhat @ tx1) - tx0
+        out = out + tx2 @ w[k]
+        tx0, tx1 = tx1, tx2
+    if bias is not None:
+        out = out + bias
+    return out
+
+
+def cheb_poly(lam, order):
+    """t_k(lam), k < order: t0=1, t1=lam, t_k = 2 lam t_{k-1} - t_{k-2}.  [order, K]"""
+    t = [torch.ones_like(lam)]
+    if order > 1:
+        t.append(lam)
+    for _ in range(2, order):
+        t.append(2.0 * lam * t[-1] - t[-2])
+    return torch.stack(t)
+
+
+def spec_filter_eig(x, u, lam, w, bias):
+    """Formulation (iii) for ONE block: eigenbasis form
+    Y = U [sum_k diag(t_k(lam)) (U^T X) W_k] + bias.  u [n, K], lam [K].
+    Equals (ii) iff U spans the whole space (K = n)."""
+    t = cheb_poly(lam, w.shape[0])
+    xt = u.t() @ x
+    yt = sum(t[k].unsqueeze(1) * (xt @ w[k]) for k in range(w.shape[0]))
+    out = u @ yt
+    if bias is not None:
+        out = out + bias
+    return out
+
+
+def eig_basis(lhat, k_eig, n_pad=None):
+    """eigh of a symmetric L_hat (fp64), ascending, first k_eig columns; rows
+    zero-padded to n_pad and columns to k_eig (SURVEY 8d 'U, lambda_hat')."""
+    n = lhat.shape[0]
+    lam, u = np.linalg.eigh(lhat.double().numpy())
+    n_pad = n if n_pad is None else n_pad
+    uu = np.zeros((n_pad, k_eig))
+    ll = np.zeros((k_eig,))
+    kk = min(k_eig, n)
+    uu[:n, :kk] = u[:, :kk]
+    ll[:kk] = lam[:kk]
+    return torch.from_numpy(uu), torch.from_numpy(ll)
+
+
+# ---------------------------------------------------------------------------
+# A2: filter-coefficient generator
+# ---------------------------------------------------------------------------
+
+
+def gcn_norm(edge_index, edge_weight, num_nodes):
+    """transformer/GenGCN.py:55-102 (dense-tensor branch, add_self_loops=True,
+    improved=False)."""
+    edge_index, edge_weight = add_remaining_self_loops(edge_index, edge_weight, 1.0, num_nodes)
+    row, col = edge_index[0], edge_index[1]
+    deg = scatter_add_rows(edge_weight, col, num_nodes)                     # :96
+    dis = deg.pow(-0.5)
+    dis = dis.masked_fill(dis == float('inf'), 0.0)                         # :100-101
+    return edge_index, dis[row] * edge_weight * dis[col]                    # :102
+
+
+def gcn_conv(x, edge_index, edge_weight, weight, bias):
+    """GCNConv.forward, transformer/GenGCN.py:361-402: x@W, propagate, + bias."""
+    ei, w = gcn_norm(edge_index, edge_weight, x.shape[0])
+    xw = x @ weight                                                         # :393
+    out = scatter_add_rows(w.view(-1, 1) * xw[ei[0]], ei[1], x.shape[0])    # :396,405-406
+    return out + bias                                                       # :399-400
+
+
+def global_mean_pool(x, batch, num_groups):
+    s = scatter_add_rows(x, batch, num_groups)
+    cnt = scatter_add_rows(torch.ones(x.shape[0], dtype=x.dtype), batch, num_groups)
+    return s / cnt.clamp(min=1).unsqueeze(1)
+
+
+def get_filter_coefficients_faithful(attn, masks, gcn_w, gcn_b, lin_w, lin_b):
+    """Un-collapsed restatement of DiffTransformerEncoderGenGCN.get_filter_coefficients,
+    transformer/models.py:240-287: Python loop over the H*B blocks, dense edge
+    lists, GCNConv on an all-ones [H*Ntot, C] input, tanh, mean pool, Linear.
+
+    attn [B,H,N,N]; masks [B,N] bool (True = pad).  Returns [H, B, C]."""
+    b, h, n, _ = attn.shape
+    c = gcn_w.shape[0]
+    masks_r = masks.repeat(h, 1)                                            # :244
+    inv = ~masks_r
+    g_len = inv.sum(-1).tolist()                                            # :246
+    eis, bat = [], []
+    off = 0
+    for blk, gl in enumerate(g_len):                                        # :252-258
+        idx = np.mgrid[off:off + gl, off:off + gl].reshape(2, -1)
+        eis.append(idx)
+        bat.append(np.full((gl,), blk, dtype=np.int64))
+        off += gl
+    edge_index = torch.from_numpy(np.concatenate(eis, axis=1)).long()
+    batch = torch.from_numpy(np.concatenate(bat))
+    t3 = inv.unsqueeze(1) & inv.unsqueeze(2)                                # :267-270
+    ew = attn.permute(1, 0, 2, 3).reshape(h * b, n, n)[t3]                  # :275
+    nz = torch.where(ew != 0.0)[0]                                          # :276
+    x_c = torch.ones(off, c, dtype=attn.dtype)                              # :280
+    x_c = torch.tanh(gcn_conv(x_c, edge_index[:, nz], ew[nz].detach(), gcn_w, gcn_b))  # :282
+    pooled = global_mean_pool(x_c, batch, h * b)                            # :283
+    coeff = F.linear(pooled, lin_w, lin_b)                                  # :284
+    return coeff.reshape(h, b, -1)                                          # :285
+
+
+def gcn_node_scalars(a, n):
+    """c_j of SURVEY Appendix A for one block: a [N,N] attention, n real nodes."""
+    w = a[:n, :n].detach().clone()
+    d = torch.diagonal(w)
+    d.copy_(torch.where(d != 0, d, torch.ones_like(d)))
+    deg = w.sum(0)
+    dis = deg.pow(-0.5)
+    dis = dis.masked_fill(dis == float('inf'), 0.0)
+    return dis * (dis.unsqueeze(1) * w).sum(0)
+
+
+def get_filter_coefficients_collapsed(attn, masks, gcn_w, gcn_b, lin_w, lin_b):
+    """Same function via the exact colsum(W) collapse."""
+    b, h, n, _ = attn.shape
+    nb = (~masks).sum(-1).tolist()
+    s = gcn_w.sum(0)
+    pooled = []
+    for hh in range(h):
+        for bb in range(b):
+            cj = gcn_node_scalars(attn[bb, hh], nb[bb])
+            pooled.append(torch.tanh(cj.unsqueeze(1) * s + gcn_b).mean(0))
+    coeff = F.linear(torch.stack(pooled), lin_w, lin_b)
+    return coeff.reshape(h, b, -1)
+
+
+# ---------------------------------------------------------------------------
+# A1: the attention layer (source absent from the reference; reconstructed from
+# its call sites transformer/models.py:166-167,179,244,275,505-506 and the form
+# witnesses LSPE/layers/graphit_gt_layer.py:39-43,120-131,164 — SURVEY 8a A1)
+# ---------------------------------------------------------------------------
+
+
+def diff_attention(src, pe, key_padding_mask, in_w, in_b, num_heads, tie_qk=False):
+    """Returns (concat [N,B,d] before out_proj, attn [B,H,N,N], out_each_head [B,N,H,dh])."""
+    n, b, d = src.shape
+    dh = d // num_heads
+    q, k, v = F.linear(src, in_w, in_b).chunk(3, dim=-1)
+    if tie_qk:
+        k = q
+    q = q * (float(dh) ** -0.5)
+
+    def heads(t):
+        return t.contiguous().view(n, b * num_heads, dh).transpose(0, 1)
+    q, k, v = heads(q), heads(k), heads(v)
+    s = torch.bmm(q, k.transpose(1, 2)).view(b, num_heads, n, n)
+    if key_padding_mask is not None:
+        s = s.masked_fill(key_padding_mask.unsqueeze(1).unsqueeze(2), float('-inf'))
+    s = torch.exp(s - s.max(dim=-1, keepdim=True)[0])
+    if pe is not None:
+        s = s * pe.unsqueeze(1)
+    a = s / s.sum(dim=-1, keepdim=True).clamp(min=1e-6)
+    o = torch.bmm(a.view(b * num_heads, n, n), v).view(b, num_heads, n, dh)
+    concat = o.permute(2, 0, 1, 3).reshape(n, b, d)
+    return concat, a, o.permute(0, 2, 1, 3)
+
+
+def _norm(x, w, b, batch_norm):
+    if batch_norm:
+        shp = x.shape
+        y = F.batch_norm(x.reshape(-1, shp[-1]), None, None, w, b, True, 0.1, 1e-5)
+        return y.view(shp)
+    return F.layer_norm(x, (x.shape[-1],), w, b, 1e-5)
+
+
+def encoder_layer(src, pe, degree, key_padding_mask, p, prefix, num_heads,
+                  batch_norm=False, tie_qk=False):
+    """DiffTransformerEncoderLayer.forward(need_heads=True) -> (src', attn, out_each_head).
+    p: dict of tensors keyed like the product's state_dict, prefix e.g. 'layers.0.'."""
+    concat, attn, oh = diff_attention(src, pe, key_padding_mask,
+                                      p[prefix + 'self_attn.in_proj_weight'],
+                                      p.get(prefix + 'self_attn.in_proj_bias'),
+                                      num_heads, tie_qk)
+    src2 = F.linear(concat, p[prefix + 'self_attn.out_proj.weight'],
+                    p.get(prefix + 'self_attn.out_proj.bias'))
+    if degree is not None:
+        src2 = degree.transpose(0, 1).unsqueeze(-1) * src2
+    src = src + src2
+    src = _norm(src, p[prefix + 'norm1.weight'], p[prefix + 'norm1.bias'], batch_norm)
+    src2 = F.linear(F.relu(F.linear(src, p[prefix + 'linear1.weight'], p[prefix + 'linear1.bias'])),
+                    p[prefix + 'linear2.weight'], p[prefix + 'linear2.bias'])
+    src = src + src2
+    src = _norm(src, p[prefix + 'norm2.weight'], p[prefix + 'norm2.bias'], batch_norm)
+    return src, attn, oh
+
+
+# ---------------------------------------------------------------------------
+# Encoder glue (A3 caller, A4) and pooling (A5)
+# ---------------------------------------------------------------------------
+
+
+def filter_stage_faithful(out_each_head, coeff_all_heads, edge_index, feature_indices,
+                          batch, bias, order, out_shape, heads_share_graph=False):
+    """Head stacking + filter + scatter: transformer/models.py:178-186,200-202,346-360.
+    heads_share_graph=False reproduces the un-replicated edge_index of :186."""
+    bsz, n, h, dh = out_each_head.shape
+    n_tot = feature_indices.shape[0]
+    coeff = coeff_all_heads.reshape(h * bsz, -1)                             # :178
+    out_heads = out_each_head.permute(2, 0, 1, 3).reshape(h * bsz, n, dh)    # :179
+    batch_all = torch.cat([batch + i * bsz for i in range(h)])               # :181-182
+    fi_all = feature_indices.repeat(h, 1).clone()                            # :184
+    fi_all[:, 0] += torch.arange(h).repeat_interleave(n_tot) * bsz           # :183,185
+    if heads_share_graph:
+        ei = torch.cat([edge_index + i * n_tot for i in range(h)], dim=1)
+    else:
+        ei = edge_index                                                      # :186
+    x = out_heads[fi_all[:, 0], fi_all[:, 1], :]                             # :347
+    fc = coeff.reshape(-1, order, dh, dh).permute(1, 0, 2, 3)                # :357
+    y = cheb_conv_dynamic_edges(x, ei, fc, batch_all, bias)                  # :360
+    filt = y.reshape(h, n_tot, dh).permute(1, 0, 2).reshape(n_tot, h * dh)   # :200
+    out = torch.zeros(out_shape, dtype=y.dtype)                              # :201
+    return out.index_put((feature_indices[:, 1], feature_indices[:, 0]), filt)  # :202
+
+
+def encoder_gengcn(src, pe, edge_index, feature_indices, batch, degree, key_padding_mask,
+                   p, num_layers, num_heads, order, batch_norm=False, tie_qk=False,
+                   heads_share_graph=False, last_layer_filter=True, collapsed=False,
+                   prefix=''):
+    """DiffTransformerEncoderGenGCN.forward, transformer/models.py:155-238
+    (gnn_type='ChebConvDynamic', use_skip_conn=True).
+    Returns (output [N,B,d], attn [B,H,N,N], coefficients [B, H*n_filtered, C])."""
+    out = src
+    allf = None
+    coeffs = []
+    attn = None
+    getc = get_filter_coefficients_collapsed if collapsed else get_filter_coefficients_faithful
+    for li in range(num_layers):
+        out, attn, oh = encoder_layer(out, pe, degree, key_padding_mask, p,
+                                      prefix + 'layers.%d.' % li, num_heads, batch_norm, tie_qk)
+        if last_layer_filter and li + 1 != num_layers:                       # :169-171
+            continue
+        c = getc(attn, key_padding_mask, p[prefix + 'gcn.weight'], p[prefix + 'gcn.bias'],
+                 p[prefix + 'linear.weight'], p[prefix + 'linear.bias'])      # :173
+        f = filter_stage_faithful(oh, c, edge_index, feature_indices, batch,
+                                  p[prefix + 'spectral_gnns.bias'], order, out.shape,
+                                  heads_share_graph)
+        coeffs.append(c)
+        allf = f if allf is None else allf + f                               # :209-213
+    if allf is not None:
+        out = F.linear(torch.cat((out, allf), dim=-1),
+                       p[prefix + 'linear_cat.weight'], p[prefix + 'linear_cat.bias'])  # :223-224
+    coefficients = torch.cat(coeffs, dim=0).permute(1, 0, 2)                 # :198,238
+    return out, attn, coefficients
+
+
+def global_avg_1d(x, mask):
+    """GlobalAvg1D.forward, transformer/models.py:590-595.  x [B,N,d], mask [B,N]."""
+    m = (~mask).to(x.dtype).unsqueeze(-1)
+    return (x * m).sum(dim=1) / m.sum(dim=1)
+
+
+def graph_transformer_gengcn(x, edge_index, batch, feature_indices, masks, pe, degree, p,
+                             num_layers, num_heads, order, **kw):
+    """DiffGraphTransformerGenGCN.forward, transformer/models.py:518-551 (no lap PE)."""
+    out = F.linear(x.permute(1, 0, 2), p['embedding.weight'])                # :521-522
+    out, attn, coeff = encoder_gengcn(out, pe, edge_index, feature_indices, batch, degree,
+                                      masks, p, num_layers, num_heads, order,
+                                      prefix='encoder.', **kw)               # :527
+    pooled = global_avg_1d(out.permute(1, 0, 2), masks)                      # :528,532
+    hid = F.relu(F.linear(pooled, p['classifier.0.weight'], p['classifier.0.bias']))
+    return F.linear(hid, p['classifier.2.weight'], p['classifier.2.bias']), coeff  # :549-551

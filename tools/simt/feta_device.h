@@ -1,0 +1,65 @@
+// Emulated counterpart of feta_tmlr_amd/csrc/feta_device.h (same API, host
+// fibers instead of gfx950 instructions).  TEST INFRASTRUCTURE ONLY; found first
+// on the include path by tools/simt/build.sh.
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct f32x4 {
+  float v[4];
+  float& operator[](int i) { return v[i]; }
+  const float& operator[](int i) const { return v[i]; }
+};
+
+extern float feta_lds[];
+
+namespace feta {
+
+inline int lane_id() { return threadIdx.x & 63; }
+inline int wave_id() { return threadIdx.x >> 6; }
+
+// v_mfma_f32_16x16x4_f32: D = A(16x4) * B(4x16) + C, lane l supplies A[l&15][l>>4]
+// and B[l>>4][l&15]; D[4*(l>>4)+r][l&15] in register r.  k-ordered fmaf chain.
+inline f32x4 mfma16(float a, float b, f32x4 c) {
+  simt::WaveScratch& s = simt::wave_scratch();
+  const int l = lane_id();
+  s.a[l] = a;
+  s.b[l] = b;
+  simt::wave_barrier();
+  f32x4 d;
+  const int col = l & 15;
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * (l >> 4) + r;
+    float acc = c[r];
+    for (int k = 0; k < 4; ++k) acc = fmaf(s.a[16 * k + row], s.b[16 * k + col], acc);
+    d[r] = acc;
+  }
+  simt::wave_barrier();
+  return d;
+}
+
+inline float shfl_xor(float v, int mask) {
+  simt::WaveScratch& s = simt::wave_scratch();
+  const int l = lane_id();
+  s.a[l] = v;
+  simt::wave_barrier();
+  float r = s.a[l ^ mask];
+  simt::wave_barrier();
+  return r;
+}
+
+inline float shfl(float v, int src) {
+  simt::WaveScratch& s = simt::wave_scratch();
+  const int l = lane_id();
+  s.a[l] = v;
+  simt::wave_barrier();
+  float r = s.a[src & 63];
+  simt::wave_barrier();
+  return r;
+}
+
+// orders this wave's LDS writes before its later LDS reads (other lanes' data)
+inline void wave_lds_sync() { simt::wave_barrier(); }
+
+inline float fast_exp(float x) { return expf(x); }
+
+}  // namespace feta
