@@ -1,0 +1,255 @@
+"""graphs/s, forward+backward of the FeTA spectral-attention hot path on synthetic ZINC-shaped
+padded-graph batches (BASELINE.json configs[1]: B=128, N_pad=37, d=64, 4 heads, K=16 eigenpairs,
+fp32), one process per GPU, weak scaling.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = zero grads, forward and backward of DiffTransformerEncoderGenGCN (all layers, attention
+-> coefficient generator -> spectral filter on the last layer -> linear_cat) on one batch that is
+already resident in HBM, plus, for N > 1, the RCCL all-reduce of the flat gradient bucket.
+Rank 0 prints ONE JSON line (contract in the task description) with two extra objects:
+  roofline      the dominant hand-written kernel of the step, timed live with HIP events
+  cpu_baseline  the reference-faithful CPU restatement (oracle/) timed on the host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from feta_tmlr_amd import _lib                                            # noqa: E402
+from feta_tmlr_amd import functional as FF                                # noqa: E402
+from feta_tmlr_amd.parallel import FlatGradAllReduce                      # noqa: E402
+from feta_tmlr_amd.transformer import data as D                           # noqa: E402
+from feta_tmlr_amd.transformer.layers import DiffTransformerEncoderLayer  # noqa: E402
+from feta_tmlr_amd.transformer.models import DiffTransformerEncoderGenGCN  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=128, help='graphs per GPU per step')
+    ap.add_argument('--layers', type=int, default=3)
+    ap.add_argument('--heads', type=int, default=4)
+    ap.add_argument('--dim', type=int, default=64)
+    ap.add_argument('--order', type=int, default=4)
+    ap.add_argument('--k-eig', type=int, default=16)
+    ap.add_argument('--n-pad', type=int, default=37)
+    ap.add_argument('--layer-norm', action='store_true', help='LayerNorm instead of the ZINC default BatchNorm')
+    ap.add_argument('--no-graph', action='store_true', help='eager launches instead of one hipGraph per step')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-steps', type=int, default=5)
+    ap.add_argument('--kernel-iters', type=int, default=200)
+    return ap.parse_args()
+
+
+def make_batch(args, rank, dev):
+    ds = D.SyntheticGraphDataset('zinc', args.batch, in_dim=args.dim, seed=rank)
+    batch9, cache = D.collate(ds.samples, k_eig=args.k_eig, n_pad=args.n_pad)
+    x, mask, pe, _, degree, _, edge_index, batch, fi = batch9
+    src = x.permute(1, 0, 2).contiguous()          # [N,B,d] seq-first, embedding skipped
+    g = torch.Generator().manual_seed(1000 + rank)
+    dout = torch.randn(src.shape, generator=g)
+    cpu = dict(src=src, mask=mask, pe=pe, degree=degree, edge_index=edge_index, batch=batch, fi=fi,
+               dout=dout, cache=cache)
+    gpu = {k: (v.to(dev) if v is not None else None) for k, v in cpu.items()}
+    return cpu, gpu
+
+
+def build_encoder(args):
+    torch.manual_seed(0)
+    layer = DiffTransformerEncoderLayer(args.dim, args.heads, 2 * args.dim, 0.0,
+                                        batch_norm=not args.layer_norm)
+    return DiffTransformerEncoderGenGCN(args.dim, args.heads, layer, args.layers,
+                                        num_coefficients=args.order, heads_share_graph=True,
+                                        filter_mode='spectral')
+
+
+def algorithmic_bytes_attn_fwd(b, n, h, dh, pe, write_attn):
+    """feta_attn_fwd, per launch: read q,k,v (3 N d), pe (N^2), n_real; write out (N d),
+    stats (2 H N) and attn (H N^2) when requested.  fp32."""
+    d = h * dh
+    per_graph = 3 * n * d + (n * n if pe else 0) + n * d + 2 * h * n + (h * n * n if write_attn else 0)
+    return 4 * per_graph * b
+
+
+def time_kernel(fn, iters):
+    for _ in range(10):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def roofline(args, gpu, dev):
+    """Average launch duration of the dominant hand-written kernel (feta_attn_fwd with the attn
+    write, the largest-traffic launch of the step), HIP events on the stream it is launched on."""
+    abi, stream = _lib.abi(), _lib.stream_handle()
+    b, n, h, dh = args.batch, args.n_pad, args.heads, args.dim // args.heads
+    qkv = torch.randn(n, b, 3 * args.dim, device=dev)
+    v5 = qkv.view(n, b, 3, h, dh)
+    q, k, v = (v5[:, :, i].permute(1, 0, 2, 3) for i in range(3))
+    out = torch.empty(n, b, h, dh, device=dev).permute(1, 0, 2, 3)
+    attn = torch.empty(b, h, n, n, device=dev)
+    stats = torch.empty(b, h, n, 2, device=dev)
+    nr = gpu['cache'].n_real
+    fn = lambda: abi.attn_fwd(q, k, v, gpu['pe'], nr, out, attn, stats, dh ** -0.5, stream)
+    t = time_kernel(fn, args.kernel_iters)
+    nbytes = algorithmic_bytes_attn_fwd(b, n, h, dh, True, True)
+    achieved = nbytes / t / 1e9
+    traffic = None
+    tp = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if os.path.exists(tp):
+        try:
+            traffic = json.load(open(tp)).get('feta_attn_fwd')
+        except Exception:
+            traffic = None
+    return {'kernel': 'feta_attn_fwd', 'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
+            'algorithmic_bytes': nbytes, 'launch_us': round(t * 1e6, 3)}
+
+
+def cpu_baseline(args, cpu, enc):
+    """Reference-faithful CPU restatement (edge-list recursion, per-node weight copies, the
+    un-collapsed GCNConv on ones, Python loop over H*B blocks), PyTorch CPU fp32, all host cores."""
+    from oracle import feta_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    p = {k: v.detach().cpu().float() for k, v in enc.state_dict().items() if v.dtype.is_floating_point}
+    sub = args.batch                               # the whole per-GPU batch, a few steps
+    m = cpu['mask'][:sub]
+    nb = (~m).sum(-1)
+    n_tot = int(nb.sum())
+    ei = cpu['edge_index']
+    ei = ei[:, ei[0] < n_tot]
+
+    def step():
+        leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        src = cpu['src'][:, :sub].clone().requires_grad_(True)
+        out, _, _ = O.encoder_gengcn(src, cpu['pe'][:sub], ei, cpu['fi'][:n_tot], cpu['batch'][:n_tot],
+                                     cpu['degree'][:sub], m, leaves, args.layers, args.heads, args.order,
+                                     batch_norm=not args.layer_norm, heads_share_graph=True)
+        (out * cpu['dout'][:, :sub]).sum().backward()
+
+    step()
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_steps):
+        step()
+    dt = (time.perf_counter() - t0) / args.cpu_steps
+    return {'value': round(sub / dt, 2), 'unit': 'graphs/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d steps of fwd+bwd on the first %d graphs of the batch (oracle.encoder_gengcn, '
+                      'faithful formulation, exact Chebyshev operator, torch CPU fp32, %d threads)'
+                      % (args.cpu_steps, sub, cores)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+    _lib.abi()
+
+    cpu, gpu = make_batch(args, rank, dev)
+    enc = build_encoder(args).to(dev)
+    enc.train()
+    params = [p for p in enc.parameters()]
+    reducer = FlatGradAllReduce(params, world)   # every .grad is a view into one flat bucket
+
+    def fwd_bwd():
+        reducer.zero()
+        out, _, _ = enc(gpu['src'], gpu['pe'], gpu['edge_index'], gpu['fi'], gpu['batch'],
+                        degree=gpu['degree'], src_key_padding_mask=gpu['mask'], graph_cache=gpu['cache'])
+        (out * gpu['dout']).sum().backward()
+
+    use_graph = not args.no_graph
+    graph = None
+    if use_graph:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                fwd_bwd()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            fwd_bwd()
+
+    def step():
+        if graph is not None:
+            graph.replay()
+        else:
+            fwd_bwd()
+        if world > 1:
+            reducer.all_reduce()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        total_graphs = args.batch * world * args.steps
+        res = {
+            'metric': 'graphs/sec fwd+bwd, ZINC batch (N<=37,d=64,K=16)',
+            'value': round(total_graphs / dt, 2), 'unit': 'graphs/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': 'ZINC-shaped synthetic padded-graph batch, ChebConvDynamic block '
+                                   '(attention + coefficient generator + spectral filter), fwd+bwd',
+                       'graphs_per_gpu': args.batch, 'global_batch': args.batch * world,
+                       'n_pad': args.n_pad, 'd_model': args.dim, 'heads': args.heads,
+                       'filter_order': args.order, 'k_eig': args.k_eig, 'layers': args.layers,
+                       'norm': 'layer' if args.layer_norm else 'batch(per-rank stats)',
+                       'heads_share_graph': True, 'hip_graph': bool(use_graph),
+                       'parallelism': 'dp%d' % world},
+        }
+        res['roofline'] = roofline(args, gpu, dev)
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(args, cpu, enc)
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -58,7 +58,8 @@ def tok_strides(t):
     last two dims are dense (stride dh, 1)."""
     assert t.dim() == 4 and t.stride(3) == 1 and t.stride(2) == t.shape[3], \
         'token tensor must be a [B,N,H,dh] view with dense (H,dh)'
-    return t.stride(0), t.stride(1)
+    # the stride of a size-1 dim is arbitrary: canonicalise it (the kernels multiply it by 0)
+    return (t.stride(0) if t.shape[0] > 1 else 0), (t.stride(1) if t.shape[1] > 1 else 0)
 
 
 class Abi:

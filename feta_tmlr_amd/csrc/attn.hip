@@ -342,6 +342,10 @@ int launch_fwd(const AttnArgs& a, int kt_max, hipStream_t stream) {
     hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
   } else {
     auto kern = attn_fwd_kernel<DH, 16>;
+    // 4 waves x 16 x 257 floats = 65.8 KB: above the 64 KB default dynamic-LDS cap
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
   }
   return check_launch("feta_attn_fwd");

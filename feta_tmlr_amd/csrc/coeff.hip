@@ -1,0 +1,155 @@
+// A2: attention-conditioned filter coefficients.  Replaces the body of
+// DiffTransformerEncoderGenGCN.get_filter_coefficients (transformer/models.py:240-283)
+// up to the mean pool: the reference materialises a dense H*sum(n_b^2)-edge graph per
+// batch on the host and runs GCNConv(C,C) on an all-ones [H*N_tot, C] input.  Because the
+// input is all ones, GCNConv(ones)[j] = c_j * colsum(W) + bias exactly, with c_j the sum of
+// the GCN-normalised weights into node j (normalisation text: transformer/GenGCN.py:55-102).
+// One workgroup per (head, graph) block:
+//   deg_j = sum_i w_ij ; c_j = sum_i deg_i^-1/2 w_ij deg_j^-1/2      (two column sweeps)
+//   pooled[c] = mean_j tanh(c_j s_c + b_c)                          (thread per channel)
+// HBM-bound: reads attn once (N^2 per block), writes C per block.
+#include <cmath>
+
+#include "feta_abi_common.h"
+#include <feta_device.h>
+
+namespace feta {
+
+constexpr int kCoeffThreads = 256;
+constexpr int kCoeffGroupsMax = 64;
+
+__global__ __launch_bounds__(kCoeffThreads) void coeff_fwd_kernel(
+    const float* __restrict__ attn, const int32_t* __restrict__ n_real, const float* __restrict__ s,
+    const float* __restrict__ gbias, float* __restrict__ cj_out, float* __restrict__ pooled, int B,
+    int N, int H, int C) {
+  float* dis = feta_lds;        // [N]
+  float* cjs = feta_lds + N;    // [N]
+  const int blk = blockIdx.x;   // h * B + b  (transformer/models.py:244,275,285)
+  const int h = blk / B, b = blk % B;
+  const int n = n_real[b];
+  const float* a = attn + ((int64_t)b * H + h) * N * N;
+  const int j = threadIdx.x;
+
+  // edges with attn == 0 are dropped (models.py:276,281): they add nothing to the sums,
+  // but a dropped self loop is re-created with weight 1 by add_remaining_self_loops.
+  float wjj = 0.0f, deg = 0.0f;
+  if (j < n) {
+    wjj = a[(int64_t)j * N + j];
+    if (wjj == 0.0f) wjj = 1.0f;
+    for (int i = 0; i < n; ++i) deg += (i == j) ? wjj : a[(int64_t)i * N + j];
+    const float d = rsqrtf(deg);
+    dis[j] = (deg > 0.0f && d < INFINITY) ? d : 0.0f;
+  }
+  __syncthreads();
+  if (j < N) {
+    float c = 0.0f;
+    if (j < n) {
+      for (int i = 0; i < n; ++i) c += dis[i] * ((i == j) ? wjj : a[(int64_t)i * N + j]);
+      c *= dis[j];
+    }
+    cjs[j] = c;
+    cj_out[(int64_t)blk * N + j] = c;
+  }
+  __syncthreads();
+  const float inv_n = 1.0f / (float)n;
+  for (int c = threadIdx.x; c < C; c += kCoeffThreads) {
+    const float sc = s[c], bc = gbias[c];
+    float acc = 0.0f;
+    for (int i = 0; i < n; ++i) acc += tanhf(cjs[i] * sc + bc);
+    pooled[(int64_t)blk * C + c] = acc * inv_n;
+  }
+}
+
+// partial[0][grp][c] = sum over the group's blocks of dpooled*(1-z^2)*c_j/n ; partial[1] without c_j
+__global__ __launch_bounds__(kCoeffThreads) void coeff_bwd_kernel(
+    const float* __restrict__ cj, const int32_t* __restrict__ n_real, const float* __restrict__ s,
+    const float* __restrict__ gbias, const float* __restrict__ dpooled, float* __restrict__ partial,
+    int B, int N, int H, int C, int G) {
+  const int c = blockIdx.x * kCoeffThreads + threadIdx.x;
+  const int grp = blockIdx.y;
+  const float sc = c < C ? s[c] : 0.0f, bc = c < C ? gbias[c] : 0.0f;
+  float as = 0.0f, ab = 0.0f;
+  for (int blk = grp; blk < B * H; blk += G) {
+    const int n = n_real[blk % B];
+    const float dp = c < C ? dpooled[(int64_t)blk * C + c] / (float)n : 0.0f;
+    const float* cjb = cj + (int64_t)blk * N;
+    for (int i = 0; i < n; ++i) {
+      const float ci = cjb[i];
+      const float z = tanhf(ci * sc + bc);
+      const float t = dp * (1.0f - z * z);
+      as += t * ci;
+      ab += t;
+    }
+  }
+  if (c < C) {
+    partial[(int64_t)grp * C + c] = as;
+    partial[((int64_t)G + grp) * C + c] = ab;
+  }
+}
+
+// out[c] = sum_r in[r][c]; 64 columns x 4 row slices per workgroup, LDS tree for the slices
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in,
+                                                      float* __restrict__ out, int R, int C) {
+  float* red = feta_lds;  // [4][64]
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int slice = threadIdx.x >> 6;
+  float acc = 0.0f;
+  if (col < C)
+    for (int r = slice; r < R; r += 4) acc += in[(int64_t)r * C + col];
+  red[slice * 64 + (threadIdx.x & 63)] = acc;
+  __syncthreads();
+  if (slice == 0 && col < C)
+    out[col] = (red[threadIdx.x] + red[64 + threadIdx.x]) + (red[128 + threadIdx.x] + red[192 + threadIdx.x]);
+}
+
+int launch_colsum(const float* in, float* out, int R, int C, hipStream_t stream) {
+  const dim3 grid((C + 63) / 64), block(256);
+  auto kern = colsum_kernel;
+  hipLaunchKernelGGL(kern, grid, block, 4 * 64 * sizeof(float), stream, in, out, R, C);
+  return check_launch("feta_colsum");
+}
+
+}  // namespace feta
+
+using namespace feta;
+
+extern "C" int feta_coeff_fwd(const float* attn, const int32_t* n_real, const float* s,
+                              const float* gcn_bias, float* cj, float* pooled, int B, int N, int H,
+                              int C, feta_stream_t stream) {
+  FETA_REQUIRE(attn && n_real && s && gcn_bias && cj && pooled, "coeff_fwd: null pointer");
+  FETA_REQUIRE(B > 0 && H > 0 && C > 0 && N > 0 && N <= kCoeffThreads,
+               "coeff_fwd: need 0 < N <= %d (got %d)", kCoeffThreads, N);
+  const dim3 grid(B * H), block(kCoeffThreads);
+  auto kern = coeff_fwd_kernel;
+  hipLaunchKernelGGL(kern, grid, block, 2 * N * sizeof(float), (hipStream_t)stream, attn, n_real, s,
+                     gcn_bias, cj, pooled, B, N, H, C);
+  return check_launch("feta_coeff_fwd");
+}
+
+extern "C" int feta_coeff_bwd_groups(int B, int H) {
+  const int t = B * H;
+  return t < kCoeffGroupsMax ? t : kCoeffGroupsMax;
+}
+
+extern "C" int feta_coeff_bwd(const float* cj, const int32_t* n_real, const float* s,
+                              const float* gcn_bias, const float* dpooled, float* partial, float* ds,
+                              float* dbias, int B, int N, int H, int C, feta_stream_t stream) {
+  FETA_REQUIRE(cj && n_real && s && gcn_bias && dpooled && partial && ds && dbias,
+               "coeff_bwd: null pointer");
+  FETA_REQUIRE(B > 0 && H > 0 && C > 0 && N > 0, "coeff_bwd: empty shape");
+  const int G = feta_coeff_bwd_groups(B, H);
+  const dim3 grid((C + kCoeffThreads - 1) / kCoeffThreads, G), block(kCoeffThreads);
+  auto kern = coeff_bwd_kernel;
+  hipLaunchKernelGGL(kern, grid, block, 0, (hipStream_t)stream, cj, n_real, s, gcn_bias, dpooled,
+                     partial, B, N, H, C, G);
+  int rc = check_launch("feta_coeff_bwd");
+  if (rc != FETA_OK) return rc;
+  rc = launch_colsum(partial, ds, G, C, (hipStream_t)stream);
+  if (rc != FETA_OK) return rc;
+  return launch_colsum(partial + (int64_t)G * C, dbias, G, C, (hipStream_t)stream);
+}
+
+extern "C" int feta_colsum(const float* in, float* out, int R, int C, feta_stream_t stream) {
+  FETA_REQUIRE(in && out && R > 0 && C > 0, "colsum: bad arguments");
+  return launch_colsum(in, out, R, C, (hipStream_t)stream);
+}

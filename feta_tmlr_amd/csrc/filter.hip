@@ -1,0 +1,865 @@
+// A3: the dynamic spectral filter of ChebConvDynamic, forward and backward, in two
+// algebraically equal forms, one wave per (graph b, head h):
+//   cheb : direct Chebyshev recursion on the dense scaled Laplacian Lhat_b
+//          (transformer/ChebNetDynamic.py:157-187), evaluated by Clenshaw's
+//          recurrence on Z_k = X W_k so that every product contracts over the node
+//          index held on accumulator rows (no transposes, no LDS round trips);
+//   spec : eigenbasis form U [sum_k diag(t_k(lam)) U^T (X W_k)].
+// Both fold in the reference's glue: per-(head,graph) weights coeff[h*B+b] reshaped
+// [P,dh,dh] (transformer/models.py:357), gather of real nodes (:347), scatter into a
+// zero-initialised [N,B,d] tensor (:200-202) and the un-replicated edge_index quirk
+// (:186; heads_share_graph = 0 gives heads >= 1 an empty graph, Lhat = 0).
+//
+// Tile conventions: feta_tiles.h.  "acc layout" of a [rows x cols] tile means register
+// r of lane (g, lq) holds element (row 4g + r, column lq).
+#include "feta_abi_common.h"
+#include "feta_tiles.h"
+
+namespace feta {
+
+struct FilterArgs {
+  const float* x;
+  const float* lhat;  // cheb
+  const float* u;     // spec
+  const float* lam;   // spec
+  const float* coeff;
+  const float* bias;
+  const int32_t* n_real;
+  const float* dy;
+  float* y;
+  float* dx;
+  float* dcoeff;
+  float* dbias_part;
+  int64_t xsb, xsn, ysb, ysn;
+  int B, N, H, P, K;
+  int share;
+  int total;  // B * H
+};
+
+constexpr int kFWaves = 4;
+
+// ---- operand helpers -------------------------------------------------------------
+
+// acc-layout load of a token-tensor tile: rows row0 + 4g + r (valid < nvalid), column 16ct + lq
+template <int DH>
+__device__ __forceinline__ f32x4 load_acc(const float* p, int64_t sb, int64_t sn, int b, int h,
+                                          int row0, int nvalid, int ct, int lq, int g) {
+  f32x4 v;
+  const int c = 16 * ct + lq;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int node = row0 + 4 * g + r;
+    v[r] = (node < nvalid && c < DH) ? tok_row(p, sb, sn, b, node, h, DH)[c] : 0.0f;
+  }
+  return v;
+}
+
+// W_k[c][c'] element for the product X . W_k: B[k <-> c = 16j+4g+s][col c' = 16ct+lq]
+template <int DH>
+__device__ __forceinline__ float w_b(const float* w, int k, int j, int s, int ct, int lq, int g) {
+  const int c = 16 * j + 4 * g + s, cp = 16 * ct + lq;
+  return (c < DH && cp < DH) ? w[(k * DH + c) * DH + cp] : 0.0f;
+}
+
+// W_k[c = 16ct+lq][c' = 16j+4g .. +3] as one 16-byte load (operand of dY . W_k^T and W_k . G)
+template <int DH>
+__device__ __forceinline__ float4 w_row4(const float* w, int k, int ct, int j, int lq, int g) {
+  const int c = 16 * ct + lq, cp = 16 * j + 4 * g;
+  if (c < DH && cp < DH) return *reinterpret_cast<const float4*>(w + (k * DH + c) * DH + cp);
+  return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+__device__ __forceinline__ float f4(const float4& v, int s) {
+  return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w));
+}
+
+// Z_k tile = X_tile . W_k  (acc layout [node][c'])
+template <int DH>
+__device__ __forceinline__ void xw_tile(const Feat<DH>& xf, const float* w, int k, int lq, int g,
+                                        f32x4 (&z)[Feat<DH>::CT]) {
+  constexpr int CT = Feat<DH>::CT, NJ = Feat<DH>::NJ;
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    z[ct] = zero4();
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) z[ct] = mfma16(xf.f[j][s], w_b<DH>(w, k, j, s, ct, lq, g), z[ct]);
+  }
+}
+
+// G_k tile = dY_tile . W_k^T  (acc layout [node][c])
+template <int DH>
+__device__ __forceinline__ void dyw_tile(const Feat<DH>& dyf, const float* w, int k, int lq, int g,
+                                         f32x4 (&gk)[Feat<DH>::CT]) {
+  constexpr int CT = Feat<DH>::CT, NJ = Feat<DH>::NJ;
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    gk[ct] = zero4();
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const float4 wv = w_row4<DH>(w, k, ct, j, lq, g);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) gk[ct] = mfma16(dyf.f[j][s], f4(wv, s), gk[ct]);
+    }
+  }
+}
+
+template <int DH>
+__device__ __forceinline__ void store_acc(float* p, int64_t sb, int64_t sn, int b, int h, int row0,
+                                          int nrows, int ct, int lq, int g, const f32x4& v) {
+  const int c = 16 * ct + lq;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int node = row0 + 4 * g + r;
+    if (node < nrows && c < DH) tok_row(p, sb, sn, b, node, h, DH)[c] = v[r];
+  }
+}
+
+// cos(k pi / 2): T_k(0)
+__device__ __forceinline__ float cheb_at_zero(int k) {
+  return (k & 1) ? 0.0f : ((k & 2) ? -1.0f : 1.0f);
+}
+
+// ---- heads without a graph (Lhat = 0): y = X sum_k T_k(0) W_k + bias ---------------------
+
+template <int DH>
+__device__ void nograph_fwd(const FilterArgs& a, int b, int h, int n, const float* w, int lq, int g) {
+  constexpr int CT = Feat<DH>::CT;
+  const int NTall = (a.N + 15) >> 4;
+  for (int nt = 0; nt < NTall; ++nt) {
+    f32x4 y[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) y[ct] = zero4();
+    if (16 * nt < n) {
+      const int node = 16 * nt + lq;
+      Feat<DH> xf;
+      load_row<DH>(xf, node < n ? tok_row(a.x, a.xsb, a.xsn, b, node, h, DH) : nullptr, g);
+      for (int k = 0; k < a.P; k += 2) {
+        f32x4 z[CT];
+        xw_tile<DH>(xf, w, k, lq, g, z);
+        const float sgn = cheb_at_zero(k);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) y[ct][r] += sgn * z[ct][r];
+      }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int c = 16 * ct + lq;
+      const float bv = (a.bias != nullptr && c < DH) ? a.bias[c] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) y[ct][r] = (16 * nt + 4 * g + r < n) ? y[ct][r] + bv : 0.0f;
+      store_acc<DH>(a.y, a.ysb, a.ysn, b, h, 16 * nt, a.N, ct, lq, g, y[ct]);
+    }
+  }
+}
+
+template <int DH>
+__device__ void nograph_bwd(const FilterArgs& a, int b, int h, int n, const float* w, float* dw,
+                            int item, int lq, int g) {
+  constexpr int CT = Feat<DH>::CT;
+  const int NTall = (a.N + 15) >> 4;
+  const int NT = (n + 15) >> 4;
+  f32x4 dbias[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) dbias[ct] = zero4();
+  // dW_k = T_k(0) X^T dY : contraction over nodes (rows of both acc-layout tiles)
+  for (int k = 0; k < a.P; ++k) {
+    const float sgn = cheb_at_zero(k);
+    f32x4 acc[CT][CT];
+#pragma unroll
+    for (int c1 = 0; c1 < CT; ++c1)
+#pragma unroll
+      for (int c2 = 0; c2 < CT; ++c2) acc[c1][c2] = zero4();
+    if (sgn != 0.0f) {
+      for (int nt = 0; nt < NT; ++nt) {
+        f32x4 xa[CT], dyb[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          xa[ct] = load_acc<DH>(a.x, a.xsb, a.xsn, b, h, 16 * nt, n, ct, lq, g);
+          dyb[ct] = load_acc<DH>(a.dy, a.ysb, a.ysn, b, h, 16 * nt, n, ct, lq, g);
+          if (k == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dbias[ct][r] += dyb[ct][r];
+          }
+        }
+#pragma unroll
+        for (int c1 = 0; c1 < CT; ++c1)
+#pragma unroll
+          for (int c2 = 0; c2 < CT; ++c2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[c1][c2] = mfma16(sgn * xa[c1][r], dyb[c2][r], acc[c1][c2]);
+      }
+    }
+#pragma unroll
+    for (int c1 = 0; c1 < CT; ++c1)
+#pragma unroll
+      for (int c2 = 0; c2 < CT; ++c2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 16 * c1 + 4 * g + r, cp = 16 * c2 + lq;
+          if (c < DH && cp < DH) dw[(k * DH + c) * DH + cp] = acc[c1][c2][r];
+        }
+  }
+  // dbias partial
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    float s = dbias[ct][0] + dbias[ct][1] + dbias[ct][2] + dbias[ct][3];
+    s += shfl_xor(s, 16);
+    s += shfl_xor(s, 32);
+    const int c = 16 * ct + lq;
+    if (g == 0 && c < DH) a.dbias_part[(int64_t)item * DH + c] = s;
+  }
+  // dX = dY (sum_k T_k(0) W_k)^T, zero on padded rows
+  for (int nt = 0; nt < NTall; ++nt) {
+    f32x4 dx[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) dx[ct] = zero4();
+    if (nt < NT) {
+      const int node = 16 * nt + lq;
+      Feat<DH> dyf;
+      load_row<DH>(dyf, node < n ? tok_row(a.dy, a.ysb, a.ysn, b, node, h, DH) : nullptr, g);
+      for (int k = 0; k < a.P; k += 2) {
+        f32x4 gk[CT];
+        dyw_tile<DH>(dyf, w, k, lq, g, gk);
+        const float sgn = cheb_at_zero(k);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dx[ct][r] += sgn * gk[ct][r];
+      }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) store_acc<DH>(a.dx, a.xsb, a.xsn, b, h, 16 * nt, a.N, ct, lq, g, dx[ct]);
+  }
+}
+
+// ---- Chebyshev recursion on dense Lhat --------------------------------------------------
+
+// out[tt] (+)= M . in over node tiles; M = Lhat (TRANS = false) or Lhat^T (TRANS = true).
+// A operand: M[t = 16tt+lq][s = 16st+4g+r]; B operand: in[st][ct][r].
+template <int DH, int NT_MAX, bool TRANS>
+__device__ __forceinline__ void lhat_apply(const float* L, int N, int n, int NT, int lq, int g,
+                                           const f32x4 (&in)[NT_MAX][Feat<DH>::CT],
+                                           f32x4 (&out)[NT_MAX][Feat<DH>::CT]) {
+  constexpr int CT = Feat<DH>::CT;
+#pragma unroll
+  for (int tt = 0; tt < NT_MAX; ++tt) {
+    if (tt < NT) {
+      f32x4 acc[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) acc[ct] = zero4();
+      const int t = 16 * tt + lq;
+#pragma unroll
+      for (int st = 0; st < NT_MAX; ++st) {
+        if (st < NT) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int s = 16 * st + 4 * g + r;
+            float m = 0.0f;
+            if (t < n && s < n) m = TRANS ? L[(int64_t)s * N + t] : L[(int64_t)t * N + s];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acc[ct] = mfma16(m, in[st][ct][r], acc[ct]);
+          }
+        }
+      }
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) out[tt][ct] = acc[ct];
+    }
+  }
+}
+
+template <int DH, int NT_MAX>
+__global__ __launch_bounds__(64 * kFWaves) void cheb_fwd_kernel(FilterArgs a) {
+  constexpr int CT = Feat<DH>::CT;
+  const int lane = lane_id(), lq = lane & 15, g = lane >> 4;
+  const int item = blockIdx.x * kFWaves + wave_id();
+  if (item >= a.total) return;
+  const int h = item % a.H, b = item / a.H;
+  const int n = a.n_real[b];
+  const float* w = a.coeff + ((int64_t)h * a.B + b) * a.P * DH * DH;
+  if (!a.share && h > 0) {
+    nograph_fwd<DH>(a, b, h, n, w, lq, g);
+    return;
+  }
+  const int NT = (n + 15) >> 4;
+  const float* L = a.lhat + (int64_t)b * a.N * a.N;
+
+  // Clenshaw: b_k = Z_k + 2 Lhat b_{k+1} - b_{k+2};  Y = Z_0 + Lhat b_1 - b_2
+  f32x4 b1[NT_MAX][CT], b2[NT_MAX][CT], lb[NT_MAX][CT];
+#pragma unroll
+  for (int nt = 0; nt < NT_MAX; ++nt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      b1[nt][ct] = zero4();
+      b2[nt][ct] = zero4();
+      lb[nt][ct] = zero4();
+    }
+  for (int k = a.P - 1; k >= 0; --k) {
+    if (k < a.P - 1) lhat_apply<DH, NT_MAX, false>(L, a.N, n, NT, lq, g, b1, lb);
+    const float two = k == 0 ? 1.0f : 2.0f;
+#pragma unroll
+    for (int nt = 0; nt < NT_MAX; ++nt) {
+      if (nt < NT) {
+        const int node = 16 * nt + lq;
+        Feat<DH> xf;
+        load_row<DH>(xf, node < n ? tok_row(a.x, a.xsb, a.xsn, b, node, h, DH) : nullptr, g);
+        f32x4 z[CT];
+        xw_tile<DH>(xf, w, k, lq, g, z);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          f32x4 nb;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) nb[r] = z[ct][r] + two * lb[nt][ct][r] - b2[nt][ct][r];
+          b2[nt][ct] = b1[nt][ct];
+          b1[nt][ct] = nb;
+        }
+      }
+    }
+  }
+  // b1 now holds Y
+  const int NTall = (a.N + 15) >> 4;
+#pragma unroll
+  for (int nt = 0; nt < NT_MAX; ++nt) {
+    if (nt < NTall) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const int c = 16 * ct + lq;
+        const float bv = (a.bias != nullptr && c < DH) ? a.bias[c] : 0.0f;
+        f32x4 y;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[r] = (nt < NT && 16 * nt + 4 * g + r < n) ? b1[nt][ct][r] + bv : 0.0f;
+        store_acc<DH>(a.y, a.ysb, a.ysn, b, h, 16 * nt, a.N, ct, lq, g, y);
+      }
+    }
+  }
+}
+
+template <int DH, int NT_MAX>
+__global__ __launch_bounds__(64 * kFWaves) void cheb_bwd_kernel(FilterArgs a) {
+  constexpr int CT = Feat<DH>::CT;
+  const int lane = lane_id(), lq = lane & 15, g = lane >> 4;
+  const int item = blockIdx.x * kFWaves + wave_id();
+  if (item >= a.total) return;
+  const int h = item % a.H, b = item / a.H;
+  const int n = a.n_real[b];
+  const int64_t blk = (int64_t)h * a.B + b;
+  const float* w = a.coeff + blk * a.P * DH * DH;
+  float* dw = a.dcoeff + blk * a.P * DH * DH;
+  if (!a.share && h > 0) {
+    nograph_bwd<DH>(a, b, h, n, w, dw, item, lq, g);
+    return;
+  }
+  const int NT = (n + 15) >> 4;
+  const int NTall = (a.N + 15) >> 4;
+  const float* L = a.lhat + (int64_t)b * a.N * a.N;
+
+  // phase 1: dW_k = (T_k(Lhat) X)^T dY, T_k by the forward recursion; dbias partial
+  {
+    f32x4 t0[NT_MAX][CT], t1[NT_MAX][CT], lt[NT_MAX][CT], dyb[NT_MAX][CT];
+    f32x4 dbias[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) dbias[ct] = zero4();
+#pragma unroll
+    for (int nt = 0; nt < NT_MAX; ++nt)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        if (nt < NT) {
+          t1[nt][ct] = load_acc<DH>(a.x, a.xsb, a.xsn, b, h, 16 * nt, n, ct, lq, g);
+          dyb[nt][ct] = load_acc<DH>(a.dy, a.ysb, a.ysn, b, h, 16 * nt, n, ct, lq, g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dbias[ct][r] += dyb[nt][ct][r];
+        } else {
+          t1[nt][ct] = zero4();
+          dyb[nt][ct] = zero4();
+        }
+        t0[nt][ct] = zero4();
+        lt[nt][ct] = zero4();
+      }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      float s = dbias[ct][0] + dbias[ct][1] + dbias[ct][2] + dbias[ct][3];
+      s += shfl_xor(s, 16);
+      s += shfl_xor(s, 32);
+      const int c = 16 * ct + lq;
+      if (g == 0 && c < DH) a.dbias_part[(int64_t)item * DH + c] = s;
+    }
+    // invariant at loop head: t1 = T_k, t0 = T_{k-1}
+    for (int k = 0; k < a.P; ++k) {
+      if (k >= 1) {
+        lhat_apply<DH, NT_MAX, false>(L, a.N, n, NT, lq, g, t1, lt);
+        const float two = k == 1 ? 1.0f : 2.0f;
+#pragma unroll
+        for (int nt = 0; nt < NT_MAX; ++nt)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            f32x4 nw;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) nw[r] = two * lt[nt][ct][r] - (k == 1 ? 0.0f : t0[nt][ct][r]);
+            t0[nt][ct] = t1[nt][ct];
+            t1[nt][ct] = nw;
+          }
+      }
+      f32x4 acc[CT][CT];
+#pragma unroll
+      for (int c1 = 0; c1 < CT; ++c1)
+#pragma unroll
+        for (int c2 = 0; c2 < CT; ++c2) acc[c1][c2] = zero4();
+#pragma unroll
+      for (int nt = 0; nt < NT_MAX; ++nt) {
+        if (nt < NT) {
+#pragma unroll
+          for (int c1 = 0; c1 < CT; ++c1)
+#pragma unroll
+            for (int c2 = 0; c2 < CT; ++c2)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[c1][c2] = mfma16(t1[nt][c1][r], dyb[nt][c2][r], acc[c1][c2]);
+        }
+      }
+#pragma unroll
+      for (int c1 = 0; c1 < CT; ++c1)
+#pragma unroll
+        for (int c2 = 0; c2 < CT; ++c2)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int c = 16 * c1 + 4 * g + r, cp = 16 * c2 + lq;
+            if (c < DH && cp < DH) dw[(k * DH + c) * DH + cp] = acc[c1][c2][r];
+          }
+    }
+  }
+
+  // phase 2: dX = sum_k T_k(Lhat^T) (dY W_k^T) by Clenshaw
+  {
+    f32x4 b1[NT_MAX][CT], b2[NT_MAX][CT], lb[NT_MAX][CT];
+#pragma unroll
+    for (int nt = 0; nt < NT_MAX; ++nt)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        b1[nt][ct] = zero4();
+        b2[nt][ct] = zero4();
+        lb[nt][ct] = zero4();
+      }
+    for (int k = a.P - 1; k >= 0; --k) {
+      if (k < a.P - 1) lhat_apply<DH, NT_MAX, true>(L, a.N, n, NT, lq, g, b1, lb);
+      const float two = k == 0 ? 1.0f : 2.0f;
+#pragma unroll
+      for (int nt = 0; nt < NT_MAX; ++nt) {
+        if (nt < NT) {
+          const int node = 16 * nt + lq;
+          Feat<DH> dyf;
+          load_row<DH>(dyf, node < n ? tok_row(a.dy, a.ysb, a.ysn, b, node, h, DH) : nullptr, g);
+          f32x4 gk[CT];
+          dyw_tile<DH>(dyf, w, k, lq, g, gk);
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            f32x4 nb;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) nb[r] = gk[ct][r] + two * lb[nt][ct][r] - b2[nt][ct][r];
+            b2[nt][ct] = b1[nt][ct];
+            b1[nt][ct] = nb;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT_MAX; ++nt) {
+      if (nt < NTall) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          f32x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (nt < NT && 16 * nt + 4 * g + r < n) ? b1[nt][ct][r] : 0.0f;
+          store_acc<DH>(a.dx, a.xsb, a.xsn, b, h, 16 * nt, a.N, ct, lq, g, v);
+        }
+      }
+    }
+  }
+}
+
+// ---- eigenbasis form ---------------------------------------------------------------------
+
+// t_k(lam) for k < P into t[0..P-1] (P <= 8)
+constexpr int kMaxOrder = 8;
+__device__ __forceinline__ void cheb_poly(float lam, int P, float (&t)[kMaxOrder]) {
+  t[0] = 1.0f;
+  t[1] = lam;
+#pragma unroll
+  for (int k = 2; k < kMaxOrder; ++k) t[k] = (k < P) ? 2.0f * lam * t[k - 1] - t[k - 2] : 0.0f;
+}
+
+template <int DH, int ET_MAX>
+__global__ __launch_bounds__(64 * kFWaves) void spec_fwd_kernel(FilterArgs a) {
+  constexpr int CT = Feat<DH>::CT;
+  const int lane = lane_id(), lq = lane & 15, g = lane >> 4;
+  const int item = blockIdx.x * kFWaves + wave_id();
+  if (item >= a.total) return;
+  const int h = item % a.H, b = item / a.H;
+  const int n = a.n_real[b];
+  const float* w = a.coeff + ((int64_t)h * a.B + b) * a.P * DH * DH;
+  if (!a.share && h > 0) {
+    nograph_fwd<DH>(a, b, h, n, w, lq, g);
+    return;
+  }
+  const int NT = (n + 15) >> 4;
+  const int NTall = (a.N + 15) >> 4;
+  const int ET = (a.K + 15) >> 4;
+  const float* U = a.u + (int64_t)b * a.N * a.K;
+  const float* lam = a.lam + (int64_t)b * a.K;
+
+  // Ytil[e][c'] = sum_k t_k(lam_e) sum_node U[node][e] (X W_k)[node][c']
+  f32x4 yt[ET_MAX][CT];
+#pragma unroll
+  for (int et = 0; et < ET_MAX; ++et)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) yt[et][ct] = zero4();
+
+  for (int nt = 0; nt < NT; ++nt) {
+    const int node = 16 * nt + lq;
+    Feat<DH> xf;
+    load_row<DH>(xf, node < n ? tok_row(a.x, a.xsb, a.xsn, b, node, h, DH) : nullptr, g);
+    for (int k = 0; k < a.P; ++k) {
+      f32x4 z[CT];
+      xw_tile<DH>(xf, w, k, lq, g, z);
+#pragma unroll
+      for (int et = 0; et < ET_MAX; ++et) {
+        if (et < ET) {
+          const int e = 16 * et + lq;
+          float tk[kMaxOrder];
+          cheb_poly(e < a.K ? lam[e] : 0.0f, a.P, tk);
+          float tke = 0.0f;
+#pragma unroll
+          for (int kk = 0; kk < kMaxOrder; ++kk)
+            if (kk == k) tke = tk[kk];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int nd = 16 * nt + 4 * g + r;
+            const float ua = (nd < n && e < a.K) ? U[(int64_t)nd * a.K + e] * tke : 0.0f;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) yt[et][ct] = mfma16(ua, z[ct][r], yt[et][ct]);
+          }
+        }
+      }
+    }
+  }
+  // Y = U Ytil + bias
+  for (int nt = 0; nt < NTall; ++nt) {
+    f32x4 y[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) y[ct] = zero4();
+    if (nt < NT) {
+      const int node = 16 * nt + lq;
+#pragma unroll
+      for (int et = 0; et < ET_MAX; ++et) {
+        if (et < ET) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int e = 16 * et + 4 * g + r;
+            const float ua = (node < n && e < a.K) ? U[(int64_t)node * a.K + e] : 0.0f;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) y[ct] = mfma16(ua, yt[et][ct][r], y[ct]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int c = 16 * ct + lq;
+      const float bv = (a.bias != nullptr && c < DH) ? a.bias[c] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) y[ct][r] = (16 * nt + 4 * g + r < n) ? y[ct][r] + bv : 0.0f;
+      store_acc<DH>(a.y, a.ysb, a.ysn, b, h, 16 * nt, a.N, ct, lq, g, y[ct]);
+    }
+  }
+}
+
+template <int DH, int ET_MAX>
+__global__ __launch_bounds__(64 * kFWaves) void spec_bwd_kernel(FilterArgs a) {
+  constexpr int CT = Feat<DH>::CT;
+  const int lane = lane_id(), lq = lane & 15, g = lane >> 4;
+  const int item = blockIdx.x * kFWaves + wave_id();
+  if (item >= a.total) return;
+  const int h = item % a.H, b = item / a.H;
+  const int n = a.n_real[b];
+  const int64_t blk = (int64_t)h * a.B + b;
+  const float* w = a.coeff + blk * a.P * DH * DH;
+  float* dw = a.dcoeff + blk * a.P * DH * DH;
+  if (!a.share && h > 0) {
+    nograph_bwd<DH>(a, b, h, n, w, dw, item, lq, g);
+    return;
+  }
+  const int NT = (n + 15) >> 4;
+  const int NTall = (a.N + 15) >> 4;
+  const int ET = (a.K + 15) >> 4;
+  const float* U = a.u + (int64_t)b * a.N * a.K;
+  const float* lam = a.lam + (int64_t)b * a.K;
+
+  // (1) Xtil = U^T X, dYtil = U^T dY (acc layout [e][c]); dbias partial
+  f32x4 xt[ET_MAX][CT], dyt[ET_MAX][CT];
+  f32x4 dbias[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) dbias[ct] = zero4();
+#pragma unroll
+  for (int et = 0; et < ET_MAX; ++et)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      xt[et][ct] = zero4();
+      dyt[et][ct] = zero4();
+    }
+  for (int nt = 0; nt < NT; ++nt) {
+    f32x4 xb[CT], dyb[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      xb[ct] = load_acc<DH>(a.x, a.xsb, a.xsn, b, h, 16 * nt, n, ct, lq, g);
+      dyb[ct] = load_acc<DH>(a.dy, a.ysb, a.ysn, b, h, 16 * nt, n, ct, lq, g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dbias[ct][r] += dyb[ct][r];
+    }
+#pragma unroll
+    for (int et = 0; et < ET_MAX; ++et) {
+      if (et < ET) {
+        const int e = 16 * et + lq;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int nd = 16 * nt + 4 * g + r;
+          const float ua = (nd < n && e < a.K) ? U[(int64_t)nd * a.K + e] : 0.0f;
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            xt[et][ct] = mfma16(ua, xb[ct][r], xt[et][ct]);
+            dyt[et][ct] = mfma16(ua, dyb[ct][r], dyt[et][ct]);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    float s = dbias[ct][0] + dbias[ct][1] + dbias[ct][2] + dbias[ct][3];
+    s += shfl_xor(s, 16);
+    s += shfl_xor(s, 32);
+    const int c = 16 * ct + lq;
+    if (g == 0 && c < DH) a.dbias_part[(int64_t)item * DH + c] = s;
+  }
+
+  // (2) dW_k[c][c'] = sum_e t_k(lam_e) Xtil[e][c] dYtil[e][c']
+  for (int k = 0; k < a.P; ++k) {
+    f32x4 acc[CT][CT];
+#pragma unroll
+    for (int c1 = 0; c1 < CT; ++c1)
+#pragma unroll
+      for (int c2 = 0; c2 < CT; ++c2) acc[c1][c2] = zero4();
+#pragma unroll
+    for (int et = 0; et < ET_MAX; ++et) {
+      if (et < ET) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int e = 16 * et + 4 * g + r;
+          float tk[kMaxOrder];
+          cheb_poly(e < a.K ? lam[e] : 0.0f, a.P, tk);
+          float tke = 0.0f;
+#pragma unroll
+          for (int kk = 0; kk < kMaxOrder; ++kk)
+            if (kk == k) tke = tk[kk];
+#pragma unroll
+          for (int c1 = 0; c1 < CT; ++c1)
+#pragma unroll
+            for (int c2 = 0; c2 < CT; ++c2)
+              acc[c1][c2] = mfma16(xt[et][c1][r] * tke, dyt[et][c2][r], acc[c1][c2]);
+        }
+      }
+    }
+#pragma unroll
+    for (int c1 = 0; c1 < CT; ++c1)
+#pragma unroll
+      for (int c2 = 0; c2 < CT; ++c2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 16 * c1 + 4 * g + r, cp = 16 * c2 + lq;
+          if (c < DH && cp < DH) dw[(k * DH + c) * DH + cp] = acc[c1][c2][r];
+        }
+  }
+
+  // (3) dX^T[c][node] = sum_k W_k[c][:] . G_k^T[:, node],
+  //     G_k^T[c'][node] = sum_e dYtil[e][c'] t_k(lam_e) U[node][e]
+  for (int nt = 0; nt < NTall; ++nt) {
+    f32x4 dxt[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) dxt[ct] = zero4();
+    const int node = 16 * nt + lq;
+    if (nt < NT) {
+      for (int k = 0; k < a.P; ++k) {
+        f32x4 gt[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) gt[ct] = zero4();
+#pragma unroll
+        for (int et = 0; et < ET_MAX; ++et) {
+          if (et < ET) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int e = 16 * et + 4 * g + r;
+              float tk[kMaxOrder];
+              cheb_poly(e < a.K ? lam[e] : 0.0f, a.P, tk);
+              float tke = 0.0f;
+#pragma unroll
+              for (int kk = 0; kk < kMaxOrder; ++kk)
+                if (kk == k) tke = tk[kk];
+              const float ub = (node < n && e < a.K) ? U[(int64_t)node * a.K + e] * tke : 0.0f;
+#pragma unroll
+              for (int ct = 0; ct < CT; ++ct) gt[ct] = mfma16(dyt[et][ct][r], ub, gt[ct]);
+            }
+          }
+        }
+        // dxt[c1] += W_k[c = 16c1+lq][c' = 16c2+4g+r] . gt[c2][r]
+#pragma unroll
+        for (int c1 = 0; c1 < CT; ++c1)
+#pragma unroll
+          for (int c2 = 0; c2 < CT; ++c2) {
+            const float4 wv = w_row4<DH>(w, k, c1, c2, lq, g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dxt[c1] = mfma16(f4(wv, r), gt[c2][r], dxt[c1]);
+          }
+      }
+    }
+    // register r of dxt[c1] <-> (c = 16c1 + 4g + r, node): 4 consecutive features of one row
+    if (node < a.N) {
+      float* row = tok_row(a.dx, a.xsb, a.xsn, b, node, h, DH);
+#pragma unroll
+      for (int c1 = 0; c1 < CT; ++c1) {
+        const int c = 16 * c1 + 4 * g;
+        if (c < DH) {
+          const bool real = node < n;
+          *reinterpret_cast<float4*>(row + c) =
+              make_float4(real ? dxt[c1][0] : 0.0f, real ? dxt[c1][1] : 0.0f,
+                          real ? dxt[c1][2] : 0.0f, real ? dxt[c1][3] : 0.0f);
+        }
+      }
+    }
+  }
+}
+
+// ---- launchers ---------------------------------------------------------------------------
+
+int check_filter(const FilterArgs& a, int dh, const void* p1, const void* p2) {
+  FETA_REQUIRE(a.B > 0 && a.N > 0 && a.H > 0, "filter: empty shape");
+  FETA_REQUIRE(a.N <= FETA_MAX_NODES, "filter: N=%d exceeds FETA_MAX_NODES", a.N);
+  FETA_REQUIRE(dh == 4 || dh == 8 || dh == 16 || dh == 32 || dh == 64,
+               "filter: head dim %d not in {4,8,16,32,64}", dh);
+  FETA_REQUIRE(a.P >= 1 && a.P <= kMaxOrder, "filter: order P=%d not in [1,%d]", a.P, kMaxOrder);
+  FETA_REQUIRE((a.xsb % 4) == 0 && (a.xsn % 4) == 0 && (a.ysb % 4) == 0 && (a.ysn % 4) == 0,
+               "filter: strides must be multiples of 4 elements");
+  FETA_REQUIRE(aligned16(p1) && aligned16(p2) && aligned16(a.coeff),
+               "filter: token tensors and coeff must be 16-byte aligned");
+  return FETA_OK;
+}
+
+template <template <int, int> class Launch>
+int dispatch(const FilterArgs& a, int dh, int tiles, hipStream_t stream) {
+  const int ct = (dh + 15) / 16;
+  FETA_REQUIRE(tiles * ct <= 16, "filter: %d row tiles x %d column tiles exceed the register budget "
+               "(need tiles*ceil(dh/16) <= 16)", tiles, ct);
+#define FETA_T(D)                                             \
+  if (tiles <= 3) return Launch<D, 3>::run(a, stream);        \
+  if (tiles <= 4) return Launch<D, 4>::run(a, stream);        \
+  if (tiles <= 8) return Launch<D, 8>::run(a, stream);        \
+  return Launch<D, 16>::run(a, stream);
+  switch (dh) {
+    case 4: FETA_T(4)
+    case 8: FETA_T(8)
+    case 16: FETA_T(16)
+    case 32:
+      if (tiles <= 3) return Launch<32, 3>::run(a, stream);
+      if (tiles <= 4) return Launch<32, 4>::run(a, stream);
+      return Launch<32, 8>::run(a, stream);
+    default:
+      if (tiles <= 3) return Launch<64, 3>::run(a, stream);
+      return Launch<64, 4>::run(a, stream);
+  }
+#undef FETA_T
+}
+
+#define FETA_LAUNCHER(NAME, KERNEL)                                            \
+  template <int DH, int T>                                                     \
+  struct NAME {                                                                \
+    static int run(const FilterArgs& a, hipStream_t stream) {                  \
+      const dim3 grid((a.total + kFWaves - 1) / kFWaves), block(64 * kFWaves); \
+      auto kern = KERNEL<DH, T>;                                               \
+      hipLaunchKernelGGL(kern, grid, block, 0, stream, a);                     \
+      return check_launch(#KERNEL);                                            \
+    }                                                                          \
+  };
+FETA_LAUNCHER(ChebFwd, cheb_fwd_kernel)
+FETA_LAUNCHER(ChebBwd, cheb_bwd_kernel)
+FETA_LAUNCHER(SpecFwd, spec_fwd_kernel)
+FETA_LAUNCHER(SpecBwd, spec_bwd_kernel)
+
+}  // namespace feta
+
+using namespace feta;
+
+extern "C" int feta_cheb_filter_fwd(const float* x, int64_t x_sb, int64_t x_sn, const float* lhat,
+                                    const float* coeff, const float* bias, const int32_t* n_real,
+                                    float* y, int64_t y_sb, int64_t y_sn, int B, int N, int H, int dh,
+                                    int P, int heads_share_graph, feta_stream_t stream) {
+  FilterArgs a{};
+  a.x = x; a.lhat = lhat; a.coeff = coeff; a.bias = bias; a.n_real = n_real; a.y = y;
+  a.xsb = x_sb; a.xsn = x_sn; a.ysb = y_sb; a.ysn = y_sn;
+  a.B = B; a.N = N; a.H = H; a.P = P; a.share = heads_share_graph; a.total = B * H;
+  FETA_REQUIRE(x && lhat && coeff && n_real && y, "cheb_filter_fwd: null pointer");
+  int rc = check_filter(a, dh, x, y);
+  if (rc != FETA_OK) return rc;
+  return dispatch<ChebFwd>(a, dh, (N + 15) / 16, (hipStream_t)stream);
+}
+
+extern "C" int feta_cheb_filter_bwd(const float* x, int64_t x_sb, int64_t x_sn, const float* lhat,
+                                    const float* coeff, const int32_t* n_real, const float* dy,
+                                    int64_t y_sb, int64_t y_sn, float* dx, float* dcoeff,
+                                    float* dbias_part, int B, int N, int H, int dh, int P,
+                                    int heads_share_graph, feta_stream_t stream) {
+  FilterArgs a{};
+  a.x = x; a.lhat = lhat; a.coeff = coeff; a.n_real = n_real; a.dy = dy;
+  a.dx = dx; a.dcoeff = dcoeff; a.dbias_part = dbias_part;
+  a.xsb = x_sb; a.xsn = x_sn; a.ysb = y_sb; a.ysn = y_sn;
+  a.B = B; a.N = N; a.H = H; a.P = P; a.share = heads_share_graph; a.total = B * H;
+  FETA_REQUIRE(x && lhat && coeff && n_real && dy && dx && dcoeff && dbias_part,
+               "cheb_filter_bwd: null pointer");
+  int rc = check_filter(a, dh, x, dy);
+  if (rc != FETA_OK) return rc;
+  FETA_REQUIRE(aligned16(dx) && aligned16(dcoeff), "cheb_filter_bwd: outputs must be 16-byte aligned");
+  return dispatch<ChebBwd>(a, dh, (N + 15) / 16, (hipStream_t)stream);
+}
+
+extern "C" int feta_spec_filter_fwd(const float* x, int64_t x_sb, int64_t x_sn, const float* u,
+                                    const float* lam, const float* coeff, const float* bias,
+                                    const int32_t* n_real, float* y, int64_t y_sb, int64_t y_sn,
+                                    int B, int N, int H, int dh, int P, int K,
+                                    int heads_share_graph, feta_stream_t stream) {
+  FilterArgs a{};
+  a.x = x; a.u = u; a.lam = lam; a.coeff = coeff; a.bias = bias; a.n_real = n_real; a.y = y;
+  a.xsb = x_sb; a.xsn = x_sn; a.ysb = y_sb; a.ysn = y_sn;
+  a.B = B; a.N = N; a.H = H; a.P = P; a.K = K; a.share = heads_share_graph; a.total = B * H;
+  FETA_REQUIRE(x && u && lam && coeff && n_real && y, "spec_filter_fwd: null pointer");
+  FETA_REQUIRE(K >= 1 && K <= FETA_MAX_NODES, "spec_filter_fwd: K=%d out of range", K);
+  int rc = check_filter(a, dh, x, y);
+  if (rc != FETA_OK) return rc;
+  return dispatch<SpecFwd>(a, dh, (K + 15) / 16, (hipStream_t)stream);
+}
+
+extern "C" int feta_spec_filter_bwd(const float* x, int64_t x_sb, int64_t x_sn, const float* u,
+                                    const float* lam, const float* coeff, const int32_t* n_real,
+                                    const float* dy, int64_t y_sb, int64_t y_sn, float* dx,
+                                    float* dcoeff, float* dbias_part, int B, int N, int H, int dh,
+                                    int P, int K, int heads_share_graph, feta_stream_t stream) {
+  FilterArgs a{};
+  a.x = x; a.u = u; a.lam = lam; a.coeff = coeff; a.n_real = n_real; a.dy = dy;
+  a.dx = dx; a.dcoeff = dcoeff; a.dbias_part = dbias_part;
+  a.xsb = x_sb; a.xsn = x_sn; a.ysb = y_sb; a.ysn = y_sn;
+  a.B = B; a.N = N; a.H = H; a.P = P; a.K = K; a.share = heads_share_graph; a.total = B * H;
+  FETA_REQUIRE(x && u && lam && coeff && n_real && dy && dx && dcoeff && dbias_part,
+               "spec_filter_bwd: null pointer");
+  FETA_REQUIRE(K >= 1 && K <= FETA_MAX_NODES, "spec_filter_bwd: K=%d out of range", K);
+  int rc = check_filter(a, dh, x, dy);
+  if (rc != FETA_OK) return rc;
+  FETA_REQUIRE(aligned16(dx) && aligned16(dcoeff), "spec_filter_bwd: outputs must be 16-byte aligned");
+  return dispatch<SpecBwd>(a, dh, (K + 15) / 16, (hipStream_t)stream);
+}

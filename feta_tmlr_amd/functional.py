@@ -1,0 +1,191 @@
+"""torch.autograd.Function wrappers over the C ABI (include/feta_hip.h).
+
+Token tensors are handed to the kernels as [B, N, H, dh] *views* with explicit strides, so the
+reference's seq-first [N, B, d] activations (transformer/models.py:521-527) are consumed and
+produced in place: no transposes, no gathers, no scatter into zero-initialised buffers.
+"""
+import torch
+
+from . import _lib
+
+
+def _token_view(t, batch_first, heads):
+    """[N,B,d] (seq-first) or [B,N,d] (batch-first) -> [B,N,H,dh] view (no copy)."""
+    d = t.shape[-1]
+    v = t.view(t.shape[0], t.shape[1], heads, d // heads)
+    return v if batch_first else v.permute(1, 0, 2, 3)
+
+
+def _dense_like(t, batch_first):
+    """grad arriving as a [B,N,H,dh]-shaped tensor -> same values in the storage order the
+    kernels were given (dense (H,dh), 16-byte aligned rows)."""
+    if batch_first:
+        return t.contiguous()
+    return t.permute(1, 0, 2, 3).contiguous().permute(1, 0, 2, 3)
+
+
+def _new_token(b, n, h, dh, batch_first, ref):
+    if batch_first:
+        return torch.empty((b, n, h, dh), dtype=torch.float32, device=ref.device)
+    return torch.empty((n, b, h, dh), dtype=torch.float32, device=ref.device).permute(1, 0, 2, 3)
+
+
+class AttentionCoreFn(torch.autograd.Function):
+    """qkv (projected, [N,B,3d] or [B,N,3d]) -> (concat heads in the same token layout,
+    attn [B,H,N,N] or None).  C ABI: feta_attn_fwd / feta_attn_bwd."""
+
+    @staticmethod
+    def forward(ctx, qkv, pe, n_real, num_heads, need_attn, tie_qk, batch_first):
+        abi, stream = _lib.backend(qkv, pe, n_real)
+        qkv = qkv.contiguous()
+        l0, l1, d3 = qkv.shape
+        d = d3 // 3
+        dh = d // num_heads
+        b, n = (l0, l1) if batch_first else (l1, l0)
+        v5 = qkv.view(l0, l1, 3, num_heads, dh)
+        sel = (lambda i: v5[:, :, i]) if batch_first else (lambda i: v5[:, :, i].permute(1, 0, 2, 3))
+        q, k, v = sel(0), (sel(0) if tie_qk else sel(1)), sel(2)
+        out = _new_token(b, n, num_heads, dh, batch_first, qkv)
+        attn = torch.empty((b, num_heads, n, n), dtype=torch.float32, device=qkv.device) if need_attn else None
+        stats = torch.empty((b, num_heads, n, 2), dtype=torch.float32, device=qkv.device)
+        pe_c = None if pe is None else pe.contiguous()
+        scale = float(dh) ** -0.5
+        abi.attn_fwd(q, k, v, pe_c, n_real, out, attn, stats, scale, stream)
+        ctx.save_for_backward(qkv, pe_c, n_real, out, stats)
+        ctx.cfg = (num_heads, tie_qk, batch_first, scale)
+        concat = (out if batch_first else out.permute(1, 0, 2, 3)).reshape(l0, l1, d)
+        if attn is not None:
+            ctx.mark_non_differentiable(attn)   # enters A2 detached (transformer/models.py:282)
+        return concat, attn
+
+    @staticmethod
+    def backward(ctx, dconcat, _dattn):
+        qkv, pe_c, n_real, out, stats = ctx.saved_tensors
+        num_heads, tie_qk, batch_first, scale = ctx.cfg
+        abi, stream = _lib.backend(qkv)
+        l0, l1, d3 = qkv.shape
+        d = d3 // 3
+        dh = d // num_heads
+        b, n = (l0, l1) if batch_first else (l1, l0)
+        v5 = qkv.view(l0, l1, 3, num_heads, dh)
+        dqkv = torch.empty_like(qkv)
+        g5 = dqkv.view(l0, l1, 3, num_heads, dh)
+        if batch_first:
+            sel, gsel = (lambda i: v5[:, :, i]), (lambda i: g5[:, :, i])
+        else:
+            sel = lambda i: v5[:, :, i].permute(1, 0, 2, 3)
+            gsel = lambda i: g5[:, :, i].permute(1, 0, 2, 3)
+        q, k, v = sel(0), (sel(0) if tie_qk else sel(1)), sel(2)
+        dout = _token_view(dconcat.contiguous(), batch_first, num_heads)
+        delta = torch.empty((b, num_heads, n), dtype=torch.float32, device=qkv.device)
+        abi.attn_bwd(q, k, v, pe_c, n_real, out, dout, stats, delta, gsel(0), gsel(1), gsel(2),
+                     scale, stream)
+        if tie_qk:
+            dqkv[..., :d] += dqkv[..., d:2 * d]
+            dqkv[..., d:2 * d] = 0
+        return dqkv, None, None, None, None, None, None
+
+
+class FilterCoefficientsFn(torch.autograd.Function):
+    """attn [B,H,N,N] (detached) + GCN parameters -> pooled [H*B, C]
+    (transformer/models.py:240-283 collapsed; C ABI: feta_colsum, feta_coeff_fwd/bwd)."""
+
+    @staticmethod
+    def forward(ctx, attn, n_real, gcn_weight, gcn_bias):
+        abi, stream = _lib.backend(attn, gcn_weight)
+        attn = attn.contiguous()
+        b, h, n, _ = attn.shape
+        c = gcn_weight.shape[1]
+        dev = attn.device
+        s = torch.empty(c, dtype=torch.float32, device=dev)
+        abi.colsum(gcn_weight.contiguous(), s, stream)
+        gb = gcn_bias.contiguous()
+        cj = torch.empty((h * b, n), dtype=torch.float32, device=dev)
+        pooled = torch.empty((h * b, c), dtype=torch.float32, device=dev)
+        abi.coeff_fwd(attn, n_real, s, gb, cj, pooled, stream)
+        ctx.save_for_backward(cj, n_real, s, gb)
+        ctx.dims = (b, n, h, gcn_weight.shape[0])
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        cj, n_real, s, gb = ctx.saved_tensors
+        b, n, h, rows = ctx.dims
+        abi, stream = _lib.backend(cj)
+        c = s.shape[0]
+        groups = abi.coeff_bwd_groups(b, h)
+        partial = torch.empty((2, groups, c), dtype=torch.float32, device=cj.device)
+        ds = torch.empty(c, dtype=torch.float32, device=cj.device)
+        db = torch.empty(c, dtype=torch.float32, device=cj.device)
+        abi.coeff_bwd(cj, n_real, s, gb, dpooled.contiguous(), partial, ds, db, b, n, h, stream)
+        # s = 1^T W  =>  every row of dW equals ds
+        return None, None, ds.unsqueeze(0).expand(rows, c), db
+
+
+class _FilterFn(torch.autograd.Function):
+    """x [B,N,H,dh] view, coeff [H*B, P*dh*dh], bias [dh] -> y (same token layout as x),
+    zero on padded rows.  mode 'cheb': graph = lhat [B,N,N]; mode 'spec': graph = (u, lam)."""
+
+    @staticmethod
+    def forward(ctx, x, coeff, bias, n_real, g0, g1, mode, order, share, batch_first):
+        abi, stream = _lib.backend(x, coeff)
+        b, n, h, dh = x.shape
+        xs = _dense_like(x, batch_first)
+        coeff = coeff.contiguous()
+        y = _new_token(b, n, h, dh, batch_first, x)
+        if mode == 'cheb':
+            abi.cheb_filter_fwd(xs, g0, coeff, bias, n_real, y, order, share, stream)
+        else:
+            abi.spec_filter_fwd(xs, g0, g1, coeff, bias, n_real, y, order, share, stream)
+        ctx.save_for_backward(xs, coeff, n_real, g0, g1)
+        ctx.cfg = (mode, order, share, batch_first, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xs, coeff, n_real, g0, g1 = ctx.saved_tensors
+        mode, order, share, batch_first, has_bias = ctx.cfg
+        abi, stream = _lib.backend(xs)
+        b, n, h, dh = xs.shape
+        dys = _dense_like(dy, batch_first)
+        dx = _new_token(b, n, h, dh, batch_first, xs)
+        dcoeff = torch.empty_like(coeff)
+        dbp = torch.empty((b * h, dh), dtype=torch.float32, device=xs.device)
+        if mode == 'cheb':
+            abi.cheb_filter_bwd(xs, g0, coeff, n_real, dys, dx, dcoeff, dbp, order, share, stream)
+        else:
+            abi.spec_filter_bwd(xs, g0, g1, coeff, n_real, dys, dx, dcoeff, dbp, order, share, stream)
+        dbias = None
+        if has_bias:
+            dbias = torch.empty(dh, dtype=torch.float32, device=xs.device)
+            abi.colsum(dbp, dbias, stream)
+        return dx, dcoeff, dbias, None, None, None, None, None, None, None
+
+
+def attention_core(qkv, pe, n_real, num_heads, need_attn=True, tie_qk=False, batch_first=False):
+    return AttentionCoreFn.apply(qkv, pe, n_real, num_heads, need_attn, tie_qk, batch_first)
+
+
+def filter_coefficients(attn, n_real, gcn_weight, gcn_bias):
+    return FilterCoefficientsFn.apply(attn, n_real, gcn_weight, gcn_bias)
+
+
+def cheb_filter(x, lhat, coeff, bias, n_real, order, heads_share_graph=False, batch_first=False):
+    return _FilterFn.apply(x, coeff, bias, n_real, lhat.contiguous(), None, 'cheb', order,
+                           bool(heads_share_graph), batch_first)
+
+
+def spec_filter(x, u, lam, coeff, bias, n_real, order, heads_share_graph=False, batch_first=False):
+    return _FilterFn.apply(x, coeff, bias, n_real, u.contiguous(), lam.contiguous(), 'spec', order,
+                           bool(heads_share_graph), batch_first)
+
+
+def lhat_from_edges(edge_index, node_graph, node_off, num_graphs, n_pad):
+    """Dense scaled Laplacian [B,N,N] of every graph of the batch (feta_lhat_from_edges)."""
+    abi, stream = _lib.backend(edge_index, node_graph)
+    dev = node_graph.device
+    lhat = torch.zeros((num_graphs, n_pad, n_pad), dtype=torch.float32, device=dev)
+    deg = torch.zeros(node_graph.shape[0], dtype=torch.float32, device=dev)
+    abi.lhat_from_edges(edge_index.contiguous(), node_graph.contiguous(), node_off.contiguous(),
+                        deg, lhat, stream)
+    return lhat

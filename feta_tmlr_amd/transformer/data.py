@@ -1,0 +1,193 @@
+"""Padded-graph batches for the FeTA block: synthetic generators of the BASELINE shapes
+and a collate that emits the reference's wire format.
+
+The reference collate (``GraphDataset_v2.collate_fn``, transformer/data.py:161-225) returns
+the 9-tuple ``padded_x, mask, pos_enc, lap_pos_enc, degree, labels, edge_index, batch,
+feature_indices`` built from Python lists; ``collate`` below returns the same tuple (same
+shapes, dtypes and zero padding) from numpy arrays, plus a ``GraphBatchCache`` with what the
+MI355X kernels consume directly: ``n_real`` (int32 node counts, replaces the host sync at
+transformer/models.py:246), graph offsets, and optionally the Laplacian eigenbasis
+``U, lam`` (the LapEncoding-style offline product, transformer/position_encoding.py:127-161).
+
+Synthetic graphs follow SURVEY 8(d): molecule-like random trees with ring closures
+(MUTAG/ZINC/molhiv shapes) and 5-block SBM graphs (PATTERN shape).  No dataset is read.
+"""
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+SHAPES = {
+    # name: (n_min, n_max, batch_size, kind)
+    'mutag': (10, 28, 32, 'mol'),
+    'zinc': (9, 37, 128, 'mol'),
+    'pattern': (44, 188, 64, 'sbm'),
+    'molhiv': (2, 222, 1024, 'mol'),
+}
+
+
+def molecule_graph(rng, n):
+    """Random tree (parent among the last 3 placed nodes) + 2 ring closures, symmetrised,
+    no self loops.  Returns edge_index [2, E] int64 with both directions of every edge."""
+    edges = set()
+    for v in range(1, n):
+        p = int(rng.integers(max(0, v - 3), v))
+        edges.add((p, v))
+    for _ in range(2 if n >= 5 else 0):
+        a, b = (int(t) for t in rng.integers(0, n, size=2))
+        if a != b and abs(a - b) > 1:
+            edges.add((min(a, b), max(a, b)))
+    e = np.array(sorted(edges), dtype=np.int64).reshape(-1, 2)
+    return np.concatenate([e, e[:, ::-1]], axis=0).T.copy()
+
+
+def sbm_graph(rng, n, blocks=5, p_in=0.5, p_out=0.35):
+    """Stochastic block model, symmetrised (PATTERN shape)."""
+    lab = rng.integers(0, blocks, size=n)
+    same = lab[:, None] == lab[None, :]
+    prob = np.where(same, p_in, p_out)
+    upper = np.triu(rng.random((n, n)) < prob, k=1)
+    src, dst = np.nonzero(upper)
+    e = np.stack([src, dst], axis=1).astype(np.int64)
+    return np.concatenate([e, e[:, ::-1]], axis=0).T.copy()
+
+
+@dataclass
+class GraphSample:
+    """One graph, the fields the reference reads off a PyG ``Data`` (g.x, g.edge_index, g.y,
+    g.pe, g.lap_pe, g.degree: transformer/data.py:130-140)."""
+    x: np.ndarray                      # [n, f] float32 node features
+    edge_index: np.ndarray             # [2, E] int64
+    y: float = 0.0
+    pe: Optional[np.ndarray] = None    # [n, n] relative positional kernel
+    lap_pe: Optional[np.ndarray] = None
+    degree: Optional[np.ndarray] = None
+    u: Optional[np.ndarray] = None     # [n, n] eigenvectors of Lhat (ascending), float64
+    lam: Optional[np.ndarray] = None   # [n]
+
+    @property
+    def num_nodes(self):
+        return self.x.shape[0]
+
+
+def lhat_numpy(edge_index, n):
+    """Dense Lhat = -D^-1/2 A D^-1/2 with the edge-list semantics of
+    ChebConvDynamic.__norm__ (transformer/ChebNetDynamic.py:108-130): Lhat[t, s] over edges s->t,
+    degree on the source row, duplicates summed."""
+    s, t = edge_index
+    keep = s != t
+    s, t = s[keep], t[keep]
+    deg = np.bincount(s, minlength=n).astype(np.float64)
+    dis = np.where(deg > 0, 1.0 / np.sqrt(np.maximum(deg, 1e-300)), 0.0)
+    m = np.zeros((n, n))
+    np.add.at(m, (t, s), -dis[s] * dis[t])
+    return m
+
+
+def diffusion_kernel(edge_index, n, beta=1.0):
+    """expm(-beta L_sym) (DiffusionEncoding, transformer/position_encoding.py:65-72) through the
+    eigendecomposition of the symmetric L = I + Lhat."""
+    lam, u = np.linalg.eigh(np.eye(n) + lhat_numpy(edge_index, n))
+    return (u * np.exp(-beta * lam)) @ u.T
+
+
+class SyntheticGraphDataset:
+    """Seeded list of GraphSample of one BASELINE shape."""
+
+    def __init__(self, shape='zinc', num_graphs=128, in_dim=64, seed=0, pos_enc=True,
+                 with_degree=True, with_eig=True, n_min=None, n_max=None):
+        lo, hi, _, kind = SHAPES[shape]
+        lo = lo if n_min is None else n_min
+        hi = hi if n_max is None else n_max
+        rng = np.random.default_rng(seed)
+        self.samples: List[GraphSample] = []
+        for _ in range(num_graphs):
+            if shape == 'molhiv':
+                n = int(np.clip(np.round(rng.lognormal(3.2, 0.35)), lo, hi))
+            else:
+                n = int(rng.integers(lo, hi + 1))
+            ei = sbm_graph(rng, n) if kind == 'sbm' else molecule_graph(rng, n)
+            g = GraphSample(x=rng.standard_normal((n, in_dim)).astype(np.float32), edge_index=ei,
+                            y=float(rng.standard_normal()))
+            if pos_enc:
+                g.pe = diffusion_kernel(ei, n).astype(np.float32)
+            if with_degree:
+                deg = np.bincount(ei[0], minlength=n).astype(np.float32)
+                g.degree = 1.0 / np.sqrt(1.0 + deg)          # transformer/data.py:145
+            if with_eig:
+                g.lam, g.u = np.linalg.eigh(lhat_numpy(ei, n))
+            self.samples.append(g)
+
+    def __len__(self):
+        return len(self.samples)
+
+    def __getitem__(self, i):
+        return self.samples[i]
+
+
+@dataclass
+class GraphBatchCache:
+    """Per-batch graph structure in the layout the kernels read (device tensors)."""
+    n_real: torch.Tensor                    # [B] int32
+    node_off: torch.Tensor                  # [B] int32, first global node id of each graph
+    n_pad: int
+    u: Optional[torch.Tensor] = None        # [B, N, K] float32, rows >= n_real and cols >= n_real zero
+    lam: Optional[torch.Tensor] = None      # [B, K]
+    lhat: Optional[torch.Tensor] = None     # [B, N, N] dense scaled Laplacian (filled lazily)
+    extra: dict = field(default_factory=dict)
+
+    def to(self, device):
+        mv = lambda t: None if t is None else t.to(device)
+        return GraphBatchCache(mv(self.n_real), mv(self.node_off), self.n_pad, mv(self.u),
+                               mv(self.lam), mv(self.lhat), dict(self.extra))
+
+
+def collate(samples, k_eig=None, n_pad=None, device='cpu'):
+    """-> (padded_x, mask, pos_enc, lap_pos_enc, degree, labels, edge_index, batch,
+    feature_indices), cache   — tuple layout of transformer/data.py:224."""
+    bsz = len(samples)
+    ns = [g.num_nodes for g in samples]
+    n = max(ns) if n_pad is None else n_pad
+    f = samples[0].x.shape[1]
+    x = np.zeros((bsz, n, f), np.float32)
+    mask = np.ones((bsz, n), bool)
+    use_pe = samples[0].pe is not None
+    use_lap = samples[0].lap_pe is not None
+    use_deg = samples[0].degree is not None
+    pe = np.zeros((bsz, n, n), np.float32) if use_pe else None
+    lap = np.zeros((bsz, n, samples[0].lap_pe.shape[1]), np.float32) if use_lap else None
+    deg = np.zeros((bsz, n), np.float32) if use_deg else None
+    eis, bat, fi = [], [], []
+    off = 0
+    offs = []
+    for i, g in enumerate(samples):
+        m = ns[i]
+        x[i, :m] = g.x
+        mask[i, :m] = False
+        if use_pe:
+            pe[i, :m, :m] = g.pe
+        if use_lap:
+            lap[i, :m, :g.lap_pe.shape[1]] = g.lap_pe
+        if use_deg:
+            deg[i, :m] = g.degree
+        eis.append(g.edge_index + off)
+        bat.append(np.full((m,), i, np.int64))
+        fi.append(np.stack([np.full((m,), i, np.int64), np.arange(m, dtype=np.int64)], 1))
+        offs.append(off)
+        off += m
+    u = lam = None
+    if k_eig is not None:
+        u = np.zeros((bsz, n, k_eig), np.float32)
+        lam = np.zeros((bsz, k_eig), np.float32)
+        for i, g in enumerate(samples):
+            kk = min(k_eig, ns[i])
+            u[i, :ns[i], :kk] = g.u[:, :kk]
+            lam[i, :kk] = g.lam[:kk]
+    t = lambda a: None if a is None else torch.from_numpy(a).to(device)
+    batch9 = (t(x), t(mask), t(pe), t(lap), t(deg),
+              torch.tensor([g.y for g in samples], dtype=torch.float32, device=device),
+              t(np.concatenate(eis, axis=1)), t(np.concatenate(bat)), t(np.concatenate(fi)))
+    cache = GraphBatchCache(n_real=t(np.array(ns, np.int32)), node_off=t(np.array(offs, np.int32)),
+                            n_pad=n, u=t(u), lam=t(lam))
+    return batch9, cache

@@ -286,11 +286,15 @@ def get_filter_coefficients_collapsed(attn, masks, gcn_w, gcn_b, lin_w, lin_b):
 # ---------------------------------------------------------------------------
 
 
-def diff_attention(src, pe, key_padding_mask, in_w, in_b, num_heads, tie_qk=False):
-    """Returns (concat [N,B,d] before out_proj, attn [B,H,N,N], out_each_head [B,N,H,dh])."""
-    n, b, d = src.shape
+def attention_core(qkv, pe, key_padding_mask, num_heads, tie_qk=False, detach_max=False):
+    """Scores -> masked exp -> (* pe) -> clamped normalisation -> weighted sum, from the
+    projected qkv [N,B,3d].  detach_max=True drops the (mathematically zero unless the
+    1e-6 clamp is active) gradient through the row maximum, which is what the kernels do.
+    Returns (concat [N,B,d], attn [B,H,N,N], out_each_head [B,N,H,dh])."""
+    n, b, d3 = qkv.shape
+    d = d3 // 3
     dh = d // num_heads
-    q, k, v = F.linear(src, in_w, in_b).chunk(3, dim=-1)
+    q, k, v = qkv.chunk(3, dim=-1)
     if tie_qk:
         k = q
     q = q * (float(dh) ** -0.5)
@@ -301,13 +305,19 @@ def diff_attention(src, pe, key_padding_mask, in_w, in_b, num_heads, tie_qk=Fals
     s = torch.bmm(q, k.transpose(1, 2)).view(b, num_heads, n, n)
     if key_padding_mask is not None:
         s = s.masked_fill(key_padding_mask.unsqueeze(1).unsqueeze(2), float('-inf'))
-    s = torch.exp(s - s.max(dim=-1, keepdim=True)[0])
+    mx = s.max(dim=-1, keepdim=True)[0]
+    s = torch.exp(s - (mx.detach() if detach_max else mx))
     if pe is not None:
         s = s * pe.unsqueeze(1)
     a = s / s.sum(dim=-1, keepdim=True).clamp(min=1e-6)
     o = torch.bmm(a.view(b * num_heads, n, n), v).view(b, num_heads, n, dh)
     concat = o.permute(2, 0, 1, 3).reshape(n, b, d)
     return concat, a, o.permute(0, 2, 1, 3)
+
+
+def diff_attention(src, pe, key_padding_mask, in_w, in_b, num_heads, tie_qk=False):
+    """in_proj + attention_core."""
+    return attention_core(F.linear(src, in_w, in_b), pe, key_padding_mask, num_heads, tie_qk)
 
 
 def _norm(x, w, b, batch_norm):

@@ -1,0 +1,279 @@
+"""Parity checks of the C-ABI kernels against the CPU oracle, written once and run twice:
+on the host SIMT emulation of the kernel sources (``-m "not gpu"``) and on the MI355X through
+libfeta_hip.so (``-m gpu``).  ``abi`` is a feta_tmlr_amd._abi.Abi; ``dev`` the torch device the
+buffers live on; ``stream`` the hipStream_t handle (None for the emulation)."""
+import numpy as np
+import torch
+
+from feta_tmlr_amd.transformer import data as D
+from oracle import feta_oracle as O
+
+TOL = 1e-5  # BASELINE north_star: within 1e-5 fp32 of the reference arithmetic
+
+
+def maxdiff(a, b):
+    return (a.detach().double().cpu() - b.detach().double().cpu()).abs().max().item()
+
+
+def assert_close(name, got, ref, tol=TOL):
+    """max-abs error <= tol * max(1, max|ref|)."""
+    err = maxdiff(got, ref)
+    scale = max(1.0, ref.detach().abs().max().item())
+    assert np.isfinite(err) and err <= tol * scale, '%s: max|err| %.3e (ref scale %.2f)' % (name, err, scale)
+    return err
+
+
+def make_batch(shape, bsz, seed, in_dim, n_min=None, n_max=None, k_eig=None, full_first=True):
+    ds = D.SyntheticGraphDataset(shape, bsz, in_dim=in_dim, seed=seed, n_min=n_min, n_max=n_max)
+    return D.collate(ds.samples, k_eig=k_eig)
+
+
+def token_buffers(bsz, n, h, dh, seq_first, dev, fill=float('nan')):
+    """A [B,N,H,dh] view over seq-first [N,B,H,dh] or batch-first storage."""
+    if seq_first:
+        return torch.full((n, bsz, h, dh), fill, dtype=torch.float32, device=dev).permute(1, 0, 2, 3)
+    return torch.full((bsz, n, h, dh), fill, dtype=torch.float32, device=dev)
+
+
+def to_view(t64, seq_first, dev):
+    """fp64 [B,N,H,dh] -> fp32 view with the requested storage order on dev."""
+    t = t64.float()
+    if seq_first:
+        return t.permute(1, 0, 2, 3).contiguous().to(dev).permute(1, 0, 2, 3)
+    return t.contiguous().to(dev)
+
+
+# ---------------------------------------------------------------------------------------
+
+
+def check_attn(abi, dev, stream, bsz, n, h, dh, use_pe, seq_first=True, seed=0, write_attn=True,
+               clamp_case=False):
+    g = torch.Generator().manual_seed(seed)
+    d = h * dh
+    nb = torch.randint(1, n + 1, (bsz,), generator=g, dtype=torch.int32)
+    nb[0] = n
+    mask = torch.arange(n)[None, :] >= nb[:, None]
+    qkv = torch.randn(n, bsz, 3 * d, generator=g, dtype=torch.float64)
+    pe = None
+    if use_pe:
+        pe = torch.rand(bsz, n, n, generator=g, dtype=torch.float64)
+        pe = pe * (~mask)[:, None, :] * (~mask)[:, :, None]
+        if clamp_case:
+            pe[0, 0, :] = 0.0       # a fully killed row: rowsum 0 -> clamp(1e-6) active
+            pe[0, 1, :] = 1e-9      # tiny row: clamp active with non-zero numerator
+    dout = torch.randn(bsz, n, h, dh, generator=g, dtype=torch.float64)
+
+    qkv_r = qkv.clone().requires_grad_(True)
+    _, a_ref, o_ref = O.attention_core(qkv_r, pe, mask, h, detach_max=clamp_case)
+    z_ref = None
+    (o_ref * dout).sum().backward()
+
+    qkv32 = qkv.float().to(dev)
+    if not seq_first:
+        qkv32 = qkv32.permute(1, 0, 2).contiguous().permute(1, 0, 2)
+    v5 = qkv32.view(n, bsz, 3, h, dh) if seq_first else None
+    if seq_first:
+        qv, kv, vv = (v5[:, :, i].permute(1, 0, 2, 3) for i in range(3))
+    else:
+        base = qkv32.permute(1, 0, 2)  # [B,N,3d] contiguous
+        v5 = base.reshape(bsz, n, 3, h, dh)
+        assert v5.data_ptr() == base.data_ptr()
+        qv, kv, vv = (v5[:, :, i] for i in range(3))
+    out = token_buffers(bsz, n, h, dh, seq_first, dev)
+    attn = torch.full((bsz, h, n, n), float('nan'), device=dev) if write_attn else None
+    stats = torch.zeros(bsz, h, n, 2, device=dev)
+    pe32 = None if pe is None else pe.float().contiguous().to(dev)
+    nbd = nb.to(dev)
+    abi.attn_fwd(qv, kv, vv, pe32, nbd, out, attn, stats, dh ** -0.5, stream)
+    errs = {}
+    if write_attn:
+        errs['attn'] = assert_close('attn', attn, a_ref)
+    errs['out'] = assert_close('out_each_head', out, o_ref)
+
+    dqkv = torch.full_like(qkv32, float('nan'))
+    if seq_first:
+        g5 = dqkv.view(n, bsz, 3, h, dh)
+        dq, dk, dv = (g5[:, :, i].permute(1, 0, 2, 3) for i in range(3))
+    else:
+        g5 = dqkv.permute(1, 0, 2).reshape(bsz, n, 3, h, dh)
+        dq, dk, dv = (g5[:, :, i] for i in range(3))
+    delta = torch.zeros(bsz, h, n, device=dev)
+    do = to_view(dout, seq_first, dev)
+    abi.attn_bwd(qv, kv, vv, pe32, nbd, out, do, stats, delta, dq, dk, dv, dh ** -0.5, stream)
+    errs['dqkv'] = assert_close('dqkv', dqkv, qkv_r.grad)
+    return errs
+
+
+def random_attention(bsz, h, n, nb, g, zero_diag=False):
+    """Row-stochastic attention with exact zeros outside the real block."""
+    mask = torch.arange(n)[None, :] >= nb[:, None]
+    a = torch.rand(bsz, h, n, n, generator=g, dtype=torch.float64) + 0.05
+    a = a.masked_fill(mask[:, None, None, :], 0.0)
+    if zero_diag:
+        a[:, 0].diagonal(dim1=-2, dim2=-1).zero_()   # dropped self loops -> refilled with 1
+    a = a / a.sum(-1, keepdim=True)
+    return a, mask
+
+
+def check_coeff(abi, dev, stream, bsz, n, h, c, seed=0, zero_diag=True, faithful=True):
+    g = torch.Generator().manual_seed(seed)
+    nb = torch.randint(1, n + 1, (bsz,), generator=g, dtype=torch.int32)
+    nb[0] = n
+    attn, mask = random_attention(bsz, h, n, nb, g, zero_diag)
+    gw = (torch.randn(c, c, generator=g, dtype=torch.float64) / c ** 0.5).requires_grad_(True)
+    gb = (0.1 * torch.randn(c, generator=g, dtype=torch.float64)).requires_grad_(True)
+    eye = torch.eye(c, dtype=torch.float64)
+    zero = torch.zeros(c, dtype=torch.float64)
+    pooled_ref = O.get_filter_coefficients_collapsed(attn, mask, gw, gb, eye, zero).reshape(h * bsz, c)
+    if faithful:
+        pooled_f = O.get_filter_coefficients_faithful(attn, mask, gw, gb, eye, zero).reshape(h * bsz, c)
+        assert maxdiff(pooled_f, pooled_ref) < 1e-12, 'oracle: collapsed != faithful'
+    dp = torch.randn(h * bsz, c, generator=g, dtype=torch.float64)
+    (pooled_ref * dp).sum().backward()
+
+    attn32 = attn.float().to(dev)
+    s = torch.empty(c, device=dev)
+    abi.colsum(gw.detach().float().to(dev), s, stream)
+    assert_close('colsum', s, gw.detach().sum(0))
+    gb32 = gb.detach().float().to(dev)
+    cj = torch.full((h * bsz, n), float('nan'), device=dev)
+    pooled = torch.full((h * bsz, c), float('nan'), device=dev)
+    nbd = nb.to(dev)
+    abi.coeff_fwd(attn32, nbd, s, gb32, cj, pooled, stream)
+    errs = {'pooled': assert_close('pooled', pooled, pooled_ref)}
+    cj_ref = torch.zeros(h * bsz, n, dtype=torch.float64)
+    for hh in range(h):
+        for bb in range(bsz):
+            cj_ref[hh * bsz + bb, :nb[bb]] = O.gcn_node_scalars(attn[bb, hh], int(nb[bb]))
+    errs['cj'] = assert_close('cj', cj, cj_ref)
+
+    groups = abi.coeff_bwd_groups(bsz, h)
+    partial = torch.zeros(2, groups, c, device=dev)
+    ds = torch.full((c,), float('nan'), device=dev)
+    db = torch.full((c,), float('nan'), device=dev)
+    abi.coeff_bwd(cj, nbd, s, gb32, dp.float().to(dev), partial, ds, db, bsz, n, h, stream)
+    # d(colsum W)/dW broadcasts: every row of gcn.weight.grad equals ds
+    assert maxdiff(gw.grad, gw.grad[0:1].expand_as(gw.grad)) < 1e-12
+    errs['ds'] = assert_close('ds', ds, gw.grad[0])
+    errs['dbias'] = assert_close('dgcn_bias', db, gb.grad)
+    return errs
+
+
+def _filter_case(bsz, h, dh, order, seed, shape, n_min, n_max, k_eig):
+    (x9, cache) = make_batch(shape, bsz, seed, h * dh, n_min=n_min, n_max=n_max, k_eig=k_eig)
+    _, mask, _, _, _, _, edge_index, batch, fi = x9
+    n = mask.shape[1]
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.randn(bsz, n, h, dh, generator=g, dtype=torch.float64)
+    x = x * (~mask)[:, :, None, None]     # values on padded rows are never gathered; keep finite
+    coeff = torch.randn(h, bsz, order * dh * dh, generator=g, dtype=torch.float64) / dh ** 0.5
+    bias = 0.1 * torch.randn(dh, generator=g, dtype=torch.float64)
+    dy = torch.randn(bsz, n, h, dh, generator=g, dtype=torch.float64)
+    return x, coeff, bias, dy, mask, edge_index, batch, fi, cache, n
+
+
+def _filter_oracle(x, coeff, bias, dy, edge_index, batch, fi, order, share):
+    bsz, n, h, dh = x.shape
+    xr = x.clone().requires_grad_(True)
+    cr = coeff.clone().requires_grad_(True)
+    br = bias.clone().requires_grad_(True)
+    y = O.filter_stage_faithful(xr, cr, edge_index, fi, batch, br, order, (n, bsz, h * dh), share)
+    y = y.view(n, bsz, h, dh).permute(1, 0, 2, 3)
+    (y * dy).sum().backward()
+    return y.detach(), xr.grad, cr.grad.reshape(h * bsz, -1), br.grad
+
+
+def check_lhat(abi, dev, stream, bsz=5, seed=0, shape='zinc', n_min=None, n_max=None, directed=False):
+    (x9, cache) = make_batch(shape, bsz, seed, 4, n_min=n_min, n_max=n_max)
+    edge_index, batch = x9[6], x9[7]
+    if directed:   # drop some edges so that Lhat != Lhat^T: exposes a transposed scatter
+        keep = torch.ones(edge_index.shape[1], dtype=torch.bool)
+        keep[::3] = False
+        edge_index = edge_index[:, keep].contiguous()
+    n = cache.n_pad
+    ref = torch.zeros(bsz, n, n, dtype=torch.float64)
+    off = cache.node_off.tolist()
+    nb = cache.n_real.tolist()
+    for b in range(bsz):
+        sel = (batch[edge_index[0]] == b)
+        ref[b, :nb[b], :nb[b]] = O.lhat_dense(edge_index[:, sel] - off[b], nb[b], torch.float64)
+    lhat = torch.zeros(bsz, n, n, device=dev)
+    deg = torch.zeros(batch.shape[0], device=dev)
+    abi.lhat_from_edges(edge_index.to(dev), batch.to(dev), cache.node_off.to(dev), deg, lhat, stream)
+    return {'lhat': assert_close('lhat', lhat, ref)}, lhat, ref
+
+
+def check_filter(abi, dev, stream, mode, bsz, h, dh, order, share, seed=0, shape='zinc',
+                 n_min=None, n_max=None, k_eig=None, seq_first=True, directed=False):
+    """mode 'cheb' | 'spec'.  k_eig None -> K = N_pad (exact operator)."""
+    x, coeff, bias, dy, mask, edge_index, batch, fi, cache, n = _filter_case(
+        bsz, h, dh, order, seed, shape, n_min, n_max, k_eig if k_eig else 1)
+    if directed:
+        assert mode == 'cheb'
+        keep = torch.ones(edge_index.shape[1], dtype=torch.bool)
+        keep[::3] = False
+        edge_index = edge_index[:, keep].contiguous()
+    nb = cache.n_real
+    off = cache.node_off.tolist()
+    exact = k_eig is None
+    if exact:
+        y_ref, dx_ref, dc_ref, db_ref = _filter_oracle(x, coeff, bias, dy, edge_index, batch, fi,
+                                                       order, share)
+    lh64 = torch.zeros(bsz, n, n, dtype=torch.float64)
+    for b in range(bsz):
+        sel = (batch[edge_index[0]] == b)
+        lh64[b, :nb[b], :nb[b]] = O.lhat_dense(edge_index[:, sel] - off[b], int(nb[b]), torch.float64)
+    if mode == 'spec':
+        kk = n if exact else k_eig
+        u64 = torch.zeros(bsz, n, kk, dtype=torch.float64)
+        lam64 = torch.zeros(bsz, kk, dtype=torch.float64)
+        for b in range(bsz):
+            ub, lb = O.eig_basis(lh64[b, :nb[b], :nb[b]], kk, n)
+            u64[b], lam64[b] = ub, lb
+        if not exact:   # truncated operator: oracle = eigenbasis formulation per block
+            xr = x.clone().requires_grad_(True)
+            cr = coeff.clone().requires_grad_(True)
+            br = bias.clone().requires_grad_(True)
+            y = torch.zeros(bsz, n, h, dh, dtype=torch.float64)
+            rows = []
+            for b in range(bsz):
+                for hh in range(h):
+                    w = cr[hh, b].reshape(order, dh, dh)
+                    m = int(nb[b])
+                    if share or hh == 0:
+                        yb = O.spec_filter_eig(xr[b, :m, hh], u64[b, :m], lam64[b], w, br)
+                    else:
+                        yb = O.cheb_filter_dense(xr[b, :m, hh], torch.zeros(m, m, dtype=torch.float64), w, br)
+                    rows.append((b, hh, m, yb))
+            y = torch.zeros(bsz, n, h, dh, dtype=torch.float64)
+            for b, hh, m, yb in rows:
+                y = y.index_put((torch.tensor(b), torch.arange(m), torch.tensor(hh)), yb)
+            (y * dy).sum().backward()
+            y_ref, dx_ref, dc_ref, db_ref = y.detach(), xr.grad, cr.grad.reshape(h * bsz, -1), br.grad
+
+    xv = to_view(x, seq_first, dev)
+    dyv = to_view(dy, seq_first, dev)
+    yv = token_buffers(bsz, n, h, dh, seq_first, dev)
+    dxv = token_buffers(bsz, n, h, dh, seq_first, dev)
+    c32 = coeff.reshape(h * bsz, -1).float().contiguous().to(dev)
+    b32 = bias.float().to(dev)
+    dcoeff = torch.full_like(c32, float('nan'))
+    dbp = torch.full((bsz * h, dh), float('nan'), device=dev)
+    nbd = nb.to(dev)
+    if mode == 'cheb':
+        lh = lh64.float().to(dev)
+        abi.cheb_filter_fwd(xv, lh, c32, b32, nbd, yv, order, share, stream)
+        abi.cheb_filter_bwd(xv, lh, c32, nbd, dyv, dxv, dcoeff, dbp, order, share, stream)
+    else:
+        u32, l32 = u64.float().to(dev), lam64.float().to(dev)
+        abi.spec_filter_fwd(xv, u32, l32, c32, b32, nbd, yv, order, share, stream)
+        abi.spec_filter_bwd(xv, u32, l32, c32, nbd, dyv, dxv, dcoeff, dbp, order, share, stream)
+    dbias = torch.empty(dh, device=dev)
+    abi.colsum(dbp, dbias, stream)
+    errs = {'y': assert_close('y', yv, y_ref)}
+    real = (~mask)[:, :, None, None].to(dev)
+    assert bool((yv.masked_select(~real.expand_as(yv)) == 0).all()), 'y must be zero on padded rows'
+    errs['dx'] = assert_close('dx', dxv * real, dx_ref * (~mask)[:, :, None, None])
+    errs['dcoeff'] = assert_close('dcoeff', dcoeff, dc_ref)
+    errs['dbias'] = assert_close('dbias', dbias, db_ref)
+    return errs

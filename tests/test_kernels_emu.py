@@ -1,0 +1,66 @@
+"""The kernel sources (feta_tmlr_amd/csrc/*.hip) compiled for the host by tools/simt and
+checked against the oracle through the C ABI - no GPU needed.  The same checks run on the
+MI355X in test_kernels_gpu.py."""
+import pytest
+import torch
+
+import kernel_checks as KC
+
+CPU = torch.device('cpu')
+
+
+@pytest.mark.parametrize('bsz,n,h,dh,use_pe,seq_first', [
+    (3, 20, 2, 16, True, True),
+    (2, 37, 4, 16, False, True),
+    (2, 37, 4, 16, True, False),
+    (2, 50, 2, 8, True, True),
+    (2, 33, 1, 32, True, False),
+    (1, 70, 1, 64, True, True),
+    (2, 9, 2, 4, False, True),
+])
+def test_attn(emu, bsz, n, h, dh, use_pe, seq_first):
+    KC.check_attn(emu, CPU, None, bsz, n, h, dh, use_pe, seq_first)
+
+
+def test_attn_no_attn_write(emu):
+    KC.check_attn(emu, CPU, None, 2, 21, 2, 16, True, write_attn=False)
+
+
+def test_attn_clamped_rows(emu):
+    KC.check_attn(emu, CPU, None, 2, 19, 2, 16, True, clamp_case=True)
+
+
+@pytest.mark.parametrize('bsz,n,h,c', [(3, 12, 2, 64), (2, 37, 4, 256), (1, 5, 1, 16)])
+def test_coeff(emu, bsz, n, h, c):
+    KC.check_coeff(emu, CPU, None, bsz, n, h, c)
+
+
+@pytest.mark.parametrize('directed', [False, True])
+def test_lhat_from_edges(emu, directed):
+    KC.check_lhat(emu, CPU, None, bsz=5, directed=directed)
+
+
+@pytest.mark.parametrize('mode', ['cheb', 'spec'])
+@pytest.mark.parametrize('share', [0, 1])
+@pytest.mark.parametrize('bsz,h,dh,order,shape,n_min,n_max,seq_first', [
+    (3, 2, 16, 4, 'zinc', None, None, True),
+    (2, 4, 16, 4, 'mutag', None, None, False),
+    (2, 2, 8, 3, 'zinc', 2, 20, True),
+    (2, 1, 32, 2, 'zinc', 17, 40, True),
+    (1, 2, 16, 1, 'zinc', None, None, True),
+    (2, 2, 16, 5, 'pattern', 44, 70, True),
+])
+def test_filter_exact(emu, mode, share, bsz, h, dh, order, shape, n_min, n_max, seq_first):
+    KC.check_filter(emu, CPU, None, mode, bsz, h, dh, order, share, shape=shape, n_min=n_min,
+                    n_max=n_max, seq_first=seq_first)
+
+
+def test_cheb_directed_graph(emu):
+    """Lhat != Lhat^T: catches a transposed propagate in forward or backward."""
+    KC.check_filter(emu, CPU, None, 'cheb', 2, 2, 16, 4, 1, directed=True)
+
+
+@pytest.mark.parametrize('k_eig', [8, 16])
+def test_spec_truncated(emu, k_eig):
+    KC.check_filter(emu, CPU, None, 'spec', 3, 2, 16, 4, 1, k_eig=k_eig)
+    KC.check_filter(emu, CPU, None, 'spec', 2, 2, 16, 4, 0, k_eig=k_eig)

@@ -1,0 +1,91 @@
+"""Parity of libfeta_hip.so (hand-written HIP, gfx950) against the CPU oracle through the C ABI.
+Same checks as test_kernels_emu.py, on the MI355X, plus BASELINE-size cases."""
+import pytest
+import torch
+
+import kernel_checks as KC
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('bsz,n,h,dh,use_pe,seq_first', [
+    (3, 20, 2, 16, True, True),
+    (2, 37, 4, 16, False, True),
+    (2, 37, 4, 16, True, False),
+    (2, 50, 2, 8, True, True),
+    (2, 33, 1, 32, True, False),
+    (1, 70, 1, 64, True, True),
+    (2, 9, 2, 4, False, True),
+    (128, 37, 4, 16, True, True),      # BASELINE config 2 (ZINC shape)
+    (32, 28, 4, 16, True, True),       # config 1 (MUTAG shape)
+    (8, 188, 4, 16, True, True),       # config 4 (PATTERN shape, N_pad 188)
+    (16, 222, 4, 16, False, True),     # config 5 (molhiv, largest bucket)
+    (4, 256, 2, 32, True, True),       # FETA_MAX_NODES
+])
+def test_attn(hip, bsz, n, h, dh, use_pe, seq_first):
+    abi, dev, stream = hip
+    KC.check_attn(abi, dev, stream, bsz, n, h, dh, use_pe, seq_first)
+
+
+def test_attn_no_attn_write(hip):
+    abi, dev, stream = hip
+    KC.check_attn(abi, dev, stream, 2, 21, 2, 16, True, write_attn=False)
+
+
+def test_attn_clamped_rows(hip):
+    abi, dev, stream = hip
+    KC.check_attn(abi, dev, stream, 2, 19, 2, 16, True, clamp_case=True)
+
+
+@pytest.mark.parametrize('bsz,n,h,c,faithful', [(3, 12, 2, 64, True), (2, 37, 4, 256, True),
+                                                (1, 5, 1, 16, True), (16, 37, 4, 1024, False),
+                                                (2, 200, 4, 1024, False)])
+def test_coeff(hip, bsz, n, h, c, faithful):
+    abi, dev, stream = hip
+    KC.check_coeff(abi, dev, stream, bsz, n, h, c, faithful=faithful)
+
+
+@pytest.mark.parametrize('directed', [False, True])
+def test_lhat_from_edges(hip, directed):
+    abi, dev, stream = hip
+    KC.check_lhat(abi, dev, stream, bsz=16, directed=directed)
+
+
+@pytest.mark.parametrize('mode', ['cheb', 'spec'])
+@pytest.mark.parametrize('share', [0, 1])
+@pytest.mark.parametrize('bsz,h,dh,order,shape,n_min,n_max,seq_first', [
+    (3, 2, 16, 4, 'zinc', None, None, True),
+    (2, 4, 16, 4, 'mutag', None, None, False),
+    (2, 2, 8, 3, 'zinc', 2, 20, True),
+    (2, 1, 32, 2, 'zinc', 17, 40, True),
+    (1, 2, 16, 1, 'zinc', None, None, True),
+    (2, 2, 16, 5, 'pattern', 44, 70, True),
+    (32, 4, 16, 4, 'zinc', None, None, True),
+    (4, 4, 16, 4, 'pattern', 100, 188, True),
+    (2, 1, 64, 4, 'zinc', 30, 60, True),
+])
+def test_filter_exact(hip, mode, share, bsz, h, dh, order, shape, n_min, n_max, seq_first):
+    abi, dev, stream = hip
+    KC.check_filter(abi, dev, stream, mode, bsz, h, dh, order, share, shape=shape, n_min=n_min,
+                    n_max=n_max, seq_first=seq_first)
+
+
+def test_cheb_directed_graph(hip):
+    abi, dev, stream = hip
+    KC.check_filter(abi, dev, stream, 'cheb', 2, 2, 16, 4, 1, directed=True)
+
+
+@pytest.mark.parametrize('k_eig,bsz', [(8, 3), (16, 3), (16, 64), (32, 4)])
+def test_spec_truncated(hip, k_eig, bsz):
+    abi, dev, stream = hip
+    shape = 'pattern' if k_eig == 32 else 'zinc'
+    KC.check_filter(abi, dev, stream, 'spec', bsz, 4, 16, 4, 1, k_eig=k_eig, shape=shape)
+    KC.check_filter(abi, dev, stream, 'spec', 2, 2, 16, 4, 0, k_eig=k_eig)
+
+
+def test_bad_arguments_raise(hip):
+    abi, dev, stream = hip
+    q = torch.zeros(2, 300, 2, 16, device=dev)
+    with pytest.raises(ValueError):
+        abi.attn_fwd(q, q, q, None, torch.ones(2, dtype=torch.int32, device=dev), torch.zeros_like(q),
+                     None, torch.zeros(2, 2, 300, 2, device=dev), 0.25, stream)

@@ -1,0 +1,126 @@
+"""Host logic (autograd Functions + nn.Modules mirroring the reference API) against the oracle,
+with the kernels running in the host SIMT emulation (test hook _lib.override_for_tests)."""
+import pytest
+import torch
+
+import kernel_checks as KC
+from feta_tmlr_amd import _lib
+from feta_tmlr_amd.transformer import data as D
+from feta_tmlr_amd.transformer.ChebNetDynamic import ChebConvDynamic
+from feta_tmlr_amd.transformer.models import DiffGraphTransformerGenGCN
+from oracle import feta_oracle as O
+
+
+def _model_case(batch_norm, share, mode, pe_on, seed=0, bsz=3, d=32, heads=2, layers=2, order=3,
+                in_dim=12):
+    torch.manual_seed(seed)
+    model = DiffGraphTransformerGenGCN(in_dim, 1, d, heads, dim_feedforward=2 * d, dropout=0.0,
+                                       nb_layers=layers, batch_norm=batch_norm, filter_order=order,
+                                       heads_share_graph=bool(share), filter_mode=mode)
+    # non-trivial values for the zero-initialised parameters
+    with torch.no_grad():
+        model.encoder.spectral_gnns.bias.normal_(0, 0.1)
+        model.encoder.gcn.bias.normal_(0, 0.1)
+        for l in model.encoder.layers:
+            l.self_attn.out_proj.bias.normal_(0, 0.1)
+    ds = D.SyntheticGraphDataset('mutag', bsz, in_dim=in_dim, seed=seed, pos_enc=pe_on, n_min=5, n_max=19)
+    n_pad = max(g.num_nodes for g in ds.samples)
+    batch9, cache = D.collate(ds.samples, k_eig=n_pad if mode == 'spectral' else None)
+    return model, batch9, cache
+
+
+@pytest.mark.parametrize('batch_norm,share,mode,pe_on', [
+    (False, 0, 'cheb', True),
+    (True, 0, 'cheb', False),
+    (False, 1, 'cheb', True),
+    (False, 1, 'spectral', True),
+    (True, 0, 'spectral', True),
+])
+def test_model_forward_backward_matches_oracle(emu, batch_norm, share, mode, pe_on):
+    model, batch9, cache = _model_case(batch_norm, share, mode, pe_on)
+    x, mask, pe, _, degree, labels, edge_index, batch, fi = batch9
+    x = x.clone().requires_grad_(True)
+    with _lib.override_for_tests(emu):
+        out, _, coeff = model(x, edge_index, batch, fi, mask, pe, degree=degree,
+                              return_filter_coeff=True, graph_cache=cache)
+        w = torch.linspace(0.5, 1.5, out.numel()).view_as(out)
+        ((out * w).sum() + 0.01 * coeff.pow(2).sum()).backward()
+
+    p64 = {k: v.detach().double().clone().requires_grad_(True) for k, v in model.state_dict().items()
+           if v.dtype.is_floating_point}
+    x64 = x.detach().double().requires_grad_(True)
+    out_ref, coeff_ref = O.graph_transformer_gengcn(
+        x64, edge_index, batch, fi, mask, None if pe is None else pe.double(),
+        None if degree is None else degree.double(), p64,
+        num_layers=len(model.encoder.layers), num_heads=model.encoder.num_heads,
+        order=model.encoder.order, batch_norm=batch_norm, heads_share_graph=bool(share))
+    ((out_ref * w.double()).sum() + 0.01 * coeff_ref.pow(2).sum()).backward()
+
+    KC.assert_close('model output', out, out_ref)
+    KC.assert_close('coefficients', coeff, coeff_ref)
+    KC.assert_close('dx', x.grad, x64.grad, tol=2e-5)
+    for name, p in model.named_parameters():
+        ref = p64[name].grad
+        if p.grad is None:
+            assert ref is None or float(ref.abs().max()) == 0.0, name
+            continue
+        KC.assert_close('grad ' + name, p.grad, ref, tol=2e-5)
+
+
+def test_unused_outer_gcn_has_no_grad(emu):
+    """transformer/models.py:508 registers a GCNConv the forward never uses (matters for the
+    data-parallel gradient bucket)."""
+    model, batch9, cache = _model_case(False, 0, 'cheb', True)
+    x, mask, pe, _, degree, _, edge_index, batch, fi = batch9
+    with _lib.override_for_tests(emu):
+        out, _ = model(x, edge_index, batch, fi, mask, pe, degree=degree, graph_cache=cache)
+        out.sum().backward()
+    assert model.gcn.weight.grad is None and model.gcn.bias.grad is None
+
+
+def test_encoder_without_graph_cache(emu):
+    """Drop-in call with the reference's arguments only: Lhat and n_real derived on the fly."""
+    model, batch9, cache = _model_case(False, 0, 'cheb', True)
+    x, mask, pe, _, degree, _, edge_index, batch, fi = batch9
+    with _lib.override_for_tests(emu):
+        a, _ = model(x, edge_index, batch, fi, mask, pe, degree=degree, graph_cache=cache)
+        b, _ = model(x, edge_index, batch, fi, mask, pe, degree=degree)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('scalar_mode', [False, True])
+def test_chebconvdynamic_operator_api(emu, scalar_mode):
+    """ChebConvDynamic.forward(x, edge_index, filter_coeff, batch=) on the gathered node list,
+    including groups that edge_index does not cover (the stacked-heads quirk)."""
+    torch.manual_seed(1)
+    bsz, heads, dh, order = 3, 2, 8, 4
+    ds = D.SyntheticGraphDataset('mutag', bsz, in_dim=4, seed=3, n_min=4, n_max=15)
+    batch9, cache = D.collate(ds.samples)
+    edge_index, batch = batch9[6], batch9[7]
+    n_tot = batch.shape[0]
+    conv = ChebConvDynamic(dh, dh, order, learn_only_filter_order_coeff=scalar_mode)
+    with torch.no_grad():
+        conv.bias.normal_(0, 0.1)
+    x = torch.randn(heads * n_tot, dh, requires_grad=True)
+    groups = heads * bsz
+    fc = torch.randn(order, groups, requires_grad=True) if scalar_mode else \
+        (torch.randn(order, groups, dh, dh) / dh ** 0.5).requires_grad_(True)
+    batch_all = torch.cat([batch + i * bsz for i in range(heads)])
+    with _lib.override_for_tests(emu):
+        y = conv(x, edge_index, fc, batch=batch_all)       # edge_index covers head 0 only
+        y.pow(2).sum().backward()
+    x64 = x.detach().double().requires_grad_(True)
+    fc64 = fc.detach().double().requires_grad_(True)
+    w64 = fc64 if not scalar_mode else fc64[:, :, None, None] * conv.weight.detach().double()[:, None]
+    y_ref = O.cheb_conv_dynamic_edges(x64, edge_index, w64, batch_all, conv.bias.detach().double())
+    y_ref.pow(2).sum().backward()
+    KC.assert_close('y', y, y_ref)
+    KC.assert_close('dx', x.grad, x64.grad, tol=2e-5)
+    KC.assert_close('dcoeff', fc.grad, fc64.grad, tol=2e-5)
+
+
+def test_ops_refuse_cpu_tensors_without_hook():
+    from feta_tmlr_amd import functional as FF
+    from feta_tmlr_amd._abi import FetaError
+    with pytest.raises(FetaError):
+        FF.attention_core(torch.zeros(4, 2, 48), None, torch.ones(2, dtype=torch.int32), 2)

@@ -60,8 +60,8 @@ void block_barrier() { arrive(block_bar); }
 
 void run_grid(const std::function<void()>& body, dim3 grid, dim3 block) {
   const int nt = (int)block.x;
-  if (block.y != 1 || block.z != 1 || grid.y != 1 || grid.z != 1) {
-    fprintf(stderr, "simt: only 1-D launches are emulated\n");
+  if (block.y != 1 || block.z != 1 || grid.z != 1) {
+    fprintf(stderr, "simt: only 1-D blocks and 2-D grids are emulated\n");
     abort();
   }
   if ((int)lanes.size() < nt) {
@@ -75,8 +75,9 @@ void run_grid(const std::function<void()>& body, dim3 grid, dim3 block) {
   body_ = &body;
   gridDim_ = grid;
   blockDim_ = block;
-  for (unsigned bx = 0; bx < grid.x; ++bx) {
-    blockIdx_ = dim3(bx, 0, 0);
+  for (unsigned bxy = 0; bxy < grid.x * grid.y; ++bxy) {
+    const unsigned bx = bxy % grid.x;
+    blockIdx_ = dim3(bx, bxy / grid.x, 0);
     for (int w = 0; w < nw; ++w) {
       wave_bars[w] = Barrier();
       wave_bars[w].n = (w == nw - 1) ? nt - 64 * w : 64;
