@@ -33,6 +33,25 @@ from feta_tmlr_amd.transformer import data as D                           # noqa
 from feta_tmlr_amd.transformer.layers import DiffTransformerEncoderLayer  # noqa: E402
 from feta_tmlr_amd.transformer.models import DiffTransformerEncoderGenGCN  # noqa: E402
 
+def log(msg):
+    sys.stderr.write('[bench %.1fs] %s\n' % (time.perf_counter() - _T0, msg))
+    sys.stderr.flush()
+
+
+def host_cores():
+    """CPU threads this process may really use: affinity mask, cgroup quota, capped at the GPU
+    box's per-GPU share of 16."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+_T0 = time.perf_counter()
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -131,7 +150,7 @@ def cpu_baseline(args, cpu, enc):
     """Reference-faithful CPU restatement (edge-list recursion, per-node weight copies, the
     un-collapsed GCNConv on ones, Python loop over H*B blocks), PyTorch CPU fp32, all host cores."""
     from oracle import feta_oracle as O
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     p = {k: v.detach().cpu().float() for k, v in enc.state_dict().items() if v.dtype.is_floating_point}
     sub = args.batch                               # the whole per-GPU batch, a few steps
@@ -150,6 +169,7 @@ def cpu_baseline(args, cpu, enc):
         (out * cpu['dout'][:, :sub]).sum().backward()
 
     step()
+    log('cpu baseline warm-up step done')
     t0 = time.perf_counter()
     for _ in range(args.cpu_steps):
         step()
@@ -172,7 +192,9 @@ def main():
         dist.init_process_group('nccl', device_id=dev)
     _lib.abi()
 
+    log('library loaded')
     cpu, gpu = make_batch(args, rank, dev)
+    log('batch built')
     enc = build_encoder(args).to(dev)
     enc.train()
     params = [p for p in enc.parameters()]
@@ -184,6 +206,9 @@ def main():
                         degree=gpu['degree'], src_key_padding_mask=gpu['mask'], graph_cache=gpu['cache'])
         (out * gpu['dout']).sum().backward()
 
+    fwd_bwd()
+    torch.cuda.synchronize()
+    log('first eager step done')
     use_graph = not args.no_graph
     graph = None
     if use_graph:
@@ -206,6 +231,7 @@ def main():
         if world > 1:
             reducer.all_reduce()
 
+    log('graph captured' if graph is not None else 'eager mode')
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -242,7 +268,9 @@ def main():
                        'heads_share_graph': True, 'hip_graph': bool(use_graph),
                        'parallelism': 'dp%d' % world},
         }
+        log('timed region done: %.3f ms/step' % (dt / args.steps * 1e3))
         res['roofline'] = roofline(args, gpu, dev)
+        log('roofline kernel timed')
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args, cpu, enc)
         print(json.dumps(res))

@@ -327,27 +327,24 @@ __global__ __launch_bounds__(64 * kWaves) void attn_bwd_dkdv_kernel(AttnArgs a) 
   }
 }
 
+template <int DH, int KT_MAX>
+void launch_fwd_t(const AttnArgs& a, hipStream_t stream) {
+  const dim3 grid((a.total + kWaves - 1) / kWaves), block(64 * kWaves);
+  // per-wave staging block of the probability tile: 16 rows x (16 KT_MAX + 1) floats
+  const size_t lds = a.attn != nullptr ? sizeof(float) * kWaves * 16 * (16 * KT_MAX + 1) : 0;
+  auto kern = attn_fwd_kernel<DH, KT_MAX>;
+  if (lds > 64 * 1024)  // KT_MAX = 16: 65.8 KB, above the 64 KB default dynamic-LDS cap
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
+}
+
 template <int DH>
 int launch_fwd(const AttnArgs& a, int kt_max, hipStream_t stream) {
-  const dim3 grid((a.total + kWaves - 1) / kWaves), block(64 * kWaves);
-  const size_t lds = a.attn != nullptr ? sizeof(float) * kWaves * 16 * (16 * kt_max + 1) : 0;
-  if (kt_max <= 3) {
-    auto kern = attn_fwd_kernel<DH, 3>;
-    hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
-  } else if (kt_max <= 4) {
-    auto kern = attn_fwd_kernel<DH, 4>;
-    hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
-  } else if (kt_max <= 8) {
-    auto kern = attn_fwd_kernel<DH, 8>;
-    hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
-  } else {
-    auto kern = attn_fwd_kernel<DH, 16>;
-    // 4 waves x 16 x 257 floats = 65.8 KB: above the 64 KB default dynamic-LDS cap
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
-  }
+  if (kt_max <= 3) launch_fwd_t<DH, 3>(a, stream);
+  else if (kt_max <= 4) launch_fwd_t<DH, 4>(a, stream);
+  else if (kt_max <= 8) launch_fwd_t<DH, 8>(a, stream);
+  else launch_fwd_t<DH, 16>(a, stream);
   return check_launch("feta_attn_fwd");
 }
 

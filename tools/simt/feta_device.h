@@ -10,7 +10,7 @@ struct f32x4 {
   const float& operator[](int i) const { return v[i]; }
 };
 
-extern float feta_lds[];
+extern float* feta_lds;  // sized per launch, NaN-poisoned guard behind it (simt_runtime.cpp)
 
 namespace feta {
 

@@ -48,7 +48,7 @@ struct WaveScratch {
 WaveScratch& wave_scratch();   // scratch of the CURRENT lane's wave
 void wave_barrier();           // all lanes of the current wave
 void block_barrier();          // all lanes of the workgroup
-void run_grid(const std::function<void()>& body, dim3 grid, dim3 block);
+void run_grid(const std::function<void()>& body, dim3 grid, dim3 block, size_t lds_bytes);
 constexpr int kLdsBytes = 160 * 1024;
 }  // namespace simt
 
@@ -71,8 +71,8 @@ struct float2 { float x, y; };
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 
 template <class K, class... A>
-inline void simt_launch(K kernel, dim3 grid, dim3 block, A... args) {
-  simt::run_grid([&]() { kernel(args...); }, grid, block);
+inline void simt_launch(K kernel, dim3 grid, dim3 block, size_t lds, A... args) {
+  simt::run_grid([&]() { kernel(args...); }, grid, block, lds);
 }
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
-  simt_launch(kernel, dim3(grid), dim3(block), __VA_ARGS__)
+  simt_launch(kernel, dim3(grid), dim3(block), (size_t)(lds), __VA_ARGS__)

@@ -4,7 +4,7 @@
 
 #include <vector>
 
-float feta_lds[simt::kLdsBytes / 4];
+float* feta_lds = nullptr;
 
 namespace simt {
 
@@ -58,7 +58,17 @@ WaveScratch& wave_scratch() { return scratch[cur->tid >> 6]; }
 void wave_barrier() { arrive(wave_bars[cur->tid >> 6]); }
 void block_barrier() { arrive(block_bar); }
 
-void run_grid(const std::function<void()>& body, dim3 grid, dim3 block) {
+void run_grid(const std::function<void()>& body, dim3 grid, dim3 block, size_t lds_bytes) {
+  // dynamic LDS of exactly the requested size; the guard behind it is NaN-poisoned so that a
+  // kernel touching more LDS than the launch asked for reads NaN (and is reported below)
+  constexpr size_t kGuard = 64 * 1024 / 4;
+  const size_t lds_n = (lds_bytes + 3) / 4;
+  if (lds_bytes > (size_t)kLdsBytes) {
+    fprintf(stderr, "simt: %zu bytes of LDS requested, CU has %d\n", lds_bytes, kLdsBytes);
+    abort();
+  }
+  std::vector<float> lds_store(lds_n + kGuard);
+  feta_lds = lds_store.data();
   const int nt = (int)block.x;
   if (block.y != 1 || block.z != 1 || grid.z != 1) {
     fprintf(stderr, "simt: only 1-D blocks and 2-D grids are emulated\n");
@@ -76,6 +86,7 @@ void run_grid(const std::function<void()>& body, dim3 grid, dim3 block) {
   gridDim_ = grid;
   blockDim_ = block;
   for (unsigned bxy = 0; bxy < grid.x * grid.y; ++bxy) {
+    for (size_t i = 0; i < lds_n + kGuard; ++i) lds_store[i] = __builtin_nanf("");
     const unsigned bx = bxy % grid.x;
     blockIdx_ = dim3(bx, bxy / grid.x, 0);
     for (int w = 0; w < nw; ++w) {
@@ -108,6 +119,14 @@ void run_grid(const std::function<void()>& body, dim3 grid, dim3 block) {
         progress = true;
         if (l.done) --remaining;
       }
+      if (remaining == 0) {
+        for (size_t i = lds_n; i < lds_n + kGuard; ++i)
+          if (lds_store[i] == lds_store[i]) {
+            fprintf(stderr, "simt: block %u wrote LDS word %zu, beyond the %zu bytes the launch requested\n",
+                    bx, i, lds_bytes);
+            abort();
+          }
+      }
       if (!progress) {
         fprintf(stderr, "simt: deadlock in block %u (divergent collective or early exit before a barrier)\n", bx);
         abort();
@@ -115,6 +134,7 @@ void run_grid(const std::function<void()>& body, dim3 grid, dim3 block) {
     }
   }
   cur = nullptr;
+  feta_lds = nullptr;
 }
 
 }  // namespace simt
