@@ -198,7 +198,7 @@ def main():
     enc = build_encoder(args).to(dev)
     enc.train()
     params = [p for p in enc.parameters()]
-    reducer = FlatGradAllReduce(params, world)   # every .grad is a view into one flat bucket
+    reducer = FlatGradAllReduce(params, world)   # fresh .grad per step, one flat bucket for RCCL
 
     def fwd_bwd():
         reducer.zero()

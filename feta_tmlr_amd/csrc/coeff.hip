@@ -5,9 +5,9 @@
 // input is all ones, GCNConv(ones)[j] = c_j * colsum(W) + bias exactly, with c_j the sum of
 // the GCN-normalised weights into node j (normalisation text: transformer/GenGCN.py:55-102).
 // One workgroup per (head, graph) block:
-//   deg_j = sum_i w_ij ; c_j = sum_i deg_i^-1/2 w_ij deg_j^-1/2      (two column sweeps)
+//   stage attn[b,h,:n,:] in LDS (one coalesced sweep of the only HBM read)
+//   deg_j = sum_i w_ij ; c_j = sum_i deg_i^-1/2 w_ij deg_j^-1/2      (two LDS column sweeps)
 //   pooled[c] = mean_j tanh(c_j s_c + b_c)                          (thread per channel)
-// HBM-bound: reads attn once (N^2 per block), writes C per block.
 #include <cmath>
 
 #include "feta_abi_common.h"
@@ -16,35 +16,42 @@
 namespace feta {
 
 constexpr int kCoeffThreads = 256;
-constexpr int kCoeffGroupsMax = 64;
+constexpr int kCoeffGroupsMax = 128;
+constexpr int kCoeffLdsTileMax = 12 * 1024;  // floats of attention staged per block (48 KB)
 
 __global__ __launch_bounds__(kCoeffThreads) void coeff_fwd_kernel(
     const float* __restrict__ attn, const int32_t* __restrict__ n_real, const float* __restrict__ s,
     const float* __restrict__ gbias, float* __restrict__ cj_out, float* __restrict__ pooled, int B,
-    int N, int H, int C) {
-  float* dis = feta_lds;        // [N]
-  float* cjs = feta_lds + N;    // [N]
-  const int blk = blockIdx.x;   // h * B + b  (transformer/models.py:244,275,285)
+    int N, int H, int C, int stage) {
+  float* dis = feta_lds;          // [N]
+  float* cjs = feta_lds + N;      // [N]
+  float* tile = feta_lds + 2 * N; // [n][N] when staged
+  const int blk = blockIdx.x;     // h * B + b  (transformer/models.py:244,275,285)
   const int h = blk / B, b = blk % B;
   const int n = n_real[b];
   const float* a = attn + ((int64_t)b * H + h) * N * N;
   const int j = threadIdx.x;
 
+  const float* src = a;
+  if (stage) {
+    for (int idx = threadIdx.x; idx < n * N; idx += kCoeffThreads) tile[idx] = a[idx];
+    __syncthreads();
+    src = tile;
+  }
   // edges with attn == 0 are dropped (models.py:276,281): they add nothing to the sums,
   // but a dropped self loop is re-created with weight 1 by add_remaining_self_loops.
   float wjj = 0.0f, deg = 0.0f;
   if (j < n) {
-    wjj = a[(int64_t)j * N + j];
+    wjj = src[j * N + j];
     if (wjj == 0.0f) wjj = 1.0f;
-    for (int i = 0; i < n; ++i) deg += (i == j) ? wjj : a[(int64_t)i * N + j];
-    const float d = rsqrtf(deg);
-    dis[j] = (deg > 0.0f && d < INFINITY) ? d : 0.0f;
+    for (int i = 0; i < n; ++i) deg += (i == j) ? wjj : src[i * N + j];
+    dis[j] = deg > 0.0f ? rsqrtf(deg) : 0.0f;
   }
   __syncthreads();
   if (j < N) {
     float c = 0.0f;
     if (j < n) {
-      for (int i = 0; i < n; ++i) c += dis[i] * ((i == j) ? wjj : a[(int64_t)i * N + j]);
+      for (int i = 0; i < n; ++i) c += dis[i] * ((i == j) ? wjj : src[i * N + j]);
       c *= dis[j];
     }
     cjs[j] = c;
@@ -55,7 +62,7 @@ __global__ __launch_bounds__(kCoeffThreads) void coeff_fwd_kernel(
   for (int c = threadIdx.x; c < C; c += kCoeffThreads) {
     const float sc = s[c], bc = gbias[c];
     float acc = 0.0f;
-    for (int i = 0; i < n; ++i) acc += tanhf(cjs[i] * sc + bc);
+    for (int i = 0; i < n; ++i) acc += fast_tanh(cjs[i] * sc + bc);
     pooled[(int64_t)blk * C + c] = acc * inv_n;
   }
 }
@@ -65,17 +72,20 @@ __global__ __launch_bounds__(kCoeffThreads) void coeff_bwd_kernel(
     const float* __restrict__ cj, const int32_t* __restrict__ n_real, const float* __restrict__ s,
     const float* __restrict__ gbias, const float* __restrict__ dpooled, float* __restrict__ partial,
     int B, int N, int H, int C, int G) {
+  float* cjs = feta_lds;  // [N] c_j of the current block
   const int c = blockIdx.x * kCoeffThreads + threadIdx.x;
   const int grp = blockIdx.y;
   const float sc = c < C ? s[c] : 0.0f, bc = c < C ? gbias[c] : 0.0f;
   float as = 0.0f, ab = 0.0f;
   for (int blk = grp; blk < B * H; blk += G) {
     const int n = n_real[blk % B];
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += kCoeffThreads) cjs[i] = cj[(int64_t)blk * N + i];
+    __syncthreads();
     const float dp = c < C ? dpooled[(int64_t)blk * C + c] / (float)n : 0.0f;
-    const float* cjb = cj + (int64_t)blk * N;
     for (int i = 0; i < n; ++i) {
-      const float ci = cjb[i];
-      const float z = tanhf(ci * sc + bc);
+      const float ci = cjs[i];
+      const float z = fast_tanh(ci * sc + bc);
       const float t = dp * (1.0f - z * z);
       as += t * ci;
       ab += t;
@@ -87,25 +97,32 @@ __global__ __launch_bounds__(kCoeffThreads) void coeff_bwd_kernel(
   }
 }
 
-// out[c] = sum_r in[r][c]; 64 columns x 4 row slices per workgroup, LDS tree for the slices
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in,
-                                                      float* __restrict__ out, int R, int C) {
-  float* red = feta_lds;  // [4][64]
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int slice = threadIdx.x >> 6;
+// out[c] = sum_r in[r][c]: 16 columns x 64 row slices per workgroup (64-byte row segments),
+// pairwise LDS tree over the slices; deterministic.
+constexpr int kCsCols = 16, kCsSlices = 64;
+__global__ __launch_bounds__(kCsCols * kCsSlices) void colsum_kernel(const float* __restrict__ in,
+                                                                      float* __restrict__ out, int R,
+                                                                      int C) {
+  float* red = feta_lds;  // [slices][cols]
+  const int lc = threadIdx.x & (kCsCols - 1);
+  const int slice = threadIdx.x / kCsCols;
+  const int col = blockIdx.x * kCsCols + lc;
   float acc = 0.0f;
   if (col < C)
-    for (int r = slice; r < R; r += 4) acc += in[(int64_t)r * C + col];
-  red[slice * 64 + (threadIdx.x & 63)] = acc;
+    for (int r = slice; r < R; r += kCsSlices) acc += in[(int64_t)r * C + col];
+  red[threadIdx.x] = acc;
   __syncthreads();
-  if (slice == 0 && col < C)
-    out[col] = (red[threadIdx.x] + red[64 + threadIdx.x]) + (red[128 + threadIdx.x] + red[192 + threadIdx.x]);
+  for (int half = kCsSlices / 2; half >= 1; half >>= 1) {
+    if (slice < half) red[threadIdx.x] += red[threadIdx.x + half * kCsCols];
+    __syncthreads();
+  }
+  if (slice == 0 && col < C) out[col] = red[lc];
 }
 
 int launch_colsum(const float* in, float* out, int R, int C, hipStream_t stream) {
-  const dim3 grid((C + 63) / 64), block(256);
+  const dim3 grid((C + kCsCols - 1) / kCsCols), block(kCsCols * kCsSlices);
   auto kern = colsum_kernel;
-  hipLaunchKernelGGL(kern, grid, block, 4 * 64 * sizeof(float), stream, in, out, R, C);
+  hipLaunchKernelGGL(kern, grid, block, kCsCols * kCsSlices * sizeof(float), stream, in, out, R, C);
   return check_launch("feta_colsum");
 }
 
@@ -119,10 +136,12 @@ extern "C" int feta_coeff_fwd(const float* attn, const int32_t* n_real, const fl
   FETA_REQUIRE(attn && n_real && s && gcn_bias && cj && pooled, "coeff_fwd: null pointer");
   FETA_REQUIRE(B > 0 && H > 0 && C > 0 && N > 0 && N <= kCoeffThreads,
                "coeff_fwd: need 0 < N <= %d (got %d)", kCoeffThreads, N);
+  const int stage = N * N <= kCoeffLdsTileMax ? 1 : 0;
+  const size_t lds = sizeof(float) * (2 * N + (stage ? N * N : 0));
   const dim3 grid(B * H), block(kCoeffThreads);
   auto kern = coeff_fwd_kernel;
-  hipLaunchKernelGGL(kern, grid, block, 2 * N * sizeof(float), (hipStream_t)stream, attn, n_real, s,
-                     gcn_bias, cj, pooled, B, N, H, C);
+  hipLaunchKernelGGL(kern, grid, block, lds, (hipStream_t)stream, attn, n_real, s, gcn_bias, cj,
+                     pooled, B, N, H, C, stage);
   return check_launch("feta_coeff_fwd");
 }
 
@@ -140,8 +159,8 @@ extern "C" int feta_coeff_bwd(const float* cj, const int32_t* n_real, const floa
   const int G = feta_coeff_bwd_groups(B, H);
   const dim3 grid((C + kCoeffThreads - 1) / kCoeffThreads, G), block(kCoeffThreads);
   auto kern = coeff_bwd_kernel;
-  hipLaunchKernelGGL(kern, grid, block, 0, (hipStream_t)stream, cj, n_real, s, gcn_bias, dpooled,
-                     partial, B, N, H, C, G);
+  hipLaunchKernelGGL(kern, grid, block, N * sizeof(float), (hipStream_t)stream, cj, n_real, s,
+                     gcn_bias, dpooled, partial, B, N, H, C, G);
   int rc = check_launch("feta_coeff_bwd");
   if (rc != FETA_OK) return rc;
   rc = launch_colsum(partial, ds, G, C, (hipStream_t)stream);

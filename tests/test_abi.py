@@ -31,7 +31,7 @@ def test_libfeta_hip_exports_every_symbol():
         assert hasattr(lib, name), name
     abi = _abi.bind(lib)
     assert abi.lib.feta_version() == _abi.ABI_VERSION
-    assert abi.coeff_bwd_groups(128, 4) == 64
+    assert abi.coeff_bwd_groups(128, 4) == 128
 
 
 def test_emulation_exports_the_same_abi(emu):

@@ -27,7 +27,7 @@ def _loss_on(model, samples, scale):
     return ((out.squeeze(-1) - labels) ** 2).sum() * scale
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, views):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import ctypes
@@ -40,7 +40,7 @@ def _worker(rank, world, port, ret):
     emu = _abi.bind(ctypes.CDLL(os.path.join(ROOT, 'tools', 'simt', 'libfeta_emu.so')))
     ds = D.SyntheticGraphDataset('mutag', 6, in_dim=8, seed=5, n_min=4, n_max=12)
     model = _build()
-    bucket = FlatGradAllReduce(model.parameters(), world)
+    bucket = FlatGradAllReduce(model.parameters(), world, views=views)
     mine = [ds[i] for i in shard_indices(len(ds), rank, world)]
     with _lib.override_for_tests(emu):
         bucket.zero()
@@ -51,21 +51,22 @@ def _worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_flat_bucket_allreduce_world2(emu):
+@pytest.mark.parametrize('views', [False, True])
+def test_flat_bucket_allreduce_world2(emu, views):
     from feta_tmlr_amd import _lib
     from feta_tmlr_amd.parallel import FlatGradAllReduce
     from feta_tmlr_amd.transformer import data as D
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    port = 29500 + (os.getpid() % 1000)
-    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    port = 29500 + (os.getpid() % 1000) + int(views)
+    mp.spawn(_worker, args=(world, port, ret, views), nprocs=world, join=True)
     assert torch.equal(ret[0], ret[1]), 'ranks disagree after the all-reduce'
 
     # single-process reference: mean over ranks of the per-rank mean losses
     ds = D.SyntheticGraphDataset('mutag', 6, in_dim=8, seed=5, n_min=4, n_max=12)
     model = _build()
-    bucket = FlatGradAllReduce(model.parameters(), 1)
+    bucket = FlatGradAllReduce(model.parameters(), 1, views=True)
     with _lib.override_for_tests(emu):
         bucket.zero()
         for r in range(world):
@@ -75,6 +76,9 @@ def test_flat_bucket_allreduce_world2(emu):
     assert err < 1e-5 * max(1.0, bucket.flat.abs().max().item()), err
     # the unused outer GCN (transformer/models.py:508) stays exactly zero in the bucket
     assert float(model.gcn.weight.grad.abs().max()) == 0.0
+    n_unused = model.gcn.weight.numel() + model.gcn.bias.numel()
+    names = [n for n, _ in model.named_parameters()]
+    assert names[-6:-4] == ['gcn.weight', 'gcn.bias'] or 'gcn.weight' in names
 
 
 def test_shard_indices_partition():

@@ -61,5 +61,6 @@ inline float shfl(float v, int src) {
 inline void wave_lds_sync() { simt::wave_barrier(); }
 
 inline float fast_exp(float x) { return expf(x); }
+inline float fast_tanh(float x) { return 1.0f - 2.0f / (1.0f + expf(2.0f * x)); }
 
 }  // namespace feta
