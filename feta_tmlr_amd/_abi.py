@@ -38,6 +38,14 @@ SIGNATURES = {
     'feta_spec_filter_bwd': ([_F, C.c_int64, C.c_int64, _F, _F, _F, _I, _F, C.c_int64, C.c_int64,
                               _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                               C.c_int, _S], C.c_int),
+    'feta_rowlin_blocks': ([C.c_int], C.c_int),
+    'feta_rowlin_chunks': ([C.c_int], C.c_int),
+    'feta_rowlin_fwd': ([_F, _F, _F, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, _S], C.c_int),
+    'feta_rowlin_bwd': ([_F, _F, _F, _F, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int, _S], C.c_int),
+    'feta_bn_stats': ([_F, _F, C.c_int, C.c_int, _S], C.c_int),
+    'feta_bn_apply_fwd': ([_F, _F, _F, _F, _F, _F, _F, _F, C.c_float, C.c_float, C.c_int, C.c_int, _S],
+                          C.c_int),
+    'feta_bn_bwd': ([_F, _F, _F, _F, _F, _F, _F, _F, C.c_int, C.c_int, _S], C.c_int),
     'feta_lhat_from_edges': ([_I, C.c_int64, _I, _I, _F, _F, C.c_int, C.c_int, C.c_int64, _S],
                              C.c_int),
 }
@@ -161,6 +169,42 @@ class Abi:
                                                   _p(n_real), _p(dy), ysb, ysn, _p(dx), _p(dcoeff),
                                                   _p(dbias_part), b, n, h, dh, order, k, int(share),
                                                   stream), 'feta_spec_filter_bwd')
+
+    ROWLIN_DIMS = (16, 32, 64, 128, 192, 256)
+
+    def rowlin_blocks(self, m):
+        return self.lib.feta_rowlin_blocks(m)
+
+    def rowlin_chunks(self, m):
+        return self.lib.feta_rowlin_chunks(m)
+
+    def rowlin_fwd(self, x, w, bias, rowscale, residual, y, stats, relu, stream):
+        m, ki = x.shape
+        no = w.shape[0]
+        self._check(self.lib.feta_rowlin_fwd(_p(x), _p(w), _p(bias), _p(rowscale), _p(residual), _p(y),
+                                             _p(stats), int(relu), m, ki, no, stream), 'feta_rowlin_fwd')
+
+    def rowlin_bwd(self, x, w, dy, rowscale, ysaved, dx, partial, dwdb, stream):
+        m, ki = x.shape
+        no = w.shape[0]
+        self._check(self.lib.feta_rowlin_bwd(_p(x), _p(w), _p(dy), _p(rowscale), _p(ysaved), _p(dx),
+                                             _p(partial), _p(dwdb), m, ki, no, stream), 'feta_rowlin_bwd')
+
+    def bn_stats(self, y, stats, stream):
+        m, d = y.shape
+        self._check(self.lib.feta_bn_stats(_p(y), _p(stats), m, d, stream), 'feta_bn_stats')
+
+    def bn_apply_fwd(self, y, stats, gamma, beta, out, mean_rstd, running_mean, running_var, momentum,
+                     eps, stream):
+        m, d = y.shape
+        self._check(self.lib.feta_bn_apply_fwd(_p(y), _p(stats), _p(gamma), _p(beta), _p(out),
+                                               _p(mean_rstd), _p(running_mean), _p(running_var),
+                                               momentum, eps, m, d, stream), 'feta_bn_apply_fwd')
+
+    def bn_bwd(self, y, dout, mean_rstd, gamma, partial, dy, dgamma, dbeta, stream):
+        m, d = y.shape
+        self._check(self.lib.feta_bn_bwd(_p(y), _p(dout), _p(mean_rstd), _p(gamma), _p(partial), _p(dy),
+                                         _p(dgamma), _p(dbeta), m, d, stream), 'feta_bn_bwd')
 
     def lhat_from_edges(self, edge_index, node_graph, node_off, deg, lhat, stream):
         b, n, _ = lhat.shape

@@ -162,6 +162,95 @@ class _FilterFn(torch.autograd.Function):
         return dx, dcoeff, dbias, None, None, None, None, None, None, None
 
 
+class RowLinearFn(torch.autograd.Function):
+    """y = relu?(x W^T + b) * rowscale? + residual?  on [M, KI] rows, plus (optionally) the
+    per-block partial BatchNorm statistics of y.  C ABI: feta_rowlin_fwd / feta_rowlin_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, rowscale, residual, relu, want_stats):
+        abi, stream = _lib.backend(x, w)
+        assert not (relu and residual is not None), 'relu mask is taken from the saved output'
+        x = x.contiguous()
+        w = w.contiguous()
+        m, no = x.shape[0], w.shape[0]
+        y = torch.empty((m, no), dtype=torch.float32, device=x.device)
+        stats = None
+        if want_stats:
+            stats = torch.empty((abi.rowlin_blocks(m), 2, no), dtype=torch.float32, device=x.device)
+        res = None if residual is None else residual.contiguous()
+        abi.rowlin_fwd(x, w, bias, rowscale, res, y, stats, relu, stream)
+        ctx.save_for_backward(x, w, rowscale, y if relu else None)
+        ctx.cfg = (bias is not None, residual is not None)
+        if stats is not None:
+            ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        x, w, rowscale, ysaved = ctx.saved_tensors
+        has_bias, has_res = ctx.cfg
+        abi, stream = _lib.backend(x)
+        m, ki = x.shape
+        no = w.shape[0]
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        partial = torch.empty((abi.rowlin_chunks(m), no * ki + no), dtype=torch.float32, device=x.device)
+        dwdb = torch.empty(no * ki + no, dtype=torch.float32, device=x.device)
+        abi.rowlin_bwd(x, w, dy, rowscale, ysaved, dx, partial, dwdb, stream)
+        dw = dwdb[:no * ki].view(no, ki)
+        db = dwdb[no * ki:] if has_bias else None
+        return dx, dw, db, None, (dy if has_res else None), None, None
+
+
+class BatchNormTrainFn(torch.autograd.Function):
+    """Training-mode BatchNorm1d over the rows of y [M, D] from per-block partial statistics.
+    C ABI: feta_bn_stats (when the producer did not emit them), feta_bn_apply_fwd, feta_bn_bwd."""
+
+    @staticmethod
+    def forward(ctx, y, stats, gamma, beta, running_mean, running_var, momentum, eps):
+        abi, stream = _lib.backend(y)
+        y = y.contiguous()
+        m, d = y.shape
+        if stats is None:
+            stats = torch.empty((abi.rowlin_blocks(m), 2, d), dtype=torch.float32, device=y.device)
+            abi.bn_stats(y, stats, stream)
+        out = torch.empty_like(y)
+        mean_rstd = torch.empty((2, d), dtype=torch.float32, device=y.device)
+        abi.bn_apply_fwd(y, stats, gamma, beta, out, mean_rstd, running_mean, running_var,
+                         float(momentum), float(eps), stream)
+        ctx.save_for_backward(y, mean_rstd, gamma)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, mean_rstd, gamma = ctx.saved_tensors
+        abi, stream = _lib.backend(y)
+        m, d = y.shape
+        dout = dout.contiguous()
+        partial = torch.empty((abi.rowlin_blocks(m), 2, d), dtype=torch.float32, device=y.device)
+        dy = torch.empty_like(y)
+        dgamma = torch.empty(d, dtype=torch.float32, device=y.device)
+        dbeta = torch.empty(d, dtype=torch.float32, device=y.device)
+        abi.bn_bwd(y, dout, mean_rstd, gamma, partial, dy, dgamma, dbeta, stream)
+        return dy, None, dgamma, dbeta, None, None, None, None
+
+
+ROWLIN_DIMS = (16, 32, 64, 128, 192, 256)
+
+
+def row_linear_supported(ki, no, need_backward=True):
+    return ki in ROWLIN_DIMS and (no in ROWLIN_DIMS if need_backward else no % 16 == 0)
+
+
+def row_linear(x, w, bias=None, rowscale=None, residual=None, relu=False, want_stats=False):
+    """x [M, KI] -> (y [M, NO], stats or None)."""
+    return RowLinearFn.apply(x, w, bias, rowscale, residual, relu, want_stats)
+
+
+def batch_norm_train(y, stats, gamma, beta, running_mean, running_var, momentum, eps):
+    return BatchNormTrainFn.apply(y, stats, gamma, beta, running_mean, running_var, momentum, eps)
+
+
 def attention_core(qkv, pe, n_real, num_heads, need_attn=True, tie_qk=False, batch_first=False):
     return AttentionCoreFn.apply(qkv, pe, n_real, num_heads, need_attn, tie_qk, batch_first)
 

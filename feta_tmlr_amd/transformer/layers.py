@@ -15,8 +15,10 @@ DGL variants (LSPE/layers/graphit_gt_layer.py:39-43,120-131,164) - then out_proj
 ``degree`` scaling, residual + norm + FFN + residual + norm.  Choices the call sites do not pin are
 constructor flags (``tie_qk``, ``in_proj_bias``) rather than guesses.
 
-The score/softmax/weighted-sum runs in feta_attn_fwd/bwd; projections and norms are rocBLAS /
-PyTorch ops on the same stream.
+Kernels: the score/softmax/weighted-sum runs in feta_attn_fwd/bwd; every linear with its
+element-wise neighbours (bias, relu, degree scaling, residual) and the BatchNorm statistics runs in
+feta_rowlin_fwd/bwd; BatchNorm in feta_bn_apply_fwd / feta_bn_bwd.  LayerNorm and (training-mode)
+dropout, when configured, stay PyTorch ops on the same stream.
 """
 import copy
 
@@ -31,6 +33,21 @@ def n_real_from_mask(key_padding_mask):
     """[B,N] bool (True = pad) -> int32 node counts on the same device (no host sync).
     Padding must be a suffix, as produced by the reference collate (transformer/data.py:210)."""
     return (~key_padding_mask).sum(dim=-1, dtype=torch.int32)
+
+
+def linear_rows(x2d, weight, bias, rowscale=None, residual=None, relu=False, want_stats=False):
+    """feta_rowlin on [M, KI] rows when the dims are instantiated, else the same arithmetic with
+    rocBLAS + PyTorch ops (still on the GPU).  -> (y, stats or None)"""
+    if FF.row_linear_supported(x2d.shape[1], weight.shape[0]):
+        return FF.row_linear(x2d, weight, bias, rowscale, residual, relu, want_stats)
+    y = F.linear(x2d, weight, bias)
+    if relu:
+        y = F.relu(y)
+    if rowscale is not None:
+        y = y * rowscale.unsqueeze(-1)
+    if residual is not None:
+        y = y + residual
+    return y, None
 
 
 class DiffMultiheadAttention(nn.Module):
@@ -60,26 +77,32 @@ class DiffMultiheadAttention(nn.Module):
             nn.init.constant_(self.in_proj_bias, 0.0)
         nn.init.constant_(self.out_proj.bias, 0.0)
 
+    def core(self, query, pe, key_padding_mask, need_weights, n_real):
+        """in_proj + attention core -> (concat [N,B,d] before out_proj, attn or None)."""
+        if self.training and self.dropout > 0.0:
+            raise NotImplementedError('attention-probability dropout is not built; the FeTA '
+                                      'scripts default to --dropout 0.0 '
+                                      '(experiments/run_transformer_gengcn.py:47)')
+        n, b, d = query.shape
+        if n_real is None:
+            if key_padding_mask is None:
+                n_real = torch.full((b,), n, dtype=torch.int32, device=query.device)
+            else:
+                n_real = n_real_from_mask(key_padding_mask)
+        qkv, _ = linear_rows(query.reshape(n * b, d), self.in_proj_weight, self.in_proj_bias)
+        return FF.attention_core(qkv.view(n, b, 3 * d), pe, n_real, self.num_heads,
+                                 need_attn=need_weights, tie_qk=self.tie_qk, batch_first=False)
+
     def forward(self, query, key, value, pe=None, key_padding_mask=None, need_weights=True,
                 attn_mask=None, need_heads=False, n_real=None):
         if key is not query or value is not query:
             raise NotImplementedError('self-attention only (query is key is value)')
         if attn_mask is not None:
             raise NotImplementedError('attn_mask is not used on the FeTA path')
-        if self.training and self.dropout > 0.0:
-            raise NotImplementedError('attention-probability dropout is not built; the FeTA '
-                                      'scripts default to --dropout 0.0 '
-                                      '(experiments/run_transformer_gengcn.py:47)')
-        n, b, _ = query.shape
-        if n_real is None:
-            if key_padding_mask is None:
-                n_real = torch.full((b,), n, dtype=torch.int32, device=query.device)
-            else:
-                n_real = n_real_from_mask(key_padding_mask)
-        qkv = F.linear(query, self.in_proj_weight, self.in_proj_bias)
-        concat, attn = FF.attention_core(qkv, pe, n_real, self.num_heads, need_attn=need_weights,
-                                         tie_qk=self.tie_qk, batch_first=False)
-        out = self.out_proj(concat)
+        n, b, d = query.shape
+        concat, attn = self.core(query, pe, key_padding_mask, need_weights, n_real)
+        out, _ = linear_rows(concat.reshape(n * b, d), self.out_proj.weight, self.out_proj.bias)
+        out = out.view(n, b, d)
         if need_heads:
             heads = concat.view(n, b, self.num_heads, self.head_dim).permute(1, 0, 2, 3)
             return out, attn, heads
@@ -107,26 +130,52 @@ class DiffTransformerEncoderLayer(nn.Module):
         self.dropout1 = nn.Dropout(dropout)
         self.dropout2 = nn.Dropout(dropout)
 
-    def _norm(self, mod, x):
-        if self.batch_norm:   # statistics over all N*B rows, padded ones included
-            shp = x.shape
-            return mod(x.reshape(-1, shp[-1])).view(shp)
-        return mod(x)
+    def _norm(self, mod, y, stats):
+        """y [M, d] -> normalised [M, d].  BatchNorm statistics run over all N*B rows, padded ones
+        included, exactly as nn.BatchNorm1d on the [N*B, d] view does."""
+        if not self.batch_norm:
+            return mod(y)
+        if mod.training and mod.momentum is not None and y.shape[1] % 4 == 0 and y.shape[1] <= 256:
+            # num_batches_tracked is not advanced (only read when momentum is None)
+            return FF.batch_norm_train(y, stats, mod.weight, mod.bias, mod.running_mean,
+                                       mod.running_var, mod.momentum, mod.eps)
+        return mod(y)
 
     def forward(self, src, pe=None, degree=None, src_mask=None, src_key_padding_mask=None,
-                need_heads=False, n_real=None, need_weights=True):
-        res = self.self_attn(src, src, src, pe=pe, key_padding_mask=src_key_padding_mask,
-                             attn_mask=src_mask, need_heads=need_heads, n_real=n_real,
-                             need_weights=need_weights)
-        src2, attn = res[0], res[1]
-        if degree is not None:
-            src2 = degree.transpose(0, 1).contiguous().unsqueeze(-1) * src2
-        src = self._norm(self.norm1, src + self.dropout1(src2))
-        src2 = self.linear2(self.dropout(F.relu(self.linear1(src))))
-        src = self._norm(self.norm2, src + self.dropout2(src2))
+                need_heads=False, n_real=None, need_weights=True, degree_rows=None):
+        """src [N,B,d] seq-first.  ``degree_rows`` (optional, this package) is ``degree`` already laid
+        out per row of the [N*B, d] view, so the encoder computes it once for all layers."""
+        if src_mask is not None:
+            raise NotImplementedError('attn_mask is not used on the FeTA path')
+        n, b, d = src.shape
+        m = n * b
+        fuse_drop = not (self.training and self.dropout1.p > 0.0)
+        x0 = src.reshape(m, d)
+        concat, attn = self.self_attn.core(src, pe, src_key_padding_mask, need_weights, n_real)
+        if degree is not None and degree_rows is None:
+            degree_rows = degree.transpose(0, 1).reshape(m).contiguous()
+        op = self.self_attn.out_proj
+        if fuse_drop:
+            # y1 = x0 + degree * (concat W_o^T + b_o), BN statistics of y1 in the same launch
+            y1, st1 = linear_rows(concat.reshape(m, d), op.weight, op.bias, rowscale=degree_rows,
+                                  residual=x0, want_stats=self.batch_norm)
+        else:
+            src2, _ = linear_rows(concat.reshape(m, d), op.weight, op.bias, rowscale=degree_rows)
+            y1, st1 = x0 + self.dropout1(src2), None
+        x1 = self._norm(self.norm1, y1, st1)
+        if fuse_drop:
+            h, _ = linear_rows(x1, self.linear1.weight, self.linear1.bias, relu=True)
+            y2, st2 = linear_rows(h, self.linear2.weight, self.linear2.bias, residual=x1,
+                                  want_stats=self.batch_norm)
+        else:
+            h, _ = linear_rows(x1, self.linear1.weight, self.linear1.bias, relu=True)
+            src2, _ = linear_rows(self.dropout(h), self.linear2.weight, self.linear2.bias)
+            y2, st2 = x1 + self.dropout2(src2), None
+        out = self._norm(self.norm2, y2, st2).view(n, b, d)
         if need_heads:
-            return src, attn, res[2]
-        return src, attn
+            heads = concat.view(n, b, self.self_attn.num_heads, self.self_attn.head_dim).permute(1, 0, 2, 3)
+            return out, attn, heads
+        return out, attn
 
 
 def clone_layers(layer, n):

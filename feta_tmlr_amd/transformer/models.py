@@ -23,7 +23,7 @@ import torch.nn.functional as F
 from .. import functional as FF
 from .ChebNetDynamic import ChebConvDynamic
 from .data import GraphBatchCache
-from .layers import DiffTransformerEncoderLayer, clone_layers, n_real_from_mask
+from .layers import DiffTransformerEncoderLayer, clone_layers, linear_rows, n_real_from_mask
 
 
 class DenseGCNParams(nn.Module):
@@ -145,13 +145,16 @@ class DiffTransformerEncoderGenGCN(nn.Module):
         coefficients = []
         allout_filtered = None
         attn = None
+        degree_rows = None
+        if degree is not None:   # degree [B,N] -> one value per row of the [N*B, d] view, once
+            degree_rows = degree.transpose(0, 1).reshape(-1).contiguous()
         for layer_num, mod in enumerate(self.layers):
             last = layer_num + 1 == self.num_layers
             filt = last or not self.last_layer_filter                            # :169-171
             output, attn, out_each_head = mod(output, pe=pe, degree=degree, src_mask=mask,
                                               src_key_padding_mask=src_key_padding_mask,
                                               need_heads=True, n_real=cache.n_real,
-                                              need_weights=filt)
+                                              need_weights=filt, degree_rows=degree_rows)
             if not filt:
                 continue
             coeff_all_heads = self.get_filter_coefficients(attn, masks=src_key_padding_mask,
@@ -165,7 +168,11 @@ class DiffTransformerEncoderGenGCN(nn.Module):
             if not self.use_skip_conn:
                 output = allout_filtered                                          # :215-216
         if self.use_skip_conn and allout_filtered is not None:
-            output = self.linear_cat(torch.cat((output, allout_filtered), dim=-1))   # :223-224
+            cat = torch.cat((output, allout_filtered), dim=-1)                   # :223
+            nn_, bb_, d2 = cat.shape
+            output, _ = linear_rows(cat.reshape(nn_ * bb_, d2), self.linear_cat.weight,
+                                    self.linear_cat.bias)                        # :224
+            output = output.view(nn_, bb_, -1)
         if self.norm is not None:
             output = self.norm(output)
         coeffs = torch.cat(coefficients, dim=0).permute(1, 0, 2) if coefficients else None

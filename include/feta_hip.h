@@ -153,6 +153,41 @@ int feta_spec_filter_bwd(const float* x, int64_t x_sb, int64_t x_sn,
                          int B, int N, int H, int dh, int P, int K, int heads_share_graph,
                          feta_stream_t stream);
 
+/* ---- A1/A4: row-wise linears of the encoder layer and BatchNorm1d --------------------------
+ * Replaces the F.linear / relu / degree scaling / residual / BatchNorm1d sequence of
+ * DiffTransformerEncoderLayer.forward (contract transformer/models.py:166-167; body per upstream
+ * GraphiT, README.md:129) and linear_cat (transformer/models.py:223-224).  Activations are
+ * [M, C] row-major, M = N*B rows.
+ *   y = relu?(x W^T + bias) * rowscale[row]? + residual?        x [M,KI], W [NO,KI], y [M,NO]
+ * stats (optional) receives per-block partial (sum, sumsq) of y: [feta_rowlin_blocks(M), 2, NO],
+ * the BatchNorm statistics of the result without a separate pass.
+ * KI in {16,32,64,128,192,256}; NO a multiple of 16 (backward: NO in the same set).
+ */
+int feta_rowlin_blocks(int M);
+int feta_rowlin_chunks(int M);
+int feta_rowlin_fwd(const float* x, const float* w, const float* bias, const float* rowscale,
+                    const float* residual, float* y, float* stats, int relu,
+                    int M, int KI, int NO, feta_stream_t stream);
+/* g = dy * rowscale? * [ysaved > 0]? ;  dx = g W ;  dwdb = [ g^T x  (NO*KI) | colsum g (NO) ].
+ * partial: scratch [feta_rowlin_chunks(M), NO*KI + NO].  dX and the split-K weight gradient run
+ * in one launch (blocks take roles), then one deterministic reduction of the partials. */
+int feta_rowlin_bwd(const float* x, const float* w, const float* dy, const float* rowscale,
+                    const float* ysaved, float* dx, float* partial, float* dwdb,
+                    int M, int KI, int NO, feta_stream_t stream);
+
+/* Training-mode BatchNorm1d over the M rows (padded rows included, as nn.BatchNorm1d on the
+ * [N*B, d] view does).  stats [feta_rowlin_blocks(M), 2, D] from feta_rowlin_fwd or feta_bn_stats.
+ * mean_rstd [2, D] is saved for backward; running_* (nullable) are updated with momentum and the
+ * unbiased variance. */
+int feta_bn_stats(const float* y, float* stats, int M, int D, feta_stream_t stream);
+int feta_bn_apply_fwd(const float* y, const float* stats, const float* gamma, const float* beta,
+                      float* out, float* mean_rstd, float* running_mean, float* running_var,
+                      float momentum, float eps, int M, int D, feta_stream_t stream);
+/* partial: scratch [feta_rowlin_blocks(M), 2, D]; dgamma, dbeta [D]. */
+int feta_bn_bwd(const float* y, const float* dout, const float* mean_rstd, const float* gamma,
+                float* partial, float* dy, float* dgamma, float* dbeta,
+                int M, int D, feta_stream_t stream);
+
 /* ---- graph preprocessing -------------------------------------------------------------
  * Dense Lhat = -D^-1/2 A D^-1/2 per graph from the batched edge list, with the exact
  * edge-list semantics of ChebConvDynamic.__norm__ (transformer/ChebNetDynamic.py:108-130):

@@ -277,3 +277,73 @@ def check_filter(abi, dev, stream, mode, bsz, h, dh, order, share, seed=0, shape
     errs['dcoeff'] = assert_close('dcoeff', dcoeff, dc_ref)
     errs['dbias'] = assert_close('dbias', dbias, db_ref)
     return errs
+
+
+def check_rowlin(abi, dev, stream, m, ki, no, relu=False, rowscale=False, residual=False, stats=False,
+                 seed=0):
+    """feta_rowlin_fwd/bwd against torch fp64: y = relu?(x W^T + b) * rs? + res?."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(m, ki, generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(no, ki, generator=g, dtype=torch.float64) / ki ** 0.5).requires_grad_(True)
+    b = torch.randn(no, generator=g, dtype=torch.float64, requires_grad=True)
+    rs = (torch.rand(m, generator=g, dtype=torch.float64) + 0.5) if rowscale else None
+    res = torch.randn(m, no, generator=g, dtype=torch.float64, requires_grad=True) if residual else None
+    dy = torch.randn(m, no, generator=g, dtype=torch.float64)
+    y = torch.nn.functional.linear(x, w, b)
+    if relu:
+        y = torch.relu(y)
+    if rs is not None:
+        y = y * rs[:, None]
+    if res is not None:
+        y = y + res
+    (y * dy).sum().backward()
+
+    f = lambda t: None if t is None else t.detach().float().contiguous().to(dev)
+    x32, w32, b32, rs32, res32 = f(x), f(w), f(b), f(rs), f(res)
+    yo = torch.full((m, no), float('nan'), device=dev)
+    st = torch.full((abi.rowlin_blocks(m), 2, no), float('nan'), device=dev) if stats else None
+    abi.rowlin_fwd(x32, w32, b32, rs32, res32, yo, st, relu, stream)
+    errs = {'y': assert_close('y', yo, y)}
+    if stats:
+        tot = st.double().sum(0).cpu()
+        assert_close('stats.sum', tot[0], y.detach().sum(0), tol=1e-5 * m ** 0.5)
+        assert_close('stats.sumsq', tot[1], (y.detach() ** 2).sum(0), tol=1e-5 * m ** 0.5)
+    dx = torch.full((m, ki), float('nan'), device=dev)
+    partial = torch.zeros(abi.rowlin_chunks(m), no * ki + no, device=dev)
+    dwdb = torch.full((no * ki + no,), float('nan'), device=dev)
+    abi.rowlin_bwd(x32, w32, f(dy), rs32, yo if relu else None, dx, partial, dwdb, stream)
+    errs['dx'] = assert_close('dx', dx, x.grad)
+    errs['dw'] = assert_close('dw', dwdb[:no * ki].view(no, ki), w.grad, tol=2e-5)
+    errs['db'] = assert_close('db', dwdb[no * ki:], b.grad, tol=2e-5)
+    return errs
+
+
+def check_bn(abi, dev, stream, m, d, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    y = (torch.randn(m, d, generator=g, dtype=torch.float64) * 2 + 0.5).requires_grad_(True)
+    gamma = (torch.rand(d, generator=g, dtype=torch.float64) + 0.5).requires_grad_(True)
+    beta = torch.randn(d, generator=g, dtype=torch.float64, requires_grad=True)
+    dout = torch.randn(m, d, generator=g, dtype=torch.float64)
+    rm, rv = torch.zeros(d, dtype=torch.float64), torch.ones(d, dtype=torch.float64)
+    out = torch.nn.functional.batch_norm(y, rm, rv, gamma, beta, True, 0.1, 1e-5)
+    (out * dout).sum().backward()
+    f = lambda t: t.detach().float().contiguous().to(dev)
+    y32 = f(y)
+    st = torch.full((abi.rowlin_blocks(m), 2, d), float('nan'), device=dev)
+    abi.bn_stats(y32, st, stream)
+    o = torch.full((m, d), float('nan'), device=dev)
+    mr = torch.full((2, d), float('nan'), device=dev)
+    rm32, rv32 = torch.zeros(d, device=dev), torch.ones(d, device=dev)
+    abi.bn_apply_fwd(y32, st, f(gamma), f(beta), o, mr, rm32, rv32, 0.1, 1e-5, stream)
+    errs = {'out': assert_close('bn out', o, out)}
+    assert_close('running_mean', rm32, rm)
+    assert_close('running_var', rv32, rv)
+    partial = torch.zeros(abi.rowlin_blocks(m), 2, d, device=dev)
+    dyo = torch.full((m, d), float('nan'), device=dev)
+    dg = torch.full((d,), float('nan'), device=dev)
+    dbt = torch.full((d,), float('nan'), device=dev)
+    abi.bn_bwd(y32, f(dout), mr, f(gamma), partial, dyo, dg, dbt, stream)
+    errs['dy'] = assert_close('bn dy', dyo, y.grad)
+    errs['dgamma'] = assert_close('dgamma', dg, gamma.grad, tol=2e-5)
+    errs['dbeta'] = assert_close('dbeta', dbt, beta.grad, tol=2e-5)
+    return errs

@@ -64,3 +64,20 @@ def test_cheb_directed_graph(emu):
 def test_spec_truncated(emu, k_eig):
     KC.check_filter(emu, CPU, None, 'spec', 3, 2, 16, 4, 1, k_eig=k_eig)
     KC.check_filter(emu, CPU, None, 'spec', 2, 2, 16, 4, 0, k_eig=k_eig)
+
+
+@pytest.mark.parametrize('m,ki,no,relu,rowscale,residual,stats', [
+    (37 * 3, 64, 192, False, False, False, False),     # in_proj
+    (100, 64, 64, False, True, True, True),            # out_proj + degree + residual + BN stats
+    (70, 64, 128, True, False, False, False),          # linear1 + relu
+    (70, 128, 64, False, False, True, True),           # linear2 + residual + BN stats
+    (33, 32, 32, False, False, False, False),
+    (200, 16, 16, True, True, False, True),
+])
+def test_rowlin(emu, m, ki, no, relu, rowscale, residual, stats):
+    KC.check_rowlin(emu, CPU, None, m, ki, no, relu, rowscale, residual, stats)
+
+
+@pytest.mark.parametrize('m,d', [(111, 64), (64, 32), (300, 128), (50, 192)])
+def test_batchnorm(emu, m, d):
+    KC.check_bn(emu, CPU, None, m, d)

@@ -89,3 +89,25 @@ def test_bad_arguments_raise(hip):
     with pytest.raises(ValueError):
         abi.attn_fwd(q, q, q, None, torch.ones(2, dtype=torch.int32, device=dev), torch.zeros_like(q),
                      None, torch.zeros(2, 2, 300, 2, device=dev), 0.25, stream)
+
+
+@pytest.mark.parametrize('m,ki,no,relu,rowscale,residual,stats', [
+    (37 * 128, 64, 192, False, False, False, False),   # in_proj at BASELINE config 2
+    (37 * 128, 64, 64, False, True, True, True),       # out_proj + degree + residual + BN stats
+    (37 * 128, 64, 128, True, False, False, False),    # linear1 + relu
+    (37 * 128, 128, 64, False, False, True, True),     # linear2 + residual + BN stats
+    (33, 32, 32, False, False, False, False),
+    (200, 16, 16, True, True, False, True),
+    (100000, 64, 64, False, True, True, True),         # more row blocks than partial slots
+    (1000, 256, 256, False, False, False, False),
+    (1000, 192, 64, False, False, False, False),
+])
+def test_rowlin(hip, m, ki, no, relu, rowscale, residual, stats):
+    abi, dev, stream = hip
+    KC.check_rowlin(abi, dev, stream, m, ki, no, relu, rowscale, residual, stats)
+
+
+@pytest.mark.parametrize('m,d', [(37 * 128, 64), (64, 32), (300, 128), (50, 192), (70000, 64)])
+def test_batchnorm(hip, m, d):
+    abi, dev, stream = hip
+    KC.check_bn(abi, dev, stream, m, d)
