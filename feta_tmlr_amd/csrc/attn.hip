@@ -327,6 +327,320 @@ __global__ __launch_bounds__(64 * kWaves) void attn_bwd_dkdv_kernel(AttnArgs a) 
   }
 }
 
+// ---- small graphs (N <= 64): every global load is issued before the first MFMA ----------------
+// The kernels above guard each load with a branch (rows beyond n_real do not exist for the
+// maths), which serialises ~30 memory round trips per wave.  At ZINC/MUTAG sizes a wave's whole
+// working set is a few dozen registers, so here every row index is CLAMPED into the tensor, the
+// loads are unconditional and issued as one batch, and validity is applied by selects.
+
+template <int DH, int KT_MAX>
+__global__ __launch_bounds__(64 * kWaves) void attn_fwd_dense_kernel(AttnArgs a) {
+  constexpr int CT = Feat<DH>::CT;
+  constexpr int KP = 16 * KT_MAX + 1;
+  const int lane = lane_id(), lq = lane & 15, g = lane >> 4;
+  const int item = blockIdx.x * kWaves + wave_id();
+  if (item >= a.total) return;
+  const int qb = item % a.NB;
+  const int bh = item / a.NB;
+  const int h = bh % a.H, b = bh / a.H;
+  const int n = a.n_real[b];
+  const int q0 = 16 * qb;
+  const int q = q0 + lq;
+  const int qc = min(q, a.N - 1);
+  const bool has_pe = a.pe != nullptr;
+
+  // ---- load batch: q row, K rows of every key tile, pe and V elements -------------------------
+  Feat<DH> qf, kf[KT_MAX];
+  load_row_sel<DH>(qf, tok_row(a.q, a.qsb, a.qsn, b, qc, h, DH), q < a.N, g, a.scale);
+#pragma unroll
+  for (int kt = 0; kt < KT_MAX; ++kt) {
+    const int key = 16 * kt + lq;
+    load_row_sel<DH>(kf[kt], tok_row(a.k, a.qsb, a.qsn, b, min(key, n - 1), h, DH), key < n, g);
+  }
+  float pv[KT_MAX][4], vb[KT_MAX][4][CT];
+  const float* pe_row = has_pe ? a.pe + ((int64_t)b * a.N + qc) * a.N : nullptr;
+#pragma unroll
+  for (int kt = 0; kt < KT_MAX; ++kt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = 16 * kt + 4 * g + r;
+      const int kc = min(key, n - 1);
+      pv[kt][r] = has_pe ? pe_row[kc] : 1.0f;
+      const float* vrow = tok_row(a.v, a.qsb, a.qsn, b, kc, h, DH);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const int c = 16 * ct + lq;
+        const float vv = vrow[c < DH ? c : 0];
+        vb[kt][r][ct] = (key < n && c < DH) ? vv : 0.0f;
+      }
+    }
+  }
+
+  // ---- S^T tiles, softmax statistics ----------------------------------------------------------
+  f32x4 acc[KT_MAX];
+#pragma unroll
+  for (int kt = 0; kt < KT_MAX; ++kt) acc[kt] = dot_rows<DH>(kf[kt], qf, zero4());
+  float m = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < KT_MAX; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (16 * kt + 4 * g + r < n) m = fmaxf(m, acc[kt][r]);
+  m = fmaxf(m, shfl_xor(m, 16));
+  m = fmaxf(m, shfl_xor(m, 32));
+  float z = 0.0f;
+#pragma unroll
+  for (int kt = 0; kt < KT_MAX; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool kok = 16 * kt + 4 * g + r < n;
+      const float e = kok ? fast_exp(acc[kt][r] - m) * pv[kt][r] : 0.0f;
+      acc[kt][r] = e;
+      z += e;
+    }
+  z += shfl_xor(z, 16);
+  z += shfl_xor(z, 32);
+  const float rinv = 1.0f / fmaxf(z, 1e-6f);
+  if (g == 0 && q < a.N) {
+    float* st = a.stats + ((int64_t)bh * a.N + q) * 2;
+    st[0] = m;
+    st[1] = z;
+  }
+
+  // ---- out = P . V ---------------------------------------------------------------------------
+  f32x4 o[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) o[ct] = zero4();
+#pragma unroll
+  for (int kt = 0; kt < KT_MAX; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      acc[kt][r] *= rinv;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) o[ct] = mfma16(acc[kt][r], vb[kt][r][ct], o[ct]);
+    }
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const int c = 16 * ct + lq;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qq = q0 + 4 * g + r;
+      if (qq < a.N && c < DH) tok_row(a.out_w, a.osb, a.osn, b, qq, h, DH)[c] = o[ct][r];
+    }
+  }
+
+  if (a.attn != nullptr) {
+    float* st = feta_lds + wave_id() * 16 * KP;
+#pragma unroll
+    for (int kt = 0; kt < KT_MAX; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st[lq * KP + 16 * kt + 4 * g + r] = acc[kt][r];
+    wave_lds_sync();
+    const int rows = min(16, a.N - q0);
+    float* dst = a.attn + ((int64_t)bh * a.N + q0) * a.N;
+    int qq = 0, kk = lane;
+    while (kk >= a.N) {
+      kk -= a.N;
+      ++qq;
+    }
+    for (int idx = lane; idx < rows * a.N; idx += 64) {
+      dst[idx] = st[qq * KP + kk];   // columns >= n hold exact zeros
+      kk += 64;
+      while (kk >= a.N) {
+        kk -= a.N;
+        ++qq;
+      }
+    }
+  }
+}
+
+template <int DH, int KT_MAX>
+__global__ __launch_bounds__(64 * kWaves) void attn_bwd_dq_dense_kernel(AttnArgs a) {
+  constexpr int CT = Feat<DH>::CT;
+  const int lane = lane_id(), lq = lane & 15, g = lane >> 4;
+  const int item = blockIdx.x * kWaves + wave_id();
+  if (item >= a.total) return;
+  const int qb = item % a.NB;
+  const int bh = item / a.NB;
+  const int h = bh % a.H, b = bh / a.H;
+  const int n = a.n_real[b];
+  const int q0 = 16 * qb;
+  const int q = q0 + lq;
+  const int qc = min(q, a.N - 1);
+  const bool qok = q < a.N;
+  const bool has_pe = a.pe != nullptr;
+
+  Feat<DH> qf, dof, of, kf[KT_MAX], vf[KT_MAX];
+  load_row_sel<DH>(qf, tok_row(a.q, a.qsb, a.qsn, b, qc, h, DH), qok, g, a.scale);
+  load_row_sel<DH>(dof, tok_row(a.dout, a.osb, a.osn, b, qc, h, DH), qok, g);
+  load_row_sel<DH>(of, tok_row(a.out, a.osb, a.osn, b, qc, h, DH), qok, g);
+  const float* st = a.stats_in + ((int64_t)bh * a.N + qc) * 2;
+  const float m = st[0], z = st[1];
+  float pv[KT_MAX][4], kb[KT_MAX][4][CT];
+  const float* pe_row = has_pe ? a.pe + ((int64_t)b * a.N + qc) * a.N : nullptr;
+#pragma unroll
+  for (int kt = 0; kt < KT_MAX; ++kt) {
+    const int krow = 16 * kt + lq;
+    const int krc = min(krow, n - 1);
+    load_row_sel<DH>(kf[kt], tok_row(a.k, a.qsb, a.qsn, b, krc, h, DH), krow < n, g);
+    load_row_sel<DH>(vf[kt], tok_row(a.v, a.qsb, a.qsn, b, krc, h, DH), krow < n, g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = 16 * kt + 4 * g + r;
+      const int kc = min(key, n - 1);
+      pv[kt][r] = has_pe ? pe_row[kc] : 1.0f;
+      const float* kr = tok_row(a.k, a.qsb, a.qsn, b, kc, h, DH);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const int c = 16 * ct + lq;
+        const float kv = kr[c < DH ? c : 0];
+        kb[kt][r][ct] = (key < n && c < DH) ? kv : 0.0f;
+      }
+    }
+  }
+
+  float delta = 0.0f;
+#pragma unroll
+  for (int j = 0; j < Feat<DH>::NJ; ++j)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) delta += dof.f[j][s] * of.f[j][s];
+  delta += shfl_xor(delta, 16);
+  delta += shfl_xor(delta, 32);
+  if (g == 0 && qok) a.delta[(int64_t)bh * a.N + q] = delta;
+  const float rinv = 1.0f / fmaxf(z, 1e-6f);
+  if (z < 1e-6f) delta = 0.0f;
+
+  f32x4 dq[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) dq[ct] = zero4();
+#pragma unroll
+  for (int kt = 0; kt < KT_MAX; ++kt) {
+    const f32x4 s = dot_rows<DH>(kf[kt], qf, zero4());
+    const f32x4 da = dot_rows<DH>(vf[kt], dof, zero4());
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool kok = 16 * kt + 4 * g + r < n;
+      const float p = kok ? fast_exp(s[r] - m) * pv[kt][r] * rinv : 0.0f;
+      const float ds = p * (da[r] - delta);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) dq[ct] = mfma16(ds, kb[kt][r][ct], dq[ct]);
+    }
+  }
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const int c = 16 * ct + lq;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qq = q0 + 4 * g + r;
+      if (qq < a.N && c < DH) tok_row(a.dq, a.qsb, a.qsn, b, qq, h, DH)[c] = dq[ct][r] * a.scale;
+    }
+  }
+}
+
+template <int DH, int KT_MAX>
+__global__ __launch_bounds__(64 * kWaves) void attn_bwd_dkdv_dense_kernel(AttnArgs a) {
+  constexpr int CT = Feat<DH>::CT;
+  const int lane = lane_id(), lq = lane & 15, g = lane >> 4;
+  const int item = blockIdx.x * kWaves + wave_id();
+  if (item >= a.total) return;
+  const int kblk = item % a.NB;
+  const int bh = item / a.NB;
+  const int h = bh % a.H, b = bh / a.H;
+  const int n = a.n_real[b];
+  const int key = 16 * kblk + lq;
+  const bool kok = key < n;
+  const int keyc = min(key, n - 1);
+  const bool has_pe = a.pe != nullptr;
+
+  // ---- load batch over every query block ------------------------------------------------------
+  Feat<DH> kf, vf, qf[KT_MAX], dof[KT_MAX];
+  load_row_sel<DH>(kf, tok_row(a.k, a.qsb, a.qsn, b, keyc, h, DH), kok, g);
+  load_row_sel<DH>(vf, tok_row(a.v, a.qsb, a.qsn, b, keyc, h, DH), kok, g);
+  float sm[KT_MAX][4], sz[KT_MAX][4], sd[KT_MAX][4], pv[KT_MAX][4];
+  float dob[KT_MAX][4][CT], qbv[KT_MAX][4][CT];
+#pragma unroll
+  for (int qb = 0; qb < KT_MAX; ++qb) {
+    const int qrow = 16 * qb + lq;
+    const int qrc = min(qrow, a.N - 1);
+    load_row_sel<DH>(qf[qb], tok_row(a.q, a.qsb, a.qsn, b, qrc, h, DH), qrow < a.N, g, a.scale);
+    load_row_sel<DH>(dof[qb], tok_row(a.dout, a.osb, a.osn, b, qrc, h, DH), qrow < a.N, g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qq = 16 * qb + 4 * g + r;
+      const int qqc = min(qq, a.N - 1);
+      const float* st = a.stats_in + ((int64_t)bh * a.N + qqc) * 2;
+      sm[qb][r] = st[0];
+      sz[qb][r] = st[1];
+      sd[qb][r] = a.delta[(int64_t)bh * a.N + qqc];
+      pv[qb][r] = has_pe ? a.pe[((int64_t)b * a.N + qqc) * a.N + keyc] : 1.0f;
+      const float* dor = tok_row(a.dout, a.osb, a.osn, b, qqc, h, DH);
+      const float* qr = tok_row(a.q, a.qsb, a.qsn, b, qqc, h, DH);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const int c = 16 * ct + lq;
+        const int cc = c < DH ? c : 0;
+        const bool ok = qq < a.N && c < DH;
+        const float dv_ = dor[cc], qv_ = qr[cc];
+        dob[qb][r][ct] = ok ? dv_ : 0.0f;
+        qbv[qb][r][ct] = ok ? qv_ * a.scale : 0.0f;
+      }
+    }
+  }
+
+  f32x4 dk[CT], dv[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    dk[ct] = zero4();
+    dv[ct] = zero4();
+  }
+#pragma unroll
+  for (int qb = 0; qb < KT_MAX; ++qb) {
+    const f32x4 s = dot_rows<DH>(qf[qb], kf, zero4());
+    const f32x4 da = dot_rows<DH>(dof[qb], vf, zero4());
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = (16 * qb + 4 * g + r < a.N) && kok;
+      const float zz = sz[qb][r];
+      const float p = ok ? fast_exp(s[r] - sm[qb][r]) * pv[qb][r] * (1.0f / fmaxf(zz, 1e-6f)) : 0.0f;
+      const float ds = p * (da[r] - (zz < 1e-6f ? 0.0f : sd[qb][r]));
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        dv[ct] = mfma16(p, dob[qb][r][ct], dv[ct]);
+        dk[ct] = mfma16(ds, qbv[qb][r][ct], dk[ct]);
+      }
+    }
+  }
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const int c = 16 * ct + lq;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int kk = 16 * kblk + 4 * g + r;
+      if (kk < a.N && c < DH) {
+        tok_row(a.dk, a.qsb, a.qsn, b, kk, h, DH)[c] = dk[ct][r];
+        tok_row(a.dv, a.qsb, a.qsn, b, kk, h, DH)[c] = dv[ct][r];
+      }
+    }
+  }
+}
+
+template <int DH, int KT_MAX>
+void launch_fwd_dense_t(const AttnArgs& a, hipStream_t stream) {
+  const dim3 grid((a.total + kWaves - 1) / kWaves), block(64 * kWaves);
+  const size_t lds = a.attn != nullptr ? sizeof(float) * kWaves * 16 * (16 * KT_MAX + 1) : 0;
+  auto kern = attn_fwd_dense_kernel<DH, KT_MAX>;
+  hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
+}
+
+template <int DH, int KT_MAX>
+void launch_bwd_dense_t(const AttnArgs& a, hipStream_t stream) {
+  const dim3 grid((a.total + kWaves - 1) / kWaves), block(64 * kWaves);
+  auto k1 = attn_bwd_dq_dense_kernel<DH, KT_MAX>;
+  hipLaunchKernelGGL(k1, grid, block, 0, stream, a);
+  auto k2 = attn_bwd_dkdv_dense_kernel<DH, KT_MAX>;
+  hipLaunchKernelGGL(k2, grid, block, 0, stream, a);
+}
+
 template <int DH, int KT_MAX>
 void launch_fwd_t(const AttnArgs& a, hipStream_t stream) {
   const dim3 grid((a.total + kWaves - 1) / kWaves), block(64 * kWaves);
@@ -341,6 +655,10 @@ void launch_fwd_t(const AttnArgs& a, hipStream_t stream) {
 
 template <int DH>
 int launch_fwd(const AttnArgs& a, int kt_max, hipStream_t stream) {
+  if constexpr (DH <= 16) {  // batched-load kernels: the register budget allows them up to N = 64
+    if (kt_max <= 3) { launch_fwd_dense_t<DH, 3>(a, stream); return check_launch("feta_attn_fwd"); }
+    if (kt_max <= 4) { launch_fwd_dense_t<DH, 4>(a, stream); return check_launch("feta_attn_fwd"); }
+  }
   if (kt_max <= 3) launch_fwd_t<DH, 3>(a, stream);
   else if (kt_max <= 4) launch_fwd_t<DH, 4>(a, stream);
   else if (kt_max <= 8) launch_fwd_t<DH, 8>(a, stream);
@@ -350,6 +668,10 @@ int launch_fwd(const AttnArgs& a, int kt_max, hipStream_t stream) {
 
 template <int DH>
 int launch_bwd(const AttnArgs& a, hipStream_t stream) {
+  if constexpr (DH <= 16) {
+    if (a.NB <= 3) { launch_bwd_dense_t<DH, 3>(a, stream); return check_launch("feta_attn_bwd"); }
+    if (a.NB <= 4) { launch_bwd_dense_t<DH, 4>(a, stream); return check_launch("feta_attn_bwd"); }
+  }
   const dim3 grid((a.total + kWaves - 1) / kWaves), block(64 * kWaves);
   auto k1 = attn_bwd_dq_kernel<DH>;
   hipLaunchKernelGGL(k1, grid, block, 0, stream, a);

@@ -43,6 +43,24 @@ __device__ __forceinline__ void load_row(Feat<DH>& t, const float* row, int g, f
   }
 }
 
+// Same operand, but the load is UNCONDITIONAL (row must point at readable memory - clamp the
+// row index) and `ok` only selects zero afterwards: no branch around the load, so the compiler
+// can issue a whole batch of such loads back to back and expose ONE memory latency.
+template <int DH>
+__device__ __forceinline__ void load_row_sel(Feat<DH>& t, const float* row, bool ok, int g,
+                                             float scale = 1.0f) {
+#pragma unroll
+  for (int j = 0; j < Feat<DH>::NJ; ++j) {
+    const int c = 16 * j + 4 * g;
+    const float4 x = *reinterpret_cast<const float4*>(row + (c < DH ? c : 0));
+    const bool sel = ok && c < DH;
+    t.f[j][0] = sel ? x.x * scale : 0.0f;
+    t.f[j][1] = sel ? x.y * scale : 0.0f;
+    t.f[j][2] = sel ? x.z * scale : 0.0f;
+    t.f[j][3] = sel ? x.w * scale : 0.0f;
+  }
+}
+
 // acc += A_rows . B_rows^T over the feature dim: result row index = a's row (lq of
 // the lane that loaded it), column index = b's row.
 template <int DH>
