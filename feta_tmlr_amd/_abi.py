@@ -50,6 +50,31 @@ SIGNATURES = {
                              C.c_int),
 }
 
+class RowLinEx(C.Structure):
+    """struct feta_rowlin_ex (include/feta_hip.h) - field order must match the header."""
+    _fields_ = [
+        ('x', _F), ('w', _F), ('bias', _F), ('rowscale', _F),
+        ('M', C.c_int), ('KI', C.c_int), ('NO', C.c_int), ('relu', C.c_int),
+        ('residual', _F), ('res_bn', _F), ('y', _F), ('stats', _F),
+        ('x_bn', _F), ('x_stats', _F), ('Gx', C.c_int),
+        ('x_gamma', _F), ('x_beta', _F), ('x_bn_out', _F), ('x_rmean', _F), ('x_rvar', _F),
+        ('momentum', C.c_float), ('eps', C.c_float),
+        ('dy', _F), ('relu_y', _F), ('dx', _F), ('partial', _F),
+        ('g_y', _F), ('g_bn', _F), ('g_sum', _F), ('Gs', C.c_int),
+        ('g_fin', _F), ('g_fin_out', _F), ('dgamma', _F), ('dbeta', _F),
+        ('add_plain', _F), ('add_dout', _F), ('add_y', _F), ('add_bn', _F), ('add_fin', _F),
+        ('sum_y', _F), ('sum_bn', _F), ('sum_out', _F),
+    ]
+
+
+SIGNATURES.update({
+    'feta_rowlin_fwd_ex': ([C.POINTER(RowLinEx), _S], C.c_int),
+    'feta_rowlin_bwd_ex': ([C.POINTER(RowLinEx), _F, _S], C.c_int),
+    'feta_bn_apply_fwd_prm': ([_F, _F, _F, _F, _F, _F, _F, _F, C.c_float, C.c_float, C.c_int, C.c_int, _S],
+                              C.c_int),
+    'feta_bn_bwd_reduce': ([_F, _F, _F, _F, C.c_int, C.c_int, _S], C.c_int),
+})
+
 ABI_VERSION = 1
 
 
@@ -205,6 +230,34 @@ class Abi:
         m, d = y.shape
         self._check(self.lib.feta_bn_bwd(_p(y), _p(dout), _p(mean_rstd), _p(gamma), _p(partial), _p(dy),
                                          _p(dgamma), _p(dbeta), m, d, stream), 'feta_bn_bwd')
+
+    def rowlin_ex(self, m, ki, no, relu=False, momentum=0.1, eps=1e-5, Gx=0, Gs=0, **ptrs):
+        """Builds a feta_rowlin_ex descriptor; tensor-valued keyword arguments become pointers."""
+        d = RowLinEx()
+        d.M, d.KI, d.NO, d.relu = m, ki, no, int(relu)
+        d.momentum, d.eps, d.Gx, d.Gs = momentum, eps, Gx, Gs
+        for k, t in ptrs.items():
+            if t is not None:
+                setattr(d, k, t.data_ptr())
+        return d
+
+    def rowlin_fwd_ex(self, desc, stream):
+        self._check(self.lib.feta_rowlin_fwd_ex(C.byref(desc), stream), 'feta_rowlin_fwd_ex')
+
+    def rowlin_bwd_ex(self, desc, dwdb, stream):
+        self._check(self.lib.feta_rowlin_bwd_ex(C.byref(desc), _p(dwdb), stream), 'feta_rowlin_bwd_ex')
+
+    def bn_apply_fwd_prm(self, y, stats, gamma, beta, out, bn_prm, running_mean, running_var, momentum,
+                         eps, stream):
+        m, d = y.shape
+        self._check(self.lib.feta_bn_apply_fwd_prm(_p(y), _p(stats), _p(gamma), _p(beta), _p(out),
+                                                   _p(bn_prm), _p(running_mean), _p(running_var),
+                                                   momentum, eps, m, d, stream), 'feta_bn_apply_fwd_prm')
+
+    def bn_bwd_reduce(self, y, dout, bn_prm, partial, stream):
+        m, d = y.shape
+        self._check(self.lib.feta_bn_bwd_reduce(_p(y), _p(dout), _p(bn_prm), _p(partial), m, d, stream),
+                    'feta_bn_bwd_reduce')
 
     def lhat_from_edges(self, edge_index, node_graph, node_off, deg, lhat, stream):
         b, n, _ = lhat.shape

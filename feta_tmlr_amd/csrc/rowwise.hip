@@ -2,10 +2,14 @@
 // projections, the FFN linears and linear_cat with their element-wise neighbours fused, and
 // training-mode BatchNorm1d over all N*B rows.  Replaces, per DiffTransformerEncoderLayer
 // call (contract transformer/models.py:166-167; body per upstream GraphiT, README.md:129):
-//   F.linear(+bias) -> [relu] -> [* degree] -> [+ residual]      one launch, plus the BN
-//   statistics of the result as per-block partial sums (no separate statistics pass);
-//   backward: dX and the split-K weight/bias gradient in ONE launch (blocks take roles), the
-//   partials reduced deterministically by colsum_kernel.
+//   [BatchNorm of the input] -> F.linear(+bias) -> [relu] -> [* degree] -> [+ residual]
+//   in one launch, plus the BN statistics of the result as per-block partial sums;
+//   backward: [BatchNorm backward of the incoming gradient] -> dX (+ residual gradient, +
+//   partial sums for the next BatchNorm backward) and the split-K weight/bias gradient in ONE
+//   launch (blocks take roles), partials reduced deterministically by colsum_kernel.
+// BatchNorm never runs as its own pass on the fused path: its statistics are produced by the
+// producer's epilogue, its apply happens in the consumers' operand loads ("a tensor seen
+// through a BatchNorm" = pre-norm values + a [4][D] parameter block scale/shift/mean/rstd).
 // Activations are [M, C] row-major with M = N*B rows (seq-first rows are contiguous).
 //
 // Decomposition: a workgroup = 64 rows (one 16-row block per wave) x a group of up to 4
@@ -27,37 +31,83 @@ constexpr int kMaxRowBlocks = 256;  // cap on per-block partial statistics
 constexpr int kMaxChunks = 128;     // cap on split-K chunks of the weight gradient
 constexpr int kChunkRowBlocks = 4;  // 16-row blocks per split-K chunk
 
-struct RowLinArgs {
-  const float* x;         // [M, KI]
-  const float* w;         // [NO, KI]
-  const float* bias;      // [NO] or null
-  const float* rowscale;  // [M] or null
-  const float* residual;  // [M, NO] or null
-  const float* dy;        // [M, NO]              (backward)
-  const float* ysaved;    // [M, NO] relu output  (backward, null = no relu)
-  float* y;               // [M, NO]
-  float* stats;           // [G, 2, NO] or null
-  float* dx;              // [M, KI]
-  float* partial;         // [RC, NO*KI + NO]
-  int M, KI, NO, relu;
+typedef feta_rowlin_ex RowLinArgs;  // include/feta_hip.h
+
+struct RowLinGeom {
   int G;          // row groups of the grid (row blocks are strided over it)
   int TG;         // output tiles per workgroup (forward) / k tiles per workgroup (dX role)
   int RC;         // weight-gradient row chunks
   int dx_blocks;  // backward: blocks [0, dx_blocks) compute dX, the rest dW/db partials
 };
 
+// sums the G partial pairs [G][2][D] with all 256 threads; on return tot[c], tot[D + c] (LDS)
+// hold the totals.  red: [slices][2][D] scratch.
+__device__ __forceinline__ void reduce_partials(const float* part, int G, int D, float* red,
+                                                float* tot) {
+  // one partial = 2D contiguous floats = nq float4; thread -> (float4 column q, slice); the
+  // loop is unrolled x4 with independent accumulators so that four 16-byte loads are in flight
+  // per thread (the dependent-latency chain of a scalar loop cost ~10 us per consumer)
+  const int nq = 2 * D / 4;
+  const int slices = kRowThreads / nq > 0 ? kRowThreads / nq : 1;
+  const int q = threadIdx.x % nq, slice = threadIdx.x / nq;
+  if ((int)threadIdx.x < slices * nq) {
+    const float4* p4 = reinterpret_cast<const float4*>(part);
+    float4 s[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    int gi = slice;
+    for (; gi + 3 * slices < G; gi += 4 * slices) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = p4[(int64_t)(gi + u * slices) * nq + q];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s[u].x += v[u].x; s[u].y += v[u].y; s[u].z += v[u].z; s[u].w += v[u].w;
+      }
+    }
+    for (; gi < G; gi += slices) {
+      const float4 v = p4[(int64_t)gi * nq + q];
+      s[0].x += v.x; s[0].y += v.y; s[0].z += v.z; s[0].w += v.w;
+    }
+    float* r = red + (slice * nq + q) * 4;
+    r[0] = (s[0].x + s[1].x) + (s[2].x + s[3].x);
+    r[1] = (s[0].y + s[1].y) + (s[2].y + s[3].y);
+    r[2] = (s[0].z + s[1].z) + (s[2].z + s[3].z);
+    r[3] = (s[0].w + s[1].w) + (s[2].w + s[3].w);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * D; c += kRowThreads) {
+    float t = 0.0f;
+    for (int sl = 0; sl < slices; ++sl) t += red[sl * 2 * D + c];
+    tot[c] = t;
+  }
+  __syncthreads();
+}
+
+__host__ __device__ inline int reduce_red_floats(int D) {
+  const int nq = 2 * D / 4;
+  const int slices = kRowThreads / nq > 0 ? kRowThreads / nq : 1;
+  return slices * 2 * D;  // red[slices][2D]
+}
+__host__ __device__ inline int reduce_scratch_floats(int D) {
+  return 2 * D + reduce_red_floats(D);  // tot[2][D] + red
+}
+
 // ---- forward ------------------------------------------------------------------------------
 template <int KI>
-__global__ __launch_bounds__(kRowThreads) void rowlin_fwd_kernel(RowLinArgs a) {
+__global__ __launch_bounds__(kRowThreads) void rowlin_fwd_kernel(RowLinArgs a, RowLinGeom ge) {
   constexpr int LDW = KI + 4;  // LDS pitch of a weight row (16-byte aligned, bank-shifted)
   const int lane = lane_id(), lq = lane & 15, g = lane >> 4;
-  const int rg = blockIdx.x % a.G, og = blockIdx.x / a.G;
-  const int tgw = a.TG * 16;
+  const int rg = blockIdx.x % ge.G, og = blockIdx.x / ge.G;
+  const int tgw = ge.TG * 16;
   const int o_base = og * tgw;
-  const int ntile = min(a.TG, a.NO / 16 - og * a.TG);
-  float* wt = feta_lds;               // [TG*16][LDW]
-  float* red = feta_lds + tgw * LDW;  // [kRowWaves][2][TG*16]
+  const int ntile = min(ge.TG, a.NO / 16 - og * ge.TG);
+  float* wt = feta_lds;                     // [TG*16][LDW]
+  float* red = wt + tgw * LDW;              // [kRowWaves][2][TG*16]
+  float* xss = red + kRowWaves * 2 * tgw;   // [2][KI] scale, shift of the input BatchNorm
+  float* scr = xss + 2 * KI;                // finalize scratch
   const bool want_stats = a.stats != nullptr;
+  const bool x_norm = a.x_stats != nullptr || a.x_bn != nullptr;
 
   const int nvec = ntile * 16 * (KI / 4);
   for (int idx = threadIdx.x; idx < nvec; idx += kRowThreads) {
@@ -67,35 +117,90 @@ __global__ __launch_bounds__(kRowThreads) void rowlin_fwd_kernel(RowLinArgs a) {
   }
   if (want_stats)
     for (int i = threadIdx.x; i < kRowWaves * 2 * tgw; i += kRowThreads) red[i] = 0.0f;
+  if (a.x_stats != nullptr) {
+    // first consumer of fresh statistics: finalize them (every block, redundantly and
+    // deterministically); block 0 publishes the parameter block and the running statistics
+    reduce_partials(a.x_stats, a.Gx, KI, scr + 2 * KI, scr);
+    for (int c = threadIdx.x; c < KI; c += kRowThreads) {
+      const float mean = scr[c] / (float)a.M;
+      const float var = fmaxf(scr[KI + c] / (float)a.M - mean * mean, 0.0f);
+      const float rstd = rsqrtf(var + a.eps);
+      const float scale = a.x_gamma[c] * rstd;
+      const float shift = a.x_beta[c] - mean * scale;
+      xss[c] = scale;
+      xss[KI + c] = shift;
+      if (blockIdx.x == 0) {
+        a.x_bn_out[c] = scale;
+        a.x_bn_out[KI + c] = shift;
+        a.x_bn_out[2 * KI + c] = mean;
+        a.x_bn_out[3 * KI + c] = rstd;
+        if (a.x_rmean != nullptr) {
+          const float unbiased = a.M > 1 ? var * (float)a.M / (float)(a.M - 1) : var;
+          a.x_rmean[c] = (1.0f - a.momentum) * a.x_rmean[c] + a.momentum * mean;
+          a.x_rvar[c] = (1.0f - a.momentum) * a.x_rvar[c] + a.momentum * unbiased;
+        }
+      }
+    }
+  } else if (a.x_bn != nullptr) {
+    for (int c = threadIdx.x; c < 2 * KI; c += kRowThreads) xss[c] = a.x_bn[c];
+  }
   __syncthreads();
 
   float* my = red + wave_id() * 2 * tgw;
   const int nrb = (a.M + kRowsPerBlock - 1) / kRowsPerBlock;
-  for (int rb = rg; rb < nrb; rb += a.G) {
+  for (int rb = rg; rb < nrb; rb += ge.G) {
     const int row = rb * kRowsPerBlock + wave_id() * 16 + lq;
     const bool rok = row < a.M;
+    const int rowc = min(row, a.M - 1);
+    // ---- load batch: everything this row block needs from memory is requested up front
+    // (clamped row, selects afterwards), so the block pays ONE memory latency
     Feat<KI> xf;
-    load_row<KI>(xf, rok ? a.x + (int64_t)row * KI : nullptr, g);
-    const float rs = (a.rowscale != nullptr && rok) ? a.rowscale[row] : 1.0f;
-    for (int t = 0; t < ntile; ++t) {
+    load_row_sel<KI>(xf, a.x + (int64_t)rowc * KI, true, g);
+    const float rs = a.rowscale != nullptr ? a.rowscale[rowc] : 1.0f;
+    const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 bv[4], rv[4], r1[4], r2[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      bv[t] = z4; rv[t] = z4; r1[t] = make_float4(1.0f, 1.0f, 1.0f, 1.0f); r2[t] = z4;
+      if (t < ntile) {
+        const int o = o_base + 16 * t + 4 * g;
+        if (a.bias != nullptr) bv[t] = *reinterpret_cast<const float4*>(a.bias + o);
+        if (a.residual != nullptr) rv[t] = *reinterpret_cast<const float4*>(a.residual + (int64_t)rowc * a.NO + o);
+        if (a.res_bn != nullptr) {
+          r1[t] = *reinterpret_cast<const float4*>(a.res_bn + o);
+          r2[t] = *reinterpret_cast<const float4*>(a.res_bn + a.NO + o);
+        }
+      }
+    }
+    if (x_norm) {
+#pragma unroll
+      for (int j = 0; j < Feat<KI>::NJ; ++j) {
+        const int c = 16 * j + 4 * g;
+        if (c < KI) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) xf.f[j][s] = xf.f[j][s] * xss[c + s] + xss[KI + c + s];
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t >= ntile) break;
       Feat<KI> wf;
       load_row<KI>(wf, wt + (16 * t + lq) * LDW, g);
       f32x4 acc = dot_rows<KI>(wf, xf, zero4());  // (o = o_base + 16t + 4g + r, row)
       const int ol = 16 * t + 4 * g, o = o_base + ol;
+      const float bb[4] = {bv[t].x, bv[t].y, bv[t].z, bv[t].w};
+      const float rr[4] = {rv[t].x * r1[t].x + r2[t].x, rv[t].y * r1[t].y + r2[t].y,
+                           rv[t].z * r1[t].z + r2[t].z, rv[t].w * r1[t].w + r2[t].w};
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        v[r] = acc[r] + (a.bias != nullptr ? a.bias[o + r] : 0.0f);
+        v[r] = acc[r] + bb[r];
         if (a.relu) v[r] = fmaxf(v[r], 0.0f);
-        v[r] *= rs;
+        v[r] = v[r] * rs + (a.residual != nullptr ? rr[r] : 0.0f);
       }
-      if (rok) {
-        if (a.residual != nullptr) {
-          const float4 rv = *reinterpret_cast<const float4*>(a.residual + (int64_t)row * a.NO + o);
-          v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-        }
+      if (rok)
         *reinterpret_cast<float4*>(a.y + (int64_t)row * a.NO + o) = make_float4(v[0], v[1], v[2], v[3]);
-      }
       if (want_stats) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -127,43 +232,96 @@ __global__ __launch_bounds__(kRowThreads) void rowlin_fwd_kernel(RowLinArgs a) {
   }
 }
 
-// ---- backward: dX role (template on the contraction dim NO) and dW/db role (template on KI) ---
+// ---- backward ---------------------------------------------------------------------------------
+// gradient source g(row, o) = T(dy)(row, o) * rowscale[row] * [relu_y > 0], with T = identity or
+// the BatchNorm backward  scale_o (dy - m1_o - xhat m2_o),  xhat = (g_y - mean_o) rstd_o,
+// m1 = mean_rows(dy), m2 = mean_rows(dy xhat).  gv (LDS) = [5][NO]: scale, mean, rstd, m1, m2.
 
 template <int NO>
-__device__ void rowlin_dx_role(const RowLinArgs& a, int lq, int g) {
-  const int rg = blockIdx.x % a.G, kg = blockIdx.x / a.G;
-  const int ks = a.TG * 16, ldw = ks + 4;
+__device__ void rowlin_dx_role(const RowLinArgs& a, const RowLinGeom& ge, const float* gv,
+                               float* lds_free, int lq, int g) {
+  const int rg = blockIdx.x % ge.G, kg = blockIdx.x / ge.G;
+  const int ks = ge.TG * 16, ldw = ks + 4;
   const int k_base = kg * ks;
-  const int ntile = min(a.TG, a.KI / 16 - kg * a.TG);
-  float* wt = feta_lds;  // [NO][ldw]: W[:, k_base : k_base + 16 ntile]
+  const int ntile = min(ge.TG, a.KI / 16 - kg * ge.TG);
+  float* wt = lds_free;                // [NO][ldw]: W[:, k_base : k_base + 16 ntile]
+  float* red = wt + NO * ldw;          // [kRowWaves][2][ks] partial sums for the next BN backward
+  float* ev = red + kRowWaves * 2 * ks;  // [7][ks] epilogue vectors of this k slice:
+  // add_bn scale, mean, rstd; add_fin m1, m2; sum_bn mean, rstd
+  const bool want_sums = a.sum_out != nullptr;
+  for (int i = threadIdx.x; i < ks; i += kRowThreads) {
+    const int k = k_base + i;
+    const bool kok = k < a.KI;
+    const bool ad = a.add_dout != nullptr && kok;
+    ev[i] = ad ? a.add_bn[k] : 0.0f;
+    ev[ks + i] = ad ? a.add_bn[2 * a.KI + k] : 0.0f;
+    ev[2 * ks + i] = ad ? a.add_bn[3 * a.KI + k] : 0.0f;
+    ev[3 * ks + i] = ad ? a.add_fin[k] : 0.0f;
+    ev[4 * ks + i] = ad ? a.add_fin[a.KI + k] : 0.0f;
+    ev[5 * ks + i] = (want_sums && kok) ? a.sum_bn[2 * a.KI + k] : 0.0f;
+    ev[6 * ks + i] = (want_sums && kok) ? a.sum_bn[3 * a.KI + k] : 0.0f;
+  }
   const int rowvec = ntile * 4;
   for (int idx = threadIdx.x; idx < NO * rowvec; idx += kRowThreads) {
     const int o = idx / rowvec, c4 = idx - o * rowvec;
     *reinterpret_cast<float4*>(wt + o * ldw + 4 * c4) =
         *reinterpret_cast<const float4*>(a.w + (int64_t)o * a.KI + k_base + 4 * c4);
   }
+  if (want_sums)
+    for (int i = threadIdx.x; i < kRowWaves * 2 * ks; i += kRowThreads) red[i] = 0.0f;
   __syncthreads();
+  float* my = red + wave_id() * 2 * ks;
   const int nrb = (a.M + kRowsPerBlock - 1) / kRowsPerBlock;
-  for (int rb = rg; rb < nrb; rb += a.G) {
+  for (int rb = rg; rb < nrb; rb += ge.G) {
     const int row = rb * kRowsPerBlock + wave_id() * 16 + lq;
     const bool rok = row < a.M;
-    const float rs = (a.rowscale != nullptr && rok) ? a.rowscale[row] : 1.0f;
-    Feat<NO> gf;  // g = dy * rowscale * [ysaved > 0]
-    load_row<NO>(gf, rok ? a.dy + (int64_t)row * NO : nullptr, g, rs);
-    if (a.ysaved != nullptr && rok) {
+    const int rowc = min(row, a.M - 1);
+    // ---- load batch (clamped row, unconditional): gradient row, its BatchNorm / relu companions
+    // and every epilogue operand of this row block are requested before the first MFMA
+    const float rs = a.rowscale != nullptr ? a.rowscale[rowc] : 1.0f;
+    Feat<NO> gf, gyf, ryf;
+    load_row_sel<NO>(gf, a.dy + (int64_t)rowc * NO, rok, g);
+    if (a.g_y != nullptr) load_row_sel<NO>(gyf, a.g_y + (int64_t)rowc * NO, true, g);
+    if (a.relu_y != nullptr) load_row_sel<NO>(ryf, a.relu_y + (int64_t)rowc * NO, true, g);
+    const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 pv4[4], dv4[4], ay4[4], sy4[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      pv4[t] = z4; dv4[t] = z4; ay4[t] = z4; sy4[t] = z4;
+      if (t < ntile) {
+        const int64_t off = (int64_t)rowc * a.KI + k_base + 16 * t + 4 * g;
+        if (a.add_plain != nullptr) pv4[t] = *reinterpret_cast<const float4*>(a.add_plain + off);
+        if (a.add_dout != nullptr) {
+          dv4[t] = *reinterpret_cast<const float4*>(a.add_dout + off);
+          ay4[t] = *reinterpret_cast<const float4*>(a.add_y + off);
+        }
+        if (want_sums) sy4[t] = *reinterpret_cast<const float4*>(a.sum_y + off);
+      }
+    }
+    if (a.g_y != nullptr) {
 #pragma unroll
       for (int j = 0; j < Feat<NO>::NJ; ++j) {
         const int o = 16 * j + 4 * g;
         if (o < NO) {
-          const float4 yv = *reinterpret_cast<const float4*>(a.ysaved + (int64_t)row * NO + o);
-          if (!(yv.x > 0.0f)) gf.f[j][0] = 0.0f;
-          if (!(yv.y > 0.0f)) gf.f[j][1] = 0.0f;
-          if (!(yv.z > 0.0f)) gf.f[j][2] = 0.0f;
-          if (!(yv.w > 0.0f)) gf.f[j][3] = 0.0f;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const float xh = (gyf.f[j][s] - gv[NO + o + s]) * gv[2 * NO + o + s];
+            gf.f[j][s] = gv[o + s] * (gf.f[j][s] - gv[3 * NO + o + s] - xh * gv[4 * NO + o + s]);
+          }
         }
       }
     }
-    for (int t = 0; t < ntile; ++t) {
+#pragma unroll
+    for (int j = 0; j < Feat<NO>::NJ; ++j)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float v = rok ? gf.f[j][s] * rs : 0.0f;
+        if (a.relu_y != nullptr && !(ryf.f[j][s] > 0.0f)) v = 0.0f;
+        gf.f[j][s] = v;
+      }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t >= ntile) break;
       // dX^T tile (k = k_base + 16t + 4g' + r, row): A[k = lq][o = 16j + 4g + s] = W[o][k]
       f32x4 acc = zero4();
 #pragma unroll
@@ -175,46 +333,102 @@ __device__ void rowlin_dx_role(const RowLinArgs& a, int lq, int g) {
           acc = mfma16(wv, gf.f[j][s], acc);
         }
       }
+      const int kl = 16 * t + 4 * g, k = k_base + kl;
+      float v[4] = {acc[0] + pv4[t].x, acc[1] + pv4[t].y, acc[2] + pv4[t].z, acc[3] + pv4[t].w};
+      if (a.add_dout != nullptr) {  // residual branch: BatchNorm backward of add_dout
+        const float dd[4] = {dv4[t].x, dv4[t].y, dv4[t].z, dv4[t].w};
+        const float yy[4] = {ay4[t].x, ay4[t].y, ay4[t].z, ay4[t].w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float xh = (yy[r] - ev[ks + kl + r]) * ev[2 * ks + kl + r];
+          v[r] += ev[kl + r] * (dd[r] - ev[3 * ks + kl + r] - xh * ev[4 * ks + kl + r]);
+        }
+      }
       if (rok)
-        *reinterpret_cast<float4*>(a.dx + (int64_t)row * a.KI + k_base + 16 * t + 4 * g) =
-            make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(a.dx + (int64_t)row * a.KI + k) = make_float4(v[0], v[1], v[2], v[3]);
+      if (want_sums) {  // sum(dx), sum(dx * xhat) over rows, for the BatchNorm that produced x
+        const float yy[4] = {sy4[t].x, sy4[t].y, sy4[t].z, sy4[t].w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float xh = (yy[r] - ev[5 * ks + kl + r]) * ev[6 * ks + kl + r];
+          float s1 = rok ? v[r] : 0.0f, s2 = s1 * xh;
+#pragma unroll
+          for (int m = 1; m < 16; m <<= 1) {
+            s1 += shfl_xor(s1, m);
+            s2 += shfl_xor(s2, m);
+          }
+          if (lq == 0) {
+            my[kl + r] += s1;
+            my[ks + kl + r] += s2;
+          }
+        }
+      }
+    }
+  }
+  if (want_sums) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * ks; i += kRowThreads) {
+      const int which = i / ks, kl = i - which * ks;
+      if (kl < ntile * 16) {
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < kRowWaves; ++w) s += red[w * 2 * ks + i];
+        a.sum_out[((int64_t)rg * 2 + which) * a.KI + k_base + kl] = s;
+      }
     }
   }
 }
 
 template <int KI>
-__device__ void rowlin_dw_role(const RowLinArgs& a, int lq, int g) {
+__device__ void rowlin_dw_role(const RowLinArgs& a, const RowLinGeom& ge, const float* gv, int lq,
+                               int g) {
   constexpr int KT = KI / 16;
   const int not_ = a.NO / 16;
-  const int item = (blockIdx.x - a.dx_blocks) * kRowWaves + wave_id();
-  if (item >= a.RC * not_) return;
+  const int item = (blockIdx.x - ge.dx_blocks) * kRowWaves + wave_id();
+  if (item >= ge.RC * not_) return;
   const int ot = item % not_, rc = item / not_;
   const int nrb16 = (a.M + 15) / 16;
-  const int per = (nrb16 + a.RC - 1) / a.RC;
+  const int per = (nrb16 + ge.RC - 1) / ge.RC;
   const int o = 16 * ot + lq;
+  const bool gbn = a.g_y != nullptr;
+  float g_sc = 1.0f, g_mu = 0.0f, g_rs = 0.0f, g_m1 = 0.0f, g_m2 = 0.0f;
+  if (gbn) {
+    g_sc = gv[o]; g_mu = gv[a.NO + o]; g_rs = gv[2 * a.NO + o]; g_m1 = gv[3 * a.NO + o]; g_m2 = gv[4 * a.NO + o];
+  }
+  float xs[KT], xh[KT];  // input BatchNorm: x = x_raw * xs + xh
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    xs[kt] = a.x_bn != nullptr ? a.x_bn[16 * kt + lq] : 1.0f;
+    xh[kt] = a.x_bn != nullptr ? a.x_bn[KI + 16 * kt + lq] : 0.0f;
+  }
   f32x4 acc[KT];
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) acc[kt] = zero4();
   float db = 0.0f;
   for (int rb = rc * per; rb < min((rc + 1) * per, nrb16); ++rb) {
     // issue every load of the row block before the first MFMA (one latency per block)
-    float gv[4], xv[4][KT];
+    float gvr[4], xv[4][KT];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = 16 * rb + 4 * g + r;
       const bool rok = row < a.M;
       float v = rok ? a.dy[(int64_t)row * a.NO + o] : 0.0f;
+      if (gbn && rok) {
+        const float xhat = (a.g_y[(int64_t)row * a.NO + o] - g_mu) * g_rs;
+        v = g_sc * (v - g_m1 - xhat * g_m2);
+      }
       if (rok && a.rowscale != nullptr) v *= a.rowscale[row];
-      if (rok && a.ysaved != nullptr && !(a.ysaved[(int64_t)row * a.NO + o] > 0.0f)) v = 0.0f;
-      gv[r] = v;
+      if (rok && a.relu_y != nullptr && !(a.relu_y[(int64_t)row * a.NO + o] > 0.0f)) v = 0.0f;
+      gvr[r] = v;
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt) xv[r][kt] = rok ? a.x[(int64_t)row * KI + 16 * kt + lq] : 0.0f;
+      for (int kt = 0; kt < KT; ++kt)
+        xv[r][kt] = rok ? a.x[(int64_t)row * KI + 16 * kt + lq] * xs[kt] + xh[kt] : 0.0f;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      db += gv[r];
+      db += gvr[r];
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt) acc[kt] = mfma16(gv[r], xv[r][kt], acc[kt]);  // (o 4g+r', k lq)
+      for (int kt = 0; kt < KT; ++kt) acc[kt] = mfma16(gvr[r], xv[r][kt], acc[kt]);  // (o 4g+r', k lq)
     }
   }
   float* p = a.partial + (int64_t)rc * ((int64_t)a.NO * KI + a.NO);
@@ -227,16 +441,153 @@ __device__ void rowlin_dw_role(const RowLinArgs& a, int lq, int g) {
   if (g == 0) p[(int64_t)a.NO * KI + o] = db;
 }
 
-template <int KI, int NO>
-__global__ __launch_bounds__(kRowThreads) void rowlin_bwd_kernel(RowLinArgs a) {
-  const int lane = lane_id(), lq = lane & 15, g = lane >> 4;
-  if ((int)blockIdx.x < a.dx_blocks)
-    rowlin_dx_role<NO>(a, lq, g);
-  else
-    rowlin_dw_role<KI>(a, lq, g);
+// dW/db role, LDS-staged (KI <= 128): a workgroup = one row chunk x a group of 4 output tiles
+// (one per wave).  The chunk's gradient slice g[64 rows][64 outputs] (all transforms applied) and
+// x[64 rows][KI] (seen through its BatchNorm) are staged by all 256 threads with 16-byte loads -
+// one memory latency for the whole tile instead of one per 16-row block - and the MFMA operands
+// come from LDS (pitch = 16 mod 32 floats: conflict-free column reads).
+template <int KI>
+__device__ void rowlin_dw_role_lds(const RowLinArgs& a, const RowLinGeom& ge, const float* gv,
+                                   float* lds_free, int lq, int g) {
+  constexpr int KT = KI / 16;
+  constexpr int GP = 64 + 16, XP = KI + 16;
+  const int not_ = a.NO / 16;
+  const int n_og = (not_ + kRowWaves - 1) / kRowWaves;
+  const int bi = blockIdx.x - ge.dx_blocks;
+  const int og = bi % n_og, rc = bi / n_og;
+  const int o_base = og * 64;
+  const int ow = min(64, a.NO - o_base);  // outputs of this group
+  float* gt = lds_free;                   // [64][GP]
+  float* xt = gt + 64 * GP;               // [64][XP]
+  const int nrb16 = (a.M + 15) / 16;
+  const int per = (nrb16 + ge.RC - 1) / ge.RC;  // 16-row blocks per chunk
+  const int row_lo = rc * per * 16, row_hi = min((rc + 1) * per * 16, a.M);
+  const int ot = og * kRowWaves + wave_id();
+  const bool wave_on = ot < not_;
+  const bool gbn = a.g_y != nullptr;
+  f32x4 acc[KT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) acc[kt] = zero4();
+  float db = 0.0f;
+  for (int r0 = row_lo; r0 < row_hi; r0 += 64) {
+    if (r0 > row_lo) __syncthreads();
+    // stage g slice: 64 rows x (ow / 4) float4
+    const int gq = ow / 4;
+    for (int idx = threadIdx.x; idx < 64 * gq; idx += kRowThreads) {
+      const int rr = idx / gq, c4 = idx - rr * gq;
+      const int row = r0 + rr, o = o_base + 4 * c4;
+      float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (row < row_hi) {
+        const float4 dv = *reinterpret_cast<const float4*>(a.dy + (int64_t)row * a.NO + o);
+        v[0] = dv.x; v[1] = dv.y; v[2] = dv.z; v[3] = dv.w;
+        if (gbn) {
+          const float4 yv = *reinterpret_cast<const float4*>(a.g_y + (int64_t)row * a.NO + o);
+          const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const float xh = (yy[s] - gv[a.NO + o + s]) * gv[2 * a.NO + o + s];
+            v[s] = gv[o + s] * (v[s] - gv[3 * a.NO + o + s] - xh * gv[4 * a.NO + o + s]);
+          }
+        }
+        if (a.rowscale != nullptr) {
+          const float rs = a.rowscale[row];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) v[s] *= rs;
+        }
+        if (a.relu_y != nullptr) {
+          const float4 yv = *reinterpret_cast<const float4*>(a.relu_y + (int64_t)row * a.NO + o);
+          if (!(yv.x > 0.0f)) v[0] = 0.0f;
+          if (!(yv.y > 0.0f)) v[1] = 0.0f;
+          if (!(yv.z > 0.0f)) v[2] = 0.0f;
+          if (!(yv.w > 0.0f)) v[3] = 0.0f;
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) gt[rr * GP + 4 * c4 + s] = v[s];
+    }
+    // stage x: 64 rows x (KI / 4) float4, seen through its BatchNorm
+    for (int idx = threadIdx.x; idx < 64 * (KI / 4); idx += kRowThreads) {
+      const int rr = idx / (KI / 4), c4 = idx - rr * (KI / 4);
+      const int row = r0 + rr, k = 4 * c4;
+      float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (row < row_hi) {
+        const float4 xv = *reinterpret_cast<const float4*>(a.x + (int64_t)row * KI + k);
+        v[0] = xv.x; v[1] = xv.y; v[2] = xv.z; v[3] = xv.w;
+        if (a.x_bn != nullptr) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) v[s] = v[s] * a.x_bn[k + s] + a.x_bn[KI + k + s];
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) xt[rr * XP + k + s] = v[s];
+    }
+    __syncthreads();
+    if (wave_on) {
+      const int ol = 16 * wave_id() + lq;
+#pragma unroll 4
+      for (int st = 0; st < 16; ++st) {
+        const int rr = 4 * st + g;
+        const float gvv = gt[rr * GP + ol];
+        db += gvv;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) acc[kt] = mfma16(gvv, xt[rr * XP + 16 * kt + lq], acc[kt]);
+      }
+    }
+  }
+  if (!wave_on) return;
+  float* p = a.partial + (int64_t)rc * ((int64_t)a.NO * KI + a.NO);
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[(int64_t)(16 * ot + 4 * g + r) * KI + 16 * kt + lq] = acc[kt][r];
+  db += shfl_xor(db, 16);
+  db += shfl_xor(db, 32);
+  if (g == 0) p[(int64_t)a.NO * KI + 16 * ot + lq] = db;
 }
 
-// ---- BatchNorm1d (training mode) over M rows ---------------------------------------------
+template <int KI, int NO>
+__global__ __launch_bounds__(kRowThreads) void rowlin_bwd_kernel(RowLinArgs a, RowLinGeom ge) {
+  const int lane = lane_id(), lq = lane & 15, g = lane >> 4;
+  float* gv = feta_lds;  // [5][NO] parameters of the gradient-side BatchNorm backward
+  float* after = gv;
+  if (a.g_y != nullptr) {
+    float* scr = gv + 5 * NO;
+    after = scr;
+    if (a.g_sum != nullptr) {
+      reduce_partials(a.g_sum, a.Gs, NO, scr + 2 * NO, scr);
+      for (int c = threadIdx.x; c < NO; c += kRowThreads) {
+        gv[3 * NO + c] = scr[c] / (float)a.M;
+        gv[4 * NO + c] = scr[NO + c] / (float)a.M;
+        if (blockIdx.x == 0) {
+          if (a.dbeta != nullptr) a.dbeta[c] = scr[c];
+          if (a.dgamma != nullptr) a.dgamma[c] = scr[NO + c];
+          if (a.g_fin_out != nullptr) {
+            a.g_fin_out[c] = gv[3 * NO + c];
+            a.g_fin_out[NO + c] = gv[4 * NO + c];
+          }
+        }
+      }
+    } else {
+      for (int c = threadIdx.x; c < 2 * NO; c += kRowThreads) gv[3 * NO + c] = a.g_fin[c];
+    }
+    for (int c = threadIdx.x; c < NO; c += kRowThreads) {
+      gv[c] = a.g_bn[c];
+      gv[NO + c] = a.g_bn[2 * NO + c];
+      gv[2 * NO + c] = a.g_bn[3 * NO + c];
+    }
+    __syncthreads();
+  }
+  if ((int)blockIdx.x < ge.dx_blocks) {
+    rowlin_dx_role<NO>(a, ge, gv, after, lq, g);
+  } else {
+    if constexpr (KI <= 128)
+      rowlin_dw_role_lds<KI>(a, ge, gv, after, lq, g);
+    else
+      rowlin_dw_role<KI>(a, ge, gv, lq, g);
+  }
+}
+
+// ---- BatchNorm1d (training mode) over M rows, stand-alone passes --------------------------------
 
 struct BnArgs {
   const float* y;       // [M, D] pre-norm input
@@ -256,35 +607,8 @@ struct BnArgs {
   float* dbeta;
   float momentum, eps;
   int M, D, G;
+  int prm4;             // mean_rstd_in is a [4][D] parameter block (mean at row 2, rstd at row 3)
 };
-
-// sums the G partial pairs [G][2][D] with all 256 threads; on return tot[0][c], tot[1][c]
-// (LDS, [2][D]) hold the totals.  red: [slices][2][D] scratch.
-__device__ __forceinline__ void bn_reduce_partials(const float* part, int G, int D, float* red,
-                                                   float* tot) {
-  const int slices = 256 / D > 0 ? 256 / D : 1;
-  const int col = threadIdx.x % D, slice = threadIdx.x / D;
-  if ((int)threadIdx.x < slices * D) {
-    float s1 = 0.0f, s2 = 0.0f;
-    for (int gi = slice; gi < G; gi += slices) {
-      s1 += part[((int64_t)gi * 2 + 0) * D + col];
-      s2 += part[((int64_t)gi * 2 + 1) * D + col];
-    }
-    red[(slice * 2 + 0) * D + col] = s1;
-    red[(slice * 2 + 1) * D + col] = s2;
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < D; c += 256) {
-    float t1 = 0.0f, t2 = 0.0f;
-    for (int s = 0; s < slices; ++s) {
-      t1 += red[(s * 2 + 0) * D + c];
-      t2 += red[(s * 2 + 1) * D + c];
-    }
-    tot[c] = t1;
-    tot[D + c] = t2;
-  }
-  __syncthreads();
-}
 
 // per-block partial (sum, sumsq) of y: threads = columns x row slices
 __global__ __launch_bounds__(256) void bn_stats_kernel(BnArgs a) {
@@ -327,7 +651,7 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(BnArgs a) {
   float* sh = feta_lds + D;        // [D] shift = beta - mean * scale
   float* tot = feta_lds + 2 * D;   // [2][D]
   float* red = feta_lds + 4 * D;   // [slices][2][D]
-  bn_reduce_partials(a.stats, a.G, D, red, tot);
+  reduce_partials(a.stats, a.G, D, red, tot);
   for (int c = threadIdx.x; c < D; c += 256) {
     const float mean = tot[c] / (float)a.M;
     const float var = fmaxf(tot[D + c] / (float)a.M - mean * mean, 0.0f);
@@ -336,8 +660,15 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(BnArgs a) {
     sc[c] = scale;
     sh[c] = a.beta[c] - mean * scale;
     if (blockIdx.x == 0) {
-      a.mean_rstd[c] = mean;
-      a.mean_rstd[D + c] = rstd;
+      if (a.prm4) {
+        a.mean_rstd[c] = scale;
+        a.mean_rstd[D + c] = sh[c];
+        a.mean_rstd[2 * D + c] = mean;
+        a.mean_rstd[3 * D + c] = rstd;
+      } else {
+        a.mean_rstd[c] = mean;
+        a.mean_rstd[D + c] = rstd;
+      }
       if (a.running_mean != nullptr) {
         const float unbiased = a.M > 1 ? var * (float)a.M / (float)(a.M - 1) : var;
         a.running_mean[c] = (1.0f - a.momentum) * a.running_mean[c] + a.momentum * mean;
@@ -364,9 +695,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnArgs a) {
   const int col = threadIdx.x % D, slice = threadIdx.x / D;
   const bool active = (int)threadIdx.x < slices * D;
   const int nrb = (a.M + kRowsPerBlock - 1) / kRowsPerBlock;
+  const int mo = a.prm4 ? 2 * D : 0;
   float s1 = 0.0f, s2 = 0.0f;
   if (active) {
-    const float mean = a.mean_rstd_in[col], rstd = a.mean_rstd_in[D + col];
+    const float mean = a.mean_rstd_in[mo + col], rstd = a.mean_rstd_in[mo + D + col];
     for (int rb = blockIdx.x; rb < nrb; rb += a.G) {
       const int r0 = rb * kRowsPerBlock;
       for (int r = r0 + slice; r < min(r0 + kRowsPerBlock, a.M); r += slices) {
@@ -399,7 +731,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnArgs a) {
   float* rs = feta_lds + 2 * D;
   float* tot = feta_lds + 3 * D;  // [2][D]: sum(dout), sum(dout*xhat)
   float* red = feta_lds + 5 * D;
-  bn_reduce_partials(a.partial, a.G, D, red, tot);
+  reduce_partials(a.partial, a.G, D, red, tot);
   for (int c = threadIdx.x; c < D; c += 256) {
     const float rstd = a.mean_rstd_in[D + c];
     k0[c] = a.gamma[c] * rstd;
@@ -443,15 +775,15 @@ int row_chunks(int M) {
 
 bool dim_ok(int c) { return c == 16 || c == 32 || c == 64 || c == 128 || c == 192 || c == 256; }
 
-// tiles per workgroup such that the staged weight slice (rows x (16 tg + 4) floats... ) fits
+// tiles per workgroup such that the staged weight slice fits beside the other LDS users
 int tiles_fwd(int KI) {  // LDS: 16 tg (KI + 4) floats
   int tg = 4;
-  while (tg > 1 && 16 * tg * (KI + 4) * 4 > 56 * 1024) --tg;
+  while (tg > 1 && 16 * tg * (KI + 4) * 4 > 48 * 1024) --tg;
   return tg;
 }
 int tiles_dx(int NO) {   // LDS: NO (16 tg + 4) floats
   int tg = 4;
-  while (tg > 1 && NO * (16 * tg + 4) * 4 > 56 * 1024) --tg;
+  while (tg > 1 && NO * (16 * tg + 4) * 4 > 48 * 1024) --tg;
   return tg;
 }
 
@@ -466,11 +798,14 @@ int tiles_dx(int NO) {   // LDS: NO (16 tg + 4) floats
   }
 
 template <int KI>
-void launch_bwd_ki(const RowLinArgs& a, int grid, size_t lds, hipStream_t stream) {
-#define CALL(NOV)                                                               \
-  {                                                                             \
-    auto kern = rowlin_bwd_kernel<KI, NOV>;                                     \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kRowThreads), lds, stream, a);    \
+void launch_bwd_ki(const RowLinArgs& a, const RowLinGeom& ge, int grid, size_t lds, hipStream_t stream) {
+#define CALL(NOV)                                                                   \
+  {                                                                                 \
+    auto kern = rowlin_bwd_kernel<KI, NOV>;                                         \
+    if (lds > 64 * 1024)                                                            \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kRowThreads), lds, stream, a, ge);    \
   }
   FETA_DIM_SWITCH(a.NO, CALL)
 #undef CALL
@@ -483,55 +818,84 @@ using namespace feta;
 extern "C" int feta_rowlin_blocks(int M) { return row_blocks(M); }
 extern "C" int feta_rowlin_chunks(int M) { return row_chunks(M); }
 
+extern "C" int feta_rowlin_fwd_ex(const feta_rowlin_ex* d, feta_stream_t stream) {
+  FETA_REQUIRE(d != nullptr, "rowlin_fwd_ex: null descriptor");
+  const RowLinArgs& a = *d;
+  FETA_REQUIRE(a.x && a.w && a.y && a.M > 0, "rowlin_fwd: null pointer / empty");
+  FETA_REQUIRE(dim_ok(a.KI) && (a.NO % 16) == 0 && a.NO > 0 && a.NO <= 1024,
+               "rowlin_fwd: unsupported dims KI=%d NO=%d", a.KI, a.NO);
+  FETA_REQUIRE(aligned16(a.x) && aligned16(a.w) && aligned16(a.y) && (!a.residual || aligned16(a.residual)),
+               "rowlin_fwd: pointers must be 16-byte aligned");
+  FETA_REQUIRE(!a.x_stats || (a.x_gamma && a.x_beta && a.x_bn_out && a.Gx > 0),
+               "rowlin_fwd: x_stats needs gamma, beta, bn_out, Gx");
+  FETA_REQUIRE(!a.res_bn || a.residual, "rowlin_fwd: res_bn without residual");
+  RowLinGeom ge{};
+  ge.G = row_blocks(a.M);
+  ge.TG = tiles_fwd(a.KI);
+  const int n_og = (a.NO / 16 + ge.TG - 1) / ge.TG;
+  const size_t lds = sizeof(float) * (16 * ge.TG * (a.KI + 4) + kRowWaves * 2 * 16 * ge.TG + 2 * a.KI +
+                                      (a.x_stats ? reduce_scratch_floats(a.KI) : 0));
+#define CALL(KV)                                                                                     \
+  {                                                                                                  \
+    auto kern = rowlin_fwd_kernel<KV>;                                                               \
+    hipLaunchKernelGGL(kern, dim3(ge.G * n_og), dim3(kRowThreads), lds, (hipStream_t)stream, a, ge); \
+  }
+  FETA_DIM_SWITCH(a.KI, CALL)
+#undef CALL
+  return check_launch("feta_rowlin_fwd");
+}
+
+extern "C" int feta_rowlin_bwd_ex(const feta_rowlin_ex* d, float* dwdb, feta_stream_t stream) {
+  FETA_REQUIRE(d != nullptr, "rowlin_bwd_ex: null descriptor");
+  const RowLinArgs& a = *d;
+  FETA_REQUIRE(a.x && a.w && a.dy && a.dx && a.partial && dwdb && a.M > 0,
+               "rowlin_bwd: null pointer / empty");
+  FETA_REQUIRE(dim_ok(a.KI) && dim_ok(a.NO), "rowlin_bwd: unsupported dims KI=%d NO=%d", a.KI, a.NO);
+  FETA_REQUIRE(aligned16(a.x) && aligned16(a.w) && aligned16(a.dy) && aligned16(a.dx) &&
+                   (!a.relu_y || aligned16(a.relu_y)) && (!a.g_y || aligned16(a.g_y)),
+               "rowlin_bwd: pointers must be 16-byte aligned");
+  FETA_REQUIRE(!a.g_y || (a.g_bn && (a.g_sum || a.g_fin)), "rowlin_bwd: g_y needs g_bn and g_sum|g_fin");
+  FETA_REQUIRE(!a.g_sum || a.Gs > 0, "rowlin_bwd: g_sum needs Gs");
+  FETA_REQUIRE(!a.add_dout || (a.add_y && a.add_bn && a.add_fin), "rowlin_bwd: incomplete add_* set");
+  FETA_REQUIRE(!a.sum_out || (a.sum_y && a.sum_bn), "rowlin_bwd: incomplete sum_* set");
+  RowLinGeom ge{};
+  ge.RC = row_chunks(a.M);
+  ge.G = row_blocks(a.M);
+  ge.TG = tiles_dx(a.NO);
+  const int n_kg = (a.KI / 16 + ge.TG - 1) / ge.TG;
+  ge.dx_blocks = ge.G * n_kg;
+  const int n_ot = a.NO / 16;
+  const int dw_blocks = a.KI <= 128 ? ge.RC * ((n_ot + kRowWaves - 1) / kRowWaves)
+                                    : (ge.RC * n_ot + kRowWaves - 1) / kRowWaves;
+  const int grid = ge.dx_blocks + dw_blocks;
+  const size_t dx_lds = a.NO * (16 * ge.TG + 4) + (kRowWaves * 2 + 7) * 16 * ge.TG;
+  const size_t dw_lds = a.KI <= 128 ? 64 * (64 + 16) + 64 * (a.KI + 16) : 0;
+  const size_t lds = sizeof(float) * ((dx_lds > dw_lds ? dx_lds : dw_lds) +
+                                      (a.g_y ? 5 * a.NO + reduce_scratch_floats(a.NO) : 0));
+#define CALL(KV) launch_bwd_ki<KV>(a, ge, grid, lds, (hipStream_t)stream);
+  FETA_DIM_SWITCH(a.KI, CALL)
+#undef CALL
+  int rc = check_launch("feta_rowlin_bwd");
+  if (rc != FETA_OK) return rc;
+  return feta_colsum(a.partial, dwdb, ge.RC, a.NO * a.KI + a.NO, stream);
+}
+
 extern "C" int feta_rowlin_fwd(const float* x, const float* w, const float* bias,
                                const float* rowscale, const float* residual, float* y, float* stats,
                                int relu, int M, int KI, int NO, feta_stream_t stream) {
-  FETA_REQUIRE(x && w && y && M > 0, "rowlin_fwd: null pointer / empty");
-  FETA_REQUIRE(dim_ok(KI) && (NO % 16) == 0 && NO > 0 && NO <= 1024,
-               "rowlin_fwd: unsupported dims KI=%d NO=%d", KI, NO);
-  FETA_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y) && (!residual || aligned16(residual)),
-               "rowlin_fwd: pointers must be 16-byte aligned");
-  RowLinArgs a{};
+  feta_rowlin_ex a{};
   a.x = x; a.w = w; a.bias = bias; a.rowscale = rowscale; a.residual = residual; a.y = y;
-  a.stats = stats; a.relu = relu; a.M = M; a.KI = KI; a.NO = NO; a.G = row_blocks(M);
-  a.TG = tiles_fwd(KI);
-  const int n_og = (NO / 16 + a.TG - 1) / a.TG;
-  const size_t lds = sizeof(float) * (16 * a.TG * (KI + 4) + (stats ? kRowWaves * 2 * 16 * a.TG : 0));
-#define CALL(KV)                                                                                \
-  {                                                                                             \
-    auto kern = rowlin_fwd_kernel<KV>;                                                          \
-    hipLaunchKernelGGL(kern, dim3(a.G * n_og), dim3(kRowThreads), lds, (hipStream_t)stream, a); \
-  }
-  FETA_DIM_SWITCH(KI, CALL)
-#undef CALL
-  return check_launch("feta_rowlin_fwd");
+  a.stats = stats; a.relu = relu; a.M = M; a.KI = KI; a.NO = NO;
+  return feta_rowlin_fwd_ex(&a, stream);
 }
 
 extern "C" int feta_rowlin_bwd(const float* x, const float* w, const float* dy,
                                const float* rowscale, const float* ysaved, float* dx, float* partial,
                                float* dwdb, int M, int KI, int NO, feta_stream_t stream) {
-  FETA_REQUIRE(x && w && dy && dx && partial && dwdb && M > 0, "rowlin_bwd: null pointer / empty");
-  FETA_REQUIRE(dim_ok(KI) && dim_ok(NO), "rowlin_bwd: unsupported dims KI=%d NO=%d", KI, NO);
-  FETA_REQUIRE(aligned16(x) && aligned16(w) && aligned16(dy) && aligned16(dx) &&
-                   (!ysaved || aligned16(ysaved)),
-               "rowlin_bwd: pointers must be 16-byte aligned");
-  RowLinArgs a{};
-  a.x = x; a.w = w; a.dy = dy; a.rowscale = rowscale; a.ysaved = ysaved; a.dx = dx;
+  feta_rowlin_ex a{};
+  a.x = x; a.w = w; a.dy = dy; a.rowscale = rowscale; a.relu_y = ysaved; a.dx = dx;
   a.partial = partial; a.M = M; a.KI = KI; a.NO = NO;
-  a.RC = row_chunks(M);
-  a.G = row_blocks(M);
-  a.TG = tiles_dx(NO);
-  const int n_kg = (KI / 16 + a.TG - 1) / a.TG;
-  a.dx_blocks = a.G * n_kg;
-  const int dw_blocks = (a.RC * (NO / 16) + kRowWaves - 1) / kRowWaves;
-  const int grid = a.dx_blocks + dw_blocks;
-  const size_t lds = sizeof(float) * NO * (16 * a.TG + 4);
-#define CALL(KV) launch_bwd_ki<KV>(a, grid, lds, (hipStream_t)stream);
-  FETA_DIM_SWITCH(KI, CALL)
-#undef CALL
-  int rc = check_launch("feta_rowlin_bwd");
-  if (rc != FETA_OK) return rc;
-  return feta_colsum(partial, dwdb, a.RC, NO * KI + NO, stream);
+  return feta_rowlin_bwd_ex(&a, dwdb, stream);
 }
 
 extern "C" int feta_bn_stats(const float* y, float* stats, int M, int D, feta_stream_t stream) {
@@ -542,6 +906,17 @@ extern "C" int feta_bn_stats(const float* y, float* stats, int M, int D, feta_st
   auto kern = bn_stats_kernel;
   hipLaunchKernelGGL(kern, dim3(a.G), dim3(256), sizeof(float) * slices * 2 * D, (hipStream_t)stream, a);
   return check_launch("feta_bn_stats");
+}
+
+static int bn_apply_launch(BnArgs& a, feta_stream_t stream) {
+  const int64_t n4 = (int64_t)a.M * a.D / 4;
+  int grid = (int)((n4 + 255) / 256);
+  grid = grid > 1024 ? 1024 : grid;
+  const int slices = 256 / a.D > 0 ? 256 / a.D : 1;
+  auto kern = bn_apply_fwd_kernel;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), sizeof(float) * (4 * a.D + reduce_red_floats(a.D)),
+                     (hipStream_t)stream, a);
+  return check_launch("feta_bn_apply_fwd");
 }
 
 extern "C" int feta_bn_apply_fwd(const float* y, const float* stats, const float* gamma,
@@ -555,14 +930,33 @@ extern "C" int feta_bn_apply_fwd(const float* y, const float* stats, const float
   a.y = y; a.stats = stats; a.gamma = gamma; a.beta = beta; a.out = out; a.mean_rstd = mean_rstd;
   a.running_mean = running_mean; a.running_var = running_var; a.momentum = momentum; a.eps = eps;
   a.M = M; a.D = D; a.G = row_blocks(M);
-  const int64_t n4 = (int64_t)M * D / 4;
-  int grid = (int)((n4 + 255) / 256);
-  grid = grid > 1024 ? 1024 : grid;
+  return bn_apply_launch(a, stream);
+}
+
+extern "C" int feta_bn_apply_fwd_prm(const float* y, const float* stats, const float* gamma,
+                                     const float* beta, float* out, float* bn_prm, float* running_mean,
+                                     float* running_var, float momentum, float eps, int M, int D,
+                                     feta_stream_t stream) {
+  FETA_REQUIRE(y && stats && gamma && beta && out && bn_prm, "bn_apply_fwd_prm: null pointer");
+  FETA_REQUIRE(M > 0 && D > 0 && D <= 256 && (D % 4) == 0, "bn_apply_fwd_prm: need D %% 4 == 0, D <= 256");
+  FETA_REQUIRE(aligned16(y) && aligned16(out), "bn_apply_fwd_prm: pointers must be 16-byte aligned");
+  BnArgs a{};
+  a.y = y; a.stats = stats; a.gamma = gamma; a.beta = beta; a.out = out; a.mean_rstd = bn_prm;
+  a.running_mean = running_mean; a.running_var = running_var; a.momentum = momentum; a.eps = eps;
+  a.M = M; a.D = D; a.G = row_blocks(M); a.prm4 = 1;
+  return bn_apply_launch(a, stream);
+}
+
+extern "C" int feta_bn_bwd_reduce(const float* y, const float* dout, const float* bn_prm,
+                                  float* partial, int M, int D, feta_stream_t stream) {
+  FETA_REQUIRE(y && dout && bn_prm && partial && M > 0 && D > 0 && D <= 256, "bn_bwd_reduce: bad arguments");
+  BnArgs a{};
+  a.y = y; a.dout = dout; a.mean_rstd_in = bn_prm; a.partial = partial; a.M = M; a.D = D;
+  a.G = row_blocks(M); a.prm4 = 1;
   const int slices = 256 / D > 0 ? 256 / D : 1;
-  auto kern = bn_apply_fwd_kernel;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), sizeof(float) * (4 + 2 * slices) * D,
-                     (hipStream_t)stream, a);
-  return check_launch("feta_bn_apply_fwd");
+  auto k1 = bn_bwd_reduce_kernel;
+  hipLaunchKernelGGL(k1, dim3(a.G), dim3(256), sizeof(float) * slices * 2 * D, (hipStream_t)stream, a);
+  return check_launch("feta_bn_bwd_reduce");
 }
 
 extern "C" int feta_bn_bwd(const float* y, const float* dout, const float* mean_rstd,
@@ -581,7 +975,7 @@ extern "C" int feta_bn_bwd(const float* y, const float* dout, const float* mean_
   int grid = (int)((n4 + 255) / 256);
   grid = grid > 1024 ? 1024 : grid;
   auto k2 = bn_bwd_apply_kernel;
-  hipLaunchKernelGGL(k2, dim3(grid), dim3(256), sizeof(float) * (5 + 2 * slices) * D,
+  hipLaunchKernelGGL(k2, dim3(grid), dim3(256), sizeof(float) * (5 * D + reduce_red_floats(D)),
                      (hipStream_t)stream, a);
   return check_launch("feta_bn_bwd");
 }

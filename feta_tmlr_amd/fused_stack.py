@@ -1,0 +1,221 @@
+"""The whole stack of DiffTransformerEncoderLayers (BatchNorm variant) as ONE autograd node with a
+hand-scheduled forward and backward over the C ABI.
+
+Per layer, forward (5 launches):
+    F1  qkv  = BN2_prev(y2_prev) W_in^T                       feta_rowlin_fwd_ex (finalizes BN2_prev)
+    F2  concat, attn = attention core                         feta_attn_fwd
+    F3  y1   = X0 + degree * (concat W_o^T + b_o), stats1     feta_rowlin_fwd_ex (residual through BN2_prev)
+    F4  h    = relu(BN1(y1) W_1^T + b_1)                      feta_rowlin_fwd_ex (finalizes BN1)
+    F5  y2   = BN1(y1) + h W_2^T + b_2, stats2                feta_rowlin_fwd_ex (residual through BN1)
+and one feta_bn_apply_fwd_prm at the end of the stack.  BatchNorm never runs as a pass of its own:
+statistics come out of the producer's epilogue, the apply happens inside the consumers' operand
+loads, and normalised activations are never materialised between layers.
+Backward (6 launches + the weight-gradient reductions per layer): the BatchNorm backward of the
+incoming gradient is applied inside the gradient loads of feta_rowlin_bwd_ex, the residual
+gradients are added in its dX epilogue, and the partial sums the next BatchNorm backward needs are
+emitted there too - no stand-alone BatchNorm, add or fill kernels.
+
+Reference semantics: DiffTransformerEncoderLayer.forward as reconstructed in
+feta_tmlr_amd/transformer/layers.py (contract transformer/models.py:166-167).
+"""
+import torch
+
+from . import _lib
+
+
+def _views(t, l0, l1, heads, dh):
+    v5 = t.view(l0, l1, 3, heads, dh)
+    return [v5[:, :, i].permute(1, 0, 2, 3) for i in range(3)]
+
+
+PER_LAYER = 12  # tensors per layer in the flat parameter list
+
+
+def layer_params(layer):
+    a = layer.self_attn
+    return [a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias,
+            layer.norm1.weight, layer.norm1.bias, layer.linear1.weight, layer.linear1.bias,
+            layer.linear2.weight, layer.linear2.bias, layer.norm2.weight, layer.norm2.bias]
+
+
+def stack_supported(layers, d_model):
+    from .functional import ROWLIN_DIMS
+    for l in layers:
+        if not l.batch_norm or not l.training:
+            return False
+        if l.dropout1.p > 0.0 or l.dropout.p > 0.0 or l.dropout2.p > 0.0 or l.self_attn.dropout > 0.0:
+            return False
+        if l.norm1.momentum is None or l.norm2.momentum is None:
+            return False
+        ff = l.linear1.out_features
+        if not all(c in ROWLIN_DIMS for c in (d_model, 3 * d_model, ff)):
+            return False
+    return True
+
+
+class FusedEncoderStackFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, src, pe, degree_rows, n_real, layers, need_attn, *params):
+        abi, stream = _lib.backend(src, pe, n_real)
+        n, b, d = src.shape
+        m = n * b
+        nl = len(layers)
+        heads = layers[0].self_attn.num_heads
+        dh = d // heads
+        tie = layers[0].self_attn.tie_qk
+        scale = float(dh) ** -0.5
+        dev = src.device
+        new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        G = abi.rowlin_blocks(m)
+        x_in = src.contiguous().view(m, d)
+        pe_c = None if pe is None else pe.contiguous()
+        saved = []
+        y_prev, st_prev, prm_prev = x_in, None, None
+        attn = None
+        for li, layer in enumerate(layers):
+            (w_in, b_in, w_o, b_o, g1, be1, w1, bb1, w2, bb2, g2, be2) = params[li * PER_LAYER:(li + 1) * PER_LAYER]
+            ff = w1.shape[0]
+            # F1
+            qkv = new(m, 3 * d)
+            if li == 0:
+                dsc = abi.rowlin_ex(m, d, 3 * d, x=x_in, w=w_in, bias=b_in, y=qkv)
+            else:
+                pl = layers[li - 1].norm2
+                prm_prev = new(4, d)
+                dsc = abi.rowlin_ex(m, d, 3 * d, x=y_prev, w=w_in, bias=b_in, y=qkv, x_stats=st_prev, Gx=G,
+                                    x_gamma=params[(li - 1) * PER_LAYER + 10], x_beta=params[(li - 1) * PER_LAYER + 11],
+                                    x_bn_out=prm_prev, x_rmean=pl.running_mean, x_rvar=pl.running_var,
+                                    momentum=float(pl.momentum), eps=float(pl.eps))
+                saved[li - 1]['prm2'] = prm_prev
+            abi.rowlin_fwd_ex(dsc, stream)
+            # F2
+            q, k, v = _views(qkv, n, b, heads, dh)
+            if tie:
+                k = q
+            out = torch.empty((n, b, heads, dh), dtype=torch.float32, device=dev)
+            want = need_attn and li == nl - 1
+            attn = new(b, heads, n, n) if want else None
+            ast = new(b, heads, n, 2)
+            abi.attn_fwd(q, k, v, pe_c, n_real, out.permute(1, 0, 2, 3), attn, ast, scale, stream)
+            concat = out.view(m, d)
+            # F3
+            y1, st1 = new(m, d), new(G, 2, d)
+            dsc = abi.rowlin_ex(m, d, d, x=concat, w=w_o, bias=b_o, rowscale=degree_rows, residual=y_prev,
+                                res_bn=prm_prev, y=y1, stats=st1)
+            abi.rowlin_fwd_ex(dsc, stream)
+            # F4
+            h, prm1 = new(m, ff), new(4, d)
+            n1 = layer.norm1
+            dsc = abi.rowlin_ex(m, d, ff, relu=True, x=y1, w=w1, bias=bb1, y=h, x_stats=st1, Gx=G, x_gamma=g1,
+                                x_beta=be1, x_bn_out=prm1, x_rmean=n1.running_mean, x_rvar=n1.running_var,
+                                momentum=float(n1.momentum), eps=float(n1.eps))
+            abi.rowlin_fwd_ex(dsc, stream)
+            # F5
+            y2, st2 = new(m, d), new(G, 2, d)
+            dsc = abi.rowlin_ex(m, ff, d, x=h, w=w2, bias=bb2, residual=y1, res_bn=prm1, y=y2, stats=st2)
+            abi.rowlin_fwd_ex(dsc, stream)
+            saved.append(dict(x0=y_prev, prm0=prm_prev, qkv=qkv, out=out, ast=ast, y1=y1, prm1=prm1, h=h, y2=y2))
+            y_prev, st_prev = y2, st2
+        # end of the stack: materialise BN2(y2) of the last layer
+        last = layers[-1].norm2
+        final = new(m, d)
+        prm2 = new(4, d)
+        abi.bn_apply_fwd_prm(y_prev, st_prev, params[(nl - 1) * PER_LAYER + 10], params[(nl - 1) * PER_LAYER + 11],
+                             final, prm2, last.running_mean, last.running_var, float(last.momentum),
+                             float(last.eps), stream)
+        saved[-1]['prm2'] = prm2
+        ctx.saved_state = saved
+        ctx.meta = (n, b, d, heads, dh, tie, scale, G, nl)
+        ctx.aux = (pe_c, degree_rows, n_real)
+        ctx.params = params
+        if attn is not None:
+            ctx.mark_non_differentiable(attn)
+        concat_last = saved[-1]['out'].view(n, b, d)
+        return final.view(n, b, d), concat_last, attn
+
+    @staticmethod
+    def backward(ctx, d_final, d_concat_last, _d_attn):
+        saved, params = ctx.saved_state, ctx.params
+        n, b, d, heads, dh, tie, scale, G, nl = ctx.meta
+        pe_c, degree_rows, n_real = ctx.aux
+        abi, stream = _lib.backend(saved[0]['qkv'])
+        m = n * b
+        dev = saved[0]['qkv'].device
+        new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        RC = abi.rowlin_chunks(m)
+        grads = [None] * len(params)
+        dcur = d_final.contiguous().view(m, d)
+        gs = new(G, 2, d)
+        abi.bn_bwd_reduce(saved[-1]['y2'], dcur, saved[-1]['prm2'], gs, stream)
+        for li in range(nl - 1, -1, -1):
+            s = saved[li]
+            (w_in, b_in, w_o, b_o, g1, be1, w1, bb1, w2, bb2, g2, be2) = params[li * PER_LAYER:(li + 1) * PER_LAYER]
+            ff = w1.shape[0]
+            base = li * PER_LAYER
+
+            def wgrad(no, ki):
+                return new(RC, no * ki + no), new(no * ki + no)
+
+            # B1: linear2 backward, gradient = BN2 backward of dcur
+            dh_ = new(m, ff)
+            fin2, dg2, db2 = new(2, d), new(d), new(d)
+            part, dwdb = wgrad(d, ff)
+            dsc = abi.rowlin_ex(m, ff, d, x=s['h'], w=w2, dy=dcur, dx=dh_, partial=part, g_y=s['y2'],
+                                g_bn=s['prm2'], g_sum=gs, Gs=G, g_fin_out=fin2, dgamma=dg2, dbeta=db2)
+            abi.rowlin_bwd_ex(dsc, dwdb, stream)
+            grads[base + 8], grads[base + 9] = dwdb[:d * ff].view(d, ff), dwdb[d * ff:]
+            grads[base + 10], grads[base + 11] = dg2, db2
+            # B2: linear1 backward (+ residual BN2 backward, + sums for BN1 backward)
+            dx1, gs1 = new(m, d), new(G, 2, d)
+            part, dwdb = wgrad(ff, d)
+            dsc = abi.rowlin_ex(m, d, ff, x=s['y1'], x_bn=s['prm1'], w=w1, dy=dh_, relu_y=s['h'], dx=dx1,
+                                partial=part, add_dout=dcur, add_y=s['y2'], add_bn=s['prm2'], add_fin=fin2,
+                                sum_y=s['y1'], sum_bn=s['prm1'], sum_out=gs1)
+            abi.rowlin_bwd_ex(dsc, dwdb, stream)
+            grads[base + 6], grads[base + 7] = dwdb[:ff * d].view(ff, d), dwdb[ff * d:]
+            # B3: out_proj backward, gradient = degree * BN1 backward of dx1
+            dconcat = new(m, d)
+            fin1, dg1, db1 = new(2, d), new(d), new(d)
+            part, dwdb = wgrad(d, d)
+            dsc = abi.rowlin_ex(m, d, d, x=s['out'].view(m, d), w=w_o, dy=dx1, rowscale=degree_rows, dx=dconcat,
+                                partial=part, g_y=s['y1'], g_bn=s['prm1'], g_sum=gs1, Gs=G, g_fin_out=fin1,
+                                dgamma=dg1, dbeta=db1)
+            abi.rowlin_bwd_ex(dsc, dwdb, stream)
+            grads[base + 2], grads[base + 3] = dwdb[:d * d].view(d, d), dwdb[d * d:]
+            grads[base + 4], grads[base + 5] = dg1, db1
+            if li == nl - 1 and d_concat_last is not None:
+                dconcat = dconcat + d_concat_last.contiguous().view(m, d)
+            # B4: attention backward
+            q, k, v = _views(s['qkv'], n, b, heads, dh)
+            if tie:
+                k = q
+            dqkv = new(m, 3 * d)
+            dq, dk, dv = _views(dqkv, n, b, heads, dh)
+            delta = new(b, heads, n)
+            abi.attn_bwd(q, k, v, pe_c, n_real, s['out'].permute(1, 0, 2, 3),
+                         dconcat.view(n, b, heads, dh).permute(1, 0, 2, 3), s['ast'], delta, dq, dk, dv, scale,
+                         stream)
+            if tie:
+                dqkv[:, :d] += dqkv[:, d:2 * d]
+                dqkv[:, d:2 * d] = 0
+            # B5: in_proj backward (+ residual BN1 backward, + sums for the previous layer's BN2)
+            dx0 = new(m, d)
+            part, dwdb = wgrad(3 * d, d)
+            gs_prev = new(G, 2, d) if li > 0 else None
+            dsc = abi.rowlin_ex(m, d, 3 * d, x=s['x0'], x_bn=s['prm0'], w=w_in, dy=dqkv, dx=dx0, partial=part,
+                                add_dout=dx1, add_y=s['y1'], add_bn=s['prm1'], add_fin=fin1,
+                                sum_y=(s['x0'] if li > 0 else None), sum_bn=s['prm0'], sum_out=gs_prev)
+            abi.rowlin_bwd_ex(dsc, dwdb, stream)
+            grads[base + 0] = dwdb[:3 * d * d].view(3 * d, d)
+            grads[base + 1] = dwdb[3 * d * d:] if b_in is not None else None
+            dcur, gs = dx0, gs_prev
+        return (dcur.view(n, b, d), None, None, None, None, None) + tuple(grads)
+
+
+def fused_encoder_stack(src, pe, degree_rows, n_real, layers, need_attn=True):
+    """-> (output [N,B,d] of the last layer, concat heads of the last layer [N,B,d], attn or None)"""
+    params = []
+    for l in layers:
+        params += layer_params(l)
+    return FusedEncoderStackFn.apply(src, pe, degree_rows, n_real, list(layers), need_attn, *params)

@@ -21,6 +21,7 @@ from torch import nn
 import torch.nn.functional as F
 
 from .. import functional as FF
+from ..fused_stack import fused_encoder_stack, stack_supported
 from .ChebNetDynamic import ChebConvDynamic
 from .data import GraphBatchCache
 from .layers import DiffTransformerEncoderLayer, clone_layers, linear_rows, n_real_from_mask
@@ -93,6 +94,7 @@ class DiffTransformerEncoderGenGCN(nn.Module):
         self.use_skip_conn = use_skip_conn
         self.heads_share_graph = heads_share_graph
         self.filter_mode = filter_mode
+        self.fused_stack = True   # BatchNorm stacks run as one autograd node when the dims allow
 
     # -- A2 ---------------------------------------------------------------------------------
     def get_filter_coefficients(self, attn_weights, edge_index=None, feature_indices=None,
@@ -148,13 +150,25 @@ class DiffTransformerEncoderGenGCN(nn.Module):
         degree_rows = None
         if degree is not None:   # degree [B,N] -> one value per row of the [N*B, d] view, once
             degree_rows = degree.transpose(0, 1).reshape(-1).contiguous()
+        fused = (self.fused_stack and self.last_layer_filter and mask is None
+                 and stack_supported(self.layers, src.shape[-1]))
         for layer_num, mod in enumerate(self.layers):
             last = layer_num + 1 == self.num_layers
             filt = last or not self.last_layer_filter                            # :169-171
-            output, attn, out_each_head = mod(output, pe=pe, degree=degree, src_mask=mask,
-                                              src_key_padding_mask=src_key_padding_mask,
-                                              need_heads=True, n_real=cache.n_real,
-                                              need_weights=filt, degree_rows=degree_rows)
+            if fused:
+                # every layer in one autograd node (feta_tmlr_amd/fused_stack.py); the loop body
+                # below then only runs the filter stage of the last layer
+                if not last:
+                    continue
+                output, concat, attn = fused_encoder_stack(output, pe, degree_rows, cache.n_real,
+                                                           self.layers, need_attn=True)
+                nn_, bb_, dd_ = concat.shape
+                out_each_head = concat.view(nn_, bb_, self.num_heads, dd_ // self.num_heads).permute(1, 0, 2, 3)
+            else:
+                output, attn, out_each_head = mod(output, pe=pe, degree=degree, src_mask=mask,
+                                                  src_key_padding_mask=src_key_padding_mask,
+                                                  need_heads=True, n_real=cache.n_real,
+                                                  need_weights=filt, degree_rows=degree_rows)
             if not filt:
                 continue
             coeff_all_heads = self.get_filter_coefficients(attn, masks=src_key_padding_mask,

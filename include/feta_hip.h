@@ -175,6 +175,66 @@ int feta_rowlin_bwd(const float* x, const float* w, const float* dy, const float
                     const float* ysaved, float* dx, float* partial, float* dwdb,
                     int M, int KI, int NO, feta_stream_t stream);
 
+/* Extended form used by the fused encoder stack: the same two kernels with BatchNorm folded into
+ * the operand loads and epilogues, so that BatchNorm never runs as a pass of its own.
+ * "bn parameter block" = float[4][D]: scale = gamma*rstd, shift = beta - mean*scale, mean, rstd.
+ * Unused pointers are NULL.  All tensors [M, .] row-major fp32. */
+typedef struct feta_rowlin_ex {
+  /* common */
+  const float* x;         /* [M,KI] input (pre-norm values when x_bn / x_stats is set) */
+  const float* w;         /* [NO,KI] */
+  const float* bias;      /* [NO] */
+  const float* rowscale;  /* [M] */
+  int M, KI, NO, relu;
+  /* forward:  y = relu?(BN?(x) W^T + bias) * rowscale? + BN?(residual)? */
+  const float* residual;  /* [M,NO] */
+  const float* res_bn;    /* bn parameter block [4][NO] through which residual is seen */
+  float* y;               /* [M,NO] */
+  float* stats;           /* [feta_rowlin_blocks(M),2,NO] partial (sum, sumsq) of y */
+  const float* x_bn;      /* finalized bn parameter block [4][KI] of the input, or */
+  const float* x_stats;   /* [Gx,2,KI] partial statistics to finalize here: needs x_gamma, x_beta, */
+  int Gx;                 /*   x_bn_out (written by block 0), optional running stats */
+  const float* x_gamma;
+  const float* x_beta;
+  float* x_bn_out;
+  float* x_rmean;
+  float* x_rvar;
+  float momentum, eps;
+  /* backward:  g = BNbwd?(dy) * rowscale? * [relu_y > 0]? ;  dx = g W (+ adds) ;  dW = g^T BN?(x) */
+  const float* dy;        /* [M,NO] */
+  const float* relu_y;    /* [M,NO] saved relu output */
+  float* dx;              /* [M,KI] */
+  float* partial;         /* [feta_rowlin_chunks(M), NO*KI + NO] scratch */
+  const float* g_y;       /* [M,NO] pre-norm values of the BatchNorm whose backward is applied to dy */
+  const float* g_bn;      /* its bn parameter block [4][NO] */
+  const float* g_sum;     /* [Gs,2,NO] partial (sum dy, sum dy*xhat): finalized here, or */
+  int Gs;
+  const float* g_fin;     /* [2][NO] already finalized (mean dy, mean dy*xhat) */
+  float* g_fin_out;       /* [2][NO] written by block 0 when g_sum is given */
+  float* dgamma;          /* [NO] = sum dy*xhat   (written with g_sum) */
+  float* dbeta;           /* [NO] = sum dy */
+  const float* add_plain; /* [M,KI] added to dx */
+  const float* add_dout;  /* [M,KI]: dx += BNbwd(add_dout) with add_y, add_bn [4][KI], add_fin [2][KI] */
+  const float* add_y;
+  const float* add_bn;
+  const float* add_fin;
+  const float* sum_y;     /* [M,KI] pre-norm values of the BatchNorm that produced x: emit */
+  const float* sum_bn;    /*   sum_out [feta_rowlin_blocks(M),2,KI] = partial (sum dx, sum dx*xhat) */
+  float* sum_out;
+} feta_rowlin_ex;
+
+int feta_rowlin_fwd_ex(const feta_rowlin_ex* d, feta_stream_t stream);
+/* dwdb [NO*KI + NO] receives the reduced weight and bias gradient. */
+int feta_rowlin_bwd_ex(const feta_rowlin_ex* d, float* dwdb, feta_stream_t stream);
+
+/* out = BN(y) written explicitly (end of the stack), publishing the bn parameter block [4][D]. */
+int feta_bn_apply_fwd_prm(const float* y, const float* stats, const float* gamma, const float* beta,
+                          float* out, float* bn_prm, float* running_mean, float* running_var,
+                          float momentum, float eps, int M, int D, feta_stream_t stream);
+/* partial [feta_rowlin_blocks(M),2,D] = per-block (sum dout, sum dout*xhat), bn_prm [4][D]. */
+int feta_bn_bwd_reduce(const float* y, const float* dout, const float* bn_prm, float* partial,
+                       int M, int D, feta_stream_t stream);
+
 /* Training-mode BatchNorm1d over the M rows (padded rows included, as nn.BatchNorm1d on the
  * [N*B, d] view does).  stats [feta_rowlin_blocks(M), 2, D] from feta_rowlin_fwd or feta_bn_stats.
  * mean_rstd [2, D] is saved for backward; running_* (nullable) are updated with momentum and the

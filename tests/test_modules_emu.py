@@ -124,3 +124,51 @@ def test_ops_refuse_cpu_tensors_without_hook():
     from feta_tmlr_amd._abi import FetaError
     with pytest.raises(FetaError):
         FF.attention_core(torch.zeros(4, 2, 48), None, torch.ones(2, dtype=torch.int32), 2)
+
+
+@pytest.mark.parametrize('share,mode,pe_on,layers', [(0, 'cheb', True, 3), (1, 'spectral', False, 2)])
+def test_fused_batchnorm_stack_matches_oracle(emu, monkeypatch, share, mode, pe_on, layers):
+    """d_model = 64 with BatchNorm takes the single-node fused stack (feta_tmlr_amd/fused_stack.py):
+    output, coefficients and every gradient against the oracle."""
+    from feta_tmlr_amd import fused_stack
+    calls = []
+    orig = fused_stack.FusedEncoderStackFn.apply
+    monkeypatch.setattr(fused_stack.FusedEncoderStackFn, 'apply',
+                        staticmethod(lambda *a: (calls.append(1), orig(*a))[1]))
+    model, batch9, cache = _model_case(True, share, mode, pe_on, bsz=4, d=64, heads=4, layers=layers, order=2)
+    x, mask, pe, _, degree, labels, edge_index, batch, fi = batch9
+    x = x.clone().requires_grad_(True)
+    with _lib.override_for_tests(emu):
+        out, _, coeff = model(x, edge_index, batch, fi, mask, pe, degree=degree,
+                              return_filter_coeff=True, graph_cache=cache)
+        w = torch.linspace(0.5, 1.5, out.numel()).view_as(out)
+        ((out * w).sum() + 0.01 * coeff.pow(2).sum()).backward()
+    assert calls, 'fused stack was not taken'
+    p64 = {k: v.detach().double().clone().requires_grad_(True) for k, v in model.state_dict().items()
+           if v.dtype.is_floating_point and 'running_' not in k}
+    x64 = x.detach().double().requires_grad_(True)
+    out_ref, coeff_ref = O.graph_transformer_gengcn(
+        x64, edge_index, batch, fi, mask, None if pe is None else pe.double(), degree.double(), p64,
+        num_layers=layers, num_heads=4, order=2, batch_norm=True, heads_share_graph=bool(share))
+    ((out_ref * w.double()).sum() + 0.01 * coeff_ref.pow(2).sum()).backward()
+    KC.assert_close('model output', out, out_ref)
+    KC.assert_close('coefficients', coeff, coeff_ref)
+    KC.assert_close('dx', x.grad, x64.grad, tol=3e-5)
+    for name, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        KC.assert_close('grad ' + name, p.grad, p64[name].grad, tol=3e-5)
+
+
+def test_fused_stack_updates_running_statistics(emu):
+    model, batch9, cache = _model_case(True, 0, 'cheb', True, bsz=3, d=64, heads=4, layers=2, order=2)
+    ref, _, _ = _model_case(True, 0, 'cheb', True, bsz=3, d=64, heads=4, layers=2, order=2)
+    ref.encoder.fused_stack = False
+    x, mask, pe, _, degree, _, edge_index, batch, fi = batch9
+    with _lib.override_for_tests(emu):
+        model(x, edge_index, batch, fi, mask, pe, degree=degree, graph_cache=cache)
+        ref(x, edge_index, batch, fi, mask, pe, degree=degree, graph_cache=cache)
+    for l, lr in zip(model.encoder.layers, ref.encoder.layers):
+        for nm in ('norm1', 'norm2'):
+            KC.assert_close(nm + '.running_mean', getattr(l, nm).running_mean, getattr(lr, nm).running_mean)
+            KC.assert_close(nm + '.running_var', getattr(l, nm).running_var, getattr(lr, nm).running_var)
