@@ -59,7 +59,7 @@ class RowLinEx(C.Structure):
         ('x_bn', _F), ('x_stats', _F), ('Gx', C.c_int),
         ('x_gamma', _F), ('x_beta', _F), ('x_bn_out', _F), ('x_rmean', _F), ('x_rvar', _F),
         ('momentum', C.c_float), ('eps', C.c_float),
-        ('dy', _F), ('relu_y', _F), ('dx', _F), ('partial', _F),
+        ('dy', _F), ('relu_y', _F), ('dx', _F), ('partial', _F), ('partial_ld', C.c_int),
         ('g_y', _F), ('g_bn', _F), ('g_sum', _F), ('Gs', C.c_int),
         ('g_fin', _F), ('g_fin_out', _F), ('dgamma', _F), ('dbeta', _F),
         ('add_plain', _F), ('add_dout', _F), ('add_y', _F), ('add_bn', _F), ('add_fin', _F),
@@ -231,11 +231,14 @@ class Abi:
         self._check(self.lib.feta_bn_bwd(_p(y), _p(dout), _p(mean_rstd), _p(gamma), _p(partial), _p(dy),
                                          _p(dgamma), _p(dbeta), m, d, stream), 'feta_bn_bwd')
 
-    def rowlin_ex(self, m, ki, no, relu=False, momentum=0.1, eps=1e-5, Gx=0, Gs=0, **ptrs):
+    def rowlin_ex(self, m, ki, no, relu=False, momentum=0.1, eps=1e-5, Gx=0, Gs=0, partial_ld=0,
+                  partial_ptr=None, **ptrs):
         """Builds a feta_rowlin_ex descriptor; tensor-valued keyword arguments become pointers."""
         d = RowLinEx()
         d.M, d.KI, d.NO, d.relu = m, ki, no, int(relu)
-        d.momentum, d.eps, d.Gx, d.Gs = momentum, eps, Gx, Gs
+        d.momentum, d.eps, d.Gx, d.Gs, d.partial_ld = momentum, eps, Gx, Gs, partial_ld
+        if partial_ptr is not None:
+            d.partial = partial_ptr
         for k, t in ptrs.items():
             if t is not None:
                 setattr(d, k, t.data_ptr())

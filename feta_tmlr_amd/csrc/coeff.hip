@@ -92,8 +92,8 @@ __global__ __launch_bounds__(kCoeffThreads) void coeff_bwd_kernel(
     }
   }
   if (c < C) {
-    partial[(int64_t)grp * C + c] = as;
-    partial[((int64_t)G + grp) * C + c] = ab;
+    partial[(int64_t)grp * 2 * C + c] = as;      // [G][2][C]: one colsum reduces both
+    partial[(int64_t)grp * 2 * C + C + c] = ab;
   }
 }
 
@@ -102,14 +102,14 @@ __global__ __launch_bounds__(kCoeffThreads) void coeff_bwd_kernel(
 constexpr int kCsCols = 16, kCsSlices = 64;
 __global__ __launch_bounds__(kCsCols * kCsSlices) void colsum_kernel(const float* __restrict__ in,
                                                                       float* __restrict__ out, int R,
-                                                                      int C) {
+                                                                      int C, int ld) {
   float* red = feta_lds;  // [slices][cols]
   const int lc = threadIdx.x & (kCsCols - 1);
   const int slice = threadIdx.x / kCsCols;
   const int col = blockIdx.x * kCsCols + lc;
   float acc = 0.0f;
   if (col < C)
-    for (int r = slice; r < R; r += kCsSlices) acc += in[(int64_t)r * C + col];
+    for (int r = slice; r < R; r += kCsSlices) acc += in[(int64_t)r * ld + col];
   red[threadIdx.x] = acc;
   __syncthreads();
   for (int half = kCsSlices / 2; half >= 1; half >>= 1) {
@@ -119,11 +119,14 @@ __global__ __launch_bounds__(kCsCols * kCsSlices) void colsum_kernel(const float
   if (slice == 0 && col < C) out[col] = red[lc];
 }
 
-int launch_colsum(const float* in, float* out, int R, int C, hipStream_t stream) {
+int launch_colsum_strided(const float* in, float* out, int R, int C, int ld, hipStream_t stream) {
   const dim3 grid((C + kCsCols - 1) / kCsCols), block(kCsCols * kCsSlices);
   auto kern = colsum_kernel;
-  hipLaunchKernelGGL(kern, grid, block, kCsCols * kCsSlices * sizeof(float), stream, in, out, R, C);
+  hipLaunchKernelGGL(kern, grid, block, kCsCols * kCsSlices * sizeof(float), stream, in, out, R, C, ld);
   return check_launch("feta_colsum");
+}
+int launch_colsum(const float* in, float* out, int R, int C, hipStream_t stream) {
+  return launch_colsum_strided(in, out, R, C, C, stream);
 }
 
 }  // namespace feta
@@ -163,9 +166,12 @@ extern "C" int feta_coeff_bwd(const float* cj, const int32_t* n_real, const floa
                      gcn_bias, dpooled, partial, B, N, H, C, G);
   int rc = check_launch("feta_coeff_bwd");
   if (rc != FETA_OK) return rc;
-  rc = launch_colsum(partial, ds, G, C, (hipStream_t)stream);
+  if (dbias == ds + C)  // contiguous outputs: one reduction launch for both
+    return launch_colsum(partial, ds, G, 2 * C, (hipStream_t)stream);
+  // separate outputs: reduce the two interleaved halves one after the other
+  rc = launch_colsum_strided(partial, ds, G, C, 2 * C, (hipStream_t)stream);
   if (rc != FETA_OK) return rc;
-  return launch_colsum(partial + (int64_t)G * C, dbias, G, C, (hipStream_t)stream);
+  return launch_colsum_strided(partial + C, dbias, G, C, 2 * C, (hipStream_t)stream);
 }
 
 extern "C" int feta_colsum(const float* in, float* out, int R, int C, feta_stream_t stream) {

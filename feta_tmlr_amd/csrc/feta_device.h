@@ -35,6 +35,8 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 // tanh(x) = 1 - 2 / (1 + e^{2x}): saturates correctly at +-1, absolute error ~1e-7
-__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f / (1.0f + __expf(2.0f * x)); }
+__device__ __forceinline__ float fast_tanh(float x) {
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x));  // v_rcp_f32: 1 ulp
+}
 
 }  // namespace feta

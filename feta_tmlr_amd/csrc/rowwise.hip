@@ -431,7 +431,7 @@ __device__ void rowlin_dw_role(const RowLinArgs& a, const RowLinGeom& ge, const 
       for (int kt = 0; kt < KT; ++kt) acc[kt] = mfma16(gvr[r], xv[r][kt], acc[kt]);  // (o 4g+r', k lq)
     }
   }
-  float* p = a.partial + (int64_t)rc * ((int64_t)a.NO * KI + a.NO);
+  float* p = a.partial + (int64_t)rc * (a.partial_ld > 0 ? (int64_t)a.partial_ld : (int64_t)a.NO * KI + a.NO);
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -535,7 +535,7 @@ __device__ void rowlin_dw_role_lds(const RowLinArgs& a, const RowLinGeom& ge, co
     }
   }
   if (!wave_on) return;
-  float* p = a.partial + (int64_t)rc * ((int64_t)a.NO * KI + a.NO);
+  float* p = a.partial + (int64_t)rc * (a.partial_ld > 0 ? (int64_t)a.partial_ld : (int64_t)a.NO * KI + a.NO);
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -848,8 +848,8 @@ extern "C" int feta_rowlin_fwd_ex(const feta_rowlin_ex* d, feta_stream_t stream)
 extern "C" int feta_rowlin_bwd_ex(const feta_rowlin_ex* d, float* dwdb, feta_stream_t stream) {
   FETA_REQUIRE(d != nullptr, "rowlin_bwd_ex: null descriptor");
   const RowLinArgs& a = *d;
-  FETA_REQUIRE(a.x && a.w && a.dy && a.dx && a.partial && dwdb && a.M > 0,
-               "rowlin_bwd: null pointer / empty");
+  FETA_REQUIRE(a.x && a.w && a.dy && a.dx && a.partial && a.M > 0, "rowlin_bwd: null pointer / empty");
+  FETA_REQUIRE(dwdb || a.partial_ld > 0, "rowlin_bwd: dwdb may only be NULL with a caller-reduced partial_ld");
   FETA_REQUIRE(dim_ok(a.KI) && dim_ok(a.NO), "rowlin_bwd: unsupported dims KI=%d NO=%d", a.KI, a.NO);
   FETA_REQUIRE(aligned16(a.x) && aligned16(a.w) && aligned16(a.dy) && aligned16(a.dx) &&
                    (!a.relu_y || aligned16(a.relu_y)) && (!a.g_y || aligned16(a.g_y)),
@@ -876,7 +876,8 @@ extern "C" int feta_rowlin_bwd_ex(const feta_rowlin_ex* d, float* dwdb, feta_str
   FETA_DIM_SWITCH(a.KI, CALL)
 #undef CALL
   int rc = check_launch("feta_rowlin_bwd");
-  if (rc != FETA_OK) return rc;
+  if (rc != FETA_OK || dwdb == nullptr) return rc;  // NULL dwdb: the caller reduces all partials at once
+  FETA_REQUIRE(a.partial_ld == 0, "rowlin_bwd: dwdb with partial_ld is not supported");
   return feta_colsum(a.partial, dwdb, ge.RC, a.NO * a.KI + a.NO, stream);
 }
 

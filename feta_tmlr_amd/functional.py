@@ -114,9 +114,9 @@ class FilterCoefficientsFn(torch.autograd.Function):
         abi, stream = _lib.backend(cj)
         c = s.shape[0]
         groups = abi.coeff_bwd_groups(b, h)
-        partial = torch.empty((2, groups, c), dtype=torch.float32, device=cj.device)
-        ds = torch.empty(c, dtype=torch.float32, device=cj.device)
-        db = torch.empty(c, dtype=torch.float32, device=cj.device)
+        partial = torch.empty((groups, 2, c), dtype=torch.float32, device=cj.device)
+        dsdb = torch.empty((2, c), dtype=torch.float32, device=cj.device)   # contiguous: one reduction
+        ds, db = dsdb[0], dsdb[1]
         abi.coeff_bwd(cj, n_real, s, gb, dpooled.contiguous(), partial, ds, db, b, n, h, stream)
         # s = 1^T W  =>  every row of dW equals ds
         return None, None, ds.unsqueeze(0).expand(rows, c), db

@@ -145,6 +145,22 @@ class FusedEncoderStackFn(torch.autograd.Function):
         new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         RC = abi.rowlin_chunks(m)
         grads = [None] * len(params)
+        # every weight/bias gradient of the stack goes through ONE [RC, total] partial buffer and
+        # ONE deterministic reduction at the end (instead of one reduction launch per linear)
+        ff0 = params[6].shape[0]
+        per_layer = (3 * d * d + 3 * d) + (d * d + d) + (ff0 * d + ff0) + (d * ff0 + d)
+        total = per_layer * nl
+        part_all = new(RC, total)
+        dwdb_all = new(total)
+        cursor = [0]
+
+        def wslot(no, ki):
+            """-> (pointer to this linear's partial columns, its offset in dwdb_all)"""
+            off = cursor[0]
+            cursor[0] += no * ki + no
+            return part_all.data_ptr() + 4 * off, off
+
+        slots = {}
         dcur = d_final.contiguous().view(m, d)
         gs = new(G, 2, d)
         abi.bn_bwd_reduce(saved[-1]['y2'], dcur, saved[-1]['prm2'], gs, stream)
@@ -153,36 +169,33 @@ class FusedEncoderStackFn(torch.autograd.Function):
             (w_in, b_in, w_o, b_o, g1, be1, w1, bb1, w2, bb2, g2, be2) = params[li * PER_LAYER:(li + 1) * PER_LAYER]
             ff = w1.shape[0]
             base = li * PER_LAYER
-
-            def wgrad(no, ki):
-                return new(RC, no * ki + no), new(no * ki + no)
-
             # B1: linear2 backward, gradient = BN2 backward of dcur
             dh_ = new(m, ff)
             fin2, dg2, db2 = new(2, d), new(d), new(d)
-            part, dwdb = wgrad(d, ff)
-            dsc = abi.rowlin_ex(m, ff, d, x=s['h'], w=w2, dy=dcur, dx=dh_, partial=part, g_y=s['y2'],
-                                g_bn=s['prm2'], g_sum=gs, Gs=G, g_fin_out=fin2, dgamma=dg2, dbeta=db2)
-            abi.rowlin_bwd_ex(dsc, dwdb, stream)
-            grads[base + 8], grads[base + 9] = dwdb[:d * ff].view(d, ff), dwdb[d * ff:]
+            pp, off = wslot(d, ff)
+            slots[base + 8] = (off, d, ff)
+            dsc = abi.rowlin_ex(m, ff, d, x=s['h'], w=w2, dy=dcur, dx=dh_, partial_ptr=pp, partial_ld=total,
+                                g_y=s['y2'], g_bn=s['prm2'], g_sum=gs, Gs=G, g_fin_out=fin2, dgamma=dg2,
+                                dbeta=db2)
+            abi.rowlin_bwd_ex(dsc, None, stream)
             grads[base + 10], grads[base + 11] = dg2, db2
             # B2: linear1 backward (+ residual BN2 backward, + sums for BN1 backward)
             dx1, gs1 = new(m, d), new(G, 2, d)
-            part, dwdb = wgrad(ff, d)
+            pp, off = wslot(ff, d)
+            slots[base + 6] = (off, ff, d)
             dsc = abi.rowlin_ex(m, d, ff, x=s['y1'], x_bn=s['prm1'], w=w1, dy=dh_, relu_y=s['h'], dx=dx1,
-                                partial=part, add_dout=dcur, add_y=s['y2'], add_bn=s['prm2'], add_fin=fin2,
-                                sum_y=s['y1'], sum_bn=s['prm1'], sum_out=gs1)
-            abi.rowlin_bwd_ex(dsc, dwdb, stream)
-            grads[base + 6], grads[base + 7] = dwdb[:ff * d].view(ff, d), dwdb[ff * d:]
+                                partial_ptr=pp, partial_ld=total, add_dout=dcur, add_y=s['y2'],
+                                add_bn=s['prm2'], add_fin=fin2, sum_y=s['y1'], sum_bn=s['prm1'], sum_out=gs1)
+            abi.rowlin_bwd_ex(dsc, None, stream)
             # B3: out_proj backward, gradient = degree * BN1 backward of dx1
             dconcat = new(m, d)
             fin1, dg1, db1 = new(2, d), new(d), new(d)
-            part, dwdb = wgrad(d, d)
+            pp, off = wslot(d, d)
+            slots[base + 2] = (off, d, d)
             dsc = abi.rowlin_ex(m, d, d, x=s['out'].view(m, d), w=w_o, dy=dx1, rowscale=degree_rows, dx=dconcat,
-                                partial=part, g_y=s['y1'], g_bn=s['prm1'], g_sum=gs1, Gs=G, g_fin_out=fin1,
-                                dgamma=dg1, dbeta=db1)
-            abi.rowlin_bwd_ex(dsc, dwdb, stream)
-            grads[base + 2], grads[base + 3] = dwdb[:d * d].view(d, d), dwdb[d * d:]
+                                partial_ptr=pp, partial_ld=total, g_y=s['y1'], g_bn=s['prm1'], g_sum=gs1, Gs=G,
+                                g_fin_out=fin1, dgamma=dg1, dbeta=db1)
+            abi.rowlin_bwd_ex(dsc, None, stream)
             grads[base + 4], grads[base + 5] = dg1, db1
             if li == nl - 1 and d_concat_last is not None:
                 dconcat = dconcat + d_concat_last.contiguous().view(m, d)
@@ -201,15 +214,21 @@ class FusedEncoderStackFn(torch.autograd.Function):
                 dqkv[:, d:2 * d] = 0
             # B5: in_proj backward (+ residual BN1 backward, + sums for the previous layer's BN2)
             dx0 = new(m, d)
-            part, dwdb = wgrad(3 * d, d)
+            pp, off = wslot(3 * d, d)
+            slots[base + 0] = (off, 3 * d, d)
             gs_prev = new(G, 2, d) if li > 0 else None
-            dsc = abi.rowlin_ex(m, d, 3 * d, x=s['x0'], x_bn=s['prm0'], w=w_in, dy=dqkv, dx=dx0, partial=part,
-                                add_dout=dx1, add_y=s['y1'], add_bn=s['prm1'], add_fin=fin1,
-                                sum_y=(s['x0'] if li > 0 else None), sum_bn=s['prm0'], sum_out=gs_prev)
-            abi.rowlin_bwd_ex(dsc, dwdb, stream)
-            grads[base + 0] = dwdb[:3 * d * d].view(3 * d, d)
-            grads[base + 1] = dwdb[3 * d * d:] if b_in is not None else None
+            dsc = abi.rowlin_ex(m, d, 3 * d, x=s['x0'], x_bn=s['prm0'], w=w_in, dy=dqkv, dx=dx0,
+                                partial_ptr=pp, partial_ld=total, add_dout=dx1, add_y=s['y1'],
+                                add_bn=s['prm1'], add_fin=fin1, sum_y=(s['x0'] if li > 0 else None),
+                                sum_bn=s['prm0'], sum_out=gs_prev)
+            abi.rowlin_bwd_ex(dsc, None, stream)
             dcur, gs = dx0, gs_prev
+        assert cursor[0] == total
+        abi.colsum(part_all, dwdb_all, stream)
+        for idx, (off, no, ki) in slots.items():
+            grads[idx] = dwdb_all[off:off + no * ki].view(no, ki)
+            if params[idx + 1] is not None:
+                grads[idx + 1] = dwdb_all[off + no * ki:off + no * ki + no]
         return (dcur.view(n, b, d), None, None, None, None, None) + tuple(grads)
 
 

@@ -95,7 +95,8 @@ int feta_coeff_fwd(const float* attn, const int32_t* n_real,
                    int B, int N, int H, int C, feta_stream_t stream);
 
 /* ds[c] = sum_{blk,j} dpooled*(1-z^2)*c_j/n ; dbias[c] likewise without c_j.
- * partial [2, G, C] scratch with G = feta_coeff_bwd_groups(B,H). */
+ * partial [G, 2, C] scratch with G = feta_coeff_bwd_groups(B,H); when dbias == ds + C both are
+ * reduced by one launch. */
 int feta_coeff_bwd_groups(int B, int H);
 int feta_coeff_bwd(const float* cj, const int32_t* n_real,
                    const float* s, const float* gcn_bias, const float* dpooled,
@@ -205,6 +206,8 @@ typedef struct feta_rowlin_ex {
   const float* relu_y;    /* [M,NO] saved relu output */
   float* dx;              /* [M,KI] */
   float* partial;         /* [feta_rowlin_chunks(M), NO*KI + NO] scratch */
+  int partial_ld;         /* row pitch of partial (0 = NO*KI+NO): lets several linears share one
+                             [chunks, total] buffer that the caller reduces with ONE feta_colsum */
   const float* g_y;       /* [M,NO] pre-norm values of the BatchNorm whose backward is applied to dy */
   const float* g_bn;      /* its bn parameter block [4][NO] */
   const float* g_sum;     /* [Gs,2,NO] partial (sum dy, sum dy*xhat): finalized here, or */
@@ -224,7 +227,8 @@ typedef struct feta_rowlin_ex {
 } feta_rowlin_ex;
 
 int feta_rowlin_fwd_ex(const feta_rowlin_ex* d, feta_stream_t stream);
-/* dwdb [NO*KI + NO] receives the reduced weight and bias gradient. */
+/* dwdb [NO*KI + NO] receives the reduced weight and bias gradient (NULL with partial_ld > 0:
+ * partials only). */
 int feta_rowlin_bwd_ex(const feta_rowlin_ex* d, float* dwdb, feta_stream_t stream);
 
 /* out = BN(y) written explicitly (end of the stack), publishing the bn parameter block [4][D]. */
