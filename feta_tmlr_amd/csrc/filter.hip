@@ -738,6 +738,267 @@ __global__ __launch_bounds__(64 * kFWaves) void spec_bwd_kernel(FilterArgs a) {
   }
 }
 
+// ---- eigenbasis form, small graphs (N <= 64, K <= 32, dh <= 16): batched loads --------------
+// Same arithmetic as spec_fwd/bwd_kernel; every global operand of the (graph, head) item - W_k,
+// the X / dY rows, both orientations of the U tiles and lambda - is requested up front with
+// clamped indices (unconditional loads, selects afterwards), so a wave pays one memory latency
+// instead of one per inner-loop step.
+
+template <int DH, int NT_MAX, int ET_MAX>
+__global__ __launch_bounds__(64 * kFWaves) void spec_fwd_dense_kernel(FilterArgs a) {
+  static_assert(DH <= 16, "dense variant: one feature chunk, one column tile");
+  const int lane = lane_id(), lq = lane & 15, g = lane >> 4;
+  const int item = blockIdx.x * kFWaves + wave_id();
+  if (item >= a.total) return;
+  const int h = item % a.H, b = item / a.H;
+  const int n = a.n_real[b];
+  const float* w = a.coeff + ((int64_t)h * a.B + b) * a.P * DH * DH;
+  if (!a.share && h > 0) {
+    nograph_fwd<DH>(a, b, h, n, w, lq, g);
+    return;
+  }
+  const float* U = a.u + (int64_t)b * a.N * a.K;
+  const float* lam = a.lam + (int64_t)b * a.K;
+  const int lqc = lq < DH ? lq : 0;
+
+  // ---- load batch -----------------------------------------------------------------------------
+  float wB[kMaxOrder][4];  // W_k[c = 4g+s][c' = lq]
+#pragma unroll
+  for (int k = 0; k < kMaxOrder; ++k)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int c = 4 * g + s;
+      float v = 0.0f;
+      if (k < a.P) v = w[(k * DH + (c < DH ? c : 0)) * DH + lqc];
+      wB[k][s] = (k < a.P && c < DH && lq < DH) ? v : 0.0f;
+    }
+  Feat<DH> xf[NT_MAX];
+  float ua[NT_MAX][4][ET_MAX], ub[NT_MAX][4][ET_MAX], lamq[ET_MAX];
+#pragma unroll
+  for (int nt = 0; nt < NT_MAX; ++nt) {
+    const int node = 16 * nt + lq;
+    load_row_sel<DH>(xf[nt], tok_row(a.x, a.xsb, a.xsn, b, min(node, n - 1), h, DH), node < n, g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int et = 0; et < ET_MAX; ++et) {
+        const int nd = 16 * nt + 4 * g + r, e = 16 * et + lq;
+        const float v1 = U[(int64_t)min(nd, n - 1) * a.K + min(e, a.K - 1)];
+        ua[nt][r][et] = (nd < n && e < a.K) ? v1 : 0.0f;
+        const int e2 = 16 * et + 4 * g + r;
+        const float v2 = U[(int64_t)min(node, n - 1) * a.K + min(e2, a.K - 1)];
+        ub[nt][r][et] = (node < n && e2 < a.K) ? v2 : 0.0f;
+      }
+  }
+#pragma unroll
+  for (int et = 0; et < ET_MAX; ++et) lamq[et] = lam[min(16 * et + lq, a.K - 1)];
+  const float bv = (a.bias != nullptr) ? a.bias[lqc] : 0.0f;
+
+  // ---- Ytil = sum_k diag(t_k) U^T (X W_k) -------------------------------------------------------
+  float tke[ET_MAX][kMaxOrder];
+#pragma unroll
+  for (int et = 0; et < ET_MAX; ++et) cheb_poly(lamq[et], a.P, tke[et]);
+  f32x4 yt[ET_MAX];
+#pragma unroll
+  for (int et = 0; et < ET_MAX; ++et) yt[et] = zero4();
+#pragma unroll
+  for (int nt = 0; nt < NT_MAX; ++nt) {
+#pragma unroll
+    for (int k = 0; k < kMaxOrder; ++k) {
+      if (k < a.P) {
+        f32x4 z = zero4();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) z = mfma16(xf[nt].f[0][s], wB[k][s], z);
+#pragma unroll
+        for (int et = 0; et < ET_MAX; ++et)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) yt[et] = mfma16(ua[nt][r][et] * tke[et][k], z[r], yt[et]);
+      }
+    }
+  }
+  // ---- Y = U Ytil + bias -------------------------------------------------------------------------
+#pragma unroll
+  for (int nt = 0; nt < NT_MAX; ++nt) {
+    if (16 * nt < a.N) {
+      f32x4 y = zero4();
+#pragma unroll
+      for (int et = 0; et < ET_MAX; ++et)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y = mfma16(ub[nt][r][et], yt[et][r], y);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) y[r] = (16 * nt + 4 * g + r < n) ? y[r] + bv : 0.0f;
+      store_acc<DH>(a.y, a.ysb, a.ysn, b, h, 16 * nt, a.N, 0, lq, g, y);
+    }
+  }
+}
+
+template <int DH, int NT_MAX, int ET_MAX>
+__global__ __launch_bounds__(64 * kFWaves) void spec_bwd_dense_kernel(FilterArgs a) {
+  static_assert(DH <= 16, "dense variant: one feature chunk, one column tile");
+  const int lane = lane_id(), lq = lane & 15, g = lane >> 4;
+  const int item = blockIdx.x * kFWaves + wave_id();
+  if (item >= a.total) return;
+  const int h = item % a.H, b = item / a.H;
+  const int n = a.n_real[b];
+  const int64_t blk = (int64_t)h * a.B + b;
+  const float* w = a.coeff + blk * a.P * DH * DH;
+  float* dw = a.dcoeff + blk * a.P * DH * DH;
+  if (!a.share && h > 0) {
+    nograph_bwd<DH>(a, b, h, n, w, dw, item, lq, g);
+    return;
+  }
+  const float* U = a.u + (int64_t)b * a.N * a.K;
+  const float* lam = a.lam + (int64_t)b * a.K;
+  const int lqc = lq < DH ? lq : 0;
+
+  // ---- load batch -----------------------------------------------------------------------------
+  f32x4 xb[NT_MAX], dyb[NT_MAX];
+  float ua[NT_MAX][4][ET_MAX], ub[NT_MAX][4][ET_MAX], lamr[ET_MAX][4];
+  float4 wr[kMaxOrder];  // W_k[c = lq][c' = 4g .. 4g+3]
+#pragma unroll
+  for (int k = 0; k < kMaxOrder; ++k) {
+    wr[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (k < a.P) {
+      const float4 v = *reinterpret_cast<const float4*>(w + (k * DH + lqc) * DH + (4 * g < DH ? 4 * g : 0));
+      if (lq < DH && 4 * g < DH) wr[k] = v;
+    }
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT_MAX; ++nt) {
+    const int node = 16 * nt + lq;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int nd = 16 * nt + 4 * g + r;
+      const int ndc = min(nd, n - 1);
+      const float xv = tok_row(a.x, a.xsb, a.xsn, b, ndc, h, DH)[lqc];
+      const float dv = tok_row(a.dy, a.ysb, a.ysn, b, ndc, h, DH)[lqc];
+      const bool ok = nd < n && lq < DH;
+      xb[nt][r] = ok ? xv : 0.0f;
+      dyb[nt][r] = ok ? dv : 0.0f;
+#pragma unroll
+      for (int et = 0; et < ET_MAX; ++et) {
+        const int e = 16 * et + lq;
+        const float v1 = U[(int64_t)ndc * a.K + min(e, a.K - 1)];
+        ua[nt][r][et] = (nd < n && e < a.K) ? v1 : 0.0f;
+        const int e2 = 16 * et + 4 * g + r;
+        const float v2 = U[(int64_t)min(node, n - 1) * a.K + min(e2, a.K - 1)];
+        ub[nt][r][et] = (node < n && e2 < a.K) ? v2 : 0.0f;
+      }
+    }
+  }
+#pragma unroll
+  for (int et = 0; et < ET_MAX; ++et)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lamr[et][r] = lam[min(16 * et + 4 * g + r, a.K - 1)];
+
+  // ---- (1) Xtil = U^T X, dYtil = U^T dY; dbias partial ------------------------------------------
+  f32x4 xt[ET_MAX], dyt[ET_MAX];
+#pragma unroll
+  for (int et = 0; et < ET_MAX; ++et) {
+    xt[et] = zero4();
+    dyt[et] = zero4();
+  }
+  float dbs = 0.0f;
+#pragma unroll
+  for (int nt = 0; nt < NT_MAX; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      dbs += dyb[nt][r];
+#pragma unroll
+      for (int et = 0; et < ET_MAX; ++et) {
+        xt[et] = mfma16(ua[nt][r][et], xb[nt][r], xt[et]);
+        dyt[et] = mfma16(ua[nt][r][et], dyb[nt][r], dyt[et]);
+      }
+    }
+  dbs += shfl_xor(dbs, 16);
+  dbs += shfl_xor(dbs, 32);
+  if (g == 0 && lq < DH) a.dbias_part[(int64_t)item * DH + lq] = dbs;
+
+  float tkr[ET_MAX][4][kMaxOrder];
+#pragma unroll
+  for (int et = 0; et < ET_MAX; ++et)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cheb_poly(lamr[et][r], a.P, tkr[et][r]);
+
+  // ---- (2) dW_k[c][c'] = sum_e t_k(lam_e) Xtil[e][c] dYtil[e][c'] --------------------------------
+#pragma unroll
+  for (int k = 0; k < kMaxOrder; ++k) {
+    if (k < a.P) {
+      f32x4 acc = zero4();
+#pragma unroll
+      for (int et = 0; et < ET_MAX; ++et)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = mfma16(xt[et][r] * tkr[et][r][k], dyt[et][r], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = 4 * g + r;
+        if (c < DH && lq < DH) dw[(k * DH + c) * DH + lq] = acc[r];
+      }
+    }
+  }
+
+  // ---- (3) dX^T = sum_k W_k (dYtil^T diag(t_k) U^T) ----------------------------------------------
+#pragma unroll
+  for (int nt = 0; nt < NT_MAX; ++nt) {
+    const int node = 16 * nt + lq;
+    if (16 * nt < a.N) {
+      f32x4 dxt = zero4();
+#pragma unroll
+      for (int k = 0; k < kMaxOrder; ++k) {
+        if (k < a.P) {
+          f32x4 gt = zero4();
+#pragma unroll
+          for (int et = 0; et < ET_MAX; ++et)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gt = mfma16(dyt[et][r], ub[nt][r][et] * tkr[et][r][k], gt);
+          dxt = mfma16(wr[k].x, gt[0], dxt);
+          dxt = mfma16(wr[k].y, gt[1], dxt);
+          dxt = mfma16(wr[k].z, gt[2], dxt);
+          dxt = mfma16(wr[k].w, gt[3], dxt);
+        }
+      }
+      if (node < a.N && 4 * g < DH) {
+        const bool real = node < n;
+        *reinterpret_cast<float4*>(tok_row(a.dx, a.xsb, a.xsn, b, node, h, DH) + 4 * g) =
+            make_float4(real ? dxt[0] : 0.0f, real ? dxt[1] : 0.0f, real ? dxt[2] : 0.0f,
+                        real ? dxt[3] : 0.0f);
+      }
+    }
+  }
+}
+
+template <int DH, int NT_MAX, int ET_MAX>
+int launch_spec_dense(const FilterArgs& a, bool bwd, hipStream_t stream) {
+  const dim3 grid((a.total + kFWaves - 1) / kFWaves), block(64 * kFWaves);
+  if (bwd) {
+    auto kern = spec_bwd_dense_kernel<DH, NT_MAX, ET_MAX>;
+    hipLaunchKernelGGL(kern, grid, block, 0, stream, a);
+  } else {
+    auto kern = spec_fwd_dense_kernel<DH, NT_MAX, ET_MAX>;
+    hipLaunchKernelGGL(kern, grid, block, 0, stream, a);
+  }
+  return check_launch(bwd ? "feta_spec_filter_bwd" : "feta_spec_filter_fwd");
+}
+
+// -> 1 if the dense variant was launched (rc holds its status), 0 if the shape is outside it
+template <int DH>
+bool try_spec_dense_dh(const FilterArgs& a, bool bwd, hipStream_t stream, int* rc) {
+  const int nt = (a.N + 15) / 16, et = (a.K + 15) / 16;
+  if (nt > 4 || et > 2) return false;
+  if (nt <= 3 && et <= 1) *rc = launch_spec_dense<DH, 3, 1>(a, bwd, stream);
+  else if (et <= 1) *rc = launch_spec_dense<DH, 4, 1>(a, bwd, stream);
+  else if (nt <= 3) *rc = launch_spec_dense<DH, 3, 2>(a, bwd, stream);
+  else *rc = launch_spec_dense<DH, 4, 2>(a, bwd, stream);
+  return true;
+}
+
+bool try_spec_dense(const FilterArgs& a, int dh, bool bwd, hipStream_t stream, int* rc) {
+  if (dh == 16) return try_spec_dense_dh<16>(a, bwd, stream, rc);
+  if (dh == 8) return try_spec_dense_dh<8>(a, bwd, stream, rc);
+  if (dh == 4) return try_spec_dense_dh<4>(a, bwd, stream, rc);
+  return false;
+}
+
 // ---- launchers ---------------------------------------------------------------------------
 
 int check_filter(const FilterArgs& a, int dh, const void* p1, const void* p2) {
@@ -842,6 +1103,8 @@ extern "C" int feta_spec_filter_fwd(const float* x, int64_t x_sb, int64_t x_sn, 
   FETA_REQUIRE(K >= 1 && K <= FETA_MAX_NODES, "spec_filter_fwd: K=%d out of range", K);
   int rc = check_filter(a, dh, x, y);
   if (rc != FETA_OK) return rc;
+  int rcd = FETA_OK;
+  if (try_spec_dense(a, dh, false, (hipStream_t)stream, &rcd)) return rcd;
   return dispatch<SpecFwd>(a, dh, (K + 15) / 16, (hipStream_t)stream);
 }
 
@@ -861,5 +1124,7 @@ extern "C" int feta_spec_filter_bwd(const float* x, int64_t x_sb, int64_t x_sn, 
   int rc = check_filter(a, dh, x, dy);
   if (rc != FETA_OK) return rc;
   FETA_REQUIRE(aligned16(dx) && aligned16(dcoeff), "spec_filter_bwd: outputs must be 16-byte aligned");
+  int rcd = FETA_OK;
+  if (try_spec_dense(a, dh, true, (hipStream_t)stream, &rcd)) return rcd;
   return dispatch<SpecBwd>(a, dh, (K + 15) / 16, (hipStream_t)stream);
 }

@@ -29,7 +29,7 @@ constexpr int kRowThreads = 64 * kRowWaves;
 constexpr int kRowsPerBlock = 16 * kRowWaves;
 constexpr int kMaxRowBlocks = 256;  // cap on per-block partial statistics
 constexpr int kMaxChunks = 128;     // cap on split-K chunks of the weight gradient
-constexpr int kChunkRowBlocks = 4;  // 16-row blocks per split-K chunk
+constexpr int kChunkRowBlocks = 4;  // 16-row blocks per split-K chunk (one 64-row LDS tile)
 
 typedef feta_rowlin_ex RowLinArgs;  // include/feta_hip.h
 
