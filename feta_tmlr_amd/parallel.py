@@ -3,8 +3,11 @@ replicated, gradients summed with ONE collective over a flat bucket.
 
 The reference's only multi-GPU mechanism is single-process nn.DataParallel in three scripts
 (experiments/run_transformer_gengcn_molpcba.py:446-452); this is a new design for
-8 MI355X on xGMI: the whole model is ~2.2 M parameters (8.8 MB fp32, dominated by encoder.gcn and
-encoder.linear), so the all-reduce is latency-bound and a single bucket is the right size.
+8 MI355X on xGMI: the whole model is ~2.2 M parameters, dominated by encoder.gcn.weight and
+encoder.linear.weight (C x C = 1 M each).  The all-reduce is latency-bound, so one bucket is the
+right size, and its volume is halved by a structural fact: encoder.gcn only ever sees an all-ones
+input (transformer/models.py:280-282), so its weight gradient is the SAME row repeated C times
+(d colsum(W) / dW) - only one row travels.
 Parameters whose gradient is never produced (the reference's unused outer GCNConv,
 transformer/models.py:508) contribute zeros on every rank.
 """
@@ -17,13 +20,20 @@ def shard_indices(num_items, rank, world_size):
     return list(range(rank, num_items, world_size))
 
 
+def mark_row_constant(param):
+    """Declare that param.grad always consists of identical rows (DenseGCNParams.weight)."""
+    param._feta_row_constant = True
+    return param
+
+
 class FlatGradAllReduce:
     """One flat fp32 bucket for all gradients.
 
     views=False (default): autograd writes fresh .grad tensors (no accumulate kernels; inside a
         hipGraph their addresses are static); all_reduce() packs them with ONE cat kernel, runs ONE
         all-reduce (RCCL ``nccl`` backend on GPUs, ``gloo`` in the CPU tests), scales by 1/world and
-        scatters back with one multi-tensor copy.
+        scatters back with one multi-tensor copy.  Row-constant gradients (mark_row_constant) are
+        packed as a single row.
     views=True: every .grad is a view into the bucket and autograd accumulates in place; zero()
         memsets the bucket.  No pack/unpack, one add kernel per parameter in backward.
     """
@@ -32,19 +42,22 @@ class FlatGradAllReduce:
         self.params = [p for p in params if p.requires_grad]
         assert self.params, 'no trainable parameters'
         dev, dt = self.params[0].device, self.params[0].dtype
-        self.numel = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(self.numel, device=dev, dtype=dt)
         self.group = process_group
         self.views = views
         if world_size is None:
             world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.world_size = world_size
+        self.rowconst = [bool(getattr(p, '_feta_row_constant', False)) and not views and p.dim() == 2
+                         for p in self.params]
+        sizes = [p.shape[1] if rc else p.numel() for p, rc in zip(self.params, self.rowconst)]
+        self.numel = sum(sizes)
+        self.flat = torch.zeros(self.numel, device=dev, dtype=dt)
         self.slices = []
         off = 0
-        for p in self.params:
+        for p, sz in zip(self.params, sizes):
             assert p.device == dev and p.dtype == dt
-            self.slices.append(self.flat[off:off + p.numel()])
-            off += p.numel()
+            self.slices.append(self.flat[off:off + sz])
+            off += sz
         if views:
             for p, s in zip(self.params, self.slices):
                 p.grad = s.view_as(p)
@@ -58,15 +71,42 @@ class FlatGradAllReduce:
 
     @torch.no_grad()
     def pack(self):
-        parts = [p.grad.reshape(-1) if p.grad is not None else torch.zeros_like(s)
-                 for p, s in zip(self.params, self.slices)]
+        parts = []
+        for p, s, rc in zip(self.params, self.slices, self.rowconst):
+            if p.grad is None:
+                parts.append(torch.zeros_like(s))
+            elif rc:
+                parts.append(p.grad[0])
+            else:
+                parts.append(p.grad.reshape(-1))
         torch.cat(parts, out=self.flat)
 
     @torch.no_grad()
     def unpack(self):
-        dst = [p.grad for p in self.params if p.grad is not None]
-        src = [s.view_as(p) for p, s in zip(self.params, self.slices) if p.grad is not None]
+        dst, src = [], []
+        for p, s, rc in zip(self.params, self.slices, self.rowconst):
+            if p.grad is None:
+                continue
+            dst.append(p.grad)
+            src.append(s.unsqueeze(0).expand_as(p.grad) if rc else s.view_as(p))
         torch._foreach_copy_(dst, src)
+
+    def start(self):
+        """Pack and launch the all-reduce asynchronously (it runs on the collective's own stream,
+        under whatever the caller enqueues next); finish(work) completes it."""
+        if self.world_size == 1:
+            return None
+        if not self.views:
+            self.pack()
+        return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self, work):
+        if work is None:
+            return
+        work.wait()
+        self.flat.mul_(1.0 / self.world_size)
+        if not self.views:
+            self.unpack()
 
     def all_reduce(self):
         """Averaged gradients in every p.grad (and in .flat), identical on all ranks."""

@@ -22,6 +22,7 @@ import torch.nn.functional as F
 
 from .. import functional as FF
 from ..fused_stack import fused_encoder_stack, stack_supported
+from ..parallel import mark_row_constant
 from .ChebNetDynamic import ChebConvDynamic
 from .data import GraphBatchCache
 from .layers import DiffTransformerEncoderLayer, clone_layers, linear_rows, n_real_from_mask
@@ -85,6 +86,7 @@ class DiffTransformerEncoderGenGCN(nn.Module):
         self.spectral_gnns = ChebConvDynamic(dh, dh, self.order, normalization=laplacian_norm,
                                              learn_only_filter_order_coeff=learn_only_filter_order_coeff)
         self.gcn = DenseGCNParams(self.num_coefficients, self.num_coefficients)  # :144
+        mark_row_constant(self.gcn.weight)   # all-ones input => every row of its gradient is equal
         self.linear = nn.Linear(self.num_coefficients, self.num_coefficients)    # :145
         self.linear_cat = nn.Linear(2 * d_model, d_model)                        # :146
         self.gnn_type = gnn_type
@@ -95,6 +97,9 @@ class DiffTransformerEncoderGenGCN(nn.Module):
         self.heads_share_graph = heads_share_graph
         self.filter_mode = filter_mode
         self.fused_stack = True   # BatchNorm stacks run as one autograd node when the dims allow
+        self.keep_stack_boundary = False   # set by trainers that use backward_head / backward_stack
+        self._stack_boundary = None
+        self._stack_grads = None
 
     # -- A2 ---------------------------------------------------------------------------------
     def get_filter_coefficients(self, attn_weights, edge_index=None, feature_indices=None,
@@ -136,6 +141,36 @@ class DiffTransformerEncoderGenGCN(nn.Module):
                                                   graph_cache.n_real.shape[0], n_pad)
         return graph_cache
 
+    # -- two-phase backward (data-parallel overlap) ---------------------------------------------
+    def head_parameters(self):
+        """Parameters of the filter stage (gcn, linear, linear_cat, spectral_gnns): ~96 % of the
+        gradient bytes, and the FIRST gradients backward produces."""
+        mods = (self.gcn, self.linear, self.linear_cat, self.spectral_gnns)
+        return [p for m in mods for p in m.parameters() if p.requires_grad]
+
+    def stack_parameters(self):
+        return [p for p in self.layers.parameters() if p.requires_grad]
+
+    def backward_head(self, out, grad_out):
+        """Phase 1 of backward after a fused-stack forward: gradients of head_parameters() (assigned
+        to .grad) and of the stack outputs (kept for backward_stack).  A data-parallel trainer starts
+        the all-reduce of the head bucket here and runs backward_stack() underneath it."""
+        bnd = self._stack_boundary
+        if bnd is None:
+            raise RuntimeError('backward_head needs keep_stack_boundary = True and a forward through '
+                               'the fused BatchNorm stack')
+        head = self.head_parameters()
+        grads = torch.autograd.grad(out, list(bnd) + head, grad_outputs=grad_out, allow_unused=True)
+        for p, g in zip(head, grads[2:]):
+            p.grad = g
+        self._stack_grads = grads[:2]
+
+    def backward_stack(self):
+        """Phase 2: backward through the encoder-layer stack (accumulates stack_parameters().grad)."""
+        bnd, grads = self._stack_boundary, self._stack_grads
+        self._stack_boundary = self._stack_grads = None   # do not keep the autograd graph alive
+        torch.autograd.backward(list(bnd), list(grads))
+
     def forward(self, src, pe, edge_index, feature_indices, batch, degree=None, mask=None,
                 src_key_padding_mask=None, eigenvalues=None, graph_cache=None):
         """-> (output [N,B,d], attn [B,H,N,N] of the last layer, coefficients [B, H*n_filtered, C]).
@@ -162,6 +197,8 @@ class DiffTransformerEncoderGenGCN(nn.Module):
                     continue
                 output, concat, attn = fused_encoder_stack(output, pe, degree_rows, cache.n_real,
                                                            self.layers, need_attn=True)
+                if self.keep_stack_boundary:   # for backward_head / backward_stack
+                    self._stack_boundary = (output, concat)
                 nn_, bb_, dd_ = concat.shape
                 out_each_head = concat.view(nn_, bb_, self.num_heads, dd_ // self.num_heads).permute(1, 0, 2, 3)
             else:

@@ -172,3 +172,32 @@ def test_fused_stack_updates_running_statistics(emu):
         for nm in ('norm1', 'norm2'):
             KC.assert_close(nm + '.running_mean', getattr(l, nm).running_mean, getattr(lr, nm).running_mean)
             KC.assert_close(nm + '.running_var', getattr(l, nm).running_var, getattr(lr, nm).running_var)
+
+
+def test_two_phase_backward_equals_single_backward(emu):
+    """encoder.backward_head + backward_stack (used to overlap the all-reduce of the filter-stage
+    gradients with the backward of the layer stack) give exactly the gradients of one backward."""
+    model, batch9, cache = _model_case(True, 1, 'cheb', True, bsz=3, d=64, heads=4, layers=2, order=2)
+    enc = model.encoder
+    x, mask, pe, _, degree, _, edge_index, batch, fi = batch9
+    src = model.embedding(x.permute(1, 0, 2)).detach()
+    g = torch.Generator().manual_seed(3)
+    dout = torch.randn(src.shape, generator=g)
+    with _lib.override_for_tests(emu):
+        out, _, _ = enc(src, pe, edge_index, fi, batch, degree=degree, src_key_padding_mask=mask, graph_cache=cache)
+        out.backward(gradient=dout)
+        ref = {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None}
+        for p in enc.parameters():
+            p.grad = None
+        enc.keep_stack_boundary = True
+        out, _, _ = enc(src, pe, edge_index, fi, batch, degree=degree, src_key_padding_mask=mask, graph_cache=cache)
+        enc.backward_head(out, dout)
+        head_names = {n for n, p in enc.named_parameters() if p.grad is not None}
+        assert any(n.startswith('linear.') for n in head_names) and not any(n.startswith('layers.') for n in head_names)
+        enc.backward_stack()
+    got = {n: p.grad for n, p in enc.named_parameters() if p.grad is not None}
+    assert set(got) == set(ref)
+    for n in ref:
+        assert torch.equal(got[n], ref[n]), n
+    assert {id(p) for p in enc.head_parameters()} | {id(p) for p in enc.stack_parameters()} == \
+        {id(p) for p in enc.parameters()}

@@ -27,6 +27,11 @@ def _loss_on(model, samples, scale):
     return ((out.squeeze(-1) - labels) ** 2).sum() * scale
 
 
+def _full_grads(model):
+    return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                      for p in model.parameters()])
+
+
 def _worker(rank, world, port, ret, views):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -46,7 +51,7 @@ def _worker(rank, world, port, ret, views):
         bucket.zero()
         _loss_on(model, mine, 1.0 / len(mine)).backward()
     bucket.all_reduce()
-    ret[rank] = bucket.flat.clone()
+    ret[rank] = _full_grads(model)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -72,8 +77,12 @@ def test_flat_bucket_allreduce_world2(emu, views):
         for r in range(world):
             mine = [ds[i] for i in range(r, len(ds), world)]
             _loss_on(model, mine, 1.0 / len(mine) / world).backward()
-    err = (bucket.flat - ret[0]).abs().max().item()
-    assert err < 1e-5 * max(1.0, bucket.flat.abs().max().item()), err
+    ref = _full_grads(model)
+    err = (ref - ret[0]).abs().max().item()
+    assert err < 1e-5 * max(1.0, ref.abs().max().item()), err
+    # encoder.gcn.weight travels as ONE row (its gradient is row-constant)
+    g = model.encoder.gcn.weight.grad
+    assert torch.equal(g, g[0:1].expand_as(g))
     # the unused outer GCN (transformer/models.py:508) stays exactly zero in the bucket
     assert float(model.gcn.weight.grad.abs().max()) == 0.0
     n_unused = model.gcn.weight.numel() + model.gcn.bias.numel()
