@@ -100,14 +100,6 @@ def build_encoder(args):
                                         filter_mode='spectral')
 
 
-def algorithmic_bytes_attn_fwd(b, n, h, dh, pe, write_attn):
-    """feta_attn_fwd, per launch: read q,k,v (3 N d), pe (N^2), n_real; write out (N d),
-    stats (2 H N) and attn (H N^2) when requested.  fp32."""
-    d = h * dh
-    per_graph = 3 * n * d + (n * n if pe else 0) + n * d + 2 * h * n + (h * n * n if write_attn else 0)
-    return 4 * per_graph * b
-
-
 def time_kernel(fn, iters):
     for _ in range(10):
         fn()
@@ -122,31 +114,63 @@ def time_kernel(fn, iters):
 
 
 def roofline(args, gpu, dev):
-    """Average launch duration of the dominant hand-written kernel (feta_attn_fwd with the attn
-    write, the largest-traffic launch of the step), HIP events on the stream it is launched on."""
-    abi, stream = _lib.abi(), _lib.stream_handle()
-    b, n, h, dh = args.batch, args.n_pad, args.heads, args.dim // args.heads
-    qkv = torch.randn(n, b, 3 * args.dim, device=dev)
+    """Times the hand-written kernels of one step in isolation (HIP events on the stream they are
+    launched on - torch's current stream), picks the DOMINANT one = largest launches-per-step x
+    launch time, and prices it against the HBM roofline with its algorithmic bytes (DESIGN.md
+    section 3).  `traffic` = HBM bytes per launch from the rocprofv3 PMC passes committed in
+    profiles/traffic.json (FETCH_SIZE x2 + WRITE_SIZE, see tools/pmc_summary.py), null if absent."""
+    abi, st = _lib.abi(), _lib.stream_handle()
+    b, n, h, d = args.batch, args.n_pad, args.heads, args.dim
+    dh, m, k_eig, p = d // h, args.n_pad * args.batch, args.k_eig, args.order
+    c = p * dh * dh
+    L = args.layers
+    rnd = lambda *s: torch.randn(*s, device=dev)
+    qkv = rnd(n, b, 3 * d)
     v5 = qkv.view(n, b, 3, h, dh)
     q, k, v = (v5[:, :, i].permute(1, 0, 2, 3) for i in range(3))
     out = torch.empty(n, b, h, dh, device=dev).permute(1, 0, 2, 3)
     attn = torch.empty(b, h, n, n, device=dev)
     stats = torch.empty(b, h, n, 2, device=dev)
     nr = gpu['cache'].n_real
-    fn = lambda: abi.attn_fwd(q, k, v, gpu['pe'], nr, out, attn, stats, dh ** -0.5, stream)
-    t = time_kernel(fn, args.kernel_iters)
-    nbytes = algorithmic_bytes_attn_fwd(b, n, h, dh, True, True)
-    achieved = nbytes / t / 1e9
-    traffic = None
+    sc = dh ** -0.5
+    cand = []   # (name, launches per step, fn, algorithmic bytes)
+    cand.append(('attn_fwd (+attn write)', 1, lambda: abi.attn_fwd(q, k, v, gpu['pe'], nr, out, attn, stats, sc, st),
+                 4 * b * (3 * n * d + n * n + n * d + 2 * h * n + h * n * n)))
+    cand.append(('attn_fwd (no attn write)', L - 1, lambda: abi.attn_fwd(q, k, v, gpu['pe'], nr, out, None, stats, sc, st),
+                 4 * b * (3 * n * d + n * n + n * d + 2 * h * n)))
+    G = abi.rowlin_blocks(m)
+    for (nm, ki, no, cnt) in (('in_proj', d, 3 * d, L), ('out_proj', d, d, L), ('linear1', d, 2 * d, L),
+                              ('linear2', 2 * d, d, L)):
+        x, w, bb, y = rnd(m, ki), rnd(no, ki), rnd(no), torch.empty(m, no, device=dev)
+        sto = torch.empty(G, 2, no, device=dev)
+        cand.append(('rowlin_fwd ' + nm, cnt, (lambda x=x, w=w, bb=bb, y=y, sto=sto: abi.rowlin_fwd(x, w, bb, None, None, y, sto, False, st)),
+                     4 * (m * ki + no * ki + m * no)))
+    xs = rnd(n, b, h, dh).permute(1, 0, 2, 3)
+    ys = torch.empty(n, b, h, dh, device=dev).permute(1, 0, 2, 3)
+    coeff, bias = rnd(h * b, c), rnd(dh)
+    cand.append(('spec_filter_fwd', 1, lambda: abi.spec_filter_fwd(xs, gpu['cache'].u, gpu['cache'].lam, coeff, bias, nr, ys, p, 1, st),
+                 4 * b * (n * d + n * k_eig + k_eig + h * c + n * d)))
+    rows = []
+    for name, cnt, fn, nbytes in cand:
+        t = time_kernel(fn, args.kernel_iters)
+        rows.append({'kernel': name, 'launches_per_step': cnt, 'launch_us': round(t * 1e6, 3),
+                     'algorithmic_bytes': nbytes, 'achieved': round(nbytes / t / 1e9, 2),
+                     'frac': round(nbytes / t / 1e9 / HBM_PEAK_GBS, 5)})
+    traffic = {}
     tp = os.path.join(ROOT, 'profiles', 'traffic.json')
     if os.path.exists(tp):
         try:
-            traffic = json.load(open(tp)).get('feta_attn_fwd')
+            traffic = json.load(open(tp))
         except Exception:
-            traffic = None
-    return {'kernel': 'feta_attn_fwd', 'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
-            'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
-            'algorithmic_bytes': nbytes, 'launch_us': round(t * 1e6, 3)}
+            traffic = {}
+    for r in rows:
+        r['traffic'] = (traffic.get(r['kernel']) or {}).get('hbm_bytes')
+    dom = max(rows, key=lambda r: r['launches_per_step'] * r['launch_us'])
+    res = {'kernel': dom['kernel'], 'bound': 'hbm', 'achieved': dom['achieved'], 'peak': HBM_PEAK_GBS,
+           'unit': 'GB/s', 'frac': dom['frac'], 'traffic': dom['traffic'],
+           'algorithmic_bytes': dom['algorithmic_bytes'], 'launch_us': dom['launch_us'],
+           'launches_per_step': dom['launches_per_step'], 'other_kernels': [r for r in rows if r is not dom]}
+    return res
 
 
 def cpu_baseline(args, cpu, enc):

@@ -1,24 +1,66 @@
-"""Joins rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/kernel_bench.py (dispatch order is
-deterministic: 3 warm-up + ITERS launches per bench row) into per-kernel-config HBM traffic.
-usage: python tools/pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <iters> <kb.log>"""
-import csv, json, re, sys
+"""Joins rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, counter unit = KB) of
+tools/kernel_bench.py into HBM traffic per kernel configuration.  The dispatch order of the
+micro-benchmark is deterministic (3 warm-up + ITERS calls per row); rows are matched by the kernel
+symbols each C-ABI call enqueues.
+
+usage: python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> ITERS [out.json]
+Correction (MI355X_MICROARCH.md, HBM section; calibrated here on bn_apply_fwd, a pure float4 stream:
+74.5 MiB counted for 148 MiB read): FETCH_SIZE counts 64 B per 128-B request -> doubled; WRITE_SIZE exact.
+"""
+import csv
+import json
+import sys
+
+ROWS = [  # (bench row, kernel-symbol substrings enqueued by one call, in order)
+    ('attn_fwd (+attn write)', ['attn_fwd']),
+    ('attn_fwd (no attn write)', ['attn_fwd']),
+    ('attn_bwd (dq + dkdv)', ['attn_bwd_dq', 'attn_bwd_dkdv']),
+    ('coeff_fwd', ['coeff_fwd_kernel']),
+    ('coeff_bwd', ['coeff_bwd_kernel', 'colsum_kernel', 'colsum_kernel']),
+    ('spec_filter_fwd', ['spec_fwd']),
+    ('spec_filter_bwd', ['spec_bwd']),
+    ('cheb_filter_fwd', ['cheb_fwd']),
+    ('cheb_filter_bwd', ['cheb_bwd']),
+    ('rowlin_fwd in_proj', ['rowlin_fwd']), ('rowlin_bwd in_proj', ['rowlin_bwd', 'colsum_kernel']),
+    ('rowlin_fwd out_proj', ['rowlin_fwd']), ('rowlin_bwd out_proj', ['rowlin_bwd', 'colsum_kernel']),
+    ('rowlin_fwd linear1', ['rowlin_fwd']), ('rowlin_bwd linear1', ['rowlin_bwd', 'colsum_kernel']),
+    ('rowlin_fwd linear2', ['rowlin_fwd']), ('rowlin_bwd linear2', ['rowlin_bwd', 'colsum_kernel']),
+    ('bn_apply_fwd', ['bn_apply_fwd']),
+    ('bn_bwd (reduce + apply)', ['bn_bwd_reduce', 'bn_bwd_apply']),
+]
+
 
 def seq(path):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r['Dispatch_Id']))
     return [(r['Kernel_Name'], float(r['Counter_Value'])) for r in rows if 'feta::' in r['Kernel_Name']]
 
-f, w = seq(sys.argv[1]), seq(sys.argv[2])
-iters = int(sys.argv[3]) + 3
-names = [l.split('  ')[0].strip() for l in open(sys.argv[4]) if re.search(r'\d+\.\d+%\s*$', l)]
-# launches per bench row (kernels each C-ABI call enqueues)
-per_call = {'attn_bwd': 2, 'coeff_bwd': 2, 'rowlin_bwd': 2, 'bn_bwd': 2}
-out, i = [], 0
-for nm in names:
-    k = next((v for p, v in per_call.items() if nm.startswith(p)), 1)
-    nf = f[i:i + iters * k]; nw = w[i:i + iters * k]
-    i += iters * k
-    fk = sum(v for _, v in nf) / iters; wk = sum(v for _, v in nw) / iters
-    out.append({'bench_row': nm, 'kernels': sorted(set(n.split('(')[0] for n, _ in nf)),
-                'FETCH_SIZE_KB_per_call': round(fk, 1), 'WRITE_SIZE_KB_per_call': round(wk, 1)})
-print(json.dumps(out, indent=1))
+
+def walk(stream, calls):
+    out, i = {}, 0
+    for name, syms in ROWS:
+        tot = 0.0
+        for _ in range(calls):
+            for s in syms:
+                while s not in stream[i][0]:   # e.g. the one-off bn_stats launch of the set-up
+                    i += 1
+                tot += stream[i][1]
+                i += 1
+        out[name] = tot / calls
+    return out
+
+
+def main():
+    f, w = seq(sys.argv[1]), seq(sys.argv[2])
+    calls = int(sys.argv[3]) + 3
+    fk, wk = walk(f, calls), walk(w, calls)
+    res = {name: {'FETCH_SIZE_KB': round(fk[name], 1), 'WRITE_SIZE_KB': round(wk[name], 1),
+                  'hbm_bytes': int(round((2.0 * fk[name] + wk[name]) * 1024))} for name, _ in ROWS}
+    txt = json.dumps(res, indent=1)
+    if len(sys.argv) > 4:
+        open(sys.argv[4], 'w').write(txt + '\n')
+    print(txt)
+
+
+if __name__ == '__main__':
+    main()
