@@ -25,6 +25,17 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }
 
+// Sum over the 16 lanes of a DPP row (lanes with equal lane >> 4); every lane of the row gets the
+// total.  Four rotate-and-add steps on the VALU (row_ror:8,4,2,1) instead of four ds_bpermute
+// round trips through the LDS crossbar per value.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+  return v;
+}
+
 // A wave's DS operations execute in order; this only stops the compiler from
 // moving a wave-private LDS read above the write that another lane made.
 __device__ __forceinline__ void wave_lds_sync() {

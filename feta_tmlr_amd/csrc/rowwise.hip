@@ -19,6 +19,8 @@
 // MFMA orientation: Y^T tile = W_tile . X_tile^T, so the accumulator holds 4 consecutive
 // output features of one row per lane -> 16-byte epilogue loads/stores, and the row-wise
 // epilogue operands (degree, residual) are lane-local.
+#include <cstdlib>
+
 #include "feta_abi_common.h"
 #include "feta_tiles.h"
 
@@ -205,11 +207,8 @@ __global__ __launch_bounds__(kRowThreads) void rowlin_fwd_kernel(RowLinArgs a, R
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float s1 = rok ? v[r] : 0.0f, s2 = s1 * s1;
-#pragma unroll
-          for (int m = 1; m < 16; m <<= 1) {
-            s1 += shfl_xor(s1, m);
-            s2 += shfl_xor(s2, m);
-          }
+          s1 = row16_sum(s1);
+          s2 = row16_sum(s2);
           if (lq == 0) {
             my[ol + r] += s1;
             my[tgw + ol + r] += s2;
@@ -352,11 +351,8 @@ __device__ void rowlin_dx_role(const RowLinArgs& a, const RowLinGeom& ge, const 
         for (int r = 0; r < 4; ++r) {
           const float xh = (yy[r] - ev[5 * ks + kl + r]) * ev[6 * ks + kl + r];
           float s1 = rok ? v[r] : 0.0f, s2 = s1 * xh;
-#pragma unroll
-          for (int m = 1; m < 16; m <<= 1) {
-            s1 += shfl_xor(s1, m);
-            s2 += shfl_xor(s2, m);
-          }
+          s1 = row16_sum(s1);
+          s2 = row16_sum(s2);
           if (lq == 0) {
             my[kl + r] += s1;
             my[ks + kl + r] += s2;
@@ -867,7 +863,11 @@ extern "C" int feta_rowlin_bwd_ex(const feta_rowlin_ex* d, float* dwdb, feta_str
   const int n_ot = a.NO / 16;
   const int dw_blocks = a.KI <= 128 ? ge.RC * ((n_ot + kRowWaves - 1) / kRowWaves)
                                     : (ge.RC * n_ot + kRowWaves - 1) / kRowWaves;
-  const int grid = ge.dx_blocks + dw_blocks;
+  int grid = ge.dx_blocks + dw_blocks;
+  if (const char* role = getenv("FETA_ROWLIN_ROLE")) {  // diagnostic: time one role alone (results incomplete)
+    if (role[0] == 'x') grid = ge.dx_blocks;
+    if (role[0] == 'w') { ge.dx_blocks = 0; grid = dw_blocks; }
+  }
   const size_t dx_lds = a.NO * (16 * ge.TG + 4) + (kRowWaves * 2 + 7) * 16 * ge.TG;
   const size_t dw_lds = a.KI <= 128 ? 64 * (64 + 16) + 64 * (a.KI + 16) : 0;
   const size_t lds = sizeof(float) * ((dx_lds > dw_lds ? dx_lds : dw_lds) +

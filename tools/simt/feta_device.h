@@ -57,6 +57,22 @@ inline float shfl(float v, int src) {
   return r;
 }
 
+// sum over the 16 lanes that share lane >> 4, in the rotate-and-add order of the device version
+inline float row16_sum(float v) {
+  simt::WaveScratch& s = simt::wave_scratch();
+  const int l = lane_id();
+  const int base = l & ~15, i = l & 15;
+  const int rot[4] = {8, 4, 2, 1};
+  for (int step = 0; step < 4; ++step) {
+    s.a[l] = v;
+    simt::wave_barrier();
+    const float o = s.a[base + ((i + 16 - rot[step]) & 15)];   // row_ror:n reads lane (i - n) mod 16
+    simt::wave_barrier();
+    v += o;
+  }
+  return v;
+}
+
 // orders this wave's LDS writes before its later LDS reads (other lanes' data)
 inline void wave_lds_sync() { simt::wave_barrier(); }
 
