@@ -67,6 +67,8 @@ def parse():
     ap.add_argument('--order', type=int, default=4)
     ap.add_argument('--k-eig', type=int, default=16)
     ap.add_argument('--n-pad', type=int, default=37)
+    ap.add_argument('--shape', default='zinc', choices=['mutag', 'zinc', 'pattern', 'molhiv'],
+                    help='synthetic graph-size distribution (SURVEY 8d); the headline metric is zinc')
     ap.add_argument('--layer-norm', action='store_true', help='LayerNorm instead of the ZINC default BatchNorm')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of one hipGraph per step')
     ap.add_argument('--two-phase', action='store_true',
@@ -79,7 +81,9 @@ def parse():
 
 
 def make_batch(args, rank, dev):
-    ds = D.SyntheticGraphDataset('zinc', args.batch, in_dim=args.dim, seed=rank)
+    n_max = min(args.n_pad, D.SHAPES[args.shape][1])
+    n_min = min(D.SHAPES[args.shape][0], n_max)
+    ds = D.SyntheticGraphDataset(args.shape, args.batch, in_dim=args.dim, seed=rank, n_min=n_min, n_max=n_max)
     batch9, cache = D.collate(ds.samples, k_eig=args.k_eig, n_pad=args.n_pad)
     x, mask, pe, _, degree, _, edge_index, batch, fi = batch9
     src = x.permute(1, 0, 2).contiguous()          # [N,B,d] seq-first, embedding skipped
@@ -340,7 +344,7 @@ def main():
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic',
-            'config': {'workload': 'ZINC-shaped synthetic padded-graph batch, ChebConvDynamic block '
+            'config': {'workload': args.shape.upper() + '-shaped synthetic padded-graph batch, ChebConvDynamic block '
                                    '(attention + coefficient generator + spectral filter), fwd+bwd',
                        'graphs_per_gpu': args.batch, 'global_batch': args.batch * world,
                        'n_pad': args.n_pad, 'd_model': args.dim, 'heads': args.heads,

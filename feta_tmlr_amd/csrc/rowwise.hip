@@ -111,6 +111,38 @@ __global__ __launch_bounds__(kRowThreads) void rowlin_fwd_kernel(RowLinArgs a, R
   const bool want_stats = a.stats != nullptr;
   const bool x_norm = a.x_stats != nullptr || a.x_bn != nullptr;
 
+  // ---- load batch of a row block: everything it needs from memory is requested up front
+  // (clamped row, selects afterwards), so the block pays ONE memory latency; the first batch is
+  // issued before the weight staging / statistics finalize so that it overlaps with them
+  struct Batch {
+    Feat<KI> xf;
+    float rs;
+    float4 bv[4], rv[4], r1[4], r2[4];
+  };
+  auto load_batch = [&](int rb, Batch& B) {
+    const int row = rb * kRowsPerBlock + wave_id() * 16 + lq;
+    const int rowc = min(row, a.M - 1);
+    load_row_sel<KI>(B.xf, a.x + (int64_t)rowc * KI, true, g);
+    B.rs = a.rowscale != nullptr ? a.rowscale[rowc] : 1.0f;
+    const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      B.bv[t] = z4; B.rv[t] = z4; B.r1[t] = make_float4(1.0f, 1.0f, 1.0f, 1.0f); B.r2[t] = z4;
+      if (t < ntile) {
+        const int o = o_base + 16 * t + 4 * g;
+        if (a.bias != nullptr) B.bv[t] = *reinterpret_cast<const float4*>(a.bias + o);
+        if (a.residual != nullptr)
+          B.rv[t] = *reinterpret_cast<const float4*>(a.residual + (int64_t)rowc * a.NO + o);
+        if (a.res_bn != nullptr) {
+          B.r1[t] = *reinterpret_cast<const float4*>(a.res_bn + o);
+          B.r2[t] = *reinterpret_cast<const float4*>(a.res_bn + a.NO + o);
+        }
+      }
+    }
+  };
+  Batch cur;
+  load_batch(rg, cur);
+
   const int nvec = ntile * 16 * (KI / 4);
   for (int idx = threadIdx.x; idx < nvec; idx += kRowThreads) {
     const int row = idx / (KI / 4), c4 = idx - row * (KI / 4);
@@ -153,27 +185,13 @@ __global__ __launch_bounds__(kRowThreads) void rowlin_fwd_kernel(RowLinArgs a, R
   for (int rb = rg; rb < nrb; rb += ge.G) {
     const int row = rb * kRowsPerBlock + wave_id() * 16 + lq;
     const bool rok = row < a.M;
-    const int rowc = min(row, a.M - 1);
-    // ---- load batch: everything this row block needs from memory is requested up front
-    // (clamped row, selects afterwards), so the block pays ONE memory latency
-    Feat<KI> xf;
-    load_row_sel<KI>(xf, a.x + (int64_t)rowc * KI, true, g);
-    const float rs = a.rowscale != nullptr ? a.rowscale[rowc] : 1.0f;
-    const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    float4 bv[4], rv[4], r1[4], r2[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      bv[t] = z4; rv[t] = z4; r1[t] = make_float4(1.0f, 1.0f, 1.0f, 1.0f); r2[t] = z4;
-      if (t < ntile) {
-        const int o = o_base + 16 * t + 4 * g;
-        if (a.bias != nullptr) bv[t] = *reinterpret_cast<const float4*>(a.bias + o);
-        if (a.residual != nullptr) rv[t] = *reinterpret_cast<const float4*>(a.residual + (int64_t)rowc * a.NO + o);
-        if (a.res_bn != nullptr) {
-          r1[t] = *reinterpret_cast<const float4*>(a.res_bn + o);
-          r2[t] = *reinterpret_cast<const float4*>(a.res_bn + a.NO + o);
-        }
-      }
-    }
+    if (rb != rg) load_batch(rb, cur);
+    Feat<KI>& xf = cur.xf;
+    const float rs = cur.rs;
+    float4 (&bv)[4] = cur.bv;
+    float4 (&rv)[4] = cur.rv;
+    float4 (&r1)[4] = cur.r1;
+    float4 (&r2)[4] = cur.r2;
     if (x_norm) {
 #pragma unroll
       for (int j = 0; j < Feat<KI>::NJ; ++j) {
@@ -260,6 +278,39 @@ __device__ void rowlin_dx_role(const RowLinArgs& a, const RowLinGeom& ge, const 
     ev[5 * ks + i] = (want_sums && kok) ? a.sum_bn[2 * a.KI + k] : 0.0f;
     ev[6 * ks + i] = (want_sums && kok) ? a.sum_bn[3 * a.KI + k] : 0.0f;
   }
+  // load batch of a row block (clamped row, unconditional): gradient row, its BatchNorm / relu
+  // companions and every epilogue operand; the first one is issued before the weight staging
+  struct Batch {
+    float rs;
+    Feat<NO> gf, gyf, ryf;
+    float4 pv4[4], dv4[4], ay4[4], sy4[4];
+  };
+  auto load_batch = [&](int rb, Batch& B) {
+    const int row = rb * kRowsPerBlock + wave_id() * 16 + lq;
+    const bool rok = row < a.M;
+    const int rowc = min(row, a.M - 1);
+    B.rs = a.rowscale != nullptr ? a.rowscale[rowc] : 1.0f;
+    load_row_sel<NO>(B.gf, a.dy + (int64_t)rowc * NO, rok, g);
+    if (a.g_y != nullptr) load_row_sel<NO>(B.gyf, a.g_y + (int64_t)rowc * NO, true, g);
+    if (a.relu_y != nullptr) load_row_sel<NO>(B.ryf, a.relu_y + (int64_t)rowc * NO, true, g);
+    const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      B.pv4[t] = z4; B.dv4[t] = z4; B.ay4[t] = z4; B.sy4[t] = z4;
+      if (t < ntile) {
+        const int64_t off = (int64_t)rowc * a.KI + k_base + 16 * t + 4 * g;
+        if (a.add_plain != nullptr) B.pv4[t] = *reinterpret_cast<const float4*>(a.add_plain + off);
+        if (a.add_dout != nullptr) {
+          B.dv4[t] = *reinterpret_cast<const float4*>(a.add_dout + off);
+          B.ay4[t] = *reinterpret_cast<const float4*>(a.add_y + off);
+        }
+        if (want_sums) B.sy4[t] = *reinterpret_cast<const float4*>(a.sum_y + off);
+      }
+    }
+  };
+  Batch cur;
+  load_batch(rg, cur);
+
   const int rowvec = ntile * 4;
   for (int idx = threadIdx.x; idx < NO * rowvec; idx += kRowThreads) {
     const int o = idx / rowvec, c4 = idx - o * rowvec;
@@ -274,29 +325,15 @@ __device__ void rowlin_dx_role(const RowLinArgs& a, const RowLinGeom& ge, const 
   for (int rb = rg; rb < nrb; rb += ge.G) {
     const int row = rb * kRowsPerBlock + wave_id() * 16 + lq;
     const bool rok = row < a.M;
-    const int rowc = min(row, a.M - 1);
-    // ---- load batch (clamped row, unconditional): gradient row, its BatchNorm / relu companions
-    // and every epilogue operand of this row block are requested before the first MFMA
-    const float rs = a.rowscale != nullptr ? a.rowscale[rowc] : 1.0f;
-    Feat<NO> gf, gyf, ryf;
-    load_row_sel<NO>(gf, a.dy + (int64_t)rowc * NO, rok, g);
-    if (a.g_y != nullptr) load_row_sel<NO>(gyf, a.g_y + (int64_t)rowc * NO, true, g);
-    if (a.relu_y != nullptr) load_row_sel<NO>(ryf, a.relu_y + (int64_t)rowc * NO, true, g);
-    const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    float4 pv4[4], dv4[4], ay4[4], sy4[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      pv4[t] = z4; dv4[t] = z4; ay4[t] = z4; sy4[t] = z4;
-      if (t < ntile) {
-        const int64_t off = (int64_t)rowc * a.KI + k_base + 16 * t + 4 * g;
-        if (a.add_plain != nullptr) pv4[t] = *reinterpret_cast<const float4*>(a.add_plain + off);
-        if (a.add_dout != nullptr) {
-          dv4[t] = *reinterpret_cast<const float4*>(a.add_dout + off);
-          ay4[t] = *reinterpret_cast<const float4*>(a.add_y + off);
-        }
-        if (want_sums) sy4[t] = *reinterpret_cast<const float4*>(a.sum_y + off);
-      }
-    }
+    if (rb != rg) load_batch(rb, cur);
+    const float rs = cur.rs;
+    Feat<NO>& gf = cur.gf;
+    Feat<NO>& gyf = cur.gyf;
+    Feat<NO>& ryf = cur.ryf;
+    float4 (&pv4)[4] = cur.pv4;
+    float4 (&dv4)[4] = cur.dv4;
+    float4 (&ay4)[4] = cur.ay4;
+    float4 (&sy4)[4] = cur.sy4;
     if (a.g_y != nullptr) {
 #pragma unroll
       for (int j = 0; j < Feat<NO>::NJ; ++j) {

@@ -191,3 +191,29 @@ def collate(samples, k_eig=None, n_pad=None, device='cpu'):
     cache = GraphBatchCache(n_real=t(np.array(ns, np.int32)), node_off=t(np.array(offs, np.int32)),
                             n_pad=n, u=t(u), lam=t(lam))
     return batch9, cache
+
+
+BUCKETS = (16, 32, 48, 64, 128, 256)
+
+
+def bucket_batches(samples, batch_size, buckets=BUCKETS, shuffle_rng=None):
+    """Variable-N batching for wide size distributions (ogbg-molhiv: 2..222 nodes, BASELINE config 5):
+    graphs are grouped by the smallest padded size in ``buckets`` that holds them, and every batch
+    is cut from one group, so the padded area (and the N^2 attention work) follows the graphs.
+    -> list of (n_pad, [sample indices]); the reference pads every batch to its own maximum
+    (transformer/data.py:165), which is the special case of one bucket per batch."""
+    groups = {}
+    for i, g in enumerate(samples):
+        n = g.num_nodes
+        npad = next((bk for bk in buckets if n <= bk), None)
+        if npad is None:
+            raise ValueError('graph %d has %d nodes, more than the largest bucket %d' % (i, n, buckets[-1]))
+        groups.setdefault(npad, []).append(i)
+    out = []
+    for npad in sorted(groups):
+        idx = groups[npad]
+        if shuffle_rng is not None:
+            idx = list(shuffle_rng.permutation(idx))
+        for k in range(0, len(idx), batch_size):
+            out.append((npad, idx[k:k + batch_size]))
+    return out

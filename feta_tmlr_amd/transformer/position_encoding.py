@@ -1,0 +1,210 @@
+"""Per-graph positional / spectral encodings, all derived from ONE symmetric eigendecomposition
+of the graph Laplacian.
+
+The reference computes each encoding separately on the host and caches the result as a pickle
+(transformer/position_encoding.py:11-52): scipy ``expm(-beta L)`` per graph for the diffusion
+kernel (:65-72), sparse matrix powers for the p-step kernel (:83-93) and a general ``np.linalg.eig``
+for the Laplacian eigenvectors (:127-161).  Here a graph is decomposed once, ``L = U diag(lam) U^T``
+(``numpy.linalg.eigh``, fp64), and every encoding is a function of (U, lam):
+
+    diffusion   U exp(-beta lam) U^T          (:71)
+    p-step      U (1 - beta lam)^p U^T        (:89-92)
+    LapEncoding columns 1..dim of U           (:137-161: ascending, first eigenvector dropped,
+                                               zero-padded columns when the graph is small)
+    spectral    (U[:, :K], lam - 1)           the eigenbasis of L_hat = L_sym - I consumed by
+                                               feta_spec_filter_fwd/bwd (filter_mode='spectral')
+
+Class names, constructor arguments and ``apply_to`` follow the reference; graphs are
+``GraphSample``s (x, edge_index, ...) instead of torch-geometric ``Data`` objects.  The cache is an
+``.npz`` per split instead of a pickle.
+"""
+import os
+
+import numpy as np
+
+
+def laplacian_dense(edge_index, n, normalization=None):
+    """Dense Laplacian with torch-geometric ``get_laplacian`` semantics (self loops removed,
+    degree on the source row, duplicate edges summed): None: D - A; 'sym': I - D^-1/2 A D^-1/2;
+    'rw': I - D^-1 A."""
+    s, t = np.asarray(edge_index)
+    keep = s != t
+    s, t = s[keep], t[keep]
+    a = np.zeros((n, n))
+    np.add.at(a, (s, t), 1.0)
+    deg = a.sum(1)
+    if normalization is None:
+        return np.diag(deg) - a
+    if normalization == 'sym':
+        dis = np.where(deg > 0, 1.0 / np.sqrt(np.maximum(deg, 1e-300)), 0.0)
+        return np.eye(n) - dis[:, None] * a * dis[None, :]
+    if normalization == 'rw':
+        dinv = np.where(deg > 0, 1.0 / np.maximum(deg, 1e-300), 0.0)
+        return np.eye(n) - dinv[:, None] * a
+    raise ValueError('Invalid normalization')
+
+
+def decompose(edge_index, n, normalization=None):
+    """-> (lam ascending [n], U [n, n]) with L = U diag(lam) U^T.  'rw' is decomposed through its
+    similar symmetric matrix (L_rw = D^-1/2 L_sym D^1/2), so U is then not orthogonal:
+    returns (lam, V, V_inv) in that case."""
+    if normalization == 'rw':
+        s, t = np.asarray(edge_index)
+        keep = s != t
+        deg = np.bincount(s[keep], minlength=n).astype(np.float64)
+        lam, u = np.linalg.eigh(laplacian_dense(edge_index, n, 'sym'))
+        d = np.sqrt(np.maximum(deg, 1e-300))
+        dis = np.where(deg > 0, 1.0 / d, 1.0)
+        dsq = np.where(deg > 0, d, 1.0)
+        return lam, dis[:, None] * u, u.T * dsq[None, :]
+    lam, u = np.linalg.eigh(laplacian_dense(edge_index, n, normalization))
+    return lam, u, u.T
+
+
+class PositionEncoding(object):
+    """reference: transformer/position_encoding.py:11-52 (apply_to / save / load / compute_pe)."""
+
+    attr = 'pe'
+
+    def __init__(self, savepath=None, zero_diag=False):
+        self.savepath = savepath
+        self.zero_diag = zero_diag
+
+    def apply_to(self, dataset, split='train'):
+        saved = self.load(split)
+        computed = []
+        out = []
+        for i, g in enumerate(dataset):
+            pe = self.compute_pe(g) if saved is None else saved[i]
+            if saved is None:
+                computed.append(pe)
+            if self.zero_diag:
+                pe = pe.copy()
+                np.fill_diagonal(pe, 0.0)
+            setattr(g, self.attr, pe)
+            out.append(pe)
+        setattr(dataset, self.attr + '_list', out)
+        if saved is None:
+            self.save(computed, split)
+        return dataset
+
+    def _file(self, split):
+        return None if self.savepath is None else self.savepath + '.' + split + '.npz'
+
+    def save(self, pos_enc, split):
+        f = self._file(split)
+        if f is not None and not os.path.isfile(f):
+            np.savez_compressed(f, **{'g%d' % i: p for i, p in enumerate(pos_enc)})
+
+    def load(self, split):
+        f = self._file(split)
+        if f is None or not os.path.isfile(f):
+            return None
+        z = np.load(f)
+        return [z['g%d' % i] for i in range(len(z.files))]
+
+    def compute_pe(self, graph):
+        raise NotImplementedError
+
+
+class DiffusionEncoding(PositionEncoding):
+    """expm(-beta L) (reference :55-72)."""
+
+    def __init__(self, savepath=None, beta=1., use_edge_attr=False, normalization=None, zero_diag=False):
+        super().__init__(savepath, zero_diag)
+        if use_edge_attr:
+            raise NotImplementedError('edge attributes are not used on the FeTA path')
+        self.beta = beta
+        self.normalization = normalization
+
+    def compute_pe(self, graph):
+        lam, v, vinv = decompose(graph.edge_index, graph.num_nodes, self.normalization)
+        return ((v * np.exp(-self.beta * lam)) @ vinv).astype(np.float32)
+
+
+class PStepRWEncoding(PositionEncoding):
+    """(I - beta L)^p (reference :75-93)."""
+
+    def __init__(self, savepath=None, p=1, beta=0.5, use_edge_attr=False, normalization=None, zero_diag=False):
+        super().__init__(savepath, zero_diag)
+        if use_edge_attr:
+            raise NotImplementedError('edge attributes are not used on the FeTA path')
+        self.p = p
+        self.beta = beta
+        self.normalization = normalization
+
+    def compute_pe(self, graph):
+        lam, v, vinv = decompose(graph.edge_index, graph.num_nodes, self.normalization)
+        return ((v * (1.0 - self.beta * lam) ** self.p) @ vinv).astype(np.float32)
+
+
+class AdjEncoding(PositionEncoding):
+    """Dense adjacency (reference :96-105)."""
+
+    def __init__(self, savepath=None, normalization=None, zero_diag=False):
+        super().__init__(savepath, zero_diag)
+        self.normalization = normalization
+
+    def compute_pe(self, graph):
+        n = graph.num_nodes
+        a = np.zeros((n, n), np.float32)
+        s, t = np.asarray(graph.edge_index)
+        a[s, t] = 1.0
+        return a
+
+
+class FullEncoding(PositionEncoding):
+    """All ones (reference :107-115)."""
+
+    def compute_pe(self, graph):
+        return np.ones((graph.num_nodes, graph.num_nodes), np.float32)
+
+
+class LapEncoding(PositionEncoding):
+    """Laplacian eigenvector node features (reference :118-169): eigenvectors in ascending order of
+    eigenvalue, the first one dropped, ``dim`` columns, zero-padded when the graph has fewer.
+    The sign of every column is arbitrary (the reference's np.linalg.eig has the same freedom and
+    its training loop flips signs at random, experiments/run_transformer_gengcn.py:126-131)."""
+
+    attr = 'lap_pe'
+
+    def __init__(self, dim, use_edge_attr=False, normalization=None):
+        super().__init__(None, False)
+        if use_edge_attr:
+            raise NotImplementedError('edge attributes are not used on the FeTA path')
+        self.pos_enc_dim = dim
+        self.normalization = normalization
+
+    def compute_pe(self, graph):
+        n = graph.num_nodes
+        _, v, _ = decompose(graph.edge_index, n, self.normalization)
+        cols = v[:, 1:self.pos_enc_dim + 1]
+        out = np.zeros((n, self.pos_enc_dim), np.float32)
+        out[:, :cols.shape[1]] = cols
+        return out
+
+    def apply_to(self, dataset, split=None):
+        return super().apply_to(dataset, split or 'train')
+
+
+class SpectralEncoding(PositionEncoding):
+    """Eigenbasis of the scaled Laplacian L_hat = L_sym - I that ChebConvDynamic filters on
+    (transformer/ChebNetDynamic.py:108-130): sets graph.u [n, n] and graph.lam [n] (ascending),
+    which ``data.collate(..., k_eig=K)`` truncates / pads into the [B,N,K] / [B,K] kernel inputs."""
+
+    attr = 'spectral'
+
+    def __init__(self):
+        super().__init__(None, False)
+
+    def compute_pe(self, graph):
+        lam, u, _ = decompose(graph.edge_index, graph.num_nodes, 'sym')
+        graph.u, graph.lam = u, lam - 1.0
+        return lam - 1.0
+
+
+POSENCODINGS = {
+    'diffusion': DiffusionEncoding,
+    'pstep': PStepRWEncoding,
+    'adj': AdjEncoding,
+}
