@@ -19,7 +19,7 @@ SIGNATURES = {
     'feta_last_error': ([], C.c_char_p),
     'feta_attn_fwd': ([_F, _F, _F, C.c_int64, C.c_int64, _F, _I, _F, C.c_int64, C.c_int64,
                        _F, _F, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, _S], C.c_int),
-    'feta_attn_bwd': ([_F, _F, _F, C.c_int64, C.c_int64, _F, _I, _F, _F, C.c_int64, C.c_int64,
+    'feta_attn_bwd': ([_F, _F, _F, C.c_int64, C.c_int64, _F, _I, _F, _F, _F, C.c_int64, C.c_int64,
                        _F, _F, _F, _F, _F, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, _S],
                       C.c_int),
     'feta_coeff_fwd': ([_F, _I, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, _S], C.c_int),
@@ -75,7 +75,7 @@ SIGNATURES.update({
     'feta_bn_bwd_reduce': ([_F, _F, _F, _F, C.c_int, C.c_int, _S], C.c_int),
 })
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class FetaError(RuntimeError):
@@ -123,7 +123,11 @@ class Abi:
                                            _p(out), osb, osn, _p(attn), _p(stats), scale,
                                            b, n, h, dh, stream), 'feta_attn_fwd')
 
-    def attn_bwd(self, q, k, v, pe, n_real, out, dout, stats, delta, dq, dk, dv, scale, stream):
+    @staticmethod
+    def attn_bwd_takes_dout2(n, dh):
+        return n <= 64 and dh <= 16
+
+    def attn_bwd(self, q, k, v, pe, n_real, out, dout, stats, delta, dq, dk, dv, scale, stream, dout2=None):
         b, n, h, dh = q.shape
         sb, sn = tok_strides(q)
         for t in (k, v, dq, dk, dv):
@@ -131,7 +135,7 @@ class Abi:
         osb, osn = tok_strides(out)
         assert tok_strides(dout) == (osb, osn)
         self._check(self.lib.feta_attn_bwd(_p(q), _p(k), _p(v), sb, sn, _p(pe), _p(n_real),
-                                           _p(out), _p(dout), osb, osn, _p(stats), _p(delta),
+                                           _p(out), _p(dout), _p(dout2), osb, osn, _p(stats), _p(delta),
                                            _p(dq), _p(dk), _p(dv), scale, b, n, h, dh, stream),
                     'feta_attn_bwd')
 

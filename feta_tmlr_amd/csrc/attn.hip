@@ -29,6 +29,7 @@ struct AttnArgs {
   const int32_t* n_real;
   const float* out;   // forward output (backward input)
   const float* dout;  // backward input
+  const float* dout2; // optional second gradient into the same output (added to dout), dense path
   const float* stats_in;
   float* out_w;
   float* attn;
@@ -455,10 +456,9 @@ __global__ __launch_bounds__(64 * kWaves) void attn_fwd_dense_kernel(AttnArgs a)
 }
 
 template <int DH, int KT_MAX>
-__global__ __launch_bounds__(64 * kWaves) void attn_bwd_dq_dense_kernel(AttnArgs a) {
+__device__ void attn_bwd_dq_dense_role(const AttnArgs& a, int item) {
   constexpr int CT = Feat<DH>::CT;
   const int lane = lane_id(), lq = lane & 15, g = lane >> 4;
-  const int item = blockIdx.x * kWaves + wave_id();
   if (item >= a.total) return;
   const int qb = item % a.NB;
   const int bh = item / a.NB;
@@ -473,6 +473,14 @@ __global__ __launch_bounds__(64 * kWaves) void attn_bwd_dq_dense_kernel(AttnArgs
   Feat<DH> qf, dof, of, kf[KT_MAX], vf[KT_MAX];
   load_row_sel<DH>(qf, tok_row(a.q, a.qsb, a.qsn, b, qc, h, DH), qok, g, a.scale);
   load_row_sel<DH>(dof, tok_row(a.dout, a.osb, a.osn, b, qc, h, DH), qok, g);
+  if (a.dout2 != nullptr) {
+    Feat<DH> d2;
+    load_row_sel<DH>(d2, tok_row(a.dout2, a.osb, a.osn, b, qc, h, DH), qok, g);
+#pragma unroll
+    for (int j = 0; j < Feat<DH>::NJ; ++j)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) dof.f[j][s] += d2.f[j][s];
+  }
   load_row_sel<DH>(of, tok_row(a.out, a.osb, a.osn, b, qc, h, DH), qok, g);
   const float* st = a.stats_in + ((int64_t)bh * a.N + qc) * 2;
   const float m = st[0], z = st[1];
@@ -538,10 +546,10 @@ __global__ __launch_bounds__(64 * kWaves) void attn_bwd_dq_dense_kernel(AttnArgs
 }
 
 template <int DH, int KT_MAX>
-__global__ __launch_bounds__(64 * kWaves) void attn_bwd_dkdv_dense_kernel(AttnArgs a) {
+__device__ void attn_bwd_dkdv_dense_role(const AttnArgs& a, int item) {
   constexpr int CT = Feat<DH>::CT;
+  static_assert(CT == 1, "dense backward: one column tile (delta is a 16-lane row sum)");
   const int lane = lane_id(), lq = lane & 15, g = lane >> 4;
-  const int item = blockIdx.x * kWaves + wave_id();
   if (item >= a.total) return;
   const int kblk = item % a.NB;
   const int bh = item / a.NB;
@@ -564,6 +572,12 @@ __global__ __launch_bounds__(64 * kWaves) void attn_bwd_dkdv_dense_kernel(AttnAr
     const int qrc = min(qrow, a.N - 1);
     load_row_sel<DH>(qf[qb], tok_row(a.q, a.qsb, a.qsn, b, qrc, h, DH), qrow < a.N, g, a.scale);
     load_row_sel<DH>(dof[qb], tok_row(a.dout, a.osb, a.osn, b, qrc, h, DH), qrow < a.N, g);
+    if (a.dout2 != nullptr) {
+      Feat<DH> d2;
+      load_row_sel<DH>(d2, tok_row(a.dout2, a.osb, a.osn, b, qrc, h, DH), qrow < a.N, g);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) dof[qb].f[0][s] += d2.f[0][s];
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int qq = 16 * qb + 4 * g + r;
@@ -571,21 +585,24 @@ __global__ __launch_bounds__(64 * kWaves) void attn_bwd_dkdv_dense_kernel(AttnAr
       const float* st = a.stats_in + ((int64_t)bh * a.N + qqc) * 2;
       sm[qb][r] = st[0];
       sz[qb][r] = st[1];
-      sd[qb][r] = a.delta[(int64_t)bh * a.N + qqc];
       pv[qb][r] = has_pe ? a.pe[((int64_t)b * a.N + qqc) * a.N + keyc] : 1.0f;
-      const float* dor = tok_row(a.dout, a.osb, a.osn, b, qqc, h, DH);
-      const float* qr = tok_row(a.q, a.qsb, a.qsn, b, qqc, h, DH);
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        const int c = 16 * ct + lq;
-        const int cc = c < DH ? c : 0;
-        const bool ok = qq < a.N && c < DH;
-        const float dv_ = dor[cc], qv_ = qr[cc];
-        dob[qb][r][ct] = ok ? dv_ : 0.0f;
-        qbv[qb][r][ct] = ok ? qv_ * a.scale : 0.0f;
-      }
+      const int cc = lq < DH ? lq : 0;
+      const bool ok = qq < a.N && lq < DH;
+      float dv_ = tok_row(a.dout, a.osb, a.osn, b, qqc, h, DH)[cc];
+      if (a.dout2 != nullptr) dv_ += tok_row(a.dout2, a.osb, a.osn, b, qqc, h, DH)[cc];
+      const float qv_ = tok_row(a.q, a.qsb, a.qsn, b, qqc, h, DH)[cc];
+      const float ov_ = tok_row(a.out, a.osb, a.osn, b, qqc, h, DH)[cc];
+      dob[qb][r][0] = ok ? dv_ : 0.0f;
+      qbv[qb][r][0] = ok ? qv_ * a.scale : 0.0f;
+      sd[qb][r] = ok ? dv_ * ov_ : 0.0f;   // summed over the 16 feature lanes below
     }
   }
+  // delta[q] = rowsum(dout * out): recomputed here (16-lane DPP sum) so that this role does not
+  // depend on the dq role and both run in ONE launch
+#pragma unroll
+  for (int qb = 0; qb < KT_MAX; ++qb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sd[qb][r] = row16_sum(sd[qb][r]);
 
   f32x4 dk[CT], dv[CT];
 #pragma unroll
@@ -632,13 +649,20 @@ void launch_fwd_dense_t(const AttnArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
 }
 
+// one launch: workgroups [0, nb) compute dq, [nb, 2 nb) compute dk and dv
+template <int DH, int KT_MAX>
+__global__ __launch_bounds__(64 * kWaves) void attn_bwd_dense_kernel(AttnArgs a, int nb) {
+  if ((int)blockIdx.x < nb)
+    attn_bwd_dq_dense_role<DH, KT_MAX>(a, blockIdx.x * kWaves + wave_id());
+  else
+    attn_bwd_dkdv_dense_role<DH, KT_MAX>(a, (blockIdx.x - nb) * kWaves + wave_id());
+}
+
 template <int DH, int KT_MAX>
 void launch_bwd_dense_t(const AttnArgs& a, hipStream_t stream) {
-  const dim3 grid((a.total + kWaves - 1) / kWaves), block(64 * kWaves);
-  auto k1 = attn_bwd_dq_dense_kernel<DH, KT_MAX>;
-  hipLaunchKernelGGL(k1, grid, block, 0, stream, a);
-  auto k2 = attn_bwd_dkdv_dense_kernel<DH, KT_MAX>;
-  hipLaunchKernelGGL(k2, grid, block, 0, stream, a);
+  const int nb = (a.total + kWaves - 1) / kWaves;
+  auto kern = attn_bwd_dense_kernel<DH, KT_MAX>;
+  hipLaunchKernelGGL(kern, dim3(2 * nb), dim3(64 * kWaves), 0, stream, a, nb);
 }
 
 template <int DH, int KT_MAX>
@@ -672,6 +696,7 @@ int launch_bwd(const AttnArgs& a, hipStream_t stream) {
     if (a.NB <= 3) { launch_bwd_dense_t<DH, 3>(a, stream); return check_launch("feta_attn_bwd"); }
     if (a.NB <= 4) { launch_bwd_dense_t<DH, 4>(a, stream); return check_launch("feta_attn_bwd"); }
   }
+  FETA_REQUIRE(a.dout2 == nullptr, "attn_bwd: dout2 is only supported for N <= 64, dh <= 16");
   const dim3 grid((a.total + kWaves - 1) / kWaves), block(64 * kWaves);
   auto k1 = attn_bwd_dq_kernel<DH>;
   hipLaunchKernelGGL(k1, grid, block, 0, stream, a);
@@ -726,17 +751,18 @@ extern "C" int feta_attn_fwd(const float* q, const float* k, const float* v, int
 
 extern "C" int feta_attn_bwd(const float* q, const float* k, const float* v, int64_t qkv_sb,
                              int64_t qkv_sn, const float* pe, const int32_t* n_real,
-                             const float* out, const float* dout, int64_t o_sb, int64_t o_sn,
-                             const float* stats, float* delta, float* dq, float* dk, float* dv,
-                             float scale, int B, int N, int H, int dh, feta_stream_t stream) {
+                             const float* out, const float* dout, const float* dout2, int64_t o_sb,
+                             int64_t o_sn, const float* stats, float* delta, float* dq, float* dk,
+                             float* dv, float scale, int B, int N, int H, int dh, feta_stream_t stream) {
   int rc = check_common(q, k, v, qkv_sb, qkv_sn, o_sb, o_sn, B, N, H, dh);
   if (rc != FETA_OK) return rc;
   FETA_REQUIRE(out && dout && stats && delta && dq && dk && dv && n_real, "attn_bwd: null pointer");
-  FETA_REQUIRE(aligned16(out) && aligned16(dout) && aligned16(dq) && aligned16(dk) && aligned16(dv),
+  FETA_REQUIRE(aligned16(out) && aligned16(dout) && aligned16(dq) && aligned16(dk) && aligned16(dv) &&
+                   (!dout2 || aligned16(dout2)),
                "attn_bwd: pointers must be 16-byte aligned");
   AttnArgs a{};
   a.q = q; a.k = k; a.v = v; a.pe = pe; a.n_real = n_real;
-  a.out = out; a.dout = dout; a.stats_in = stats; a.delta = delta;
+  a.out = out; a.dout = dout; a.dout2 = dout2; a.stats_in = stats; a.delta = delta;
   a.dq = dq; a.dk = dk; a.dv = dv;
   a.qsb = qkv_sb; a.qsn = qkv_sn; a.osb = o_sb; a.osn = o_sn;
   a.scale = scale; a.B = B; a.N = N; a.H = H; a.NB = (N + 15) / 16;

@@ -197,8 +197,12 @@ class FusedEncoderStackFn(torch.autograd.Function):
                                 g_fin_out=fin1, dgamma=dg1, dbeta=db1)
             abi.rowlin_bwd_ex(dsc, None, stream)
             grads[base + 4], grads[base + 5] = dg1, db1
+            dout2 = None
             if li == nl - 1 and d_concat_last is not None:
-                dconcat = dconcat + d_concat_last.contiguous().view(m, d)
+                if abi.attn_bwd_takes_dout2(n, dh):   # added inside the kernel's loads
+                    dout2 = d_concat_last.contiguous().view(n, b, heads, dh).permute(1, 0, 2, 3)
+                else:
+                    dconcat = dconcat + d_concat_last.contiguous().view(m, d)
             # B4: attention backward
             q, k, v = _views(s['qkv'], n, b, heads, dh)
             if tie:
@@ -208,7 +212,7 @@ class FusedEncoderStackFn(torch.autograd.Function):
             delta = new(b, heads, n)
             abi.attn_bwd(q, k, v, pe_c, n_real, s['out'].permute(1, 0, 2, 3),
                          dconcat.view(n, b, heads, dh).permute(1, 0, 2, 3), s['ast'], delta, dq, dk, dv, scale,
-                         stream)
+                         stream, dout2=dout2)
             if tie:
                 dqkv[:, :d] += dqkv[:, d:2 * d]
                 dqkv[:, d:2 * d] = 0

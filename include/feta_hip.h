@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FETA_ABI_VERSION 1
+#define FETA_ABI_VERSION 2
 
 #define FETA_OK 0
 #define FETA_E_ARG (-1)     /* bad shape / stride / alignment / unsupported size */
@@ -68,12 +68,14 @@ int feta_attn_fwd(const float* q, const float* k, const float* v,
 /* Backward of feta_attn_fwd w.r.t. q,k,v given dout (same strides as out).
  * delta [B,H,N] is caller-provided scratch (rowsum(dout*out)).
  * dq,dk,dv use the q/k/v strides and are fully written (zeros on padded keys).
+ * dout2 (nullable; N <= 64 and dh <= 16 only) is a second gradient into the same output, added to
+ * dout on load (the filter path's gradient into out_each_head).
  * The gradient through the rowmax subtraction is dropped (it is exactly zero
  * unless the 1e-6 clamp is active). */
 int feta_attn_bwd(const float* q, const float* k, const float* v,
                   int64_t qkv_sb, int64_t qkv_sn,
                   const float* pe, const int32_t* n_real,
-                  const float* out, const float* dout, int64_t o_sb, int64_t o_sn,
+                  const float* out, const float* dout, const float* dout2, int64_t o_sb, int64_t o_sn,
                   const float* stats, float* delta,
                   float* dq, float* dk, float* dv, float scale,
                   int B, int N, int H, int dh, feta_stream_t stream);
