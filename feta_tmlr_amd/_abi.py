@@ -63,6 +63,7 @@ class RowLinEx(C.Structure):
         ('g_y', _F), ('g_bn', _F), ('g_sum', _F), ('Gs', C.c_int),
         ('g_fin', _F), ('g_fin_out', _F), ('dgamma', _F), ('dbeta', _F),
         ('add_plain', _F), ('add_dout', _F), ('add_y', _F), ('add_bn', _F), ('add_fin', _F),
+        ('x2', _F), ('x_split', C.c_int), ('dx2', _F),
         ('sum_y', _F), ('sum_bn', _F), ('sum_out', _F),
     ]
 
@@ -236,11 +237,12 @@ class Abi:
                                          _p(dgamma), _p(dbeta), m, d, stream), 'feta_bn_bwd')
 
     def rowlin_ex(self, m, ki, no, relu=False, momentum=0.1, eps=1e-5, Gx=0, Gs=0, partial_ld=0,
-                  partial_ptr=None, **ptrs):
+                  partial_ptr=None, x_split=0, **ptrs):
         """Builds a feta_rowlin_ex descriptor; tensor-valued keyword arguments become pointers."""
         d = RowLinEx()
         d.M, d.KI, d.NO, d.relu = m, ki, no, int(relu)
         d.momentum, d.eps, d.Gx, d.Gs, d.partial_ld = momentum, eps, Gx, Gs, partial_ld
+        d.x_split = x_split
         if partial_ptr is not None:
             d.partial = partial_ptr
         for k, t in ptrs.items():

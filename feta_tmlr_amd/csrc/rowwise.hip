@@ -42,6 +42,17 @@ struct RowLinGeom {
   int dx_blocks;  // backward: blocks [0, dx_blocks) compute dX, the rest dW/db partials
 };
 
+// x may be the virtual concatenation [x (first x_split columns) | x2 (the rest)] - linear_cat without
+// materialising torch.cat (transformer/models.py:223).  x_split is a multiple of 16.
+__device__ __forceinline__ const float* x_at(const RowLinArgs& a, int64_t row, int k) {
+  if (a.x2 == nullptr) return a.x + row * a.KI + k;
+  return k < a.x_split ? a.x + row * a.x_split + k : a.x2 + row * (a.KI - a.x_split) + (k - a.x_split);
+}
+__device__ __forceinline__ float* dx_at(const RowLinArgs& a, int64_t row, int k) {
+  if (a.dx2 == nullptr) return a.dx + row * a.KI + k;
+  return k < a.x_split ? a.dx + row * a.x_split + k : a.dx2 + row * (a.KI - a.x_split) + (k - a.x_split);
+}
+
 // sums the G partial pairs [G][2][D] with all 256 threads; on return tot[c], tot[D + c] (LDS)
 // hold the totals.  red: [slices][2][D] scratch.
 __device__ __forceinline__ void reduce_partials(const float* part, int G, int D, float* red,
@@ -122,7 +133,16 @@ __global__ __launch_bounds__(kRowThreads) void rowlin_fwd_kernel(RowLinArgs a, R
   auto load_batch = [&](int rb, Batch& B) {
     const int row = rb * kRowsPerBlock + wave_id() * 16 + lq;
     const int rowc = min(row, a.M - 1);
-    load_row_sel<KI>(B.xf, a.x + (int64_t)rowc * KI, true, g);
+    if (a.x2 == nullptr) {
+      load_row_sel<KI>(B.xf, a.x + (int64_t)rowc * KI, true, g);
+    } else {
+#pragma unroll
+      for (int j = 0; j < Feat<KI>::NJ; ++j) {
+        const int c = 16 * j + 4 * g;
+        const float4 xv = *reinterpret_cast<const float4*>(x_at(a, rowc, c < KI ? c : 0));
+        B.xf.f[j][0] = xv.x; B.xf.f[j][1] = xv.y; B.xf.f[j][2] = xv.z; B.xf.f[j][3] = xv.w;
+      }
+    }
     B.rs = a.rowscale != nullptr ? a.rowscale[rowc] : 1.0f;
     const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
@@ -381,7 +401,7 @@ __device__ void rowlin_dx_role(const RowLinArgs& a, const RowLinGeom& ge, const 
         }
       }
       if (rok)
-        *reinterpret_cast<float4*>(a.dx + (int64_t)row * a.KI + k) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(dx_at(a, row, k)) = make_float4(v[0], v[1], v[2], v[3]);
       if (want_sums) {  // sum(dx), sum(dx * xhat) over rows, for the BatchNorm that produced x
         const float yy[4] = {sy4[t].x, sy4[t].y, sy4[t].z, sy4[t].w};
 #pragma unroll
@@ -455,7 +475,7 @@ __device__ void rowlin_dw_role(const RowLinArgs& a, const RowLinGeom& ge, const 
       gvr[r] = v;
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt)
-        xv[r][kt] = rok ? a.x[(int64_t)row * KI + 16 * kt + lq] * xs[kt] + xh[kt] : 0.0f;
+        xv[r][kt] = rok ? *x_at(a, row, 16 * kt + lq) * xs[kt] + xh[kt] : 0.0f;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -544,7 +564,7 @@ __device__ void rowlin_dw_role_lds(const RowLinArgs& a, const RowLinGeom& ge, co
       const int row = r0 + rr, k = 4 * c4;
       float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
       if (row < row_hi) {
-        const float4 xv = *reinterpret_cast<const float4*>(a.x + (int64_t)row * KI + k);
+        const float4 xv = *reinterpret_cast<const float4*>(x_at(a, row, k));
         v[0] = xv.x; v[1] = xv.y; v[2] = xv.z; v[3] = xv.w;
         if (a.x_bn != nullptr) {
 #pragma unroll
@@ -862,6 +882,9 @@ extern "C" int feta_rowlin_fwd_ex(const feta_rowlin_ex* d, feta_stream_t stream)
   FETA_REQUIRE(!a.x_stats || (a.x_gamma && a.x_beta && a.x_bn_out && a.Gx > 0),
                "rowlin_fwd: x_stats needs gamma, beta, bn_out, Gx");
   FETA_REQUIRE(!a.res_bn || a.residual, "rowlin_fwd: res_bn without residual");
+  FETA_REQUIRE(!a.x2 || (a.x_split > 0 && a.x_split < a.KI && (a.x_split % 16) == 0 && aligned16(a.x2) &&
+                         !a.x_bn && !a.x_stats),
+               "rowlin_fwd: x2 needs 0 < x_split < KI, x_split %% 16 == 0, no input BatchNorm");
   RowLinGeom ge{};
   ge.G = row_blocks(a.M);
   ge.TG = tiles_fwd(a.KI);
@@ -891,6 +914,10 @@ extern "C" int feta_rowlin_bwd_ex(const feta_rowlin_ex* d, float* dwdb, feta_str
   FETA_REQUIRE(!a.g_sum || a.Gs > 0, "rowlin_bwd: g_sum needs Gs");
   FETA_REQUIRE(!a.add_dout || (a.add_y && a.add_bn && a.add_fin), "rowlin_bwd: incomplete add_* set");
   FETA_REQUIRE(!a.sum_out || (a.sum_y && a.sum_bn), "rowlin_bwd: incomplete sum_* set");
+  FETA_REQUIRE(!a.x2 == !a.dx2, "rowlin_bwd: x2 and dx2 go together");
+  FETA_REQUIRE(!a.x2 || (a.x_split > 0 && a.x_split < a.KI && (a.x_split % 16) == 0 && aligned16(a.x2) &&
+                         aligned16(a.dx2) && !a.x_bn && !a.add_plain && !a.add_dout && !a.sum_out),
+               "rowlin_bwd: x2 needs 0 < x_split < KI, x_split %% 16 == 0 and no add_* / sum_* / x_bn");
   RowLinGeom ge{};
   ge.RC = row_chunks(a.M);
   ge.G = row_blocks(a.M);

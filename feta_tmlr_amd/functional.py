@@ -202,6 +202,38 @@ class RowLinearFn(torch.autograd.Function):
         return dx, dw, db, None, (dy if has_res else None), None, None
 
 
+class RowLinearCatFn(torch.autograd.Function):
+    """y = [x1 | x2] W^T + b without materialising the concatenation (linear_cat,
+    transformer/models.py:223-224); backward writes dx1 and dx2 directly."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, w, bias):
+        abi, stream = _lib.backend(x1, x2, w)
+        x1, x2, w = x1.contiguous(), x2.contiguous(), w.contiguous()
+        m, k1 = x1.shape
+        ki, no = k1 + x2.shape[1], w.shape[0]
+        y = torch.empty((m, no), dtype=torch.float32, device=x1.device)
+        d = abi.rowlin_ex(m, ki, no, x=x1, x2=x2, x_split=k1, w=w, bias=bias, y=y)
+        abi.rowlin_fwd_ex(d, stream)
+        ctx.save_for_backward(x1, x2, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, x2, w = ctx.saved_tensors
+        abi, stream = _lib.backend(x1)
+        m, k1 = x1.shape
+        ki, no = k1 + x2.shape[1], w.shape[0]
+        dy = dy.contiguous()
+        dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
+        partial = torch.empty((abi.rowlin_chunks(m), no * ki + no), dtype=torch.float32, device=x1.device)
+        dwdb = torch.empty(no * ki + no, dtype=torch.float32, device=x1.device)
+        d = abi.rowlin_ex(m, ki, no, x=x1, x2=x2, x_split=k1, w=w, dy=dy, dx=dx1, dx2=dx2, partial=partial)
+        abi.rowlin_bwd_ex(d, dwdb, stream)
+        return dx1, dx2, dwdb[:no * ki].view(no, ki), (dwdb[no * ki:] if ctx.has_bias else None)
+
+
 class BatchNormTrainFn(torch.autograd.Function):
     """Training-mode BatchNorm1d over the rows of y [M, D] from per-block partial statistics.
     C ABI: feta_bn_stats (when the producer did not emit them), feta_bn_apply_fwd, feta_bn_bwd."""
@@ -245,6 +277,11 @@ def row_linear_supported(ki, no, need_backward=True):
 def row_linear(x, w, bias=None, rowscale=None, residual=None, relu=False, want_stats=False):
     """x [M, KI] -> (y [M, NO], stats or None)."""
     return RowLinearFn.apply(x, w, bias, rowscale, residual, relu, want_stats)
+
+
+def row_linear_cat(x1, x2, w, bias=None):
+    """[x1 | x2] W^T + b on [M, .] rows; needs x1.shape[1] % 16 == 0 and supported total dims."""
+    return RowLinearCatFn.apply(x1, x2, w, bias)
 
 
 def batch_norm_train(y, stats, gamma, beta, running_mean, running_var, momentum, eps):

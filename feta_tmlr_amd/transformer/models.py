@@ -219,11 +219,16 @@ class DiffTransformerEncoderGenGCN(nn.Module):
             if not self.use_skip_conn:
                 output = allout_filtered                                          # :215-216
         if self.use_skip_conn and allout_filtered is not None:
-            cat = torch.cat((output, allout_filtered), dim=-1)                   # :223
-            nn_, bb_, d2 = cat.shape
-            output, _ = linear_rows(cat.reshape(nn_ * bb_, d2), self.linear_cat.weight,
-                                    self.linear_cat.bias)                        # :224
-            output = output.view(nn_, bb_, -1)
+            nn_, bb_, dd_ = output.shape
+            wc = self.linear_cat.weight
+            if (dd_ % 16 == 0 and FF.row_linear_supported(2 * dd_, wc.shape[0])):
+                # [output | allout_filtered] W^T + b without materialising the concatenation (:223-224)
+                output = FF.row_linear_cat(output.reshape(nn_ * bb_, dd_), allout_filtered.reshape(nn_ * bb_, dd_),
+                                           wc, self.linear_cat.bias).view(nn_, bb_, -1)
+            else:
+                cat = torch.cat((output, allout_filtered), dim=-1)               # :223
+                output, _ = linear_rows(cat.reshape(nn_ * bb_, 2 * dd_), wc, self.linear_cat.bias)   # :224
+                output = output.view(nn_, bb_, -1)
         if self.norm is not None:
             output = self.norm(output)
         coeffs = torch.cat(coefficients, dim=0).permute(1, 0, 2) if coefficients else None
