@@ -829,13 +829,21 @@ int row_chunks(int M) {
 bool dim_ok(int c) { return c == 16 || c == 32 || c == 64 || c == 128 || c == 192 || c == 256; }
 
 // tiles per workgroup such that the staged weight slice fits beside the other LDS users
+// tiles per workgroup (tuning knobs FETA_ROWLIN_TG / FETA_ROWLIN_TG_DX = 1..4).  Measured on the
+// BASELINE batch (M = 4736 rows): 2 output tiles per workgroup beat 4 in the forward (more, shorter
+// workgroups: 0.520 -> 0.488 ms per step); see DESIGN.md section 6.
+int tg_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  const int v = e ? atoi(e) : 0;
+  return (v >= 1 && v <= 4) ? v : dflt;
+}
 int tiles_fwd(int KI) {  // LDS: 16 tg (KI + 4) floats
-  int tg = 4;
+  int tg = tg_env("FETA_ROWLIN_TG", 2);
   while (tg > 1 && 16 * tg * (KI + 4) * 4 > 48 * 1024) --tg;
   return tg;
 }
 int tiles_dx(int NO) {   // LDS: NO (16 tg + 4) floats
-  int tg = 4;
+  int tg = tg_env("FETA_ROWLIN_TG_DX", 4);
   while (tg > 1 && NO * (16 * tg + 4) * 4 > 48 * 1024) --tg;
   return tg;
 }
