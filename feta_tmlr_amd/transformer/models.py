@@ -28,6 +28,9 @@ from .data import GraphBatchCache
 from .layers import DiffTransformerEncoderLayer, clone_layers, linear_rows, n_real_from_mask
 
 
+_SIDE_STREAMS = {}   # one auxiliary HIP stream per device (kept out of the modules: not picklable)
+
+
 class DenseGCNParams(nn.Module):
     """Parameters of the reference's ``self.gcn = GCNConv(C, C)`` (transformer/models.py:144):
     ``weight [in, out]`` glorot, ``bias [out]`` zeros (vendored text transformer/GenGCN.py:340-356).
@@ -98,6 +101,8 @@ class DiffTransformerEncoderGenGCN(nn.Module):
         self.filter_mode = filter_mode
         self.fused_stack = True   # BatchNorm stacks run as one autograd node when the dims allow
         self.keep_stack_boundary = False   # set by trainers that use backward_head / backward_stack
+        self.coeff_side_stream = False     # second-stream coefficient generator: measured SLOWER (0.505 vs 0.488 ms/step:
+                                           # the fork/join edges of the hipGraph cost more than the overlap buys)
         self._stack_boundary = None
         self._stack_grads = None
 
@@ -108,9 +113,31 @@ class DiffTransformerEncoderGenGCN(nn.Module):
         ignored there as well, :248-249)."""
         if n_real is None:
             n_real = n_real_from_mask(masks)
+        if self.coeff_side_stream and attn_weights.is_cuda:
+            return self._coefficients_on_side_stream(attn_weights, n_real)
+        return self._coefficients(attn_weights, n_real)
+
+    def _coefficients(self, attn_weights, n_real):
         pooled = FF.filter_coefficients(attn_weights.detach(), n_real, self.gcn.weight, self.gcn.bias)
         coeff = self.linear(pooled)                                              # :284
         return coeff.reshape(self.num_heads, attn_weights.shape[0], -1)          # :285
+
+    def _coefficients_on_side_stream(self, attn_weights, n_real):
+        """Same arithmetic on a second HIP stream.  Autograd runs a node's backward on the stream of
+        its forward, so the whole parameter-gradient chain of the generator (C x C GEMMs, the tanh
+        recompute, their reductions: ~60 us per step) leaves the critical path of backward and runs
+        beside the backward of the layer stack; under hipGraph capture the fork/join becomes two
+        branches of the graph."""
+        main = torch.cuda.current_stream()
+        side = _SIDE_STREAMS.get(attn_weights.device)
+        if side is None:
+            side = _SIDE_STREAMS[attn_weights.device] = torch.cuda.Stream(device=attn_weights.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            coeff = self._coefficients(attn_weights, n_real)
+        main.wait_stream(side)
+        coeff.record_stream(main)
+        return coeff
 
     # -- A3 ---------------------------------------------------------------------------------
     def filter(self, coeff_all_heads, out_each_head, cache):
