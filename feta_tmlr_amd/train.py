@@ -1,0 +1,191 @@
+"""One optimisation step of the FeTA models, per task family, as the reference's training scripts
+do it - the direct caller of the hot path.
+
+    task      loss                                     optimiser                    reference
+    'zinc'    L1                                       Adam(lr), warm-up schedule   experiments/run_transformer_gengcn.py:115-164,301-317
+    'tu'      CrossEntropy (BCE-with-logits if 1 out)  AdamW(lr, wd=1e-4), StepLR   experiments/run_transformer_gengcn_cv.py:123-193,356-362
+    'molhiv'  BCE-with-logits on non-NaN labels        AdamW                        experiments/run_transformer_gengcn_molhiv.py:136-222
+    'sbm'     CrossEntropy over real nodes             AdamW                        experiments/run_transformer_gengcn_SBM_cv.py:145-218,367-373
+
+What is not reproduced: the per-step NaN / |param|>1000 scans that drop into pdb
+(run_transformer_gengcn_cv.py:161-179), the host timers and prints, the `.cuda()` copies (the
+collate already emits device tensors), dataset download and CSV logging.
+
+``GraphedTrainStep`` is the MI355X form of the loop body: forward, loss, backward and the optimiser
+update captured once per padded size into a hipGraph and replayed - the reference pays ~10^3 kernel
+launches and a host sync (`.cpu()` at transformer/models.py:246) per step.
+"""
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+
+def warmup_lr(step, lr, warmup):
+    """experiments/run_transformer_gengcn.py:310-317."""
+    if step < warmup:
+        return 1e-6 + step * (lr - 1e-6) / warmup
+    return lr * warmup ** 0.5 * step ** -0.5
+
+
+def lap_sign_flip(lap_pe, generator=None):
+    """Random sign per Laplacian-PE column, one draw per batch
+    (experiments/run_transformer_gengcn.py:126-131)."""
+    flip = torch.rand(lap_pe.shape[-1], generator=generator)
+    flip = torch.where(flip >= 0.5, torch.ones_like(flip), -torch.ones_like(flip))
+    return lap_pe * flip.to(lap_pe.device).unsqueeze(0)
+
+
+def make_criterion(task, nb_class=1):
+    if task == 'zinc':
+        return nn.L1Loss()
+    if task in ('tu', 'sbm'):
+        return nn.BCEWithLogitsLoss() if nb_class == 1 else nn.CrossEntropyLoss()
+    if task == 'molhiv':
+        return nn.BCEWithLogitsLoss()
+    raise ValueError('unknown task %r' % (task,))
+
+
+def make_optimizer(task, params, lr, weight_decay=1e-4, capturable=False):
+    """Adam for ZINC (run_transformer_gengcn.py:302), AdamW elsewhere (..._cv.py:360)."""
+    params = [p for p in params if p.requires_grad]
+    if task == 'zinc':
+        return torch.optim.Adam(params, lr=lr, capturable=capturable)
+    return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay, capturable=capturable)
+
+
+def pad_node_labels(labels, feature_indices, bsz, n_pad):
+    """[N_tot] node labels (graph-major, transformer/data.py:456) -> [B, N_pad] with -100 on the
+    padded positions (the ignore_index of cross_entropy)."""
+    out = torch.full((bsz, n_pad), -100, dtype=torch.int64, device=labels.device)
+    out[feature_indices[:, 0], feature_indices[:, 1]] = labels
+    return out
+
+
+def task_loss(task, model, criterion, batch9, graph_cache=None, padded_node_labels=False):
+    """forward + loss of one collated batch; returns (loss, model output).
+    padded_node_labels ('sbm'): labels are [B, N_pad] from pad_node_labels and the model returns the
+    logits of every position - the same mean over the real nodes as the reference's boolean gather
+    (transformer/models.py:1070-1071) with static shapes and no host sync."""
+    x, mask, pe, lap_pe, degree, labels, edge_index, batch, feature_indices = batch9
+    extra = {'padded_logits': True} if padded_node_labels else {}
+    res = model(x, edge_index, batch, feature_indices, mask, pe, lap_pe, degree,
+                graph_cache=graph_cache, **extra)
+    output = res[0]
+    if padded_node_labels:
+        if not isinstance(criterion, nn.CrossEntropyLoss):
+            raise ValueError('padded node labels need a CrossEntropyLoss criterion')
+        return F.cross_entropy(output.reshape(-1, output.shape[-1]), labels.reshape(-1),
+                               weight=criterion.weight, ignore_index=-100), output
+    if task == 'zinc':
+        labels = labels.view(output.shape)          # default_collate of g.y [1] gives [B, 1]
+        return criterion(output, labels), output
+    if task == 'molhiv':
+        labels = labels.view(-1)
+        # BCE over the labeled graphs (run_transformer_gengcn_molhiv.py:177-178) without the
+        # boolean gather (a host sync): NaN labels get weight 0, the mean runs over the others
+        keep = ~torch.isnan(labels)
+        tgt = torch.where(keep, labels, torch.zeros_like(labels)).to(output.dtype)
+        w = keep.to(output.dtype)
+        per = F.binary_cross_entropy_with_logits(output.view(-1), tgt, reduction='none')
+        return (per * w).sum() / w.sum(), output
+    labels = labels.view(-1)
+    if isinstance(criterion, nn.BCEWithLogitsLoss):
+        return criterion(output.view(-1), labels.to(output.dtype)), output
+    return criterion(output, labels), output
+
+
+def train_step(task, model, criterion, optimizer, batch9, graph_cache=None, lr=None):
+    """One iteration of the reference's train_epoch loop body.  -> loss (0-d tensor, no sync)."""
+    if lr is not None:
+        for group in optimizer.param_groups:
+            group['lr'] = lr
+    optimizer.zero_grad(set_to_none=True)
+    loss, _ = task_loss(task, model, criterion, batch9, graph_cache)
+    loss.backward()
+    optimizer.step()
+    return loss.detach()
+
+
+def accuracy_SBM(scores, targets, nb_class=None):
+    """experiments/run_transformer_gengcn_SBM_cv.py:126-143: mean per-class recall in percent.
+    Classes are 0..max(label, prediction) as sklearn's confusion_matrix would order them (or
+    nb_class when given); computed on the device, one host read at the end."""
+    pred = scores.argmax(dim=1)
+    if nb_class is None:
+        nb_class = int(max(int(targets.max()), int(pred.max())) + 1)
+    size = torch.bincount(targets, minlength=nb_class).to(torch.float64)
+    hit = torch.bincount(targets[pred == targets], minlength=nb_class).to(torch.float64)
+    recall = torch.where(size > 0, hit / size.clamp(min=1), torch.zeros_like(size))
+    return float(100.0 * recall.sum() / nb_class)
+
+
+def prepare_cache(model, batch9, graph_cache=None):
+    """Graph structure in kernel layout, built outside any hipGraph: node counts / offsets from the
+    mask and, for filter_mode='cheb', the dense scaled Laplacian from the edge list (the edge list
+    has a different length in every batch, so it cannot be an input of a captured graph)."""
+    x, mask, edge_index, batch = batch9[0], batch9[1], batch9[6], batch9[7]
+    return model.encoder._graph_cache(graph_cache, edge_index, batch, mask, x.shape[1])
+
+
+class GraphedTrainStep:
+    """forward + loss + backward + optimiser update of one padded batch shape, captured into ONE
+    hipGraph.  The fixed-shape batch tensors are copied into static buffers, so every batch
+    replayed through one instance must have the [B, N_pad] of the example (one instance per bucket
+    of ``data.bucket_batches``); the variable-length members of the tuple (edge_index, batch,
+    feature_indices) are consumed before the graph by ``prepare_cache`` / ``pad_node_labels``.
+    The learning rate lives in a device scalar (capturable optimiser), so the warm-up schedule does
+    not re-capture."""
+
+    def __init__(self, task, model, criterion, optimizer, batch9, graph_cache=None, warmup_iters=3):
+        self.task, self.model, self.criterion, self.optimizer = task, model, criterion, optimizer
+        for group in optimizer.param_groups:
+            if not group.get('capturable', False):
+                raise ValueError('GraphedTrainStep needs make_optimizer(..., capturable=True)')
+            if not torch.is_tensor(group['lr']):
+                group['lr'] = torch.tensor(float(group['lr']), device=batch9[0].device)
+        clone = lambda t: None if t is None else t.clone()
+        graph_cache = prepare_cache(model, batch9, graph_cache)
+        self.static = tuple(clone(t) for t in self._fixed(batch9))
+        self.cache = type(graph_cache)(clone(graph_cache.n_real), clone(graph_cache.node_off),
+                                       graph_cache.n_pad, clone(graph_cache.u),
+                                       clone(graph_cache.lam), clone(graph_cache.lhat),
+                                       dict(graph_cache.extra))
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup_iters):
+                self._body()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._body()
+
+    def _fixed(self, batch9):
+        x, mask, pe, lap_pe, degree, labels, edge_index, batch, feature_indices = batch9
+        if self.task == 'sbm':
+            labels = pad_node_labels(labels, feature_indices, x.shape[0], x.shape[1])
+        return (x, mask, pe, lap_pe, degree, labels, None, None, None)
+
+    def _body(self):
+        self.optimizer.zero_grad(set_to_none=True)
+        loss, _ = task_loss(self.task, self.model, self.criterion, self.static, self.cache,
+                            padded_node_labels=self.task == 'sbm')
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach()
+
+    def set_lr(self, lr):
+        for group in self.optimizer.param_groups:
+            group['lr'].fill_(lr)
+
+    def __call__(self, batch9, graph_cache=None):
+        graph_cache = prepare_cache(self.model, batch9, graph_cache)
+        for dst, src in zip(self.static, self._fixed(batch9)):
+            if dst is not None:
+                dst.copy_(src, non_blocking=True)
+        for name in ('n_real', 'node_off', 'u', 'lam', 'lhat'):
+            dst, src = getattr(self.cache, name), getattr(graph_cache, name)
+            if dst is not None and src is not None:
+                dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.loss

@@ -42,7 +42,7 @@ def molecule_graph(rng, n):
     return np.concatenate([e, e[:, ::-1]], axis=0).T.copy()
 
 
-def sbm_graph(rng, n, blocks=5, p_in=0.5, p_out=0.35):
+def sbm_graph(rng, n, blocks=5, p_in=0.5, p_out=0.35, return_blocks=False):
     """Stochastic block model, symmetrised (PATTERN shape)."""
     lab = rng.integers(0, blocks, size=n)
     same = lab[:, None] == lab[None, :]
@@ -50,16 +50,17 @@ def sbm_graph(rng, n, blocks=5, p_in=0.5, p_out=0.35):
     upper = np.triu(rng.random((n, n)) < prob, k=1)
     src, dst = np.nonzero(upper)
     e = np.stack([src, dst], axis=1).astype(np.int64)
-    return np.concatenate([e, e[:, ::-1]], axis=0).T.copy()
+    ei = np.concatenate([e, e[:, ::-1]], axis=0).T.copy()
+    return (ei, lab.astype(np.int64)) if return_blocks else ei
 
 
 @dataclass
 class GraphSample:
     """One graph, the fields the reference reads off a PyG ``Data`` (g.x, g.edge_index, g.y,
     g.pe, g.lap_pe, g.degree: transformer/data.py:130-140)."""
-    x: np.ndarray                      # [n, f] float32 node features
+    x: np.ndarray                      # [n, f] float32 node features (integer-valued for 'atom')
     edge_index: np.ndarray             # [2, E] int64
-    y: float = 0.0
+    y: object = 0.0                    # graph label (float / int / nan) or [n] int64 node labels
     pe: Optional[np.ndarray] = None    # [n, n] relative positional kernel
     lap_pe: Optional[np.ndarray] = None
     degree: Optional[np.ndarray] = None
@@ -96,7 +97,12 @@ class SyntheticGraphDataset:
     """Seeded list of GraphSample of one BASELINE shape."""
 
     def __init__(self, shape='zinc', num_graphs=128, in_dim=64, seed=0, pos_enc=True,
-                 with_degree=True, with_eig=True, n_min=None, n_max=None):
+                 with_degree=True, with_eig=True, n_min=None, n_max=None, features='normal',
+                 labels='regression', nb_class=2, nan_label_frac=0.0):
+        """features: 'normal' N(0,1) [n, in_dim] | 'atom' integer columns within ATOM_FEATURE_DIMS
+        (ogbg-molhiv wire format).  labels: 'regression' float | 'class' int in [0, nb_class) |
+        'binary' {0., 1.} with a fraction of NaN (the unlabeled molhiv graphs,
+        experiments/run_transformer_gengcn_molhiv.py:177) | 'node' per-node block id (SBM)."""
         lo, hi, _, kind = SHAPES[shape]
         lo = lo if n_min is None else n_min
         hi = hi if n_max is None else n_max
@@ -107,9 +113,28 @@ class SyntheticGraphDataset:
                 n = int(np.clip(np.round(rng.lognormal(3.2, 0.35)), lo, hi))
             else:
                 n = int(rng.integers(lo, hi + 1))
-            ei = sbm_graph(rng, n) if kind == 'sbm' else molecule_graph(rng, n)
-            g = GraphSample(x=rng.standard_normal((n, in_dim)).astype(np.float32), edge_index=ei,
-                            y=float(rng.standard_normal()))
+            blocks = None
+            if kind == 'sbm':
+                ei, blocks = sbm_graph(rng, n, return_blocks=True)
+            else:
+                ei = molecule_graph(rng, n)
+            if features == 'atom':
+                from .models import ATOM_FEATURE_DIMS
+                xf = np.stack([rng.integers(0, dmax, size=n) for dmax in ATOM_FEATURE_DIMS], 1).astype(np.float32)
+            else:
+                xf = rng.standard_normal((n, in_dim)).astype(np.float32)
+            yv = float(rng.standard_normal())
+            if labels == 'class':
+                y = int(rng.integers(0, nb_class))
+            elif labels == 'binary':
+                y = float(rng.integers(0, 2))
+                if rng.random() < nan_label_frac:
+                    y = float('nan')
+            elif labels == 'node':
+                y = blocks if blocks is not None else rng.integers(0, nb_class, size=n).astype(np.int64)
+            else:
+                y = yv
+            g = GraphSample(x=xf, edge_index=ei, y=y)
             if pos_enc:
                 g.pe = diffusion_kernel(ei, n).astype(np.float32)
             if with_degree:
@@ -185,8 +210,14 @@ def collate(samples, k_eig=None, n_pad=None, device='cpu'):
             u[i, :ns[i], :kk] = g.u[:, :kk]
             lam[i, :kk] = g.lam[:kk]
     t = lambda a: None if a is None else torch.from_numpy(a).to(device)
-    batch9 = (t(x), t(mask), t(pe), t(lap), t(deg),
-              torch.tensor([g.y for g in samples], dtype=torch.float32, device=device),
+    y0 = samples[0].y
+    if isinstance(y0, np.ndarray) and y0.ndim >= 1 and y0.shape[0] == ns[0]:
+        labels = t(np.concatenate([np.asarray(g.y) for g in samples]))       # node labels: transformer/data.py:456
+    elif isinstance(y0, (int, np.integer)):
+        labels = torch.tensor([int(g.y) for g in samples], dtype=torch.int64, device=device)
+    else:
+        labels = torch.tensor([g.y for g in samples], dtype=torch.float32, device=device)
+    batch9 = (t(x), t(mask), t(pe), t(lap), t(deg), labels,
               t(np.concatenate(eis, axis=1)), t(np.concatenate(bat)), t(np.concatenate(fi)))
     cache = GraphBatchCache(n_real=t(np.array(ns, np.int32)), node_off=t(np.array(offs, np.int32)),
                             n_pad=n, u=t(u), lam=t(lam))

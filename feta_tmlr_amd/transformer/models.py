@@ -316,3 +316,177 @@ class DiffGraphTransformerGenGCN(nn.Module):
         if return_filter_coeff:
             return out, reg, filter_coeff
         return out, reg                                                           # :548-551
+
+
+def regularisation_max_cos(coeff):
+    """transformer/models.py:727-742, :1078-1093: largest off-diagonal cosine between the heads'
+    coefficient vectors of a graph, summed over graphs."""
+    gm = torch.bmm(coeff, coeff.permute(0, 2, 1))
+    gm = gm * (1.0 - torch.eye(coeff.shape[1], device=coeff.device, dtype=coeff.dtype)).unsqueeze(0)
+    v1 = torch.norm(coeff, p=2, dim=2)
+    reg = gm / torch.bmm(v1.unsqueeze(-1), v1.unsqueeze(1))
+    return reg.max(dim=1).values.max(dim=1).values.sum()
+
+
+# ogb.utils.features.get_atom_feature_dims(): atomic number, chirality, degree, formal charge,
+# number of H, radical electrons, hybridisation, aromatic, in-ring.  ogb is not pinned by the
+# reference (README.md:21-33); later ogb releases use 5 chirality / 7 hybridisation classes -
+# pass ``feature_dims`` to match a checkpoint.
+ATOM_FEATURE_DIMS = (119, 4, 12, 12, 10, 6, 6, 2, 2)
+BOND_FEATURE_DIMS = (5, 6, 2)
+
+
+class AtomEncoder(nn.Module):
+    """Stand-alone counterpart of ``ogb.graphproppred.mol_encoder.AtomEncoder`` (imported at
+    transformer/models.py:12, used at :619,646): one embedding table per integer atom feature,
+    xavier-uniform, summed.  State-dict keys ``atom_embedding_list.{i}.weight`` as in ogb."""
+
+    list_name = 'atom_embedding_list'
+
+    def __init__(self, emb_dim, feature_dims=ATOM_FEATURE_DIMS):
+        super().__init__()
+        tables = nn.ModuleList()
+        for dim in feature_dims:
+            emb = nn.Embedding(dim, emb_dim)
+            nn.init.xavier_uniform_(emb.weight.data)
+            tables.append(emb)
+        setattr(self, self.list_name, tables)
+
+    def forward(self, x):
+        tables = getattr(self, self.list_name)
+        out = 0
+        for i in range(x.shape[1]):
+            out = out + tables[i](x[:, i])
+        return out
+
+
+class BondEncoder(AtomEncoder):
+    """ogb BondEncoder; registered but never called by the reference (transformer/models.py:620-621)."""
+
+    list_name = 'bond_embedding_list'
+
+    def __init__(self, emb_dim, feature_dims=BOND_FEATURE_DIMS):
+        super().__init__(emb_dim, feature_dims)
+
+
+class DiffGraphTransformerGenGCNMolHiv(nn.Module):
+    """transformer/models.py:598-742 (ogbg-molhiv shell, BASELINE config 5): AtomEncoder embedding
+    of integer node features, FeTA encoder, masked mean pooling, 2-layer classifier whose
+    ``nn.LeakyReLU(True)`` is the identity (negative_slope = True = 1.0, :637), logits + sigmoid."""
+
+    def __init__(self, in_size, nb_class, d_model, nb_heads, dim_feedforward=2048, dropout=0.1,
+                 nb_layers=4, batch_norm=False, lap_pos_enc=False, lap_pos_enc_dim=0,
+                 filter_order=4, gnn_type='ChebConvDynamic', last_layer_filter=True,
+                 learn_only_filter_order_coeff=False, use_skip_conn=True, use_default_encoder=False,
+                 heads_share_graph=False, filter_mode='cheb', tie_qk=False,
+                 atom_feature_dims=ATOM_FEATURE_DIMS):
+        super().__init__()
+        self.lap_pos_enc = lap_pos_enc
+        self.lap_pos_enc_dim = lap_pos_enc_dim
+        if lap_pos_enc and lap_pos_enc_dim > 0:
+            self.embedding_lap_pos_enc = nn.Linear(lap_pos_enc_dim, d_model)
+        self.d_model = d_model
+        self.embedding = AtomEncoder(d_model, atom_feature_dims)                 # :619
+        self.edge_embeddings = BondEncoder(d_model)                              # :621, unused
+        encoder_layer = DiffTransformerEncoderLayer(d_model, nb_heads, dim_feedforward, dropout,
+                                                    batch_norm=batch_norm, tie_qk=tie_qk)
+        self.use_default_encoder = use_default_encoder
+        if use_default_encoder:
+            # the reference passes (d_model, nb_heads, layer, n) to a 2-argument constructor here
+            # (:626) and would raise; the plain encoder is built with the arguments it takes
+            self.encoder = DiffTransformerEncoder(encoder_layer, nb_layers)
+        else:
+            self.encoder = DiffTransformerEncoderGenGCN(
+                d_model, nb_heads, encoder_layer, nb_layers, num_coefficients=filter_order,
+                gnn_type=gnn_type, last_layer_filter=last_layer_filter,
+                learn_only_filter_order_coeff=learn_only_filter_order_coeff,
+                use_skip_conn=use_skip_conn, heads_share_graph=heads_share_graph,
+                filter_mode=filter_mode)
+        self.gcn = DenseGCNParams(d_model, d_model)                              # :630, unused
+        self.pooling = GlobalAvg1D()
+        self.classifier = nn.Sequential(nn.Linear(d_model, d_model), nn.LeakyReLU(True),
+                                        nn.Linear(d_model, nb_class))            # :635-639
+        self.sigmoid = nn.Sigmoid()
+
+    def forward(self, x, edge_index, batch, feature_indices, masks, pe, x_lap_pos_enc=None,
+                degree=None, regularization=0.0, return_filter_coeff=False, graph_cache=None):
+        emb = self.embedding(x.reshape(-1, x.shape[-1]).to(torch.long))          # :645-646
+        output = emb.reshape(x.shape[0], x.shape[1], self.d_model).permute(1, 0, 2)   # :648,667
+        if self.lap_pos_enc and x_lap_pos_enc is not None:
+            output = output + self.embedding_lap_pos_enc(x_lap_pos_enc.transpose(0, 1))
+        if self.use_default_encoder:
+            output = self.encoder(output, pe, degree=degree, src_key_padding_mask=masks)
+            filter_coeff = None
+        else:
+            output, attn, filter_coeff = self.encoder(output, pe, edge_index, feature_indices, batch,
+                                                      degree=degree, src_key_padding_mask=masks,
+                                                      graph_cache=graph_cache)   # :674
+        pooled = self.pooling(output.permute(1, 0, 2), masks)                    # :675,679
+        reg = self.regularisation(filter_coeff) if regularization > 0 else 0     # :715-718
+        cls_out = self.classifier(pooled)                                        # :720
+        if return_filter_coeff:
+            return cls_out.squeeze(), reg, self.sigmoid(cls_out).squeeze(), filter_coeff
+        return cls_out.squeeze(), reg, self.sigmoid(cls_out).squeeze()           # :722-725
+
+    def regularisation(self, coeff):
+        return regularisation_max_cos(coeff)
+
+
+class DiffGraphTransformerGenGCNSBM(nn.Module):
+    """transformer/models.py:1008-1110 (PATTERN/CLUSTER node classification, BASELINE config 4):
+    no pooling - the classifier runs on every node and the logits of the real nodes are returned
+    graph-major, ``[N_tot, nb_class]`` (:1069-1071)."""
+
+    def __init__(self, in_size, nb_class, d_model, nb_heads, dim_feedforward=2048, dropout=0.1,
+                 nb_layers=4, batch_norm=False, lap_pos_enc=False, lap_pos_enc_dim=0,
+                 filter_order=4, gnn_type='ChebConvDynamic', last_layer_filter=True,
+                 learn_only_filter_order_coeff=False, heads_share_graph=False, filter_mode='cheb',
+                 tie_qk=False):
+        super().__init__()
+        self.lap_pos_enc = lap_pos_enc
+        self.lap_pos_enc_dim = lap_pos_enc_dim
+        if lap_pos_enc and lap_pos_enc_dim > 0:
+            self.embedding_lap_pos_enc = nn.Linear(lap_pos_enc_dim, d_model)
+        self.embedding = nn.Linear(in_features=in_size, out_features=d_model, bias=False)
+        encoder_layer = DiffTransformerEncoderLayer(d_model, nb_heads, dim_feedforward, dropout,
+                                                    batch_norm=batch_norm, tie_qk=tie_qk)
+        self.encoder = DiffTransformerEncoderGenGCN(
+            d_model, nb_heads, encoder_layer, nb_layers, num_coefficients=filter_order,
+            gnn_type=gnn_type, last_layer_filter=last_layer_filter,
+            learn_only_filter_order_coeff=learn_only_filter_order_coeff,
+            heads_share_graph=heads_share_graph, filter_mode=filter_mode)
+        self.classifier = nn.Sequential(nn.Linear(d_model, d_model), nn.ReLU(True),
+                                        nn.Linear(d_model, nb_class))
+        # the reference's loss() reads self.n_classes / self.device, which its constructor never
+        # sets (:1101) - it would raise; they are derived here
+        self.n_classes = nb_class
+
+    def forward(self, x, edge_index, batch, feature_indices, masks, pe, x_lap_pos_enc=None,
+                degree=None, regularization=0.0, return_filter_coeff=False, graph_cache=None,
+                padded_logits=False):
+        """padded_logits=True returns the logits of every position [B, N_pad, nb_class] instead of
+        the boolean gather of the real nodes (whose length differs per batch: not capturable)."""
+        output = self.embedding(x.permute(1, 0, 2))                              # :1042-1043
+        if self.lap_pos_enc and x_lap_pos_enc is not None:
+            output = output + self.embedding_lap_pos_enc(x_lap_pos_enc.transpose(0, 1))
+        output, attn, filter_coeff = self.encoder(output, pe, edge_index, feature_indices, batch,
+                                                  degree=degree, src_key_padding_mask=masks,
+                                                  graph_cache=graph_cache)       # :1048
+        reg = self.regularisation(filter_coeff) if regularization > 0 else 0
+        cls_output = self.classifier(output.permute(1, 0, 2))                    # :1069
+        if not padded_logits:
+            cls_output = cls_output[~masks]                                      # :1070-1071
+        if return_filter_coeff:
+            return cls_output, reg, filter_coeff
+        return cls_output, reg
+
+    def regularisation(self, coeff):
+        return regularisation_max_cos(coeff)
+
+    def loss(self, pred, label):
+        """:1095-1110, class weights (V - |class|) / V of the classes present, without the host
+        round trips of bincount/nonzero/unique."""
+        v = label.shape[0]
+        sizes = torch.bincount(label, minlength=self.n_classes)
+        weight = (v - sizes).to(pred.dtype) / v * (sizes > 0).to(pred.dtype)
+        return F.cross_entropy(pred, label, weight=weight)

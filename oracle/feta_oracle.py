@@ -424,3 +424,85 @@ def graph_transformer_gengcn(x, edge_index, batch, feature_indices, masks, pe, d
     pooled = global_avg_1d(out.permute(1, 0, 2), masks)                      # :528,532
     hid = F.relu(F.linear(pooled, p['classifier.0.weight'], p['classifier.0.bias']))
     return F.linear(hid, p['classifier.2.weight'], p['classifier.2.bias']), coeff  # :549-551
+
+
+# ---- model shells of the other FeTA task families + losses ------------------
+
+def atom_encoder(x_int, p, prefix='embedding.'):
+    """ogb AtomEncoder (un-vendored ``ogb.graphproppred.mol_encoder``, used at
+    transformer/models.py:619,646): sum over the integer feature columns of one embedding table per
+    column, ``atom_embedding_list.{i}.weight`` [dim_i, d]."""
+    out = 0
+    for i in range(x_int.shape[1]):
+        out = out + p['%satom_embedding_list.%d.weight' % (prefix, i)][x_int[:, i]]
+    return out
+
+
+def regularisation_max_cos(coeff):
+    """transformer/models.py:727-742 (MolHiv), :1078-1093 (SBM): per graph, the largest
+    off-diagonal cosine between the coefficient vectors of the heads, summed over graphs."""
+    gm = torch.bmm(coeff, coeff.permute(0, 2, 1))
+    gm = gm * (1.0 - torch.eye(coeff.shape[1], dtype=coeff.dtype)).unsqueeze(0)
+    v1 = torch.norm(coeff, p=2, dim=2)
+    reg = gm / torch.bmm(v1.unsqueeze(-1), v1.unsqueeze(1))
+    return reg.max(dim=1).values.max(dim=1).values.sum()
+
+
+def regularisation_pairwise(coeff):
+    """What transformer/models.py:570-580 returns for reg_type='pairwise' (the cosine matrix it
+    builds first is discarded): mean Frobenius norm of the per-graph coefficient block."""
+    return torch.norm(coeff, p=2, dim=[1, 2]).mean()
+
+
+def graph_transformer_gengcn_molhiv(x_int, edge_index, batch, feature_indices, masks, pe, degree, p,
+                                    num_layers, num_heads, order, **kw):
+    """DiffGraphTransformerGenGCNMolHiv.forward, transformer/models.py:642-725.
+    ``nn.LeakyReLU(True)`` (:637) is LeakyReLU(negative_slope=1.0): the identity, kept as written."""
+    bsz, n = x_int.shape[0], x_int.shape[1]
+    emb = atom_encoder(x_int.reshape(-1, x_int.shape[-1]).long(), p)          # :645-646
+    out = emb.reshape(bsz, n, -1).permute(1, 0, 2)                            # :648,667
+    out, attn, coeff = encoder_gengcn(out, pe, edge_index, feature_indices, batch, degree,
+                                      masks, p, num_layers, num_heads, order,
+                                      prefix='encoder.', **kw)                # :674
+    pooled = global_avg_1d(out.permute(1, 0, 2), masks)                       # :675,679
+    hid = F.leaky_relu(F.linear(pooled, p['classifier.0.weight'], p['classifier.0.bias']), 1.0)
+    cls = F.linear(hid, p['classifier.2.weight'], p['classifier.2.bias'])     # :720
+    return cls.squeeze(), torch.sigmoid(cls).squeeze(), coeff                 # :723-725
+
+
+def graph_transformer_gengcn_sbm(x, edge_index, batch, feature_indices, masks, pe, degree, p,
+                                 num_layers, num_heads, order, **kw):
+    """DiffGraphTransformerGenGCNSBM.forward, transformer/models.py:1039-1076: node-level logits of
+    the real nodes, graph-major ([N_tot, nb_class])."""
+    out = F.linear(x.permute(1, 0, 2), p['embedding.weight'])                 # :1042-1043
+    out, attn, coeff = encoder_gengcn(out, pe, edge_index, feature_indices, batch, degree,
+                                      masks, p, num_layers, num_heads, order,
+                                      prefix='encoder.', **kw)                # :1048
+    out = out.permute(1, 0, 2)                                                # :1049
+    hid = F.relu(F.linear(out, p['classifier.0.weight'], p['classifier.0.bias']))
+    cls = F.linear(hid, p['classifier.2.weight'], p['classifier.2.bias'])     # :1069
+    return cls[~masks], coeff                                                 # :1070-1071
+
+
+def sbm_weighted_loss(pred, label, n_classes):
+    """DiffGraphTransformerGenGCNSBM.loss, transformer/models.py:1095-1110: cross-entropy with
+    class weight (V - |class|)/V for the classes present in the batch, 0 for absent ones."""
+    v = label.shape[0]
+    sizes = torch.bincount(label, minlength=n_classes)
+    weight = (v - sizes).to(pred.dtype) / v * (sizes > 0).to(pred.dtype)
+    return F.cross_entropy(pred, label, weight=weight)
+
+
+def molhiv_loss(output, labels):
+    """experiments/run_transformer_gengcn_molhiv.py:177-178: BCE-with-logits over the graphs whose
+    label is not NaN."""
+    keep = ~torch.isnan(labels)
+    return F.binary_cross_entropy_with_logits(output[keep], labels[keep].to(output.dtype))
+
+
+def warmup_lr(step, lr, warmup):
+    """experiments/run_transformer_gengcn.py:310-317: linear warm-up from 1e-6 to lr over `warmup`
+    iterations, then lr * sqrt(warmup / step)."""
+    if step < warmup:
+        return 1e-6 + step * (lr - 1e-6) / warmup
+    return lr * warmup ** 0.5 * step ** -0.5

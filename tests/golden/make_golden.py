@@ -85,7 +85,43 @@ def filter_vectors(name, shape, bsz, heads, dh, order, seed, n_min=None, n_max=N
     np.savez_compressed(os.path.join(HERE, name + '.npz'), **arrays)
 
 
+def train_step(name, task, seed, batch_norm, mode='cheb', lr=1e-3):
+    """One full optimisation step of a task shell: batch tuple + parameters ->
+    loss, model output, the L2 norm of every parameter gradient and of every parameter after one
+    Adam/AdamW update (fp64 oracle, torch CPU optimiser)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import train_checks as TC
+    from feta_tmlr_amd import train as T
+    model, batch9, cache = TC.build_case(task, torch.device('cpu'), seed=seed, bsz=6, d=16, heads=2,
+                                         layers=2, order=2, batch_norm=batch_norm, mode=mode)
+    p64 = TC.params64(model)
+    out, loss, coeff, _ = TC.oracle_forward(task, model, batch9, p64, batch_norm)
+    loss.backward()
+    arrays = {'loss': f32(loss), 'out': f32(out), 'coeff': f32(coeff),
+              'cfg': np.array([16, 2, 2, 2, int(batch_norm), 1]), 'lr': np.array(lr)}
+    for k, v in zip(('x', 'mask', 'pe', 'lap_pe', 'degree', 'labels', 'edge_index', 'batch',
+                     'feature_indices'), batch9):
+        if v is not None:
+            arrays['batch/' + k] = v.numpy()
+    if cache.u is not None:
+        arrays['cache/u'], arrays['cache/lam'] = cache.u.numpy(), cache.lam.numpy()
+    for k, v in p64.items():
+        arrays['param/' + k] = f32(v)
+        if v.grad is not None:
+            arrays['gnorm/' + k] = np.array(float(v.grad.norm()))
+    opt = T.make_optimizer(task, [v for v in p64.values() if v.grad is not None], lr=lr)
+    opt.step()
+    for k, v in p64.items():
+        if v.grad is not None:
+            arrays['pnorm_after/' + k] = np.array(float(v.detach().norm()))
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **arrays)
+
+
 def main():
+    train_step('step_zinc_bn', 'zinc', 21, True)
+    train_step('step_tu', 'tu', 22, False)
+    train_step('step_molhiv_spectral', 'molhiv', 23, False, mode='spectral')
+    train_step('step_sbm', 'sbm', 24, False)
     model_step('model_mutag_b4', 'mutag', 4, 16, 2, 2, 4, False, 0, seed=11)
     model_step('model_zinc_b8_bn', 'zinc', 8, 32, 4, 2, 4, True, 0, seed=12)
     filter_vectors('filter_zinc_b8', 'zinc', 8, 4, 16, 4, seed=13)

@@ -17,3 +17,9 @@ def test_model_fixture(name):
 def test_filter_fixture(hip, name, mode):
     abi, dev, stream = hip
     G.check_filter_fixture(name, abi, dev, stream, mode)
+
+
+@pytest.mark.parametrize('name', sorted(G.STEP_FIXTURES))
+def test_step_fixture(name):
+    import contextlib
+    G.check_step_fixture(name, torch.device('cuda:0'), contextlib.nullcontext)

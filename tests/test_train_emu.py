@@ -1,0 +1,63 @@
+"""Task shells (graph regression / classification, ogbg-molhiv, SBM node classification) and one
+optimisation step per task against the oracle; kernels run in the host SIMT emulation."""
+import contextlib
+
+import pytest
+import torch
+
+import train_checks as TC
+from feta_tmlr_amd import _lib
+from feta_tmlr_amd import train as T
+from oracle import feta_oracle as O
+
+
+def _ctx(emu):
+    return lambda: _lib.override_for_tests(emu)
+
+
+@pytest.mark.parametrize('task,batch_norm,mode', [
+    ('zinc', True, 'cheb'),
+    ('tu', False, 'cheb'),
+    ('molhiv', False, 'spectral'),
+    ('sbm', False, 'cheb'),
+])
+def test_one_optimisation_step_matches_oracle(emu, task, batch_norm, mode):
+    TC.check_task_step(task, torch.device('cpu'), _ctx(emu), batch_norm=batch_norm, mode=mode)
+
+
+def test_molhiv_shell_outputs(emu):
+    TC.check_molhiv_outputs(torch.device('cpu'), _ctx(emu))
+
+
+def test_sbm_padded_loss_and_weighted_loss(emu):
+    TC.check_sbm_padded_equals_gather(torch.device('cpu'), _ctx(emu))
+
+
+def test_warmup_schedule_matches_oracle():
+    for s in (0, 1, 99, 100, 101, 5000):
+        assert abs(T.warmup_lr(s, 1e-3, 100) - O.warmup_lr(s, 1e-3, 100)) < 1e-15
+    assert abs(T.warmup_lr(0, 1e-3, 100) - 1e-6) < 1e-15
+    assert abs(T.warmup_lr(100, 1e-3, 100) - 1e-3) < 1e-12
+    assert abs(T.warmup_lr(400, 1e-3, 100) - 5e-4) < 1e-12
+
+
+def test_lap_sign_flip_is_a_column_sign():
+    g = torch.Generator().manual_seed(3)
+    lap = torch.randn(4, 7, 5)
+    out = T.lap_sign_flip(lap, g)
+    ratio = (out / lap).reshape(-1, 5)
+    assert torch.all((ratio.abs() - 1).abs() < 1e-6)
+    assert torch.all(ratio == ratio[0:1])           # one sign per column for the whole batch
+
+
+def test_accuracy_sbm_known_answer():
+    scores = torch.tensor([[2., 0, 0], [2., 0, 0], [0, 2., 0], [0, 0, 2.], [2., 0, 0]])
+    targets = torch.tensor([0, 0, 1, 1, 2])
+    # recall: class0 2/2, class1 1/2, class2 0/1 -> mean 50 %
+    assert abs(T.accuracy_SBM(scores, targets) - 50.0) < 1e-9
+
+
+def test_regularisation_matches_oracle():
+    from feta_tmlr_amd.transformer.models import regularisation_max_cos
+    c = torch.randn(3, 4, 16, dtype=torch.float64)
+    assert abs(float(regularisation_max_cos(c)) - float(O.regularisation_max_cos(c))) < 1e-12

@@ -1,0 +1,72 @@
+"""Task shells and optimisation steps on the MI355X against the oracle, plus the hipGraph-captured
+training step (forward + loss + backward + optimiser in one replay)."""
+import contextlib
+
+import pytest
+import torch
+
+import kernel_checks as KC
+import train_checks as TC
+from feta_tmlr_amd import train as T
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('task,batch_norm,mode', [
+    ('zinc', True, 'cheb'),
+    ('zinc', True, 'spectral'),
+    ('tu', False, 'cheb'),
+    ('molhiv', False, 'spectral'),
+    ('molhiv', True, 'cheb'),
+    ('sbm', False, 'cheb'),
+    ('sbm', True, 'spectral'),
+])
+def test_one_optimisation_step_matches_oracle(hip, task, batch_norm, mode):
+    TC.check_task_step(task, hip[1], contextlib.nullcontext, batch_norm=batch_norm, mode=mode)
+
+
+def test_molhiv_shell_outputs(hip):
+    TC.check_molhiv_outputs(hip[1], contextlib.nullcontext)
+
+
+def test_sbm_padded_loss_and_weighted_loss(hip):
+    TC.check_sbm_padded_equals_gather(hip[1], contextlib.nullcontext)
+
+
+@pytest.mark.parametrize('task', ['zinc', 'sbm', 'molhiv'])
+def test_graphed_train_step_equals_eager_steps(hip, task):
+    """three steps through the captured hipGraph == three eager train_step calls (same batches,
+    same initial weights), including a learning-rate change between replays."""
+    dev = hip[1]
+    bn = task == 'zinc'
+    model_a, batch9, cache = TC.build_case(task, dev, batch_norm=bn)
+    model_b, _, _ = TC.build_case(task, dev, batch_norm=bn)
+    model_b.load_state_dict(model_a.state_dict())
+    nb = 3 if task == 'sbm' else 1
+    crit = T.make_criterion(task, nb_class=nb)
+    opt_a = T.make_optimizer(task, model_a.parameters(), lr=1e-3)
+    opt_b = T.make_optimizer(task, model_b.parameters(), lr=1e-3, capturable=True)
+    start = {k: v.clone() for k, v in model_b.state_dict().items()}
+    graphed = T.GraphedTrainStep(task, model_b, crit, opt_b, batch9, cache)
+    # capture ran warm-up steps: restore weights, BatchNorm buffers and optimiser state
+    model_b.load_state_dict(start)
+    for st in opt_b.state.values():
+        for v in st.values():
+            if torch.is_tensor(v):
+                v.zero_()
+    lrs = [1e-3, 5e-4, 2e-3]
+    for lr in lrs:
+        la = T.train_step(task, model_a, crit, opt_a, batch9, T.prepare_cache(model_a, batch9, cache), lr=lr)
+        graphed.set_lr(lr)
+        lb = graphed(batch9, cache)
+        KC.assert_close('loss', lb.cpu(), la.cpu().double(), tol=3e-5)
+    # elements whose gradient is rounding noise (biases in front of a BatchNorm: exactly zero in
+    # exact arithmetic) take Adam steps of arbitrary sign; compare where the first moment is real
+    for (k, pa), (_, pb) in zip(model_a.named_parameters(), model_b.named_parameters()):
+        if pa not in opt_a.state:
+            assert torch.equal(pa, pb), k
+            continue
+        sig = opt_a.state[pa]['exp_avg'].abs() > 1e-6
+        assert float((pa.detach() - pb.detach()).abs().max()) <= 3 * max(lrs) * 1.01, k
+        if sig.any():
+            KC.assert_close('param ' + k, pb.detach()[sig].cpu(), pa.detach()[sig].cpu().double(), tol=3e-5)
