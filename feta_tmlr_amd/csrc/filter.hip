@@ -69,6 +69,11 @@ __device__ __forceinline__ float4 w_row4(const float* w, int k, int ct, int j, i
   return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
+// component-wise select (a ternary on a whole float4 can be lowered to a private-memory select)
+__device__ __forceinline__ float4 keep4(bool c, const float4& v) {
+  return make_float4(c ? v.x : 0.0f, c ? v.y : 0.0f, c ? v.z : 0.0f, c ? v.w : 0.0f);
+}
+
 __device__ __forceinline__ float f4(const float4& v, int s) {
   return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w));
 }
@@ -489,6 +494,15 @@ __device__ __forceinline__ void cheb_poly(float lam, int P, float (&t)[kMaxOrder
   for (int k = 2; k < kMaxOrder; ++k) t[k] = (k < P) ? 2.0f * lam * t[k - 1] - t[k - 2] : 0.0f;
 }
 
+// Both directions are evaluated in the eigenbasis: X is projected first (Xtil = U^T X costs
+// N K dh multiply-adds once, not once per order k), the P weight products run on the K x dh
+// projected block, and one product with U returns to the node basis.  Orientation of every
+// intermediate is chosen so that the next product contracts over its accumulator rows:
+//   forward   Xtil^T [c][e]  --A-->  Ytil [e][c']  --B-->  Y [node][c']
+//   backward  Xtil [e][c], dYtil [e][c']  --A,B-->  dW_k [c][c']
+//             dYtil^T [c'][e]  --A-->  dXtil [e][c]  --B-->  dX [node][c]
+// ("--A-->": the accumulator is fed back as the MFMA A operand, i <-> its column, k <-> its rows.)
+
 template <int DH, int ET_MAX>
 __global__ __launch_bounds__(64 * kFWaves) void spec_fwd_kernel(FilterArgs a) {
   constexpr int CT = Feat<DH>::CT;
@@ -508,42 +522,68 @@ __global__ __launch_bounds__(64 * kFWaves) void spec_fwd_kernel(FilterArgs a) {
   const float* U = a.u + (int64_t)b * a.N * a.K;
   const float* lam = a.lam + (int64_t)b * a.K;
 
-  // Ytil[e][c'] = sum_k t_k(lam_e) sum_node U[node][e] (X W_k)[node][c']
-  f32x4 yt[ET_MAX][CT];
+  // (1) Xtil^T[c][e] = sum_node X[node][c] U[node][e]
+  f32x4 xtT[CT][ET_MAX];
 #pragma unroll
-  for (int et = 0; et < ET_MAX; ++et)
+  for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) yt[et][ct] = zero4();
-
+    for (int et = 0; et < ET_MAX; ++et) xtT[ct][et] = zero4();
   for (int nt = 0; nt < NT; ++nt) {
-    const int node = 16 * nt + lq;
-    Feat<DH> xf;
-    load_row<DH>(xf, node < n ? tok_row(a.x, a.xsb, a.xsn, b, node, h, DH) : nullptr, g);
-    for (int k = 0; k < a.P; ++k) {
-      f32x4 z[CT];
-      xw_tile<DH>(xf, w, k, lq, g, z);
+    float xa[4][CT], uu[4][ET_MAX];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int nd = 16 * nt + 4 * g + r;
+      const int ndc = min(nd, n - 1);
+      const float* row = tok_row(a.x, a.xsb, a.xsn, b, ndc, h, DH);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const int c = 16 * ct + lq;
+        const float v = row[c < DH ? c : 0];
+        xa[r][ct] = (nd < n && c < DH) ? v : 0.0f;
+      }
 #pragma unroll
       for (int et = 0; et < ET_MAX; ++et) {
+        const int e = 16 * et + lq;
+        const float v = U[(int64_t)ndc * a.K + min(e, a.K - 1)];
+        uu[r][et] = (nd < n && e < a.K) ? v : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int et = 0; et < ET_MAX; ++et)
         if (et < ET) {
-          const int e = 16 * et + lq;
-          float tk[kMaxOrder];
-          cheb_poly(e < a.K ? lam[e] : 0.0f, a.P, tk);
-          float tke = 0.0f;
 #pragma unroll
-          for (int kk = 0; kk < kMaxOrder; ++kk)
-            if (kk == k) tke = tk[kk];
+          for (int ct = 0; ct < CT; ++ct) xtT[ct][et] = mfma16(xa[r][ct], uu[r][et], xtT[ct][et]);
+        }
+  }
+  // (2) Ytil[e][c'] = sum_k t_k(lam_e) sum_c Xtil[e][c] W_k[c][c']
+  f32x4 yt[ET_MAX][CT];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int nd = 16 * nt + 4 * g + r;
-            const float ua = (nd < n && e < a.K) ? U[(int64_t)nd * a.K + e] * tke : 0.0f;
+  for (int et = 0; et < ET_MAX; ++et) {
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) yt[et][ct] = mfma16(ua, z[ct][r], yt[et][ct]);
-          }
+    for (int ct = 0; ct < CT; ++ct) yt[et][ct] = zero4();
+    if (et < ET) {
+      const int e = 16 * et + lq;
+      float tk[kMaxOrder];
+      cheb_poly(e < a.K ? lam[e] : 0.0f, a.P, tk);
+#pragma unroll
+      for (int k = 0; k < kMaxOrder; ++k) {
+        if (k < a.P) {
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float av = xtT[ct][et][r] * tk[k];
+#pragma unroll
+              for (int c2 = 0; c2 < CT; ++c2)
+                yt[et][c2] = mfma16(av, w_b<DH>(w, k, ct, r, c2, lq, g), yt[et][c2]);
+            }
         }
       }
     }
   }
-  // Y = U Ytil + bias
+  // (3) Y = U Ytil + bias
   for (int nt = 0; nt < NTall; ++nt) {
     f32x4 y[CT];
 #pragma unroll
@@ -577,6 +617,9 @@ __global__ __launch_bounds__(64 * kFWaves) void spec_fwd_kernel(FilterArgs a) {
 template <int DH, int ET_MAX>
 __global__ __launch_bounds__(64 * kFWaves) void spec_bwd_kernel(FilterArgs a) {
   constexpr int CT = Feat<DH>::CT;
+  // dYtil^T doubles the live accumulators of pass (1); for wide shapes it gets its own pass over
+  // the nodes (operands come from L2) instead of spilling
+  constexpr bool kTwoPass = ET_MAX * CT > 8;
   const int lane = lane_id(), lq = lane & 15, g = lane >> 4;
   const int item = blockIdx.x * kFWaves + wave_id();
   if (item >= a.total) return;
@@ -595,8 +638,8 @@ __global__ __launch_bounds__(64 * kFWaves) void spec_bwd_kernel(FilterArgs a) {
   const float* U = a.u + (int64_t)b * a.N * a.K;
   const float* lam = a.lam + (int64_t)b * a.K;
 
-  // (1) Xtil = U^T X, dYtil = U^T dY (acc layout [e][c]); dbias partial
-  f32x4 xt[ET_MAX][CT], dyt[ET_MAX][CT];
+  // (1) Xtil = U^T X, dYtil = U^T dY (acc layout [e][c]), dYtil^T ([c'][e]); dbias partial
+  f32x4 xt[ET_MAX][CT], dyt[ET_MAX][CT], dytT[CT][ET_MAX];
   f32x4 dbias[CT];
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) dbias[ct] = zero4();
@@ -606,6 +649,7 @@ __global__ __launch_bounds__(64 * kFWaves) void spec_bwd_kernel(FilterArgs a) {
     for (int ct = 0; ct < CT; ++ct) {
       xt[et][ct] = zero4();
       dyt[et][ct] = zero4();
+      dytT[ct][et] = zero4();
     }
   for (int nt = 0; nt < NT; ++nt) {
     f32x4 xb[CT], dyb[CT];
@@ -628,6 +672,7 @@ __global__ __launch_bounds__(64 * kFWaves) void spec_bwd_kernel(FilterArgs a) {
           for (int ct = 0; ct < CT; ++ct) {
             xt[et][ct] = mfma16(ua, xb[ct][r], xt[et][ct]);
             dyt[et][ct] = mfma16(ua, dyb[ct][r], dyt[et][ct]);
+            if constexpr (!kTwoPass) dytT[ct][et] = mfma16(dyb[ct][r], ua, dytT[ct][et]);
           }
         }
       }
@@ -680,61 +725,77 @@ __global__ __launch_bounds__(64 * kFWaves) void spec_bwd_kernel(FilterArgs a) {
         }
   }
 
-  // (3) dX^T[c][node] = sum_k W_k[c][:] . G_k^T[:, node],
-  //     G_k^T[c'][node] = sum_e dYtil[e][c'] t_k(lam_e) U[node][e]
-  for (int nt = 0; nt < NTall; ++nt) {
-    f32x4 dxt[CT];
+  if constexpr (kTwoPass) {
+    for (int nt = 0; nt < NT; ++nt) {
+      f32x4 dyb[CT];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) dxt[ct] = zero4();
-    const int node = 16 * nt + lq;
-    if (nt < NT) {
-      for (int k = 0; k < a.P; ++k) {
-        f32x4 gt[CT];
+      for (int ct = 0; ct < CT; ++ct)
+        dyb[ct] = load_acc<DH>(a.dy, a.ysb, a.ysn, b, h, 16 * nt, n, ct, lq, g);
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) gt[ct] = zero4();
+      for (int et = 0; et < ET_MAX; ++et) {
+        if (et < ET) {
+          const int e = 16 * et + lq;
 #pragma unroll
-        for (int et = 0; et < ET_MAX; ++et) {
-          if (et < ET) {
+          for (int r = 0; r < 4; ++r) {
+            const int nd = 16 * nt + 4 * g + r;
+            const float ua = (nd < n && e < a.K) ? U[(int64_t)nd * a.K + e] : 0.0f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int e = 16 * et + 4 * g + r;
-              float tk[kMaxOrder];
-              cheb_poly(e < a.K ? lam[e] : 0.0f, a.P, tk);
-              float tke = 0.0f;
+            for (int ct = 0; ct < CT; ++ct) dytT[ct][et] = mfma16(dyb[ct][r], ua, dytT[ct][et]);
+          }
+        }
+      }
+    }
+  }
+
+  // (3) dXtil[e][c] = sum_k t_k(lam_e) sum_c' dYtil[e][c'] W_k[c][c']   (overwrites xt)
 #pragma unroll
-              for (int kk = 0; kk < kMaxOrder; ++kk)
-                if (kk == k) tke = tk[kk];
-              const float ub = (node < n && e < a.K) ? U[(int64_t)node * a.K + e] * tke : 0.0f;
+  for (int et = 0; et < ET_MAX; ++et) {
 #pragma unroll
-              for (int ct = 0; ct < CT; ++ct) gt[ct] = mfma16(dyt[et][ct][r], ub, gt[ct]);
+    for (int ct = 0; ct < CT; ++ct) xt[et][ct] = zero4();
+    if (et < ET) {
+      const int e = 16 * et + lq;
+      float tk[kMaxOrder];
+      cheb_poly(e < a.K ? lam[e] : 0.0f, a.P, tk);
+#pragma unroll
+      for (int k = 0; k < kMaxOrder; ++k) {
+        if (k < a.P) {
+#pragma unroll
+          for (int c2 = 0; c2 < CT; ++c2)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+              const float4 wv = w_row4<DH>(w, k, ct, c2, lq, g);
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                xt[et][ct] = mfma16(dytT[c2][et][r] * tk[k], f4(wv, r), xt[et][ct]);
             }
-          }
-        }
-        // dxt[c1] += W_k[c = 16c1+lq][c' = 16c2+4g+r] . gt[c2][r]
-#pragma unroll
-        for (int c1 = 0; c1 < CT; ++c1)
-#pragma unroll
-          for (int c2 = 0; c2 < CT; ++c2) {
-            const float4 wv = w_row4<DH>(w, k, c1, c2, lq, g);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dxt[c1] = mfma16(f4(wv, r), gt[c2][r], dxt[c1]);
-          }
-      }
-    }
-    // register r of dxt[c1] <-> (c = 16c1 + 4g + r, node): 4 consecutive features of one row
-    if (node < a.N) {
-      float* row = tok_row(a.dx, a.xsb, a.xsn, b, node, h, DH);
-#pragma unroll
-      for (int c1 = 0; c1 < CT; ++c1) {
-        const int c = 16 * c1 + 4 * g;
-        if (c < DH) {
-          const bool real = node < n;
-          *reinterpret_cast<float4*>(row + c) =
-              make_float4(real ? dxt[c1][0] : 0.0f, real ? dxt[c1][1] : 0.0f,
-                          real ? dxt[c1][2] : 0.0f, real ? dxt[c1][3] : 0.0f);
         }
       }
     }
+  }
+
+  // (4) dX = U dXtil (rows >= n_real come out zero: their U rows are masked)
+  for (int nt = 0; nt < NTall; ++nt) {
+    f32x4 dx[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) dx[ct] = zero4();
+    if (nt < NT) {
+      const int node = 16 * nt + lq;
+#pragma unroll
+      for (int et = 0; et < ET_MAX; ++et) {
+        if (et < ET) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int e = 16 * et + 4 * g + r;
+            const float ub = (node < n && e < a.K) ? U[(int64_t)node * a.K + e] : 0.0f;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) dx[ct] = mfma16(ub, xt[et][ct][r], dx[ct]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+      store_acc<DH>(a.dx, a.xsb, a.xsn, b, h, 16 * nt, a.N, ct, lq, g, dx[ct]);
   }
 }
 
@@ -760,6 +821,7 @@ __global__ __launch_bounds__(64 * kFWaves) void spec_fwd_dense_kernel(FilterArgs
   const float* U = a.u + (int64_t)b * a.N * a.K;
   const float* lam = a.lam + (int64_t)b * a.K;
   const int lqc = lq < DH ? lq : 0;
+  const int nm1 = max(n - 1, 0);
 
   // ---- load batch -----------------------------------------------------------------------------
   float wB[kMaxOrder][4];  // W_k[c = 4g+s][c' = lq]
@@ -772,59 +834,71 @@ __global__ __launch_bounds__(64 * kFWaves) void spec_fwd_dense_kernel(FilterArgs
       if (k < a.P) v = w[(k * DH + (c < DH ? c : 0)) * DH + lqc];
       wB[k][s] = (k < a.P && c < DH && lq < DH) ? v : 0.0f;
     }
-  Feat<DH> xf[NT_MAX];
+  float xa[NT_MAX][4];  // X[node = 16nt+4g+r][c = lq]
   float ua[NT_MAX][4][ET_MAX], ub[NT_MAX][4][ET_MAX], lamq[ET_MAX];
 #pragma unroll
   for (int nt = 0; nt < NT_MAX; ++nt) {
     const int node = 16 * nt + lq;
-    load_row_sel<DH>(xf[nt], tok_row(a.x, a.xsb, a.xsn, b, min(node, n - 1), h, DH), node < n, g);
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < 4; ++r) {
+      const int nd = 16 * nt + 4 * g + r;
+      const int ndc = min(nd, nm1);
+      const float xv = tok_row(a.x, a.xsb, a.xsn, b, ndc, h, DH)[lqc];
+      xa[nt][r] = (nd < n && lq < DH) ? xv : 0.0f;
 #pragma unroll
       for (int et = 0; et < ET_MAX; ++et) {
-        const int nd = 16 * nt + 4 * g + r, e = 16 * et + lq;
-        const float v1 = U[(int64_t)min(nd, n - 1) * a.K + min(e, a.K - 1)];
+        const int e = 16 * et + lq;
+        const float v1 = U[(int64_t)ndc * a.K + min(e, a.K - 1)];
         ua[nt][r][et] = (nd < n && e < a.K) ? v1 : 0.0f;
         const int e2 = 16 * et + 4 * g + r;
-        const float v2 = U[(int64_t)min(node, n - 1) * a.K + min(e2, a.K - 1)];
+        const float v2 = U[(int64_t)min(node, nm1) * a.K + min(e2, a.K - 1)];
         ub[nt][r][et] = (node < n && e2 < a.K) ? v2 : 0.0f;
       }
+    }
   }
 #pragma unroll
   for (int et = 0; et < ET_MAX; ++et) lamq[et] = lam[min(16 * et + lq, a.K - 1)];
   const float bv = (a.bias != nullptr) ? a.bias[lqc] : 0.0f;
 
-  // ---- Ytil = sum_k diag(t_k) U^T (X W_k) -------------------------------------------------------
-  float tke[ET_MAX][kMaxOrder];
+  // ---- (1) Xtil^T[c][e] = sum_node X[node][c] U[node][e] ----------------------------------------
+  f32x4 xtT[ET_MAX];
 #pragma unroll
-  for (int et = 0; et < ET_MAX; ++et) cheb_poly(lamq[et], a.P, tke[et]);
-  f32x4 yt[ET_MAX];
-#pragma unroll
-  for (int et = 0; et < ET_MAX; ++et) yt[et] = zero4();
+  for (int et = 0; et < ET_MAX; ++et) xtT[et] = zero4();
 #pragma unroll
   for (int nt = 0; nt < NT_MAX; ++nt) {
+    if (16 * nt < n) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int et = 0; et < ET_MAX; ++et) xtT[et] = mfma16(xa[nt][r], ua[nt][r][et], xtT[et]);
+    }
+  }
+  // ---- (2) Ytil[e][c'] = sum_k t_k(lam_e) sum_c Xtil[e][c] W_k[c][c'] ---------------------------
+  f32x4 yt[ET_MAX];
+#pragma unroll
+  for (int et = 0; et < ET_MAX; ++et) {
+    float tk[kMaxOrder];
+    cheb_poly(lamq[et], a.P, tk);
+    yt[et] = zero4();
 #pragma unroll
     for (int k = 0; k < kMaxOrder; ++k) {
       if (k < a.P) {
-        f32x4 z = zero4();
 #pragma unroll
-        for (int s = 0; s < 4; ++s) z = mfma16(xf[nt].f[0][s], wB[k][s], z);
-#pragma unroll
-        for (int et = 0; et < ET_MAX; ++et)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) yt[et] = mfma16(ua[nt][r][et] * tke[et][k], z[r], yt[et]);
+        for (int r = 0; r < 4; ++r) yt[et] = mfma16(xtT[et][r] * tk[k], wB[k][r], yt[et]);
       }
     }
   }
-  // ---- Y = U Ytil + bias -------------------------------------------------------------------------
+  // ---- (3) Y = U Ytil + bias -------------------------------------------------------------------
 #pragma unroll
   for (int nt = 0; nt < NT_MAX; ++nt) {
     if (16 * nt < a.N) {
       f32x4 y = zero4();
+      if (16 * nt < n) {
 #pragma unroll
-      for (int et = 0; et < ET_MAX; ++et)
+        for (int et = 0; et < ET_MAX; ++et)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) y = mfma16(ub[nt][r][et], yt[et][r], y);
+          for (int r = 0; r < 4; ++r) y = mfma16(ub[nt][r][et], yt[et][r], y);
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) y[r] = (16 * nt + 4 * g + r < n) ? y[r] + bv : 0.0f;
       store_acc<DH>(a.y, a.ysb, a.ysn, b, h, 16 * nt, a.N, 0, lq, g, y);
@@ -850,10 +924,11 @@ __global__ __launch_bounds__(64 * kFWaves) void spec_bwd_dense_kernel(FilterArgs
   const float* U = a.u + (int64_t)b * a.N * a.K;
   const float* lam = a.lam + (int64_t)b * a.K;
   const int lqc = lq < DH ? lq : 0;
+  const int nm1 = max(n - 1, 0);
 
   // ---- load batch -----------------------------------------------------------------------------
   f32x4 xb[NT_MAX], dyb[NT_MAX];
-  float ua[NT_MAX][4][ET_MAX], ub[NT_MAX][4][ET_MAX], lamr[ET_MAX][4];
+  float ua[NT_MAX][4][ET_MAX], ub[NT_MAX][4][ET_MAX], lamr[ET_MAX][4], lamq[ET_MAX];
   float4 wr[kMaxOrder];  // W_k[c = lq][c' = 4g .. 4g+3]
 #pragma unroll
   for (int k = 0; k < kMaxOrder; ++k) {
@@ -869,7 +944,7 @@ __global__ __launch_bounds__(64 * kFWaves) void spec_bwd_dense_kernel(FilterArgs
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int nd = 16 * nt + 4 * g + r;
-      const int ndc = min(nd, n - 1);
+      const int ndc = min(nd, nm1);
       const float xv = tok_row(a.x, a.xsb, a.xsn, b, ndc, h, DH)[lqc];
       const float dv = tok_row(a.dy, a.ysb, a.ysn, b, ndc, h, DH)[lqc];
       const bool ok = nd < n && lq < DH;
@@ -881,44 +956,53 @@ __global__ __launch_bounds__(64 * kFWaves) void spec_bwd_dense_kernel(FilterArgs
         const float v1 = U[(int64_t)ndc * a.K + min(e, a.K - 1)];
         ua[nt][r][et] = (nd < n && e < a.K) ? v1 : 0.0f;
         const int e2 = 16 * et + 4 * g + r;
-        const float v2 = U[(int64_t)min(node, n - 1) * a.K + min(e2, a.K - 1)];
+        const float v2 = U[(int64_t)min(node, nm1) * a.K + min(e2, a.K - 1)];
         ub[nt][r][et] = (node < n && e2 < a.K) ? v2 : 0.0f;
       }
     }
   }
 #pragma unroll
-  for (int et = 0; et < ET_MAX; ++et)
+  for (int et = 0; et < ET_MAX; ++et) {
+    lamq[et] = lam[min(16 * et + lq, a.K - 1)];
 #pragma unroll
     for (int r = 0; r < 4; ++r) lamr[et][r] = lam[min(16 * et + 4 * g + r, a.K - 1)];
+  }
 
-  // ---- (1) Xtil = U^T X, dYtil = U^T dY; dbias partial ------------------------------------------
-  f32x4 xt[ET_MAX], dyt[ET_MAX];
+  // ---- (1) Xtil = U^T X, dYtil = U^T dY ([e][c]), dYtil^T ([c'][e]); dbias partial --------------
+  f32x4 xt[ET_MAX], dyt[ET_MAX], dytT[ET_MAX];
 #pragma unroll
   for (int et = 0; et < ET_MAX; ++et) {
     xt[et] = zero4();
     dyt[et] = zero4();
+    dytT[et] = zero4();
   }
   float dbs = 0.0f;
 #pragma unroll
-  for (int nt = 0; nt < NT_MAX; ++nt)
+  for (int nt = 0; nt < NT_MAX; ++nt) {
+    if (16 * nt < n) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      dbs += dyb[nt][r];
+      for (int r = 0; r < 4; ++r) {
+        dbs += dyb[nt][r];
 #pragma unroll
-      for (int et = 0; et < ET_MAX; ++et) {
-        xt[et] = mfma16(ua[nt][r][et], xb[nt][r], xt[et]);
-        dyt[et] = mfma16(ua[nt][r][et], dyb[nt][r], dyt[et]);
+        for (int et = 0; et < ET_MAX; ++et) {
+          xt[et] = mfma16(ua[nt][r][et], xb[nt][r], xt[et]);
+          dyt[et] = mfma16(ua[nt][r][et], dyb[nt][r], dyt[et]);
+          dytT[et] = mfma16(dyb[nt][r], ua[nt][r][et], dytT[et]);
+        }
       }
     }
+  }
   dbs += shfl_xor(dbs, 16);
   dbs += shfl_xor(dbs, 32);
   if (g == 0 && lq < DH) a.dbias_part[(int64_t)item * DH + lq] = dbs;
 
-  float tkr[ET_MAX][4][kMaxOrder];
+  float tkr[ET_MAX][4][kMaxOrder], tkq[ET_MAX][kMaxOrder];
 #pragma unroll
-  for (int et = 0; et < ET_MAX; ++et)
+  for (int et = 0; et < ET_MAX; ++et) {
+    cheb_poly(lamq[et], a.P, tkq[et]);
 #pragma unroll
     for (int r = 0; r < 4; ++r) cheb_poly(lamr[et][r], a.P, tkr[et][r]);
+  }
 
   // ---- (2) dW_k[c][c'] = sum_e t_k(lam_e) Xtil[e][c] dYtil[e][c'] --------------------------------
 #pragma unroll
@@ -937,32 +1021,35 @@ __global__ __launch_bounds__(64 * kFWaves) void spec_bwd_dense_kernel(FilterArgs
     }
   }
 
-  // ---- (3) dX^T = sum_k W_k (dYtil^T diag(t_k) U^T) ----------------------------------------------
+  // ---- (3) dXtil[e][c] = sum_k t_k(lam_e) sum_c' dYtil[e][c'] W_k[c][c'] -------------------------
+  f32x4 dxt[ET_MAX];
+#pragma unroll
+  for (int et = 0; et < ET_MAX; ++et) {
+    dxt[et] = zero4();
+#pragma unroll
+    for (int k = 0; k < kMaxOrder; ++k) {
+      if (k < a.P) {
+        const float t = tkq[et][k];
+        dxt[et] = mfma16(dytT[et][0] * t, wr[k].x, dxt[et]);
+        dxt[et] = mfma16(dytT[et][1] * t, wr[k].y, dxt[et]);
+        dxt[et] = mfma16(dytT[et][2] * t, wr[k].z, dxt[et]);
+        dxt[et] = mfma16(dytT[et][3] * t, wr[k].w, dxt[et]);
+      }
+    }
+  }
+
+  // ---- (4) dX = U dXtil (rows >= n_real come out zero: their U rows are masked) ------------------
 #pragma unroll
   for (int nt = 0; nt < NT_MAX; ++nt) {
-    const int node = 16 * nt + lq;
     if (16 * nt < a.N) {
-      f32x4 dxt = zero4();
+      f32x4 dx = zero4();
+      if (16 * nt < n) {
 #pragma unroll
-      for (int k = 0; k < kMaxOrder; ++k) {
-        if (k < a.P) {
-          f32x4 gt = zero4();
+        for (int et = 0; et < ET_MAX; ++et)
 #pragma unroll
-          for (int et = 0; et < ET_MAX; ++et)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) gt = mfma16(dyt[et][r], ub[nt][r][et] * tkr[et][r][k], gt);
-          dxt = mfma16(wr[k].x, gt[0], dxt);
-          dxt = mfma16(wr[k].y, gt[1], dxt);
-          dxt = mfma16(wr[k].z, gt[2], dxt);
-          dxt = mfma16(wr[k].w, gt[3], dxt);
-        }
+          for (int r = 0; r < 4; ++r) dx = mfma16(ub[nt][r][et], dxt[et][r], dx);
       }
-      if (node < a.N && 4 * g < DH) {
-        const bool real = node < n;
-        *reinterpret_cast<float4*>(tok_row(a.dx, a.xsb, a.xsn, b, node, h, DH) + 4 * g) =
-            make_float4(real ? dxt[0] : 0.0f, real ? dxt[1] : 0.0f, real ? dxt[2] : 0.0f,
-                        real ? dxt[3] : 0.0f);
-      }
+      store_acc<DH>(a.dx, a.xsb, a.xsn, b, h, 16 * nt, a.N, 0, lq, g, dx);
     }
   }
 }
@@ -992,7 +1079,324 @@ bool try_spec_dense_dh(const FilterArgs& a, bool bwd, hipStream_t stream, int* r
   return true;
 }
 
+// ---- eigenbasis form, one workgroup per graph (d = 64: 4 heads x dh 16, N <= 64, K <= 32, K % 4 = 0) --
+// The 4 waves of a workgroup are the 4 heads of ONE graph, so everything the heads share is fetched
+// from HBM once and with 16-byte accesses: the eigenvector tile U_b [N, K] and lambda_b (the per-head
+// kernels above read U eight times per graph: 4 heads x 2 operand orientations), and the node rows of
+// X / dY as whole 256-byte rows (all heads) instead of one 64-byte head slice per wave.  Staged in LDS
+// with pitches chosen for conflict-free operand reads (row pitch = 4 mod 8 floats: the two 4-row
+// groups of a half-wave land on disjoint banks); both MFMA operand orientations of U come from the
+// same LDS tile.  Results go back through LDS so that the stores are whole rows too.
+constexpr int kGraphXP = 64 + 4;  // pitch of the staged [node][4 x 16] token rows
+constexpr int kGraphWP = 16 + 4;  // pitch of the staged W_k rows
+
+template <int NT_MAX, int ET_MAX, int PP>
+__global__ __launch_bounds__(256) void spec_fwd_graph_kernel(FilterArgs a) {
+  constexpr int DH = 16, XP = kGraphXP, UP = 16 * ET_MAX + 4, WP = kGraphWP, NR = 16 * NT_MAX;
+  const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6, lq = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x;
+  const int n = a.n_real[b], nm1 = max(n - 1, 0);
+  float* Xs = feta_lds;               // [NR][XP]
+  float* Us = Xs + NR * XP;           // [NR][UP], zero outside [n, K]
+  float* lams = Us + NR * UP;         // [16 ET_MAX]
+  float* Ws = lams + 16 * ET_MAX + h * (PP * DH * WP);  // this head's [P * DH][WP]
+  const float* U = a.u + (int64_t)b * a.N * a.K;
+  const float* w = a.coeff + ((int64_t)h * a.B + b) * PP * DH * DH;
+
+  // ---- cooperative loads: all requests first, LDS writes afterwards -----------------------------
+  float4 xv[NT_MAX];
+#pragma unroll
+  for (int i = 0; i < NT_MAX; ++i) {
+    const int idx = tid + 256 * i, node = idx >> 4, q = idx & 15;
+    const float4 v = *reinterpret_cast<const float4*>(tok_row(a.x, a.xsb, a.xsn, b, min(node, nm1), 0, DH) + 4 * q);
+    xv[i] = keep4(node < n, v);
+  }
+  constexpr int UQ = 4 * ET_MAX, UI = (NR * UQ + 255) / 256;
+  float4 uv[UI];
+#pragma unroll
+  for (int i = 0; i < UI; ++i) {
+    const int idx = tid + 256 * i, node = idx / UQ, e = 4 * (idx % UQ);
+    const float4 v = *reinterpret_cast<const float4*>(U + (int64_t)min(node, nm1) * a.K + min(e, a.K - 4));
+    uv[i] = keep4(node < n && e < a.K, v);
+  }
+  float4 wv[PP];
+#pragma unroll
+  for (int i = 0; i < PP; ++i) wv[i] = reinterpret_cast<const float4*>(w)[lane + 64 * i];
+  const float lv = a.lam[(int64_t)b * a.K + min(tid, a.K - 1)];
+  const float bv = (a.bias != nullptr) ? a.bias[lq] : 0.0f;
+#pragma unroll
+  for (int i = 0; i < NT_MAX; ++i) {
+    const int idx = tid + 256 * i;
+    *reinterpret_cast<float4*>(Xs + (idx >> 4) * XP + 4 * (idx & 15)) = xv[i];
+  }
+#pragma unroll
+  for (int i = 0; i < UI; ++i) {
+    const int idx = tid + 256 * i;
+    if (idx < NR * UQ) *reinterpret_cast<float4*>(Us + (idx / UQ) * UP + 4 * (idx % UQ)) = uv[i];
+  }
+#pragma unroll
+  for (int i = 0; i < PP; ++i) {
+    const int idx = lane + 64 * i;
+    *reinterpret_cast<float4*>(Ws + (idx >> 2) * WP + 4 * (idx & 3)) = wv[i];
+  }
+  if (tid < 16 * ET_MAX) lams[tid] = tid < a.K ? lv : 0.0f;
+  __syncthreads();
+
+  // ---- (1) Xtil^T[c][e] = sum_node X[node][c] U[node][e] ----------------------------------------
+  f32x4 xtT[ET_MAX];
+#pragma unroll
+  for (int et = 0; et < ET_MAX; ++et) xtT[et] = zero4();
+#pragma unroll
+  for (int nt = 0; nt < NT_MAX; ++nt) {
+    if (16 * nt < n) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nd = 16 * nt + 4 * g + r;
+        const float xa = Xs[nd * XP + DH * h + lq];
+#pragma unroll
+        for (int et = 0; et < ET_MAX; ++et) xtT[et] = mfma16(xa, Us[nd * UP + 16 * et + lq], xtT[et]);
+      }
+    }
+  }
+  // ---- (2) Ytil[e][c'] = sum_k t_k(lam_e) sum_c Xtil[e][c] W_k[c][c'] ---------------------------
+  f32x4 yt[ET_MAX];
+#pragma unroll
+  for (int et = 0; et < ET_MAX; ++et) {
+    float tk[kMaxOrder];
+    cheb_poly(lams[16 * et + lq], PP, tk);
+    yt[et] = zero4();
+#pragma unroll
+    for (int k = 0; k < PP; ++k)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        yt[et] = mfma16(xtT[et][r] * tk[k], Ws[(k * DH + 4 * g + r) * WP + lq], yt[et]);
+  }
+  // ---- (3) Y = U Ytil + bias, written over the X tile --------------------------------------------
+  f32x4 y[NT_MAX];
+#pragma unroll
+  for (int nt = 0; nt < NT_MAX; ++nt) {
+    y[nt] = zero4();
+    if (16 * nt < n) {
+#pragma unroll
+      for (int et = 0; et < ET_MAX; ++et) {
+        const float4 ub = *reinterpret_cast<const float4*>(Us + (16 * nt + lq) * UP + 16 * et + 4 * g);
+        y[nt] = mfma16(ub.x, yt[et][0], y[nt]);
+        y[nt] = mfma16(ub.y, yt[et][1], y[nt]);
+        y[nt] = mfma16(ub.z, yt[et][2], y[nt]);
+        y[nt] = mfma16(ub.w, yt[et][3], y[nt]);
+      }
+    }
+  }
+  __syncthreads();  // every wave has read its X operands
+#pragma unroll
+  for (int nt = 0; nt < NT_MAX; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int nd = 16 * nt + 4 * g + r;
+      Xs[nd * XP + DH * h + lq] = nd < n ? y[nt][r] + bv : 0.0f;
+    }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NT_MAX; ++i) {
+    const int idx = tid + 256 * i, node = idx >> 4, q = idx & 15;
+    if (node < a.N)
+      *reinterpret_cast<float4*>(tok_row(a.y, a.ysb, a.ysn, b, node, 0, DH) + 4 * q) =
+          *reinterpret_cast<const float4*>(Xs + node * XP + 4 * q);
+  }
+}
+
+template <int NT_MAX, int ET_MAX, int PP>
+__global__ __launch_bounds__(256) void spec_bwd_graph_kernel(FilterArgs a) {
+  constexpr int DH = 16, XP = kGraphXP, UP = 16 * ET_MAX + 4, NR = 16 * NT_MAX;
+  const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6, lq = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x;
+  const int item = b * a.H + h;
+  const int n = a.n_real[b], nm1 = max(n - 1, 0);
+  float* Xs = feta_lds;               // [NR][XP]
+  float* Ds = Xs + NR * XP;           // [NR][XP]  dY
+  float* Us = Ds + NR * XP;           // [NR][UP]
+  float* lams = Us + NR * UP;         // [16 ET_MAX]
+  const float* U = a.u + (int64_t)b * a.N * a.K;
+  const int64_t blk = (int64_t)h * a.B + b;
+  const float* w = a.coeff + blk * PP * DH * DH;
+  float* dw = a.dcoeff + blk * PP * DH * DH;
+
+  // ---- cooperative loads ----------------------------------------------------------------------
+  float4 xv[NT_MAX], dv[NT_MAX];
+#pragma unroll
+  for (int i = 0; i < NT_MAX; ++i) {
+    const int idx = tid + 256 * i, node = idx >> 4, q = idx & 15;
+    const float4 v1 = *reinterpret_cast<const float4*>(tok_row(a.x, a.xsb, a.xsn, b, min(node, nm1), 0, DH) + 4 * q);
+    const float4 v2 = *reinterpret_cast<const float4*>(tok_row(a.dy, a.ysb, a.ysn, b, min(node, nm1), 0, DH) + 4 * q);
+    xv[i] = keep4(node < n, v1);
+    dv[i] = keep4(node < n, v2);
+  }
+  constexpr int UQ = 4 * ET_MAX, UI = (NR * UQ + 255) / 256;
+  float4 uv[UI];
+#pragma unroll
+  for (int i = 0; i < UI; ++i) {
+    const int idx = tid + 256 * i, node = idx / UQ, e = 4 * (idx % UQ);
+    const float4 v = *reinterpret_cast<const float4*>(U + (int64_t)min(node, nm1) * a.K + min(e, a.K - 4));
+    uv[i] = keep4(node < n && e < a.K, v);
+  }
+  float4 wr[PP];  // W_k[c = lq][c' = 4g .. 4g+3]
+#pragma unroll
+  for (int k = 0; k < PP; ++k) wr[k] = *reinterpret_cast<const float4*>(w + (k * DH + lq) * DH + 4 * g);
+  const float lv = a.lam[(int64_t)b * a.K + min(tid, a.K - 1)];
+#pragma unroll
+  for (int i = 0; i < NT_MAX; ++i) {
+    const int idx = tid + 256 * i, off = (idx >> 4) * XP + 4 * (idx & 15);
+    *reinterpret_cast<float4*>(Xs + off) = xv[i];
+    *reinterpret_cast<float4*>(Ds + off) = dv[i];
+  }
+#pragma unroll
+  for (int i = 0; i < UI; ++i) {
+    const int idx = tid + 256 * i;
+    if (idx < NR * UQ) *reinterpret_cast<float4*>(Us + (idx / UQ) * UP + 4 * (idx % UQ)) = uv[i];
+  }
+  if (tid < 16 * ET_MAX) lams[tid] = tid < a.K ? lv : 0.0f;
+  __syncthreads();
+
+  // ---- (1) Xtil = U^T X, dYtil = U^T dY ([e][c]), dYtil^T ([c'][e]); dbias partial --------------
+  f32x4 xt[ET_MAX], dyt[ET_MAX], dytT[ET_MAX];
+#pragma unroll
+  for (int et = 0; et < ET_MAX; ++et) {
+    xt[et] = zero4();
+    dyt[et] = zero4();
+    dytT[et] = zero4();
+  }
+  float dbs = 0.0f;
+#pragma unroll
+  for (int nt = 0; nt < NT_MAX; ++nt) {
+    if (16 * nt < n) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nd = 16 * nt + 4 * g + r;
+        const float xb = Xs[nd * XP + DH * h + lq];
+        const float db = Ds[nd * XP + DH * h + lq];
+        dbs += db;
+#pragma unroll
+        for (int et = 0; et < ET_MAX; ++et) {
+          const float ua = Us[nd * UP + 16 * et + lq];
+          xt[et] = mfma16(ua, xb, xt[et]);
+          dyt[et] = mfma16(ua, db, dyt[et]);
+          dytT[et] = mfma16(db, ua, dytT[et]);
+        }
+      }
+    }
+  }
+  dbs += shfl_xor(dbs, 16);
+  dbs += shfl_xor(dbs, 32);
+  if (g == 0) a.dbias_part[(int64_t)item * DH + lq] = dbs;
+
+  // ---- (2) dW_k[c][c'] = sum_e t_k(lam_e) Xtil[e][c] dYtil[e][c'] --------------------------------
+  f32x4 dwa[PP];
+#pragma unroll
+  for (int k = 0; k < PP; ++k) dwa[k] = zero4();
+#pragma unroll
+  for (int et = 0; et < ET_MAX; ++et) {
+    const float4 l4 = *reinterpret_cast<const float4*>(lams + 16 * et + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float tk[kMaxOrder];
+      cheb_poly(f4(l4, r), PP, tk);
+#pragma unroll
+      for (int k = 0; k < PP; ++k) dwa[k] = mfma16(xt[et][r] * tk[k], dyt[et][r], dwa[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < PP; ++k)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dw[(k * DH + 4 * g + r) * DH + lq] = dwa[k][r];
+
+  // ---- (3) dXtil[e][c] = sum_k t_k(lam_e) sum_c' dYtil[e][c'] W_k[c][c'] -------------------------
+  f32x4 dxt[ET_MAX];
+#pragma unroll
+  for (int et = 0; et < ET_MAX; ++et) {
+    float tk[kMaxOrder];
+    cheb_poly(lams[16 * et + lq], PP, tk);
+    dxt[et] = zero4();
+#pragma unroll
+    for (int k = 0; k < PP; ++k) {
+      dxt[et] = mfma16(dytT[et][0] * tk[k], wr[k].x, dxt[et]);
+      dxt[et] = mfma16(dytT[et][1] * tk[k], wr[k].y, dxt[et]);
+      dxt[et] = mfma16(dytT[et][2] * tk[k], wr[k].z, dxt[et]);
+      dxt[et] = mfma16(dytT[et][3] * tk[k], wr[k].w, dxt[et]);
+    }
+  }
+
+  // ---- (4) dX = U dXtil, written over the X tile (rows >= n_real come out zero) ------------------
+  f32x4 dx[NT_MAX];
+#pragma unroll
+  for (int nt = 0; nt < NT_MAX; ++nt) {
+    dx[nt] = zero4();
+    if (16 * nt < n) {
+#pragma unroll
+      for (int et = 0; et < ET_MAX; ++et) {
+        const float4 ub = *reinterpret_cast<const float4*>(Us + (16 * nt + lq) * UP + 16 * et + 4 * g);
+        dx[nt] = mfma16(ub.x, dxt[et][0], dx[nt]);
+        dx[nt] = mfma16(ub.y, dxt[et][1], dx[nt]);
+        dx[nt] = mfma16(ub.z, dxt[et][2], dx[nt]);
+        dx[nt] = mfma16(ub.w, dxt[et][3], dx[nt]);
+      }
+    }
+  }
+  __syncthreads();  // every wave has read its X / dY operands
+#pragma unroll
+  for (int nt = 0; nt < NT_MAX; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Xs[(16 * nt + 4 * g + r) * XP + DH * h + lq] = dx[nt][r];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NT_MAX; ++i) {
+    const int idx = tid + 256 * i, node = idx >> 4, q = idx & 15;
+    if (node < a.N)
+      *reinterpret_cast<float4*>(tok_row(a.dx, a.xsb, a.xsn, b, node, 0, DH) + 4 * q) =
+          *reinterpret_cast<const float4*>(Xs + node * XP + 4 * q);
+  }
+}
+
+template <int NT_MAX, int ET_MAX, int PP>
+int launch_spec_graph_p(const FilterArgs& a, bool bwd, hipStream_t stream) {
+  constexpr int NR = 16 * NT_MAX, UP = 16 * ET_MAX + 4;
+  const dim3 grid(a.B), block(256);
+  if (bwd) {
+    const size_t lds = sizeof(float) * (2 * NR * kGraphXP + NR * UP + 16 * ET_MAX);
+    auto kern = spec_bwd_graph_kernel<NT_MAX, ET_MAX, PP>;
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
+  } else {
+    const size_t lds = sizeof(float) * (NR * kGraphXP + NR * UP + 16 * ET_MAX + 4 * PP * 16 * kGraphWP);
+    auto kern = spec_fwd_graph_kernel<NT_MAX, ET_MAX, PP>;
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
+  }
+  return check_launch(bwd ? "feta_spec_filter_bwd" : "feta_spec_filter_fwd");
+}
+
+template <int NT_MAX, int ET_MAX>
+int launch_spec_graph(const FilterArgs& a, bool bwd, hipStream_t stream) {
+  switch (a.P) {   // the filter order is a compile-time constant of these kernels (branch-free operand batches)
+    case 2: return launch_spec_graph_p<NT_MAX, ET_MAX, 2>(a, bwd, stream);
+    case 3: return launch_spec_graph_p<NT_MAX, ET_MAX, 3>(a, bwd, stream);
+    case 4: return launch_spec_graph_p<NT_MAX, ET_MAX, 4>(a, bwd, stream);
+    default: return launch_spec_graph_p<NT_MAX, ET_MAX, 5>(a, bwd, stream);
+  }
+}
+
+// -> true if the one-workgroup-per-graph variant was launched.  It needs all heads on the graph
+// (heads_share_graph), 4 heads x dh 16 stored as one 64-float row per node, 16-byte aligned rows of U.
+bool try_spec_graph(const FilterArgs& a, int dh, bool bwd, hipStream_t stream, int* rc) {
+  const int nt = (a.N + 15) / 16, et = (a.K + 15) / 16;
+  if (!a.share || a.H != 4 || dh != 16 || nt > 4 || et > 2 || (a.K & 3) != 0 || a.P < 2 || a.P > 5) return false;
+  if (!aligned16(a.u)) return false;
+  if (nt <= 3 && et <= 1) *rc = launch_spec_graph<3, 1>(a, bwd, stream);
+  else if (et <= 1) *rc = launch_spec_graph<4, 1>(a, bwd, stream);
+  else if (nt <= 3) *rc = launch_spec_graph<3, 2>(a, bwd, stream);
+  else *rc = launch_spec_graph<4, 2>(a, bwd, stream);
+  return true;
+}
+
 bool try_spec_dense(const FilterArgs& a, int dh, bool bwd, hipStream_t stream, int* rc) {
+  if (try_spec_graph(a, dh, bwd, stream, rc)) return true;
   if (dh == 16) return try_spec_dense_dh<16>(a, bwd, stream, rc);
   if (dh == 8) return try_spec_dense_dh<8>(a, bwd, stream, rc);
   if (dh == 4) return try_spec_dense_dh<4>(a, bwd, stream, rc);

@@ -49,6 +49,7 @@ def test_lhat_from_edges(emu, directed):
     (2, 1, 32, 2, 'zinc', 17, 40, True),
     (1, 2, 16, 1, 'zinc', None, None, True),
     (2, 2, 16, 5, 'pattern', 44, 70, True),
+    (1, 1, 64, 2, 'zinc', 30, 40, True),          # wide shape: second node pass in spec_bwd_kernel
 ])
 def test_filter_exact(emu, mode, share, bsz, h, dh, order, shape, n_min, n_max, seq_first):
     KC.check_filter(emu, CPU, None, mode, bsz, h, dh, order, share, shape=shape, n_min=n_min,
@@ -64,6 +65,18 @@ def test_cheb_directed_graph(emu):
 def test_spec_truncated(emu, k_eig):
     KC.check_filter(emu, CPU, None, 'spec', 3, 2, 16, 4, 1, k_eig=k_eig)
     KC.check_filter(emu, CPU, None, 'spec', 2, 2, 16, 4, 0, k_eig=k_eig)
+
+
+@pytest.mark.parametrize('k_eig,shape,n_min,n_max,order,seq_first', [
+    (16, 'zinc', None, None, 4, True),        # BASELINE config 2: N_pad <= 37, K = 16
+    (8, 'mutag', None, None, 4, False),
+    (32, 'pattern', 44, 64, 3, True),         # 4 row tiles, 2 eigen tiles
+    (None, 'zinc', 12, 32, 5, True),          # exact operator, K = N_pad = 32
+])
+def test_spec_one_workgroup_per_graph(emu, k_eig, shape, n_min, n_max, order, seq_first):
+    """4 heads x dh 16, all heads on the graph: the LDS-staged kernels (spec_*_graph_kernel)."""
+    KC.check_filter(emu, CPU, None, 'spec', 3, 4, 16, order, 1, k_eig=k_eig, shape=shape, n_min=n_min,
+                    n_max=n_max, seq_first=seq_first)
 
 
 @pytest.mark.parametrize('m,ki,no,relu,rowscale,residual,stats', [

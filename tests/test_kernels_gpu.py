@@ -83,6 +83,18 @@ def test_spec_truncated(hip, k_eig, bsz):
     KC.check_filter(abi, dev, stream, 'spec', 2, 2, 16, 4, 0, k_eig=k_eig)
 
 
+@pytest.mark.parametrize('k_eig,shape,n_min,n_max,order,seq_first,bsz', [
+    (16, 'zinc', None, None, 4, True, 130),
+    (8, 'mutag', None, None, 4, False, 5),
+    (32, 'pattern', 44, 64, 3, True, 9),
+    (None, 'zinc', 12, 32, 5, True, 4),
+])
+def test_spec_one_workgroup_per_graph(hip, k_eig, shape, n_min, n_max, order, seq_first, bsz):
+    abi, dev, stream = hip
+    KC.check_filter(abi, dev, stream, 'spec', bsz, 4, 16, order, 1, k_eig=k_eig, shape=shape, n_min=n_min,
+                    n_max=n_max, seq_first=seq_first)
+
+
 def test_bad_arguments_raise(hip):
     abi, dev, stream = hip
     q = torch.zeros(2, 300, 2, 16, device=dev)

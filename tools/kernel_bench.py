@@ -43,6 +43,8 @@ def main():
     ap.add_argument('--k-eig', type=int, default=16)
     ap.add_argument('--iters', type=int, default=100)
     ap.add_argument('--json', action='store_true')
+    ap.add_argument('--batch-first', action='store_true',
+                    help='token tensors stored [B,N,...] (a graph is contiguous) instead of the reference seq-first [N,B,...]')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     abi, st = _lib.abi(), _lib.stream_handle()
@@ -55,18 +57,21 @@ def main():
     nr = torch.randint(9, n + 1, (b,), generator=g, dtype=torch.int32).to(dev)
     mean_n = float(nr.float().mean())
 
-    qkv = rnd(n, b, 3 * d)
-    v5 = qkv.view(n, b, 3, h, dh)
-    q, kk, v = (v5[:, :, i].permute(1, 0, 2, 3) for i in range(3))
-    tok = lambda: torch.empty(n, b, h, dh, device=dev).permute(1, 0, 2, 3)
-    out, dout = tok(), rnd(n, b, h, dh).permute(1, 0, 2, 3)
+    bf = a.batch_first
+    lead = (b, n) if bf else (n, b)
+    as_bn = (lambda t: t) if bf else (lambda t: t.transpose(0, 1))   # -> [B, N, ...] view
+    qkv = rnd(*lead, 3 * d)
+    v5 = qkv.view(*lead, 3, h, dh)
+    q, kk, v = (as_bn(v5[:, :, i]) for i in range(3))
+    tok = lambda: as_bn(torch.empty(*lead, h, dh, device=dev))
+    out, dout = tok(), as_bn(rnd(*lead, h, dh))
     attn = torch.empty(b, h, n, n, device=dev)
     stats = torch.empty(b, h, n, 2, device=dev)
     pe = torch.rand(b, n, n, generator=g).to(dev)
     delta = torch.empty(b, h, n, device=dev)
     dqkv = torch.empty_like(qkv)
-    g5 = dqkv.view(n, b, 3, h, dh)
-    dq, dk, dv = (g5[:, :, i].permute(1, 0, 2, 3) for i in range(3))
+    g5 = dqkv.view(*lead, 3, h, dh)
+    dq, dk, dv = (as_bn(g5[:, :, i]) for i in range(3))
     sc = dh ** -0.5
     rows = []
 
@@ -95,8 +100,8 @@ def main():
     add('coeff_bwd (+2 colsum)', lambda: abi.coeff_bwd(cj, nr, s, gb, dpool, partial, ds, db, b, n, h, st),
         f4 * b * (h * c + h * n))
 
-    x = rnd(n, b, h, dh).permute(1, 0, 2, 3)
-    y, dy, dx = tok(), rnd(n, b, h, dh).permute(1, 0, 2, 3), tok()
+    x = as_bn(rnd(*lead, h, dh))
+    y, dy, dx = tok(), as_bn(rnd(*lead, h, dh)), tok()
     coeff = rnd(h * b, c)
     bias = rnd(dh)
     u = rnd(b, n, k)
