@@ -119,7 +119,38 @@ __global__ __launch_bounds__(kCsCols * kCsSlices) void colsum_kernel(const float
   if (slice == 0 && col < C) out[col] = red[lc];
 }
 
+// few rows x very many columns (the split-K weight-gradient partials of a whole layer stack:
+// ~20 x 100k): one thread per 4 columns, every row requested before the first add
+__global__ __launch_bounds__(64) void colsum_wide_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                         int R, int C4, int ld) {
+  const int c4 = blockIdx.x * 64 + threadIdx.x;
+  if (c4 >= C4) return;
+  const float* p = in + 4 * (int64_t)c4;
+  float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  int r = 0;
+  for (; r + 8 <= R; r += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(p + (int64_t)(r + i) * ld);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w;
+    }
+  }
+  for (; r < R; ++r) {
+    const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)r * ld);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  *reinterpret_cast<float4*>(out + 4 * (int64_t)c4) = acc;
+}
+
 int launch_colsum_strided(const float* in, float* out, int R, int C, int ld, hipStream_t stream) {
+  if (R <= 64 && C >= 4096 && (C & 3) == 0 && (ld & 3) == 0 && aligned16(in) && aligned16(out)) {
+    const int c4 = C / 4;
+    auto kern = colsum_wide_kernel;
+    hipLaunchKernelGGL(kern, dim3((c4 + 63) / 64), dim3(64), 0, stream, in, out, R, c4, ld);
+    return check_launch("feta_colsum");
+  }
   const dim3 grid((C + kCsCols - 1) / kCsCols), block(kCsCols * kCsSlices);
   auto kern = colsum_kernel;
   hipLaunchKernelGGL(kern, grid, block, kCsCols * kCsSlices * sizeof(float), stream, in, out, R, C, ld);

@@ -37,6 +37,7 @@ class AttentionCoreFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, pe, n_real, num_heads, need_attn, tie_qk, batch_first):
         abi, stream = _lib.backend(qkv, pe, n_real)
+        ctx.set_materialize_grads(False)   # no zero tensor for the non-differentiable attn output
         qkv = qkv.contiguous()
         l0, l1, d3 = qkv.shape
         d = d3 // 3
@@ -61,6 +62,8 @@ class AttentionCoreFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dconcat, _dattn):
         qkv, pe_c, n_real, out, stats = ctx.saved_tensors
+        if dconcat is None:
+            return (None,) * 7
         num_heads, tie_qk, batch_first, scale = ctx.cfg
         abi, stream = _lib.backend(qkv)
         l0, l1, d3 = qkv.shape
@@ -122,6 +125,30 @@ class FilterCoefficientsFn(torch.autograd.Function):
         return None, None, ds.unsqueeze(0).expand(rows, c), db
 
 
+class DenseLinearFn(torch.autograd.Function):
+    """y = x W^T + b for the C x C ``self.linear`` of the coefficient generator
+    (transformer/models.py:284): the three GEMMs stay rocBLAS (plain library GEMMs), the bias
+    gradient is one feta_colsum instead of a generic reduction kernel."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        ctx.save_for_backward(x, w)
+        return torch.addmm(bias, x, w.t())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        abi, stream = _lib.backend(dy)
+        dy = dy.contiguous()
+        db = torch.empty(dy.shape[1], dtype=dy.dtype, device=dy.device)
+        abi.colsum(dy, db, stream)
+        return dy.mm(w), dy.t().mm(x), db
+
+
+def dense_linear(x, w, bias):
+    return DenseLinearFn.apply(x, w, bias)
+
+
 class _FilterFn(torch.autograd.Function):
     """x [B,N,H,dh] view, coeff [H*B, P*dh*dh], bias [dh] -> y (same token layout as x),
     zero on padded rows.  mode 'cheb': graph = lhat [B,N,N]; mode 'spec': graph = (u, lam)."""
@@ -169,6 +196,7 @@ class RowLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, rowscale, residual, relu, want_stats):
         abi, stream = _lib.backend(x, w)
+        ctx.set_materialize_grads(False)   # no zero tensor for the non-differentiable stats output
         assert not (relu and residual is not None), 'relu mask is taken from the saved output'
         x = x.contiguous()
         w = w.contiguous()
@@ -188,6 +216,8 @@ class RowLinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dstats):
         x, w, rowscale, ysaved = ctx.saved_tensors
+        if dy is None:
+            return (None,) * 7
         has_bias, has_res = ctx.cfg
         abi, stream = _lib.backend(x)
         m, ki = x.shape

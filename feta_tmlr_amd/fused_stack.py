@@ -58,6 +58,7 @@ class FusedEncoderStackFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src, pe, degree_rows, n_real, layers, need_attn, *params):
         abi, stream = _lib.backend(src, pe, n_real)
+        ctx.set_materialize_grads(False)   # no zero tensor for the (non-differentiable) attn output
         n, b, d = src.shape
         m = n * b
         nl = len(layers)
@@ -161,6 +162,8 @@ class FusedEncoderStackFn(torch.autograd.Function):
             return part_all.data_ptr() + 4 * off, off
 
         slots = {}
+        if d_final is None:   # only the per-head output of the last layer was used
+            d_final = torch.zeros(n, b, d, dtype=torch.float32, device=dev)
         dcur = d_final.contiguous().view(m, d)
         gs = new(G, 2, d)
         abi.bn_bwd_reduce(saved[-1]['y2'], dcur, saved[-1]['prm2'], gs, stream)

@@ -149,7 +149,8 @@ class GraphedTrainStep:
         self.cache = type(graph_cache)(clone(graph_cache.n_real), clone(graph_cache.node_off),
                                        graph_cache.n_pad, clone(graph_cache.u),
                                        clone(graph_cache.lam), clone(graph_cache.lhat),
-                                       dict(graph_cache.extra))
+                                       {k: (v.clone() if torch.is_tensor(v) else v)
+                                        for k, v in graph_cache.extra.items()})
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -187,5 +188,8 @@ class GraphedTrainStep:
             dst, src = getattr(self.cache, name), getattr(graph_cache, name)
             if dst is not None and src is not None:
                 dst.copy_(src, non_blocking=True)
+        for key, dst in self.cache.extra.items():   # e.g. the per-row degree scale of this batch
+            if torch.is_tensor(dst):
+                dst.copy_(graph_cache.extra[key], non_blocking=True)
         self.graph.replay()
         return self.loss

@@ -165,10 +165,11 @@ class GraphBatchCache:
     def to(self, device):
         mv = lambda t: None if t is None else t.to(device)
         return GraphBatchCache(mv(self.n_real), mv(self.node_off), self.n_pad, mv(self.u),
-                               mv(self.lam), mv(self.lhat), dict(self.extra))
+                               mv(self.lam), mv(self.lhat),
+                               {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in self.extra.items()})
 
 
-def collate(samples, k_eig=None, n_pad=None, device='cpu'):
+def collate(samples, k_eig=None, n_pad=None, device='cpu', seq_first_degree=True):
     """-> (padded_x, mask, pos_enc, lap_pos_enc, degree, labels, edge_index, batch,
     feature_indices), cache   — tuple layout of transformer/data.py:224."""
     bsz = len(samples)
@@ -221,6 +222,10 @@ def collate(samples, k_eig=None, n_pad=None, device='cpu'):
               t(np.concatenate(eis, axis=1)), t(np.concatenate(bat)), t(np.concatenate(fi)))
     cache = GraphBatchCache(n_real=t(np.array(ns, np.int32)), node_off=t(np.array(offs, np.int32)),
                             n_pad=n, u=t(u), lam=t(lam))
+    if use_deg and seq_first_degree:
+        # the degree scale per row of the seq-first [N*B, d] activation view (row = node * B + graph),
+        # so that no transpose kernel runs per step
+        cache.extra['degree_rows'] = t(np.ascontiguousarray(deg.T).reshape(-1))
     return batch9, cache
 
 

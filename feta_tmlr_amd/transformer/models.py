@@ -119,7 +119,7 @@ class DiffTransformerEncoderGenGCN(nn.Module):
 
     def _coefficients(self, attn_weights, n_real):
         pooled = FF.filter_coefficients(attn_weights.detach(), n_real, self.gcn.weight, self.gcn.bias)
-        coeff = self.linear(pooled)                                              # :284
+        coeff = FF.dense_linear(pooled, self.linear.weight, self.linear.bias)    # :284
         return coeff.reshape(self.num_heads, attn_weights.shape[0], -1)          # :285
 
     def _coefficients_on_side_stream(self, attn_weights, n_real):
@@ -211,7 +211,9 @@ class DiffTransformerEncoderGenGCN(nn.Module):
         attn = None
         degree_rows = None
         if degree is not None:   # degree [B,N] -> one value per row of the [N*B, d] view, once
-            degree_rows = degree.transpose(0, 1).reshape(-1).contiguous()
+            degree_rows = cache.extra.get('degree_rows')   # collate(..., seq_first_degree=True) emits it
+            if degree_rows is None or degree_rows.shape[0] != degree.numel():
+                degree_rows = degree.transpose(0, 1).reshape(-1).contiguous()
         fused = (self.fused_stack and self.last_layer_filter and mask is None
                  and stack_supported(self.layers, src.shape[-1]))
         for layer_num, mod in enumerate(self.layers):
@@ -258,7 +260,10 @@ class DiffTransformerEncoderGenGCN(nn.Module):
                 output = output.view(nn_, bb_, -1)
         if self.norm is not None:
             output = self.norm(output)
-        coeffs = torch.cat(coefficients, dim=0).permute(1, 0, 2) if coefficients else None
+        if len(coefficients) == 1:      # last_layer_filter: a view, no copy of the [H, B, C] block
+            coeffs = coefficients[0].permute(1, 0, 2)
+        else:
+            coeffs = torch.cat(coefficients, dim=0).permute(1, 0, 2) if coefficients else None
         return output, attn, coeffs                                               # :238
 
 

@@ -347,3 +347,13 @@ def check_bn(abi, dev, stream, m, d, seed=0):
     errs['dgamma'] = assert_close('dgamma', dg, gamma.grad, tol=2e-5)
     errs['dbeta'] = assert_close('dbeta', dbt, beta.grad, tol=2e-5)
     return errs
+
+
+def check_colsum(abi, dev, stream, r, c, seed=0):
+    """feta_colsum over [r, c]: the tall (coefficient generator) and the few-rows-many-columns
+    (split-K weight-gradient partials) variants."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(r, c, generator=g)
+    out = torch.full((c,), float('nan'), device=dev)
+    abi.colsum(x.to(dev), out, stream)
+    assert_close('colsum %dx%d' % (r, c), out, x.double().sum(0))

@@ -94,3 +94,8 @@ def test_rowlin(emu, m, ki, no, relu, rowscale, residual, stats):
 @pytest.mark.parametrize('m,d', [(111, 64), (64, 32), (300, 128), (50, 192)])
 def test_batchnorm(emu, m, d):
     KC.check_bn(emu, CPU, None, m, d)
+
+
+@pytest.mark.parametrize('r,c', [(19, 4096 + 64), (3, 8192), (64, 4100), (70, 4096), (200, 48), (1, 16)])
+def test_colsum_shapes(emu, r, c):
+    KC.check_colsum(emu, CPU, None, r, c)

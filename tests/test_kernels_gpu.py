@@ -123,3 +123,8 @@ def test_rowlin(hip, m, ki, no, relu, rowscale, residual, stats):
 def test_batchnorm(hip, m, d):
     abi, dev, stream = hip
     KC.check_bn(abi, dev, stream, m, d)
+
+
+@pytest.mark.parametrize('r,c', [(19, 4096 + 64), (3, 8192), (64, 4100), (70, 4096), (200, 48), (1, 16)])
+def test_colsum_shapes(hip, r, c):
+    KC.check_colsum(*hip, r, c)

@@ -52,6 +52,10 @@ def walk(stream, calls):
 
 def main():
     f, w = seq(sys.argv[1]), seq(sys.argv[2])
+    if any('attn_bwd_dense' in name for name, _ in f):   # N <= 64: dq and dk/dv roles of ONE launch
+        for i, (row, _) in enumerate(ROWS):
+            if row.startswith('attn_bwd'):
+                ROWS[i] = (row, ['attn_bwd_dense'])
     calls = int(sys.argv[3]) + 3
     fk, wk = walk(f, calls), walk(w, calls)
     res = {name: {'FETCH_SIZE_KB': round(fk[name], 1), 'WRITE_SIZE_KB': round(wk[name], 1),
