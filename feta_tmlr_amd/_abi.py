@@ -76,7 +76,27 @@ SIGNATURES.update({
     'feta_bn_bwd_reduce': ([_F, _F, _F, _F, C.c_int, C.c_int, _S], C.c_int),
 })
 
-ABI_VERSION = 2
+
+
+class AttnBlock(C.Structure):
+    """struct feta_attn_block (include/feta_hip.h) - field order must match the header."""
+    _fields_ = [
+        ('x', _F), ('x_bn', _F), ('x_stats', _F), ('Gx', C.c_int),
+        ('x_gamma', _F), ('x_beta', _F), ('x_bn_out', _F), ('x_rmean', _F), ('x_rvar', _F),
+        ('momentum', C.c_float), ('eps', C.c_float),
+        ('w_in', _F), ('b_in', _F), ('w_out', _F), ('b_out', _F), ('pe', _F), ('n_real', _I),
+        ('rowscale', _F), ('qkv', _F), ('out', _F), ('attn_stats', _F), ('attn', _F), ('y', _F),
+        ('y_stats', _F), ('scale', C.c_float), ('B', C.c_int), ('N', C.c_int), ('M', C.c_int),
+        ('row_sb', C.c_int64), ('row_sn', C.c_int64), ('tie_qk', C.c_int),
+    ]
+
+
+SIGNATURES.update({
+    'feta_attn_block_supported': ([C.c_int, C.c_int, C.c_int], C.c_int),
+    'feta_attn_block_fwd': ([C.POINTER(AttnBlock), _S], C.c_int),
+})
+
+ABI_VERSION = 3
 
 
 class FetaError(RuntimeError):
@@ -255,6 +275,21 @@ class Abi:
 
     def rowlin_bwd_ex(self, desc, dwdb, stream):
         self._check(self.lib.feta_rowlin_bwd_ex(C.byref(desc), _p(dwdb), stream), 'feta_rowlin_bwd_ex')
+
+    def attn_block_supported(self, n, d_model, heads):
+        return bool(self.lib.feta_attn_block_supported(n, d_model, heads))
+
+    def attn_block_fwd(self, b, n, scale, stream, seq_first=True, momentum=0.1, eps=1e-5, Gx=0, tie_qk=False,
+                       **ptrs):
+        """feta_attn_block_fwd; tensor-valued keyword arguments become the descriptor's pointers."""
+        d = AttnBlock()
+        d.B, d.N, d.M, d.scale = b, n, b * n, scale
+        d.row_sb, d.row_sn = (1, b) if seq_first else (n, 1)
+        d.momentum, d.eps, d.Gx, d.tie_qk = momentum, eps, Gx, int(tie_qk)
+        for k, t in ptrs.items():
+            if t is not None:
+                setattr(d, k, t.data_ptr())
+        self._check(self.lib.feta_attn_block_fwd(C.byref(d), stream), 'feta_attn_block_fwd')
 
     def bn_apply_fwd_prm(self, y, stats, gamma, beta, out, bn_prm, running_mean, running_var, momentum,
                          eps, stream):

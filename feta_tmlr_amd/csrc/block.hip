@@ -1,0 +1,378 @@
+// A1, the attention sub-block of DiffTransformerEncoderLayer as ONE launch per layer for the
+// BASELINE shape (d = 64 = 4 heads x 16, N <= 64): in_proj -> attention core -> out_proj ->
+// degree scale -> residual -> BatchNorm statistics (contract transformer/models.py:166-167,179,244;
+// body per upstream GraphiT, README.md:129).  One workgroup per graph, one wave per head.
+//
+// The three stages share everything on chip:
+//   * the graph's node rows X_b [N, 64] are fetched once as whole 256-byte rows, normalised on the
+//     way in (the BatchNorm of the previous layer is folded into this load; the first consumer of
+//     fresh statistics finalizes them), and stay in LDS - they are the in_proj operand AND the
+//     residual of the out_proj epilogue;
+//   * W_in [192, 64] and W_out [64, 64] are staged once per workgroup (padded pitch: 16-byte operand
+//     reads hit disjoint banks for the two 4-row groups of a half-wave);
+//   * Q^T / K^T tiles come out of the MFMA in exactly the lane layout the score product takes as
+//     "row operands", V in the layout P.V takes as B operand (feta_tiles.h) - no shuffles, no LDS;
+//   * the per-head outputs meet in an LDS tile [N, 64] which is the out_proj operand; wave w then
+//     owns output columns 16w .. 16w+15, so the column statistics need no cross-wave reduction.
+// q, k, v, the per-head output and the softmax statistics are still written to HBM: the backward
+// pass (attn.hip, rowwise.hip) and the spectral filter read them.
+#include "feta_abi_common.h"
+#include "feta_rowops.h"
+
+namespace feta {
+
+typedef feta_attn_block BlockArgs;  // include/feta_hip.h
+
+constexpr int kBlkD = 64, kBlkH = 4, kBlkDH = 16;
+constexpr int kBlkP = kBlkD + 4;  // LDS pitch of every staged 64-float row
+
+__host__ __device__ inline int block_lds_floats(int nt, bool attn) {
+  const int nr = 16 * nt;
+  int f = 3 * kBlkD * kBlkP + kBlkD * kBlkP;  // W_in, W_out
+  f += 2 * nr * kBlkP;                         // X tile, OUT tile
+  f += 2 * kBlkD;                              // scale / shift of the input BatchNorm
+  const int fin = reduce_scratch_floats(kBlkD);
+  const int stg = attn ? kBlkH * 16 * (nr + 1) : 0;  // per-wave probability staging
+  f += fin > stg ? fin : stg;
+  return f;
+}
+
+// In-kernel phase stamps (diagnostic build only, tools/block_timing.py): -DFETA_TIMING
+#ifdef FETA_TIMING
+__device__ unsigned long long feta_block_stamps[16];
+#define FETA_STAMP(i)                                                                   \
+  do {                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+    unsigned long long t_;                                                              \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+    if (blockIdx.x == 0 && threadIdx.x == 0) feta_block_stamps[i] = t_;                 \
+  } while (0)
+#else
+#define FETA_STAMP(i)
+#endif
+
+template <int NT>
+__global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a) {
+  constexpr int D = kBlkD, DH = kBlkDH, P = kBlkP, NR = 16 * NT, KP = NR + 1;
+  const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6, lq = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x;
+  const int n = a.n_real[b];
+  float* Wi = feta_lds;              // [192][P]
+  float* Wo = Wi + 3 * D * P;        // [64][P]
+  float* Xs = Wo + D * P;            // [NR][P]  layer input, BatchNorm applied
+  float* Os = Xs + NR * P;           // [NR][P]  per-head outputs (concat)
+  float* xss = Os + NR * P;          // [2][64]
+  float* scr = xss + 2 * D;          // finalize scratch, later the probability staging
+  const bool x_norm = a.x_stats != nullptr || a.x_bn != nullptr;
+  FETA_STAMP(0);
+
+  // ---- requests first: node rows, then the weights ------------------------------------------------
+  float4 xv[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int idx = tid + kRowThreads * i, node = idx >> 4, q = idx & 15;
+    const int64_t row = (int64_t)b * a.row_sb + (int64_t)min(node, a.N - 1) * a.row_sn;
+    xv[i] = *reinterpret_cast<const float4*>(a.x + row * D + 4 * q);
+  }
+  // pe values of this lane's (query, key) pairs, degree scale and biases: requested now, used after the
+  // projections (stores to qkv / attn_stats in between would otherwise pin these loads behind them)
+  const bool has_pe = a.pe != nullptr;
+  float pv[NT][NT][4];
+  float rsv[NT];
+#pragma unroll
+  for (int qb = 0; qb < NT; ++qb) {
+    const int qc = min(16 * qb + lq, a.N - 1);
+    rsv[qb] = a.rowscale != nullptr ? a.rowscale[(int64_t)b * a.row_sb + (int64_t)qc * a.row_sn] : 1.0f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        pv[qb][kt][r] = has_pe ? a.pe[((int64_t)b * a.N + qc) * a.N + min(16 * kt + 4 * g + r, a.N - 1)] : 1.0f;
+  }
+  float4 bin4[3], bo = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  float bin1 = 0.0f;
+#pragma unroll
+  for (int part = 0; part < 3; ++part) {
+    bin4[part] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (a.b_in != nullptr) bin4[part] = *reinterpret_cast<const float4*>(a.b_in + part * D + DH * h + 4 * g);
+  }
+  if (a.b_in != nullptr) bin1 = a.b_in[2 * D + DH * h + lq];
+  if (a.b_out != nullptr) bo = *reinterpret_cast<const float4*>(a.b_out + DH * h + 4 * g);
+  {  // 256 rows of 16 float4 (W_in then W_out), 16 per thread: all loads, then all LDS writes
+    float4 wv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int idx = tid + kRowThreads * i, r = idx >> 4, q = idx & 15;
+      const float* src = r < 3 * D ? a.w_in + (int64_t)r * D : a.w_out + (int64_t)(r - 3 * D) * D;
+      wv[i] = *reinterpret_cast<const float4*>(src + 4 * q);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int idx = tid + kRowThreads * i;
+      *reinterpret_cast<float4*>(Wi + (idx >> 4) * P + 4 * (idx & 15)) = wv[i];
+    }
+  }
+  if (a.x_stats != nullptr) {
+    // first consumer of fresh statistics: every workgroup finalizes them (redundantly and
+    // deterministically); workgroup 0 publishes the parameter block and the running statistics
+    reduce_partials(a.x_stats, a.Gx, D, scr + 2 * D, scr);
+    for (int c = tid; c < D; c += kRowThreads) {
+      const float mean = scr[c] / (float)a.M;
+      const float var = fmaxf(scr[D + c] / (float)a.M - mean * mean, 0.0f);
+      const float rstd = rsqrtf(var + a.eps);
+      const float scale = a.x_gamma[c] * rstd;
+      const float shift = a.x_beta[c] - mean * scale;
+      xss[c] = scale;
+      xss[D + c] = shift;
+      if (b == 0) {
+        a.x_bn_out[c] = scale;
+        a.x_bn_out[D + c] = shift;
+        a.x_bn_out[2 * D + c] = mean;
+        a.x_bn_out[3 * D + c] = rstd;
+        if (a.x_rmean != nullptr) {
+          const float unbiased = a.M > 1 ? var * (float)a.M / (float)(a.M - 1) : var;
+          a.x_rmean[c] = (1.0f - a.momentum) * a.x_rmean[c] + a.momentum * mean;
+          a.x_rvar[c] = (1.0f - a.momentum) * a.x_rvar[c] + a.momentum * unbiased;
+        }
+      }
+    }
+  } else if (a.x_bn != nullptr) {
+    for (int c = tid; c < 2 * D; c += kRowThreads) xss[c] = a.x_bn[c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int idx = tid + kRowThreads * i, node = idx >> 4, q = idx & 15;
+    float4 v = xv[i];
+    if (x_norm) {
+      const float4 sc = *reinterpret_cast<const float4*>(xss + 4 * q);
+      const float4 sh = *reinterpret_cast<const float4*>(xss + D + 4 * q);
+      v = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+    }
+    *reinterpret_cast<float4*>(Xs + node * P + 4 * q) = v;  // rows >= N: a copy of row N-1, never stored
+  }
+  __syncthreads();
+  FETA_STAMP(1);
+
+  // ---- in_proj for this head: Q^T, K^T ("row operand" layout), V (B-operand layout) ---------------
+  Feat<DH> qf[NT], kf[NT];
+  f32x4 vb[NT];
+  {
+    Feat<D> xf[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) load_row<D>(xf[nt], Xs + (16 * nt + lq) * P, g);
+#pragma unroll
+    for (int part = 0; part < 3; ++part) {
+      if (part == 1 && a.tie_qk) continue;
+      Feat<D> wf;
+      load_row<D>(wf, Wi + (part * D + DH * h + lq) * P, g);
+      const float4 bv4 = bin4[part];
+      const float bv1 = bin1;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int node = 16 * nt + lq;
+        if (part > 0 && 16 * nt >= n) {  // a key tile without a real node: no K, no V (wave-uniform)
+          if (part == 1) kf[nt].f[0][0] = kf[nt].f[0][1] = kf[nt].f[0][2] = kf[nt].f[0][3] = 0.0f;
+          else vb[nt] = zero4();
+          continue;
+        }
+        if (part < 2) {
+          // (c = 4g + r, node = lq): four consecutive features of one node per lane
+          f32x4 t = dot_rows<D>(wf, xf[nt], zero4());
+          t[0] += bv4.x; t[1] += bv4.y; t[2] += bv4.z; t[3] += bv4.w;
+          if (node < a.N) {
+            const int64_t row = (int64_t)b * a.row_sb + (int64_t)node * a.row_sn;
+            *reinterpret_cast<float4*>(a.qkv + row * 3 * D + part * D + DH * h + 4 * g) =
+                make_float4(t[0], t[1], t[2], t[3]);
+          }
+          Feat<DH>& dst = part == 0 ? qf[nt] : kf[nt];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) dst.f[0][s] = t[s];
+        } else {
+          // (node = 4g + r, c' = lq)
+          f32x4 t = dot_rows<D>(xf[nt], wf, zero4());
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            t[r] += bv1;
+            const int nd = 16 * nt + 4 * g + r;
+            if (nd < a.N) {
+              const int64_t row = (int64_t)b * a.row_sb + (int64_t)nd * a.row_sn;
+              a.qkv[row * 3 * D + 2 * D + DH * h + lq] = t[r];
+            }
+            if (nd >= n) t[r] = 0.0f;  // padded keys carry no value
+          }
+          vb[nt] = t;
+        }
+      }
+    }
+  }
+  if (a.tie_qk) {  // K tied to Q: tiles beyond n_real are never used
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) kf[nt] = qf[nt];
+  }
+
+  FETA_STAMP(2);
+  // ---- attention core per 16-query tile (same arithmetic as attn_fwd_dense_kernel) ---------------
+  const int bh = b * kBlkH + h;
+  float* stg = scr + h * 16 * KP;
+#pragma unroll
+  for (int qb = 0; qb < NT; ++qb) {
+    if (16 * qb >= a.N) break;
+    const int q = 16 * qb + lq;
+    Feat<DH> qs;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qs.f[0][s] = qf[qb].f[0][s] * a.scale;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      acc[kt] = zero4();
+      if (16 * kt < n) acc[kt] = dot_rows<DH>(kf[kt], qs, zero4());  // (key 4g+r, query lq)
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (16 * kt + 4 * g + r < n) m = fmaxf(m, acc[kt][r]);
+    m = fmaxf(m, shfl_xor(m, 16));
+    m = fmaxf(m, shfl_xor(m, 32));
+    float z = 0.0f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      if (16 * kt >= n) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool kok = 16 * kt + 4 * g + r < n;
+        const float e = kok ? fast_exp(acc[kt][r] - m) * pv[qb][kt][r] : 0.0f;
+        acc[kt][r] = e;
+        z += e;
+      }
+    }
+    z += shfl_xor(z, 16);
+    z += shfl_xor(z, 32);
+    const float rinv = 1.0f / fmaxf(z, 1e-6f);
+    if (g == 0 && q < a.N) {
+      float* st = a.attn_stats + ((int64_t)bh * a.N + q) * 2;
+      st[0] = m;
+      st[1] = z;
+    }
+    f32x4 o = zero4();
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      if (16 * kt >= n) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc[kt][r] *= rinv;
+        o = mfma16(acc[kt][r], vb[kt][r], o);  // (query 4g+r, c' lq)
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Os[(16 * qb + 4 * g + r) * P + DH * h + lq] = o[r];
+    if (a.attn != nullptr) {
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stg[lq * KP + 16 * kt + 4 * g + r] = acc[kt][r];
+      wave_lds_sync();
+      const int rows = min(16, a.N - 16 * qb);
+      float* dst = a.attn + ((int64_t)bh * a.N + 16 * qb) * a.N;
+      for (int i = lane; i < rows * a.N; i += 64) {
+        const int qq = i / a.N, kk = i - qq * a.N;
+        dst[i] = stg[qq * KP + kk];
+      }
+      wave_lds_sync();
+    }
+  }
+  FETA_STAMP(3);
+  __syncthreads();
+  FETA_STAMP(4);
+
+  // ---- concat to HBM (whole rows) and out_proj: wave w owns output columns 16w .. 16w+15 ----------
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int idx = tid + kRowThreads * i, node = idx >> 4, q = idx & 15;
+    if (node < a.N) {
+      const int64_t row = (int64_t)b * a.row_sb + (int64_t)node * a.row_sn;
+      *reinterpret_cast<float4*>(a.out + row * D + 4 * q) = *reinterpret_cast<const float4*>(Os + node * P + 4 * q);
+    }
+  }
+  {
+    Feat<D> wf;
+    load_row<D>(wf, Wo + (DH * h + lq) * P, g);
+    const int o0 = DH * h + 4 * g;
+    float s1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (16 * nt >= a.N) break;
+      const int node = 16 * nt + lq;
+      const bool rok = node < a.N;
+      const int64_t row = (int64_t)b * a.row_sb + (int64_t)min(node, a.N - 1) * a.row_sn;
+      const float rs = rsv[nt];
+      Feat<D> of;
+      load_row<D>(of, Os + node * P, g);
+      const f32x4 t = dot_rows<D>(wf, of, zero4());  // (o = 16h + 4g + r, node lq)
+      const float4 res = *reinterpret_cast<const float4*>(Xs + node * P + o0);
+      float v[4] = {(t[0] + bo.x) * rs + res.x, (t[1] + bo.y) * rs + res.y, (t[2] + bo.z) * rs + res.z,
+                    (t[3] + bo.w) * rs + res.w};
+      if (rok) *reinterpret_cast<float4*>(a.y + row * D + o0) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float x1 = rok ? v[r] : 0.0f;
+        s1[r] += row16_sum(x1);
+        s2[r] += row16_sum(x1 * x1);
+      }
+    }
+    if (lq == 0) {
+      float* st = a.y_stats + (int64_t)b * 2 * D;
+      *reinterpret_cast<float4*>(st + o0) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+      *reinterpret_cast<float4*>(st + D + o0) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+    }
+  }
+  FETA_STAMP(5);
+}
+
+template <int NT>
+int launch_block_fwd(const BlockArgs& a, hipStream_t stream) {
+  const size_t lds = sizeof(float) * block_lds_floats(NT, a.attn != nullptr);
+  auto kern = attn_block_fwd_kernel<NT>;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3(a.B), dim3(kRowThreads), lds, stream, a);
+  return check_launch("feta_attn_block_fwd");
+}
+
+}  // namespace feta
+
+using namespace feta;
+
+#ifdef FETA_TIMING
+extern "C" int feta_debug_block_stamps(unsigned long long* out16) {
+  return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(feta_block_stamps), sizeof(unsigned long long) * 16);
+}
+#endif
+
+extern "C" int feta_attn_block_supported(int N, int d_model, int heads) {
+  return (d_model == kBlkD && heads == kBlkH && N >= 1 && N <= 64) ? 1 : 0;
+}
+
+extern "C" int feta_attn_block_fwd(const feta_attn_block* d, feta_stream_t stream) {
+  FETA_REQUIRE(d != nullptr, "attn_block_fwd: null descriptor");
+  const BlockArgs& a = *d;
+  FETA_REQUIRE(a.x && a.w_in && a.w_out && a.n_real && a.qkv && a.out && a.attn_stats && a.y && a.y_stats,
+               "attn_block_fwd: null pointer");
+  FETA_REQUIRE(a.B > 0 && a.N >= 1 && a.N <= 64, "attn_block_fwd: N=%d outside [1,64]", a.N);
+  FETA_REQUIRE(a.M == a.B * a.N, "attn_block_fwd: M=%d is not B*N", a.M);
+  FETA_REQUIRE(a.x_stats == nullptr || (a.x_gamma && a.x_beta && a.x_bn_out && a.Gx > 0),
+               "attn_block_fwd: x_stats needs x_gamma, x_beta, x_bn_out, Gx");
+  FETA_REQUIRE(aligned16(a.x) && aligned16(a.w_in) && aligned16(a.w_out) && aligned16(a.qkv) && aligned16(a.out) &&
+               aligned16(a.y) && aligned16(a.y_stats) && aligned16(a.x_stats) && aligned16(a.b_in) && aligned16(a.b_out),
+               "attn_block_fwd: tensors must be 16-byte aligned");
+  const int nt = (a.N + 15) / 16;
+  switch (nt) {
+    case 1: return launch_block_fwd<1>(a, (hipStream_t)stream);
+    case 2: return launch_block_fwd<2>(a, (hipStream_t)stream);
+    case 3: return launch_block_fwd<3>(a, (hipStream_t)stream);
+    default: return launch_block_fwd<4>(a, (hipStream_t)stream);
+  }
+}

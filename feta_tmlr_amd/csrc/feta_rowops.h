@@ -1,0 +1,64 @@
+// Shared pieces of the row-wise kernels (rowwise.hip) and the fused attention block (block.hip):
+// the workgroup shape and the deterministic reduction of per-block BatchNorm partial sums.
+#pragma once
+#include "feta_tiles.h"
+
+namespace feta {
+
+constexpr int kRowWaves = 4;
+constexpr int kRowThreads = 64 * kRowWaves;
+
+// sums the G partial pairs [G][2][D] with all 256 threads; on return tot[c], tot[D + c] (LDS)
+// hold the totals.  red: [slices][2][D] scratch.
+__device__ __forceinline__ void reduce_partials(const float* part, int G, int D, float* red,
+                                                float* tot) {
+  // one partial = 2D contiguous floats = nq float4; thread -> (float4 column q, slice); the
+  // loop is unrolled x4 with independent accumulators so that four 16-byte loads are in flight
+  // per thread (the dependent-latency chain of a scalar loop cost ~10 us per consumer)
+  const int nq = 2 * D / 4;
+  const int slices = kRowThreads / nq > 0 ? kRowThreads / nq : 1;
+  const int q = threadIdx.x % nq, slice = threadIdx.x / nq;
+  if ((int)threadIdx.x < slices * nq) {
+    const float4* p4 = reinterpret_cast<const float4*>(part);
+    float4 s[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    int gi = slice;
+    for (; gi + 3 * slices < G; gi += 4 * slices) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = p4[(int64_t)(gi + u * slices) * nq + q];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s[u].x += v[u].x; s[u].y += v[u].y; s[u].z += v[u].z; s[u].w += v[u].w;
+      }
+    }
+    for (; gi < G; gi += slices) {
+      const float4 v = p4[(int64_t)gi * nq + q];
+      s[0].x += v.x; s[0].y += v.y; s[0].z += v.z; s[0].w += v.w;
+    }
+    float* r = red + (slice * nq + q) * 4;
+    r[0] = (s[0].x + s[1].x) + (s[2].x + s[3].x);
+    r[1] = (s[0].y + s[1].y) + (s[2].y + s[3].y);
+    r[2] = (s[0].z + s[1].z) + (s[2].z + s[3].z);
+    r[3] = (s[0].w + s[1].w) + (s[2].w + s[3].w);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * D; c += kRowThreads) {
+    float t = 0.0f;
+    for (int sl = 0; sl < slices; ++sl) t += red[sl * 2 * D + c];
+    tot[c] = t;
+  }
+  __syncthreads();
+}
+
+__host__ __device__ inline int reduce_red_floats(int D) {
+  const int nq = 2 * D / 4;
+  const int slices = kRowThreads / nq > 0 ? kRowThreads / nq : 1;
+  return slices * 2 * D;  // red[slices][2D]
+}
+__host__ __device__ inline int reduce_scratch_floats(int D) {
+  return 2 * D + reduce_red_floats(D);  // tot[2][D] + red
+}
+
+}  // namespace feta

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FETA_ABI_VERSION 2
+#define FETA_ABI_VERSION 3
 
 #define FETA_OK 0
 #define FETA_E_ARG (-1)     /* bad shape / stride / alignment / unsupported size */
@@ -256,6 +256,54 @@ int feta_bn_apply_fwd(const float* y, const float* stats, const float* gamma, co
 int feta_bn_bwd(const float* y, const float* dout, const float* mean_rstd, const float* gamma,
                 float* partial, float* dy, float* dgamma, float* dbeta,
                 int M, int D, feta_stream_t stream);
+
+/* ---- attention sub-block of one encoder layer in ONE launch --------------------------------
+ * Replaces, for d_model = 64 = 4 heads x 16 and N <= 64 (feta_attn_block_supported), the sequence
+ * feta_rowlin_fwd_ex (in_proj) -> feta_attn_fwd -> feta_rowlin_fwd_ex (out_proj + degree + residual
+ * + BatchNorm statistics) of DiffTransformerEncoderLayer.forward (contract
+ * transformer/models.py:166-167,179,244; body per upstream GraphiT, README.md:129).
+ * One workgroup per graph; rows of the [M = B*N, .] activations are addressed as
+ * row(b, i) = b*row_sb + i*row_sn (seq-first [N,B,d]: row_sb = 1, row_sn = B).
+ * x is "seen through a BatchNorm" exactly as in feta_rowlin_ex: either x_bn (a published [4][64]
+ * parameter block) or x_stats [Gx][2][64] fresh partial sums that this launch finalizes
+ * (publishing x_bn_out and updating x_rmean / x_rvar), or neither (first layer).
+ * Outputs: qkv [M,192] (in_proj result, for backward), out [M,64] (per-head attention outputs,
+ * concatenated: out_each_head), attn_stats [B,4,N,2] (row max, un-clamped row sum), attn
+ * [B,4,N,N] or NULL, y [M,64] = x_norm + rowscale * (out W_out^T + b_out), y_stats [B][2][64]
+ * per-graph (sum, sum of squares) over the N rows of the graph - padded rows included, as
+ * nn.BatchNorm1d over the [N*B, d] view counts them. */
+typedef struct feta_attn_block {
+  const float* x;
+  const float* x_bn;
+  const float* x_stats;
+  int Gx;
+  const float* x_gamma;
+  const float* x_beta;
+  float* x_bn_out;
+  float* x_rmean;
+  float* x_rvar;
+  float momentum, eps;
+  const float* w_in;   /* [192,64] */
+  const float* b_in;   /* [192] or NULL */
+  const float* w_out;  /* [64,64] */
+  const float* b_out;  /* [64] or NULL */
+  const float* pe;     /* [B,N,N] or NULL */
+  const int32_t* n_real;
+  const float* rowscale; /* [M] degree scale per row, or NULL */
+  float* qkv;
+  float* out;
+  float* attn_stats;
+  float* attn;
+  float* y;
+  float* y_stats;
+  float scale;         /* d_h^-1/2 */
+  int B, N, M;
+  int64_t row_sb, row_sn;
+  int tie_qk;
+} feta_attn_block;
+
+int feta_attn_block_supported(int N, int d_model, int heads);
+int feta_attn_block_fwd(const feta_attn_block* d, feta_stream_t stream);
 
 /* ---- graph preprocessing -------------------------------------------------------------
  * Dense Lhat = -D^-1/2 A D^-1/2 per graph from the batched edge list, with the exact

@@ -10,6 +10,8 @@ from feta_tmlr_amd.transformer.ChebNetDynamic import ChebConvDynamic
 from feta_tmlr_amd.transformer.models import DiffGraphTransformerGenGCN
 from oracle import feta_oracle as O
 
+CPU = torch.device('cpu')
+
 
 def _model_case(batch_norm, share, mode, pe_on, seed=0, bsz=3, d=32, heads=2, layers=2, order=3,
                 in_dim=12):
@@ -201,3 +203,53 @@ def test_two_phase_backward_equals_single_backward(emu):
         assert torch.equal(got[n], ref[n]), n
     assert {id(p) for p in enc.head_parameters()} | {id(p) for p in enc.stack_parameters()} == \
         {id(p) for p in enc.parameters()}
+
+
+def _stack_run(model, batch9, cache, use_block, monkeypatch, hook):
+    from feta_tmlr_amd import fused_stack
+    monkeypatch.setattr(fused_stack, 'USE_ATTN_BLOCK', use_block)
+    x, mask, pe, _, degree, _, edge_index, batch, fi = batch9
+    x = x.clone().requires_grad_(True)
+    model.zero_grad()
+    with hook():
+        out, _, coeff = model(x, edge_index, batch, fi, mask, pe, degree=degree, return_filter_coeff=True,
+                              graph_cache=cache)
+        w = torch.linspace(0.5, 1.5, out.numel(), device=out.device).view_as(out)
+        ((out * w).sum() + 0.01 * coeff.pow(2).sum()).backward()
+    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    return out.detach(), coeff.detach(), x.grad.detach(), grads
+
+
+def check_attn_block_equals_three_launches(dev, hook, monkeypatch, shape, n_min, n_max, tie_qk, pe_on, bsz=3):
+    """in_proj + attention + out_proj as one launch (csrc/block.hip) == the three-launch sequence"""
+    torch.manual_seed(5)
+    model = DiffGraphTransformerGenGCN(9, 1, 64, 4, dim_feedforward=128, dropout=0.0, nb_layers=2,
+                                       batch_norm=True, filter_order=2, heads_share_graph=True,
+                                       filter_mode='spectral', tie_qk=tie_qk)
+    with torch.no_grad():
+        for l in model.encoder.layers:
+            l.self_attn.out_proj.bias.normal_(0, 0.1)
+            if l.self_attn.in_proj_bias is not None:
+                l.self_attn.in_proj_bias.normal_(0, 0.1)
+    ds = D.SyntheticGraphDataset(shape, bsz, in_dim=9, seed=3, pos_enc=pe_on, n_min=n_min, n_max=n_max)
+    n_pad = max(g.num_nodes for g in ds.samples)
+    batch9, cache = D.collate(ds.samples, k_eig=n_pad, device=dev)
+    model = model.to(dev)
+    a = _stack_run(model, batch9, cache, True, monkeypatch, hook)
+    b = _stack_run(model, batch9, cache, False, monkeypatch, hook)
+    KC.assert_close('output', a[0], b[0].double(), tol=2e-6)
+    KC.assert_close('coefficients', a[1], b[1].double(), tol=2e-6)
+    KC.assert_close('dx', a[2], b[2].double(), tol=1e-5)
+    assert a[3].keys() == b[3].keys()
+    for k in a[3]:
+        KC.assert_close('grad ' + k, a[3][k], b[3][k].double(), tol=1e-5)
+
+
+@pytest.mark.parametrize('shape,n_min,n_max,tie_qk,pe_on', [
+    ('zinc', 20, 37, False, True),       # 3 row tiles
+    ('mutag', 3, 14, True, True),        # 1 row tile, K tied to Q
+    ('pattern', 44, 64, False, False),   # 4 row tiles, no positional kernel
+])
+def test_attn_block_equals_three_launches(emu, monkeypatch, shape, n_min, n_max, tie_qk, pe_on):
+    check_attn_block_equals_three_launches(CPU, lambda: _lib.override_for_tests(emu), monkeypatch, shape,
+                                           n_min, n_max, tie_qk, pe_on)

@@ -87,6 +87,18 @@ def main():
     add('attn_bwd (dq + dkdv)', lambda: abi.attn_bwd(q, kk, v, pe, nr, out, dout, stats, delta, dq, dk, dv, sc, st),
         f4 * b * (3 * n * d + 2 * n * d + n * n + 2 * h * n + 3 * n * d + h * n))
 
+    if abi.attn_block_supported(n, d, h) and not bf:
+        xb, w_in, b_in, w_o, b_o = rnd(m, d), rnd(3 * d, d) / d ** 0.5, rnd(3 * d), rnd(d, d) / d ** 0.5, rnd(d)
+        yb1, stb1 = torch.empty(m, d, device=dev), torch.empty(b, 2, d, device=dev)
+        outb = torch.empty(n, b, h, dh, device=dev)
+        deg = torch.rand(m, generator=g).to(dev)
+        for nm, att in (('attn_block_fwd (+attn write)', attn), ('attn_block_fwd (no attn write)', None)):
+            add(nm, lambda att=att: abi.attn_block_fwd(b, n, sc, st, x=xb, w_in=w_in, b_in=b_in, w_out=w_o, b_out=b_o,
+                                                       pe=pe, n_real=nr, rowscale=deg, qkv=qkv, out=outb,
+                                                       attn_stats=stats, attn=att, y=yb1, y_stats=stb1),
+                f4 * (b * (n * d + n * n + 3 * n * d + n * d + 2 * h * n + n * d + (h * n * n if att is not None else 0))
+                      + 4 * d * d))
+
     s = rnd(c)
     gb = rnd(c) * 0.1
     cj = torch.empty(h * b, n, device=dev)
