@@ -71,8 +71,8 @@ class RowLinEx(C.Structure):
 SIGNATURES.update({
     'feta_rowlin_fwd_ex': ([C.POINTER(RowLinEx), _S], C.c_int),
     'feta_rowlin_bwd_ex': ([C.POINTER(RowLinEx), _F, _S], C.c_int),
-    'feta_bn_apply_fwd_prm': ([_F, _F, _F, _F, _F, _F, _F, _F, C.c_float, C.c_float, C.c_int, C.c_int, _S],
-                              C.c_int),
+    'feta_bn_apply_fwd_prm': ([_F, _F, _F, _F, _F, _F, _F, _F, C.c_float, C.c_float, C.c_int, C.c_int,
+                               C.c_int, _S], C.c_int),
     'feta_bn_bwd_reduce': ([_F, _F, _F, _F, C.c_int, C.c_int, _S], C.c_int),
 })
 
@@ -94,6 +94,25 @@ class AttnBlock(C.Structure):
 SIGNATURES.update({
     'feta_attn_block_supported': ([C.c_int, C.c_int, C.c_int], C.c_int),
     'feta_attn_block_fwd': ([C.POINTER(AttnBlock), _S], C.c_int),
+})
+
+
+
+class Ffn(C.Structure):
+    """struct feta_ffn (include/feta_hip.h) - field order must match the header."""
+    _fields_ = [
+        ('x', _F), ('x_bn', _F), ('x_stats', _F), ('Gx', C.c_int),
+        ('x_gamma', _F), ('x_beta', _F), ('x_bn_out', _F), ('x_rmean', _F), ('x_rvar', _F),
+        ('momentum', C.c_float), ('eps', C.c_float),
+        ('w1', _F), ('b1', _F), ('w2', _F), ('b2', _F), ('h', _F), ('y', _F), ('y_stats', _F),
+        ('M', C.c_int), ('FF', C.c_int),
+    ]
+
+
+SIGNATURES.update({
+    'feta_ffn_supported': ([C.c_int, C.c_int], C.c_int),
+    'feta_ffn_blocks': ([C.c_int], C.c_int),
+    'feta_ffn_fwd': ([C.POINTER(Ffn), _S], C.c_int),
 })
 
 ABI_VERSION = 3
@@ -291,12 +310,28 @@ class Abi:
                 setattr(d, k, t.data_ptr())
         self._check(self.lib.feta_attn_block_fwd(C.byref(d), stream), 'feta_attn_block_fwd')
 
+    def ffn_supported(self, d_model, ff):
+        return bool(self.lib.feta_ffn_supported(d_model, ff))
+
+    def ffn_blocks(self, m):
+        return int(self.lib.feta_ffn_blocks(m))
+
+    def ffn_fwd(self, m, ff, stream, momentum=0.1, eps=1e-5, Gx=0, **ptrs):
+        """feta_ffn_fwd; tensor-valued keyword arguments become the descriptor's pointers."""
+        d = Ffn()
+        d.M, d.FF, d.momentum, d.eps, d.Gx = m, ff, momentum, eps, Gx
+        for k, t in ptrs.items():
+            if t is not None:
+                setattr(d, k, t.data_ptr())
+        self._check(self.lib.feta_ffn_fwd(C.byref(d), stream), 'feta_ffn_fwd')
+
     def bn_apply_fwd_prm(self, y, stats, gamma, beta, out, bn_prm, running_mean, running_var, momentum,
                          eps, stream):
         m, d = y.shape
         self._check(self.lib.feta_bn_apply_fwd_prm(_p(y), _p(stats), _p(gamma), _p(beta), _p(out),
                                                    _p(bn_prm), _p(running_mean), _p(running_var),
-                                                   momentum, eps, m, d, stream), 'feta_bn_apply_fwd_prm')
+                                                   momentum, eps, m, d, stats.shape[0], stream),
+                    'feta_bn_apply_fwd_prm')
 
     def bn_bwd_reduce(self, y, dout, bn_prm, partial, stream):
         m, d = y.shape

@@ -1,0 +1,218 @@
+// Feed-forward half of DiffTransformerEncoderLayer (BatchNorm variant) as ONE launch:
+//   x = BN1(y1);  h = relu(x W1^T + b1);  y2 = x + h W2^T + b2;  statistics of y2 for BN2
+// (contract transformer/models.py:166-167; body per upstream GraphiT, README.md:129: linear2(relu(
+// linear1(.))) with dim_feedforward = 2 d, residual, norm2).  Replaces two feta_rowlin_fwd_ex
+// launches: the hidden activations never leave the registers between the two products - the
+// accumulator tile of the first product (rows = hidden units) is exactly the B operand of the
+// second one, which contracts over hidden units (feta_tiles.h: contraction over accumulator rows).
+//
+// Workgroup = 32 rows x 4 waves; wave (rt, hh) owns row tile rt and HALF of the hidden units, so a
+// wave's dependent MFMA chain is 128 instead of 256 instructions (the problem is latency-bound at
+// BASELINE batch sizes: 4736 rows).  The two halves exchange their partial y2 tiles through LDS and
+// each finishes two of the four output tiles; the residual BN1(y1) is the wave's own x operand.
+// h is still written to HBM: backward needs it (relu mask, dW2).
+#include "feta_abi_common.h"
+#include "feta_rowops.h"
+
+namespace feta {
+
+typedef feta_ffn FfnArgs;  // include/feta_hip.h
+
+constexpr int kFfnD = 64;
+constexpr int kFfnRows = 32;  // rows per workgroup
+
+__host__ __device__ inline int ffn_lds_floats(int ff) {
+  return ff * (kFfnD + 4) + kFfnD * (ff + 4)  // W1 [FF][68], W2 [64][FF+4]
+         + 2 * kFfnD                            // scale / shift of BN1
+         + reduce_scratch_floats(kFfnD)         // finalize scratch, later: partial-tile exchange + stats
+         + 4 * 2 * 4 * 64;                      // exchange [wave][2 tiles][4 regs][64 lanes]
+}
+
+template <int FF>
+__global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a) {
+  constexpr int D = kFfnD, P1 = D + 4, P2 = FF + 4, HT = FF / 32;  // HT hidden tiles per half
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lq = lane & 15, g = lane >> 4;
+  const int rt = wv >> 1, hh = wv & 1;
+  float* W1 = feta_lds;            // [FF][P1]
+  float* W2 = W1 + FF * P1;        // [64][P2]
+  float* xss = W2 + D * P2;        // [2][64]
+  float* scr = xss + 2 * D;        // finalize scratch
+  float* xch = scr + reduce_scratch_floats(D);  // [4 waves][2][4][64]
+  const int row = blockIdx.x * kFfnRows + 16 * rt + lq;
+  const bool rok = row < a.M;
+  const int rowc = min(row, a.M - 1);
+
+  // ---- requests: the wave's x rows, biases, then the weights ------------------------------------------
+  Feat<D> xf;
+  load_row_sel<D>(xf, a.x + (int64_t)rowc * D, true, g);
+  float4 b1v[HT], b2v[2];
+#pragma unroll
+  for (int t = 0; t < HT; ++t)
+    b1v[t] = a.b1 != nullptr ? *reinterpret_cast<const float4*>(a.b1 + hh * (FF / 2) + 16 * t + 4 * g)
+                             : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+    b2v[t] = a.b2 != nullptr ? *reinterpret_cast<const float4*>(a.b2 + 16 * (2 * hh + t) + 4 * g)
+                             : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  {
+    constexpr int NV = 2 * FF * D / 4 / kRowThreads;  // float4 per thread: W1 then W2
+    float4 wv4[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + kRowThreads * i;
+      wv4[i] = idx < FF * D / 4 ? reinterpret_cast<const float4*>(a.w1)[idx]
+                                : reinterpret_cast<const float4*>(a.w2)[idx - FF * D / 4];
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + kRowThreads * i;
+      if (idx < FF * D / 4) {
+        *reinterpret_cast<float4*>(W1 + (idx / (D / 4)) * P1 + 4 * (idx % (D / 4))) = wv4[i];
+      } else {
+        const int j = idx - FF * D / 4;
+        *reinterpret_cast<float4*>(W2 + (j / (FF / 4)) * P2 + 4 * (j % (FF / 4))) = wv4[i];
+      }
+    }
+  }
+  if (a.x_stats != nullptr) {
+    reduce_partials(a.x_stats, a.Gx, D, scr + 2 * D, scr);
+    for (int c = tid; c < D; c += kRowThreads) {
+      const float mean = scr[c] / (float)a.M;
+      const float var = fmaxf(scr[D + c] / (float)a.M - mean * mean, 0.0f);
+      const float rstd = rsqrtf(var + a.eps);
+      const float scale = a.x_gamma[c] * rstd;
+      const float shift = a.x_beta[c] - mean * scale;
+      xss[c] = scale;
+      xss[D + c] = shift;
+      if (blockIdx.x == 0) {
+        a.x_bn_out[c] = scale;
+        a.x_bn_out[D + c] = shift;
+        a.x_bn_out[2 * D + c] = mean;
+        a.x_bn_out[3 * D + c] = rstd;
+        if (a.x_rmean != nullptr) {
+          const float unbiased = a.M > 1 ? var * (float)a.M / (float)(a.M - 1) : var;
+          a.x_rmean[c] = (1.0f - a.momentum) * a.x_rmean[c] + a.momentum * mean;
+          a.x_rvar[c] = (1.0f - a.momentum) * a.x_rvar[c] + a.momentum * unbiased;
+        }
+      }
+    }
+  } else {
+    for (int c = tid; c < 2 * D; c += kRowThreads) xss[c] = a.x_bn != nullptr ? a.x_bn[c] : (c < D ? 1.0f : 0.0f);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float4 sc = *reinterpret_cast<const float4*>(xss + 16 * j + 4 * g);
+    const float4 sh = *reinterpret_cast<const float4*>(xss + D + 16 * j + 4 * g);
+    xf.f[j][0] = xf.f[j][0] * sc.x + sh.x;
+    xf.f[j][1] = xf.f[j][1] * sc.y + sh.y;
+    xf.f[j][2] = xf.f[j][2] * sc.z + sh.z;
+    xf.f[j][3] = xf.f[j][3] * sc.w + sh.w;
+  }
+
+  // ---- h (this half of the hidden units) = relu(x W1^T + b1): (hidden 4g+r, row lq) ------------------
+  f32x4 hacc[HT];
+#pragma unroll
+  for (int t = 0; t < HT; ++t) {
+    const int o = hh * (FF / 2) + 16 * t;
+    Feat<D> wf;
+    load_row<D>(wf, W1 + (o + lq) * P1, g);
+    f32x4 v = dot_rows<D>(wf, xf, zero4());
+    v[0] = fmaxf(v[0] + b1v[t].x, 0.0f);
+    v[1] = fmaxf(v[1] + b1v[t].y, 0.0f);
+    v[2] = fmaxf(v[2] + b1v[t].z, 0.0f);
+    v[3] = fmaxf(v[3] + b1v[t].w, 0.0f);
+    hacc[t] = v;
+    if (rok) *reinterpret_cast<float4*>(a.h + (int64_t)row * FF + o + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  // ---- partial y2^T tiles over this half: (output 4g+r, row lq) --------------------------------------
+  f32x4 yp[4];
+#pragma unroll
+  for (int t2 = 0; t2 < 4; ++t2) {
+    f32x4 acc = zero4();
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+      const float4 w4 = *reinterpret_cast<const float4*>(W2 + (16 * t2 + lq) * P2 + hh * (FF / 2) + 16 * t + 4 * g);
+      acc = mfma16(w4.x, hacc[t][0], acc);
+      acc = mfma16(w4.y, hacc[t][1], acc);
+      acc = mfma16(w4.z, hacc[t][2], acc);
+      acc = mfma16(w4.w, hacc[t][3], acc);
+    }
+    yp[t2] = acc;
+  }
+  // ---- exchange: this wave finishes output tiles 2hh, 2hh+1; the partner gets the other two -----------
+  {
+    float* mine = xch + wv * (2 * 4 * 64);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mine[(t * 4 + r) * 64 + lane] = yp[2 * (1 - hh) + t][r];
+  }
+  __syncthreads();
+  const float* theirs = xch + (wv ^ 1) * (2 * 4 * 64);
+  float* red = scr;  // [2 row tiles][2][64] column sums, reduced below
+  const bool want_stats = a.y_stats != nullptr;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int t2 = 2 * hh + t, o2 = 16 * t2 + 4 * g;
+    const float bb[4] = {b2v[t].x, b2v[t].y, b2v[t].z, b2v[t].w};
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = yp[t2][r] + theirs[(t * 4 + r) * 64 + lane] + bb[r] + xf.f[t2][r];
+    if (rok) *reinterpret_cast<float4*>(a.y + (int64_t)row * D + o2) = make_float4(v[0], v[1], v[2], v[3]);
+    if (want_stats) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float x1 = rok ? v[r] : 0.0f;
+        const float s1 = row16_sum(x1), s2 = row16_sum(x1 * x1);
+        if (lq == 0) {
+          red[(rt * 2 + 0) * D + o2 + r] = s1;
+          red[(rt * 2 + 1) * D + o2 + r] = s2;
+        }
+      }
+    }
+  }
+  if (want_stats) {
+    __syncthreads();
+    for (int i = tid; i < 2 * D; i += kRowThreads)
+      a.y_stats[(int64_t)blockIdx.x * 2 * D + i] = red[i] + red[2 * D + i];
+  }
+}
+
+template <int FF>
+int launch_ffn_fwd(const FfnArgs& a, hipStream_t stream) {
+  const size_t lds = sizeof(float) * ffn_lds_floats(FF);
+  auto kern = ffn_fwd_kernel<FF>;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int grid = (a.M + kFfnRows - 1) / kFfnRows;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kRowThreads), lds, stream, a);
+  return check_launch("feta_ffn_fwd");
+}
+
+}  // namespace feta
+
+using namespace feta;
+
+extern "C" int feta_ffn_supported(int d_model, int ff) {
+  return (d_model == kFfnD && (ff == 64 || ff == 128 || ff == 256)) ? 1 : 0;
+}
+
+extern "C" int feta_ffn_blocks(int M) { return (M + kFfnRows - 1) / kFfnRows; }
+
+extern "C" int feta_ffn_fwd(const feta_ffn* d, feta_stream_t stream) {
+  FETA_REQUIRE(d != nullptr, "ffn_fwd: null descriptor");
+  const FfnArgs& a = *d;
+  FETA_REQUIRE(a.x && a.w1 && a.w2 && a.h && a.y && a.M > 0, "ffn_fwd: null pointer / empty");
+  FETA_REQUIRE(feta_ffn_supported(kFfnD, a.FF), "ffn_fwd: dim_feedforward %d not in {64,128,256}", a.FF);
+  FETA_REQUIRE(a.x_stats == nullptr || (a.x_gamma && a.x_beta && a.x_bn_out && a.Gx > 0),
+               "ffn_fwd: x_stats needs x_gamma, x_beta, x_bn_out, Gx");
+  FETA_REQUIRE(aligned16(a.x) && aligned16(a.w1) && aligned16(a.w2) && aligned16(a.h) && aligned16(a.y) &&
+                   aligned16(a.b1) && aligned16(a.b2) && aligned16(a.x_stats) && aligned16(a.y_stats),
+               "ffn_fwd: tensors must be 16-byte aligned");
+  switch (a.FF) {
+    case 64: return launch_ffn_fwd<64>(a, (hipStream_t)stream);
+    case 128: return launch_ffn_fwd<128>(a, (hipStream_t)stream);
+    default: return launch_ffn_fwd<256>(a, (hipStream_t)stream);
+  }
+}

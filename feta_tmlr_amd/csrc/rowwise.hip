@@ -606,6 +606,7 @@ struct BnArgs {
   float* dbeta;
   float momentum, eps;
   int M, D, G;
+  int Gs;               // number of partial rows in `stats` (0: G)
   int prm4;             // mean_rstd_in is a [4][D] parameter block (mean at row 2, rstd at row 3)
 };
 
@@ -650,7 +651,7 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(BnArgs a) {
   float* sh = feta_lds + D;        // [D] shift = beta - mean * scale
   float* tot = feta_lds + 2 * D;   // [2][D]
   float* red = feta_lds + 4 * D;   // [slices][2][D]
-  reduce_partials(a.stats, a.G, D, red, tot);
+  reduce_partials(a.stats, a.Gs > 0 ? a.Gs : a.G, D, red, tot);
   for (int c = threadIdx.x; c < D; c += 256) {
     const float mean = tot[c] / (float)a.M;
     const float var = fmaxf(tot[D + c] / (float)a.M - mean * mean, 0.0f);
@@ -955,14 +956,14 @@ extern "C" int feta_bn_apply_fwd(const float* y, const float* stats, const float
 extern "C" int feta_bn_apply_fwd_prm(const float* y, const float* stats, const float* gamma,
                                      const float* beta, float* out, float* bn_prm, float* running_mean,
                                      float* running_var, float momentum, float eps, int M, int D,
-                                     feta_stream_t stream) {
+                                     int G_stats, feta_stream_t stream) {
   FETA_REQUIRE(y && stats && gamma && beta && out && bn_prm, "bn_apply_fwd_prm: null pointer");
   FETA_REQUIRE(M > 0 && D > 0 && D <= 256 && (D % 4) == 0, "bn_apply_fwd_prm: need D %% 4 == 0, D <= 256");
   FETA_REQUIRE(aligned16(y) && aligned16(out), "bn_apply_fwd_prm: pointers must be 16-byte aligned");
   BnArgs a{};
   a.y = y; a.stats = stats; a.gamma = gamma; a.beta = beta; a.out = out; a.mean_rstd = bn_prm;
   a.running_mean = running_mean; a.running_var = running_var; a.momentum = momentum; a.eps = eps;
-  a.M = M; a.D = D; a.G = row_blocks(M); a.prm4 = 1;
+  a.M = M; a.D = D; a.G = row_blocks(M); a.Gs = G_stats; a.prm4 = 1;
   return bn_apply_launch(a, stream);
 }
 

@@ -34,6 +34,7 @@ PER_LAYER = 12  # tensors per layer in the flat parameter list
 # in_proj + attention + out_proj of a layer as one launch where the shape allows (csrc/block.hip);
 # FETA_ATTN_BLOCK=0 keeps the three-launch sequence (A/B timing, fallback for other shapes)
 USE_ATTN_BLOCK = os.environ.get('FETA_ATTN_BLOCK', '1') != '0'
+USE_FFN_FUSED = os.environ.get('FETA_FFN_FUSED', '1') != '0'
 
 
 def layer_params(layer):
@@ -93,7 +94,7 @@ class FusedEncoderStackFn(torch.autograd.Function):
             if li > 0:
                 pl = layers[li - 1].norm2
                 prm_prev = new(4, d)
-                bn_prev = dict(x_stats=st_prev, Gx=G, x_gamma=params[(li - 1) * PER_LAYER + 10],
+                bn_prev = dict(x_stats=st_prev, Gx=G2_prev, x_gamma=params[(li - 1) * PER_LAYER + 10],
                                x_beta=params[(li - 1) * PER_LAYER + 11], x_bn_out=prm_prev,
                                x_rmean=pl.running_mean, x_rvar=pl.running_var,
                                momentum=float(pl.momentum), eps=float(pl.eps))
@@ -120,19 +121,27 @@ class FusedEncoderStackFn(torch.autograd.Function):
                 dsc = abi.rowlin_ex(m, d, d, x=out.view(m, d), w=w_o, bias=b_o, rowscale=degree_rows,
                                     residual=y_prev, res_bn=prm_prev, y=y1, stats=st1)
                 abi.rowlin_fwd_ex(dsc, stream)
-            # F4
             h, prm1 = new(m, ff), new(4, d)
             n1 = layer.norm1
-            dsc = abi.rowlin_ex(m, d, ff, relu=True, x=y1, w=w1, bias=bb1, y=h, x_stats=st1, Gx=G1, x_gamma=g1,
-                                x_beta=be1, x_bn_out=prm1, x_rmean=n1.running_mean, x_rvar=n1.running_var,
-                                momentum=float(n1.momentum), eps=float(n1.eps))
-            abi.rowlin_fwd_ex(dsc, stream)
-            # F5
-            y2, st2 = new(m, d), new(G, 2, d)
-            dsc = abi.rowlin_ex(m, ff, d, x=h, w=w2, bias=bb2, residual=y1, res_bn=prm1, y=y2, stats=st2)
-            abi.rowlin_fwd_ex(dsc, stream)
+            bn1 = dict(x_stats=st1, Gx=G1, x_gamma=g1, x_beta=be1, x_bn_out=prm1, x_rmean=n1.running_mean,
+                       x_rvar=n1.running_var, momentum=float(n1.momentum), eps=float(n1.eps))
+            y2 = new(m, d)
+            if USE_FFN_FUSED and abi.ffn_supported(d, ff):
+                # F4 + F5 in one launch: the hidden activations stay in registers (csrc/ffn.hip)
+                G2 = abi.ffn_blocks(m)
+                st2 = new(G2, 2, d)
+                abi.ffn_fwd(m, ff, stream, x=y1, w1=w1, b1=bb1, w2=w2, b2=bb2, h=h, y=y2, y_stats=st2, **bn1)
+            else:
+                # F4
+                dsc = abi.rowlin_ex(m, d, ff, relu=True, x=y1, w=w1, bias=bb1, y=h, **bn1)
+                abi.rowlin_fwd_ex(dsc, stream)
+                # F5
+                G2 = G
+                st2 = new(G2, 2, d)
+                dsc = abi.rowlin_ex(m, ff, d, x=h, w=w2, bias=bb2, residual=y1, res_bn=prm1, y=y2, stats=st2)
+                abi.rowlin_fwd_ex(dsc, stream)
             saved.append(dict(x0=y_prev, prm0=prm_prev, qkv=qkv, out=out, ast=ast, y1=y1, prm1=prm1, h=h, y2=y2))
-            y_prev, st_prev = y2, st2
+            y_prev, st_prev, G2_prev = y2, st2, G2
         # end of the stack: materialise BN2(y2) of the last layer
         last = layers[-1].norm2
         final = new(m, d)

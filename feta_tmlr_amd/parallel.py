@@ -47,6 +47,10 @@ class FlatGradAllReduce:
         if world_size is None:
             world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.world_size = world_size
+        # RCCL averages inside the collective (ReduceOp.AVG): no scaling kernel after it; gloo (the
+        # CPU tests) has no AVG, there the sum is scaled
+        self.avg_in_collective = (dist.is_initialized() and world_size > 1
+                                  and dist.get_backend(process_group) == 'nccl')
         self.rowconst = [bool(getattr(p, '_feta_row_constant', False)) and not views and p.dim() == 2
                          for p in self.params]
         sizes = [p.shape[1] if rc else p.numel() for p, rc in zip(self.params, self.rowconst)]
@@ -98,13 +102,17 @@ class FlatGradAllReduce:
             return None
         if not self.views:
             self.pack()
-        return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return dist.all_reduce(self.flat, op=self._op(), group=self.group, async_op=True)
+
+    def _op(self):
+        return dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM
 
     def finish(self, work):
         if work is None:
             return
         work.wait()
-        self.flat.mul_(1.0 / self.world_size)
+        if not self.avg_in_collective:
+            self.flat.mul_(1.0 / self.world_size)
         if not self.views:
             self.unpack()
 
@@ -114,7 +122,8 @@ class FlatGradAllReduce:
             return
         if not self.views:
             self.pack()
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-        self.flat.mul_(1.0 / self.world_size)
+        dist.all_reduce(self.flat, op=self._op(), group=self.group)
+        if not self.avg_in_collective:
+            self.flat.mul_(1.0 / self.world_size)
         if not self.views:
             self.unpack()

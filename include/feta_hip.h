@@ -236,10 +236,12 @@ int feta_rowlin_fwd_ex(const feta_rowlin_ex* d, feta_stream_t stream);
  * partials only). */
 int feta_rowlin_bwd_ex(const feta_rowlin_ex* d, float* dwdb, feta_stream_t stream);
 
-/* out = BN(y) written explicitly (end of the stack), publishing the bn parameter block [4][D]. */
+/* out = BN(y) written explicitly (end of the stack), publishing the bn parameter block [4][D].
+ * stats holds G_stats partial rows [G_stats][2][D] (0: feta_rowlin_blocks(M), the producer was a
+ * feta_rowlin_fwd*; feta_ffn_blocks(M) after feta_ffn_fwd; B after feta_attn_block_fwd). */
 int feta_bn_apply_fwd_prm(const float* y, const float* stats, const float* gamma, const float* beta,
                           float* out, float* bn_prm, float* running_mean, float* running_var,
-                          float momentum, float eps, int M, int D, feta_stream_t stream);
+                          float momentum, float eps, int M, int D, int G_stats, feta_stream_t stream);
 /* partial [feta_rowlin_blocks(M),2,D] = per-block (sum dout, sum dout*xhat), bn_prm [4][D]. */
 int feta_bn_bwd_reduce(const float* y, const float* dout, const float* bn_prm, float* partial,
                        int M, int D, feta_stream_t stream);
@@ -304,6 +306,36 @@ typedef struct feta_attn_block {
 
 int feta_attn_block_supported(int N, int d_model, int heads);
 int feta_attn_block_fwd(const feta_attn_block* d, feta_stream_t stream);
+
+/* ---- feed-forward half of one encoder layer in ONE launch -----------------------------------
+ * x = BN1(y1) (x_bn | x_stats as in feta_rowlin_ex / feta_attn_block);  h = relu(x W1^T + b1);
+ * y = x + h W2^T + b2;  y_stats [feta_ffn_blocks(M)][2][64] per-workgroup (sum, sum of squares).
+ * Replaces the two feta_rowlin_fwd_ex launches of linear1 / linear2 for d_model = 64 and
+ * dim_feedforward in {64,128,256} (feta_ffn_supported).  h [M,FF] is written for backward. */
+typedef struct feta_ffn {
+  const float* x;
+  const float* x_bn;
+  const float* x_stats;
+  int Gx;
+  const float* x_gamma;
+  const float* x_beta;
+  float* x_bn_out;
+  float* x_rmean;
+  float* x_rvar;
+  float momentum, eps;
+  const float* w1;  /* [FF,64] */
+  const float* b1;  /* [FF] or NULL */
+  const float* w2;  /* [64,FF] */
+  const float* b2;  /* [64] or NULL */
+  float* h;
+  float* y;
+  float* y_stats;   /* or NULL */
+  int M, FF;
+} feta_ffn;
+
+int feta_ffn_supported(int d_model, int ff);
+int feta_ffn_blocks(int M);
+int feta_ffn_fwd(const feta_ffn* d, feta_stream_t stream);
 
 /* ---- graph preprocessing -------------------------------------------------------------
  * Dense Lhat = -D^-1/2 A D^-1/2 per graph from the batched edge list, with the exact
