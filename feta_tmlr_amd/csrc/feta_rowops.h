@@ -8,6 +8,25 @@ namespace feta {
 constexpr int kRowWaves = 4;
 constexpr int kRowThreads = 64 * kRowWaves;
 
+// Global -> LDS staging of `count` 16-byte items by the whole workgroup: a plain `for (idx...) lds[..] = gmem[..]` loop compiles to load / wait / store per
+// iteration, i.e. one full memory latency per 256 items.  src(idx) -> const float4*, dst(idx) -> float4*.
+// Four requests are in flight per thread.
+template <class Src, class Dst>
+__device__ __forceinline__ void stage_float4(int count, Src src, Dst dst) {
+  for (int base = threadIdx.x; base < count; base += kRowThreads * 4) {
+    const int i0 = base, i1 = base + kRowThreads, i2 = base + 2 * kRowThreads, i3 = base + 3 * kRowThreads;
+    const int last = count - 1;
+    const float4 v0 = *src(i0);
+    const float4 v1 = *src(i1 < count ? i1 : last);
+    const float4 v2 = *src(i2 < count ? i2 : last);
+    const float4 v3 = *src(i3 < count ? i3 : last);
+    *dst(i0) = v0;
+    if (i1 < count) *dst(i1) = v1;
+    if (i2 < count) *dst(i2) = v2;
+    if (i3 < count) *dst(i3) = v3;
+  }
+}
+
 // sums the G partial pairs [G][2][D] with all 256 threads; on return tot[c], tot[D + c] (LDS)
 // hold the totals.  red: [slices][2][D] scratch.
 __device__ __forceinline__ void reduce_partials(const float* part, int G, int D, float* red,

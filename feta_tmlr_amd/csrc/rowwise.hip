@@ -110,11 +110,16 @@ __global__ __launch_bounds__(kRowThreads) void rowlin_fwd_kernel(RowLinArgs a, R
   load_batch(rg, cur);
 
   const int nvec = ntile * 16 * (KI / 4);
-  for (int idx = threadIdx.x; idx < nvec; idx += kRowThreads) {
-    const int row = idx / (KI / 4), c4 = idx - row * (KI / 4);
-    *reinterpret_cast<float4*>(wt + row * LDW + 4 * c4) =
-        *reinterpret_cast<const float4*>(a.w + (int64_t)(o_base + row) * KI + 4 * c4);
-  }
+  stage_float4(
+      nvec,
+      [&](int idx) {
+        const int row = idx / (KI / 4), c4 = idx - row * (KI / 4);
+        return reinterpret_cast<const float4*>(a.w + (int64_t)(o_base + row) * KI + 4 * c4);
+      },
+      [&](int idx) {
+        const int row = idx / (KI / 4), c4 = idx - row * (KI / 4);
+        return reinterpret_cast<float4*>(wt + row * LDW + 4 * c4);
+      });
   if (want_stats)
     for (int i = threadIdx.x; i < kRowWaves * 2 * tgw; i += kRowThreads) red[i] = 0.0f;
   if (a.x_stats != nullptr) {
@@ -278,11 +283,16 @@ __device__ void rowlin_dx_role(const RowLinArgs& a, const RowLinGeom& ge, const 
   load_batch(rg, cur);
 
   const int rowvec = ntile * 4;
-  for (int idx = threadIdx.x; idx < NO * rowvec; idx += kRowThreads) {
-    const int o = idx / rowvec, c4 = idx - o * rowvec;
-    *reinterpret_cast<float4*>(wt + o * ldw + 4 * c4) =
-        *reinterpret_cast<const float4*>(a.w + (int64_t)o * a.KI + k_base + 4 * c4);
-  }
+  stage_float4(
+      NO * rowvec,
+      [&](int idx) {
+        const int o = idx / rowvec, c4 = idx - o * rowvec;
+        return reinterpret_cast<const float4*>(a.w + (int64_t)o * a.KI + k_base + 4 * c4);
+      },
+      [&](int idx) {
+        const int o = idx / rowvec, c4 = idx - o * rowvec;
+        return reinterpret_cast<float4*>(wt + o * ldw + 4 * c4);
+      });
   if (want_sums)
     for (int i = threadIdx.x; i < kRowWaves * 2 * ks; i += kRowThreads) red[i] = 0.0f;
   __syncthreads();
@@ -470,55 +480,78 @@ __device__ void rowlin_dw_role_lds(const RowLinArgs& a, const RowLinGeom& ge, co
   float db = 0.0f;
   for (int r0 = row_lo; r0 < row_hi; r0 += 64) {
     if (r0 > row_lo) __syncthreads();
-    // stage g slice: 64 rows x (ow / 4) float4
+    // stage g slice (64 rows x ow / 4 float4) and x (64 rows x KI / 4 float4, seen through its
+    // BatchNorm): four items per thread per pass, every load of the pass (clamped row, unconditional)
+    // issued before the first use - one memory latency per pass instead of one per item
     const int gq = ow / 4;
-    for (int idx = threadIdx.x; idx < 64 * gq; idx += kRowThreads) {
-      const int rr = idx / gq, c4 = idx - rr * gq;
-      const int row = r0 + rr, o = o_base + 4 * c4;
-      float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (row < row_hi) {
-        const float4 dv = *reinterpret_cast<const float4*>(a.dy + (int64_t)row * a.NO + o);
-        v[0] = dv.x; v[1] = dv.y; v[2] = dv.z; v[3] = dv.w;
+    const int row_last = row_hi - 1;
+    for (int base = threadIdx.x; base < 64 * gq; base += 4 * kRowThreads) {
+      float4 dv[4], yv[4], rv[4];
+      float rsv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = min(base + u * kRowThreads, 64 * gq - 1);
+        const int rr = idx / gq, c4 = idx - rr * gq;
+        const int64_t off = (int64_t)min(r0 + rr, row_last) * a.NO + o_base + 4 * c4;
+        dv[u] = *reinterpret_cast<const float4*>(a.dy + off);
+        if (gbn) yv[u] = *reinterpret_cast<const float4*>(a.g_y + off);
+        if (a.relu_y != nullptr) rv[u] = *reinterpret_cast<const float4*>(a.relu_y + off);
+        rsv[u] = a.rowscale != nullptr ? a.rowscale[min(r0 + rr, row_last)] : 1.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = base + u * kRowThreads;
+        if (idx >= 64 * gq) break;
+        const int rr = idx / gq, c4 = idx - rr * gq;
+        const int o = o_base + 4 * c4;
+        float v[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w};
         if (gbn) {
-          const float4 yv = *reinterpret_cast<const float4*>(a.g_y + (int64_t)row * a.NO + o);
-          const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
+          const float yy[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const float xh = (yy[s] - gv[a.NO + o + s]) * gv[2 * a.NO + o + s];
             v[s] = gv[o + s] * (v[s] - gv[3 * a.NO + o + s] - xh * gv[4 * a.NO + o + s]);
           }
         }
-        if (a.rowscale != nullptr) {
-          const float rs = a.rowscale[row];
-#pragma unroll
-          for (int s = 0; s < 4; ++s) v[s] *= rs;
-        }
         if (a.relu_y != nullptr) {
-          const float4 yv = *reinterpret_cast<const float4*>(a.relu_y + (int64_t)row * a.NO + o);
-          if (!(yv.x > 0.0f)) v[0] = 0.0f;
-          if (!(yv.y > 0.0f)) v[1] = 0.0f;
-          if (!(yv.z > 0.0f)) v[2] = 0.0f;
-          if (!(yv.w > 0.0f)) v[3] = 0.0f;
+          if (!(rv[u].x > 0.0f)) v[0] = 0.0f;
+          if (!(rv[u].y > 0.0f)) v[1] = 0.0f;
+          if (!(rv[u].z > 0.0f)) v[2] = 0.0f;
+          if (!(rv[u].w > 0.0f)) v[3] = 0.0f;
         }
-      }
+        const bool ok = r0 + rr < row_hi;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) gt[rr * GP + 4 * c4 + s] = v[s];
+        for (int s = 0; s < 4; ++s) gt[rr * GP + 4 * c4 + s] = ok ? v[s] * rsv[u] : 0.0f;
+      }
     }
-    // stage x: 64 rows x (KI / 4) float4, seen through its BatchNorm
-    for (int idx = threadIdx.x; idx < 64 * (KI / 4); idx += kRowThreads) {
-      const int rr = idx / (KI / 4), c4 = idx - rr * (KI / 4);
-      const int row = r0 + rr, k = 4 * c4;
-      float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (row < row_hi) {
-        const float4 xv = *reinterpret_cast<const float4*>(x_at(a, row, k));
-        v[0] = xv.x; v[1] = xv.y; v[2] = xv.z; v[3] = xv.w;
-        if (a.x_bn != nullptr) {
+    for (int base = threadIdx.x; base < 64 * (KI / 4); base += 4 * kRowThreads) {
+      float4 xv[4], sc[4], sh[4];
 #pragma unroll
-          for (int s = 0; s < 4; ++s) v[s] = v[s] * a.x_bn[k + s] + a.x_bn[KI + k + s];
+      for (int u = 0; u < 4; ++u) {
+        const int idx = min(base + u * kRowThreads, 64 * (KI / 4) - 1);
+        const int rr = idx / (KI / 4), k = 4 * (idx - rr * (KI / 4));
+        xv[u] = *reinterpret_cast<const float4*>(x_at(a, min(r0 + rr, row_last), k));
+        if (a.x_bn != nullptr) {
+          sc[u] = *reinterpret_cast<const float4*>(a.x_bn + k);
+          sh[u] = *reinterpret_cast<const float4*>(a.x_bn + KI + k);
         }
       }
 #pragma unroll
-      for (int s = 0; s < 4; ++s) xt[rr * XP + k + s] = v[s];
+      for (int u = 0; u < 4; ++u) {
+        const int idx = base + u * kRowThreads;
+        if (idx >= 64 * (KI / 4)) break;
+        const int rr = idx / (KI / 4), k = 4 * (idx - rr * (KI / 4));
+        float v[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+        if (a.x_bn != nullptr) {
+          v[0] = v[0] * sc[u].x + sh[u].x;
+          v[1] = v[1] * sc[u].y + sh[u].y;
+          v[2] = v[2] * sc[u].z + sh[u].z;
+          v[3] = v[3] * sc[u].w + sh[u].w;
+        }
+        const bool ok = r0 + rr < row_hi;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) xt[rr * XP + k + s] = ok ? v[s] : 0.0f;
+      }
     }
     __syncthreads();
     if (wave_on) {
