@@ -37,20 +37,10 @@ __host__ __device__ inline int block_lds_floats(int nt, bool attn) {
   return f;
 }
 
-// In-kernel phase stamps (diagnostic build only, tools/block_timing.py): -DFETA_TIMING
 #ifdef FETA_TIMING
 __device__ unsigned long long feta_block_stamps[16];
-#define FETA_STAMP(i)                                                                   \
-  do {                                                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                  \
-    unsigned long long t_;                                                              \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
-    __builtin_amdgcn_sched_barrier(0);                                                  \
-    if (blockIdx.x == 0 && threadIdx.x == 0) feta_block_stamps[i] = t_;                 \
-  } while (0)
-#else
-#define FETA_STAMP(i)
 #endif
+#define FETA_STAMP(i) FETA_STAMP_TO(feta_block_stamps, i, blockIdx.x == 0 && threadIdx.x == 0)
 
 template <int NT>
 __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a) {

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(64) void colsum_wide_kernel(const float* __restrict
 }
 
 int launch_colsum_strided(const float* in, float* out, int R, int C, int ld, hipStream_t stream) {
-  if (R <= 64 && C >= 4096 && (C & 3) == 0 && (ld & 3) == 0 && aligned16(in) && aligned16(out)) {
+  if (R <= 256 && C >= 4096 && (C & 3) == 0 && (ld & 3) == 0 && aligned16(in) && aligned16(out)) {
     const int c4 = C / 4;
     auto kern = colsum_wide_kernel;
     hipLaunchKernelGGL(kern, dim3((c4 + 63) / 64), dim3(64), 0, stream, in, out, R, c4, ld);

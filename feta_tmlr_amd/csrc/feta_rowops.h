@@ -3,6 +3,21 @@
 #pragma once
 #include "feta_tiles.h"
 
+// In-kernel phase stamps, diagnostic build only (-DFETA_TIMING, tools/block_timing.py): s_memtime of
+// one chosen thread into a per-source-file device array.
+#ifdef FETA_TIMING
+#define FETA_STAMP_TO(arr, i, cond)                                                     \
+  do {                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+    unsigned long long t_;                                                              \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+    if (cond) arr[i] = t_;                                                              \
+  } while (0)
+#else
+#define FETA_STAMP_TO(arr, i, cond)
+#endif
+
 namespace feta {
 
 constexpr int kRowWaves = 4;

@@ -96,6 +96,6 @@ def test_batchnorm(emu, m, d):
     KC.check_bn(emu, CPU, None, m, d)
 
 
-@pytest.mark.parametrize('r,c', [(19, 4096 + 64), (3, 8192), (64, 4100), (70, 4096), (200, 48), (1, 16)])
+@pytest.mark.parametrize('r,c', [(19, 4096 + 64), (3, 8192), (64, 4100), (74, 4096), (300, 4096), (200, 48), (1, 16)])
 def test_colsum_shapes(emu, r, c):
     KC.check_colsum(emu, CPU, None, r, c)

@@ -125,6 +125,6 @@ def test_batchnorm(hip, m, d):
     KC.check_bn(abi, dev, stream, m, d)
 
 
-@pytest.mark.parametrize('r,c', [(19, 4096 + 64), (3, 8192), (64, 4100), (70, 4096), (200, 48), (1, 16)])
+@pytest.mark.parametrize('r,c', [(19, 4096 + 64), (3, 8192), (64, 4100), (74, 4096), (300, 4096), (200, 48), (1, 16)])
 def test_colsum_shapes(hip, r, c):
     KC.check_colsum(*hip, r, c)
