@@ -220,6 +220,12 @@ __global__ __launch_bounds__(kRowThreads) void rowlin_fwd_kernel(RowLinArgs a, R
   }
 }
 
+#ifdef FETA_TIMING
+__device__ unsigned long long feta_rowlin_stamps[32];
+#endif
+#define RL_STAMP_X(i) FETA_STAMP_TO(feta_rowlin_stamps, i, blockIdx.x == 0 && threadIdx.x == 0)
+#define RL_STAMP_W(i) FETA_STAMP_TO(feta_rowlin_stamps, 16 + (i), (int)blockIdx.x == ge.dx_blocks && threadIdx.x == 0)
+
 // ---- backward ---------------------------------------------------------------------------------
 // gradient source g(row, o) = T(dy)(row, o) * rowscale[row] * [relu_y > 0], with T = identity or
 // the BatchNorm backward  scale_o (dy - m1_o - xhat m2_o),  xhat = (g_y - mean_o) rstd_o,
@@ -279,6 +285,7 @@ __device__ void rowlin_dx_role(const RowLinArgs& a, const RowLinGeom& ge, const 
       }
     }
   };
+  RL_STAMP_X(1);
   Batch cur;
   load_batch(rg, cur);
 
@@ -296,6 +303,7 @@ __device__ void rowlin_dx_role(const RowLinArgs& a, const RowLinGeom& ge, const 
   if (want_sums)
     for (int i = threadIdx.x; i < kRowWaves * 2 * ks; i += kRowThreads) red[i] = 0.0f;
   __syncthreads();
+  RL_STAMP_X(2);
   float* my = red + wave_id() * 2 * ks;
   const int nrb = (a.M + kRowsPerBlock - 1) / kRowsPerBlock;
   for (int rb = rg; rb < nrb; rb += ge.G) {
@@ -374,6 +382,7 @@ __device__ void rowlin_dx_role(const RowLinArgs& a, const RowLinGeom& ge, const 
       }
     }
   }
+  RL_STAMP_X(3);
   if (want_sums) {
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * ks; i += kRowThreads) {
@@ -386,6 +395,7 @@ __device__ void rowlin_dx_role(const RowLinArgs& a, const RowLinGeom& ge, const 
       }
     }
   }
+  RL_STAMP_X(4);
 }
 
 template <int KI>
@@ -553,7 +563,9 @@ __device__ void rowlin_dw_role_lds(const RowLinArgs& a, const RowLinGeom& ge, co
         for (int s = 0; s < 4; ++s) xt[rr * XP + k + s] = ok ? v[s] : 0.0f;
       }
     }
+    RL_STAMP_W(2);
     __syncthreads();
+    RL_STAMP_W(3);
     if (wave_on) {
       const int ol = 16 * wave_id() + lq;
 #pragma unroll 4
@@ -566,6 +578,7 @@ __device__ void rowlin_dw_role_lds(const RowLinArgs& a, const RowLinGeom& ge, co
       }
     }
   }
+  RL_STAMP_W(4);
   if (!wave_on) return;
   float* p = a.partial + (int64_t)rc * (a.partial_ld > 0 ? (int64_t)a.partial_ld : (int64_t)a.NO * KI + a.NO);
 #pragma unroll
@@ -575,11 +588,14 @@ __device__ void rowlin_dw_role_lds(const RowLinArgs& a, const RowLinGeom& ge, co
   db += shfl_xor(db, 16);
   db += shfl_xor(db, 32);
   if (g == 0) p[(int64_t)a.NO * KI + 16 * ot + lq] = db;
+  RL_STAMP_W(5);
 }
 
 template <int KI, int NO>
 __global__ __launch_bounds__(kRowThreads) void rowlin_bwd_kernel(RowLinArgs a, RowLinGeom ge) {
   const int lane = lane_id(), lq = lane & 15, g = lane >> 4;
+  RL_STAMP_X(0);
+  RL_STAMP_W(0);
   float* gv = feta_lds;  // [5][NO] parameters of the gradient-side BatchNorm backward
   float* after = gv;
   if (a.g_y != nullptr) {
@@ -609,6 +625,7 @@ __global__ __launch_bounds__(kRowThreads) void rowlin_bwd_kernel(RowLinArgs a, R
     }
     __syncthreads();
   }
+  RL_STAMP_W(1);
   if ((int)blockIdx.x < ge.dx_blocks) {
     rowlin_dx_role<NO>(a, ge, gv, after, lq, g);
   } else {
@@ -888,6 +905,12 @@ extern "C" int feta_rowlin_fwd_ex(const feta_rowlin_ex* d, feta_stream_t stream)
 #undef CALL
   return check_launch("feta_rowlin_fwd");
 }
+
+#ifdef FETA_TIMING
+extern "C" int feta_debug_rowlin_stamps(unsigned long long* out32) {
+  return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(feta_rowlin_stamps), sizeof(unsigned long long) * 32);
+}
+#endif
 
 extern "C" int feta_rowlin_bwd_ex(const feta_rowlin_ex* d, float* dwdb, feta_stream_t stream) {
   FETA_REQUIRE(d != nullptr, "rowlin_bwd_ex: null descriptor");
