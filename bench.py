@@ -120,42 +120,55 @@ def time_kernel(fn, iters):
 
 
 def roofline(args, gpu, dev):
-    """Times the hand-written kernels of one step in isolation (HIP events on the stream they are
-    launched on - torch's current stream), picks the DOMINANT one = largest launches-per-step x
-    launch time, and prices it against the HBM roofline with its algorithmic bytes (DESIGN.md
-    section 3).  `traffic` = HBM bytes per launch from the rocprofv3 PMC passes committed in
-    profiles/traffic.json (FETCH_SIZE x2 + WRITE_SIZE, see tools/pmc_summary.py), null if absent."""
+    """Times the hand-written kernels of one step in isolation, in exactly the variants the fused stack
+    issues (feta_tmlr_amd/benchcases.py; HIP events on the stream they are launched on - torch's
+    current stream), picks the DOMINANT one = largest launches-per-step x launch time, and prices it
+    against the HBM roofline with its algorithmic bytes.  `traffic` = HBM bytes
+    per launch from the rocprofv3 PMC passes committed in profiles/traffic.json (FETCH_SIZE x2 +
+    WRITE_SIZE, tools/pmc_summary.py), null if absent."""
+    from feta_tmlr_amd.benchcases import stack_layer_cases
     abi, st = _lib.abi(), _lib.stream_handle()
     b, n, h, d = args.batch, args.n_pad, args.heads, args.dim
-    dh, m, k_eig, p = d // h, args.n_pad * args.batch, args.k_eig, args.order
+    dh, k_eig, p = d // h, args.k_eig, args.order
     c = p * dh * dh
     L = args.layers
+    nr = gpu['cache'].n_real
     rnd = lambda *s: torch.randn(*s, device=dev)
+    cand = []   # (name, launches per step, fn, algorithmic bytes)
+    for name, per_layer, fn, nbytes, _ in stack_layer_cases(abi, st, dev, b, n, d, h, 2 * d, gpu['pe'], nr):
+        if name == 'attn_block_fwd (no attn write)':
+            cnt = L - 1
+        elif name == 'attn_block_fwd (+attn write)':
+            cnt = 1
+        elif 'linear2' in name:
+            cnt = L + 1      # + linear_cat backward (same shape class)
+        else:
+            cnt = L
+        cand.append((name, cnt, fn, nbytes))
     qkv = rnd(n, b, 3 * d)
     v5 = qkv.view(n, b, 3, h, dh)
     q, k, v = (v5[:, :, i].permute(1, 0, 2, 3) for i in range(3))
-    out = torch.empty(n, b, h, dh, device=dev).permute(1, 0, 2, 3)
-    attn = torch.empty(b, h, n, n, device=dev)
-    stats = torch.empty(b, h, n, 2, device=dev)
-    nr = gpu['cache'].n_real
+    tok = lambda: torch.empty(n, b, h, dh, device=dev).permute(1, 0, 2, 3)
+    out, dout = tok(), rnd(n, b, h, dh).permute(1, 0, 2, 3)
+    stats = torch.rand(b, h, n, 2, device=dev) + 1.0
+    delta = torch.empty(b, h, n, device=dev)
+    dqkv = torch.empty_like(qkv)
+    g5 = dqkv.view(n, b, 3, h, dh)
+    dq, dk, dv = (g5[:, :, i].permute(1, 0, 2, 3) for i in range(3))
     sc = dh ** -0.5
-    cand = []   # (name, launches per step, fn, algorithmic bytes)
-    cand.append(('attn_fwd (+attn write)', 1, lambda: abi.attn_fwd(q, k, v, gpu['pe'], nr, out, attn, stats, sc, st),
-                 4 * b * (3 * n * d + n * n + n * d + 2 * h * n + h * n * n)))
-    cand.append(('attn_fwd (no attn write)', L - 1, lambda: abi.attn_fwd(q, k, v, gpu['pe'], nr, out, None, stats, sc, st),
-                 4 * b * (3 * n * d + n * n + n * d + 2 * h * n)))
-    G = abi.rowlin_blocks(m)
-    for (nm, ki, no, cnt) in (('in_proj', d, 3 * d, L), ('out_proj', d, d, L), ('linear1', d, 2 * d, L),
-                              ('linear2', 2 * d, d, L)):
-        x, w, bb, y = rnd(m, ki), rnd(no, ki), rnd(no), torch.empty(m, no, device=dev)
-        sto = torch.empty(G, 2, no, device=dev)
-        cand.append(('rowlin_fwd ' + nm, cnt, (lambda x=x, w=w, bb=bb, y=y, sto=sto: abi.rowlin_fwd(x, w, bb, None, None, y, sto, False, st)),
-                     4 * (m * ki + no * ki + m * no)))
-    xs = rnd(n, b, h, dh).permute(1, 0, 2, 3)
-    ys = torch.empty(n, b, h, dh, device=dev).permute(1, 0, 2, 3)
+    cand.append(('attn_bwd (dq + dkdv)', L,
+                 lambda: abi.attn_bwd(q, k, v, gpu['pe'], nr, out, dout, stats, delta, dq, dk, dv, sc, st),
+                 4 * b * (3 * n * d + 2 * n * d + n * n + 2 * h * n + 3 * n * d + h * n)))
+    xs, dys = rnd(n, b, h, dh).permute(1, 0, 2, 3), rnd(n, b, h, dh).permute(1, 0, 2, 3)
+    ys, dxs = tok(), tok()
     coeff, bias = rnd(h * b, c), rnd(dh)
-    cand.append(('spec_filter_fwd', 1, lambda: abi.spec_filter_fwd(xs, gpu['cache'].u, gpu['cache'].lam, coeff, bias, nr, ys, p, 1, st),
+    dcoeff, dbp = torch.empty_like(coeff), torch.empty(b * h, dh, device=dev)
+    u, lam = gpu['cache'].u, gpu['cache'].lam
+    cand.append(('spec_filter_fwd', 1, lambda: abi.spec_filter_fwd(xs, u, lam, coeff, bias, nr, ys, p, 1, st),
                  4 * b * (n * d + n * k_eig + k_eig + h * c + n * d)))
+    cand.append(('spec_filter_bwd', 1,
+                 lambda: abi.spec_filter_bwd(xs, u, lam, coeff, nr, dys, dxs, dcoeff, dbp, p, 1, st),
+                 4 * b * (2 * n * d + n * k_eig + k_eig + h * c + n * d + h * c)))
     rows = []
     for name, cnt, fn, nbytes in cand:
         t = time_kernel(fn, args.kernel_iters)

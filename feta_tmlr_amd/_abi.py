@@ -301,6 +301,10 @@ class Abi:
     def attn_block_fwd(self, b, n, scale, stream, seq_first=True, momentum=0.1, eps=1e-5, Gx=0, tie_qk=False,
                        **ptrs):
         """feta_attn_block_fwd; tensor-valued keyword arguments become the descriptor's pointers."""
+        self.attn_block_launch(self.attn_block_desc(b, n, scale, seq_first, momentum, eps, Gx, tie_qk, **ptrs),
+                               stream)
+
+    def attn_block_desc(self, b, n, scale, seq_first=True, momentum=0.1, eps=1e-5, Gx=0, tie_qk=False, **ptrs):
         d = AttnBlock()
         d.B, d.N, d.M, d.scale = b, n, b * n, scale
         d.row_sb, d.row_sn = (1, b) if seq_first else (n, 1)
@@ -308,7 +312,10 @@ class Abi:
         for k, t in ptrs.items():
             if t is not None:
                 setattr(d, k, t.data_ptr())
-        self._check(self.lib.feta_attn_block_fwd(C.byref(d), stream), 'feta_attn_block_fwd')
+        return d
+
+    def attn_block_launch(self, desc, stream):
+        self._check(self.lib.feta_attn_block_fwd(C.byref(desc), stream), 'feta_attn_block_fwd')
 
     def ffn_supported(self, d_model, ff):
         return bool(self.lib.feta_ffn_supported(d_model, ff))
@@ -318,12 +325,18 @@ class Abi:
 
     def ffn_fwd(self, m, ff, stream, momentum=0.1, eps=1e-5, Gx=0, **ptrs):
         """feta_ffn_fwd; tensor-valued keyword arguments become the descriptor's pointers."""
+        self.ffn_launch(self.ffn_desc(m, ff, momentum, eps, Gx, **ptrs), stream)
+
+    def ffn_desc(self, m, ff, momentum=0.1, eps=1e-5, Gx=0, **ptrs):
         d = Ffn()
         d.M, d.FF, d.momentum, d.eps, d.Gx = m, ff, momentum, eps, Gx
         for k, t in ptrs.items():
             if t is not None:
                 setattr(d, k, t.data_ptr())
-        self._check(self.lib.feta_ffn_fwd(C.byref(d), stream), 'feta_ffn_fwd')
+        return d
+
+    def ffn_launch(self, desc, stream):
+        self._check(self.lib.feta_ffn_fwd(C.byref(desc), stream), 'feta_ffn_fwd')
 
     def bn_apply_fwd_prm(self, y, stats, gamma, beta, out, bn_prm, running_mean, running_var, momentum,
                          eps, stream):

@@ -1,0 +1,82 @@
+"""Launch closures of the kernels of one fused-stack layer in exactly the variants the stack issues
+(feta_tmlr_amd/fused_stack.py), with their algorithmic HBM bytes - shared by
+bench.py (roofline object) and tools/kernel_bench.py (per-kernel timing, PMC traffic passes).
+
+Every entry: (name, launches per layer, fn, algorithmic bytes per launch, kernel symbols of one call).
+"""
+import torch
+
+
+def stack_layer_cases(abi, st, dev, b, n, d, heads, ff, pe, n_real, last_layer_attn=True, seed=0):
+    m = b * n
+    dh = d // heads
+    g = torch.Generator().manual_seed(seed)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    new = lambda *s: torch.empty(*s, device=dev)
+    f4 = 4
+    G = abi.rowlin_blocks(m)
+    RC = abi.rowlin_chunks(m)
+    cases = []
+    prm = torch.rand(4, max(d, ff, 3 * d), generator=g).to(dev) + 0.5
+
+    def prm_of(c):
+        return prm[:, :c].contiguous()
+
+    if abi.attn_block_supported(n, d, heads):
+        x, w_in, b_in = rnd(m, d), rnd(3 * d, d) / d ** 0.5, rnd(3 * d)
+        w_o, b_o, deg = rnd(d, d) / d ** 0.5, rnd(d), torch.rand(m, generator=g).to(dev)
+        qkv, out, y1, st1 = new(m, 3 * d), new(m, d), new(m, d), new(b, 2, d)
+        ast, attn = new(b, heads, n, 2), new(b, heads, n, n)
+        stats_prev = rnd(G, 2, d).abs()
+        common = dict(x=x, w_in=w_in, b_in=b_in, w_out=w_o, b_out=b_o, pe=pe, n_real=n_real, rowscale=deg,
+                      qkv=qkv, out=out, attn_stats=ast, y=y1, y_stats=st1, x_stats=stats_prev, Gx=G,
+                      x_gamma=prm_of(d)[0], x_beta=prm_of(d)[1], x_bn_out=new(4, d))
+        base = b * (n * d + (n * n if pe is not None else 0) + 3 * n * d + n * d + 2 * heads * n + n * d) + 4 * d * d
+        scale = dh ** -0.5
+        # descriptors are built once: the eager timing loop must not be bound by Python
+        d0 = abi.attn_block_desc(b, n, scale, attn=None, **common)
+        d1 = abi.attn_block_desc(b, n, scale, attn=attn, **common)
+        cases.append(('attn_block_fwd (no attn write)', 1.0,
+                      lambda: (abi.attn_block_launch(d0, st), common)[0], f4 * base, ['attn_block_fwd']))
+        if last_layer_attn:
+            cases.append(('attn_block_fwd (+attn write)', 0.0,
+                          lambda: (abi.attn_block_launch(d1, st), common)[0],
+                          f4 * (base + b * heads * n * n), ['attn_block_fwd']))
+    if abi.ffn_supported(d, ff):
+        x, w1, b1, w2, b2 = rnd(m, d), rnd(ff, d) / d ** 0.5, rnd(ff), rnd(d, ff) / ff ** 0.5, rnd(d)
+        hbuf, y2, st2 = new(m, ff), new(m, d), new(abi.ffn_blocks(m), 2, d)
+        g1 = min(b, 256)      # the stack caps the partial rows a consumer re-reduces (fused_stack.MAX_STAT_ROWS)
+        stats1 = rnd(g1, 2, d).abs()
+        fkw = dict(x=x, w1=w1, b1=b1, w2=w2, b2=b2, h=hbuf, y=y2, y_stats=st2, x_stats=stats1,
+                   x_gamma=prm_of(d)[0], x_beta=prm_of(d)[1], x_bn_out=new(4, d))
+        fd = abi.ffn_desc(m, ff, Gx=g1, **fkw)
+        cases.append(('ffn_fwd', 1.0, lambda: (abi.ffn_launch(fd, st), fkw)[0],
+                      f4 * (m * d + 2 * d * ff + m * ff + m * d), ['ffn_fwd']))
+
+    def bwd_case(name, ki, no, extras):
+        x, w, dy, dx = rnd(m, ki), rnd(no, ki) / ki ** 0.5, rnd(m, no), new(m, ki)
+        total = no * ki + no
+        part = new(RC, total)
+        kw = dict(x=x, w=w, dy=dy, dx=dx, partial_ptr=part.data_ptr(), partial_ld=total)
+        nbytes = m * ki + no * ki + m * no + m * ki + RC * total        # x, W, dy -> dx, partials
+        if 'g' in extras:       # BatchNorm backward folded into the gradient loads
+            kw.update(g_y=rnd(m, no), g_bn=prm_of(no), g_sum=rnd(G, 2, no), Gs=G, g_fin_out=new(2, no),
+                      dgamma=new(no), dbeta=new(no))
+            nbytes += m * no
+        if 'r' in extras:       # relu mask from the saved activation
+            kw.update(relu_y=rnd(m, no))
+            nbytes += m * no
+        if 'a' in extras:       # residual gradient through a BatchNorm backward, added in the epilogue
+            kw.update(add_dout=rnd(m, ki), add_y=rnd(m, ki), add_bn=prm_of(ki), add_fin=rnd(2, ki))
+            nbytes += 2 * m * ki
+        if 's' in extras:       # partial sums for the previous BatchNorm backward (its y is x itself)
+            kw.update(sum_y=x, sum_bn=prm_of(ki), sum_out=new(G, 2, ki))
+        dsc = abi.rowlin_ex(m, ki, no, **kw)
+        keep = (x, w, dy, dx, part, kw)
+        cases.append((name, 1.0, lambda: (abi.rowlin_bwd_ex(dsc, None, st), keep)[0], f4 * nbytes, ['rowlin_bwd']))
+
+    bwd_case('rowlin_bwd linear2 (stack: BN-backward gradient)', ff, d, 'g')
+    bwd_case('rowlin_bwd linear1 (stack: relu, add, sums)', d, ff, 'ras')
+    bwd_case('rowlin_bwd out_proj (stack: BN-backward gradient)', d, d, 'g')
+    bwd_case('rowlin_bwd in_proj (stack: add, sums)', d, 3 * d, 'as')
+    return cases

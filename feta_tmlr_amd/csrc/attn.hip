@@ -671,9 +671,8 @@ void launch_fwd_t(const AttnArgs& a, hipStream_t stream) {
   // per-wave staging block of the probability tile: 16 rows x (16 KT_MAX + 1) floats
   const size_t lds = a.attn != nullptr ? sizeof(float) * kWaves * 16 * (16 * KT_MAX + 1) : 0;
   auto kern = attn_fwd_kernel<DH, KT_MAX>;
-  if (lds > 64 * 1024)  // KT_MAX = 16: 65.8 KB, above the 64 KB default dynamic-LDS cap
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static size_t lds_seen = 0;  // KT_MAX = 16: 65.8 KB, above the 64 KB default dynamic-LDS cap
+  allow_dynamic_lds(kern, lds, lds_seen);
   hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
 }
 

@@ -326,8 +326,8 @@ template <int NT>
 int launch_block_fwd(const BlockArgs& a, hipStream_t stream) {
   const size_t lds = sizeof(float) * block_lds_floats(NT, a.attn != nullptr);
   auto kern = attn_block_fwd_kernel<NT>;
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static size_t lds_seen = 0;
+  allow_dynamic_lds(kern, lds, lds_seen);
   hipLaunchKernelGGL(kern, dim3(a.B), dim3(kRowThreads), lds, stream, a);
   return check_launch("feta_attn_block_fwd");
 }

@@ -183,8 +183,8 @@ template <int FF>
 int launch_ffn_fwd(const FfnArgs& a, hipStream_t stream) {
   const size_t lds = sizeof(float) * ffn_lds_floats(FF);
   auto kern = ffn_fwd_kernel<FF>;
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static size_t lds_seen = 0;
+  allow_dynamic_lds(kern, lds, lds_seen);
   const int grid = (a.M + kFfnRows - 1) / kFfnRows;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kRowThreads), lds, stream, a);
   return check_launch("feta_ffn_fwd");

@@ -860,9 +860,8 @@ void launch_bwd_ki(const RowLinArgs& a, const RowLinGeom& ge, int grid, size_t l
 #define CALL(NOV)                                                                   \
   {                                                                                 \
     auto kern = rowlin_bwd_kernel<KI, NOV>;                                         \
-    if (lds > 64 * 1024)                                                            \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    static size_t lds_seen = 0;                                                     \
+    allow_dynamic_lds(kern, lds, lds_seen);                                         \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kRowThreads), lds, stream, a, ge);    \
   }
   FETA_DIM_SWITCH(a.NO, CALL)

@@ -59,6 +59,19 @@ def stack_supported(layers, d_model):
     return True
 
 
+MAX_STAT_ROWS = 256   # every consumer workgroup re-reduces the partial statistics: keep them few
+
+
+def _cap_partials(abi, stream, st, new):
+    """[G, 2, D] partial BatchNorm sums -> the same if G is small, else their total as [1, 2, D]
+    (one extra reduction launch, only at batch sizes where a step takes milliseconds anyway)."""
+    if st.shape[0] <= MAX_STAT_ROWS:
+        return st, st.shape[0]
+    tot = new(1, 2, st.shape[2])
+    abi.colsum(st.view(st.shape[0], -1), tot.view(-1), stream)
+    return tot, 1
+
+
 class FusedEncoderStackFn(torch.autograd.Function):
 
     @staticmethod
@@ -106,6 +119,7 @@ class FusedEncoderStackFn(torch.autograd.Function):
                 abi.attn_block_fwd(b, n, scale, stream, tie_qk=tie, x=y_prev, w_in=w_in, b_in=b_in, w_out=w_o,
                                    b_out=b_o, pe=pe_c, n_real=n_real, rowscale=degree_rows, qkv=qkv, out=out,
                                    attn_stats=ast, attn=attn, y=y1, y_stats=st1, **bn_prev)
+                st1, G1 = _cap_partials(abi, stream, st1, new)
             else:
                 # F1
                 dsc = abi.rowlin_ex(m, d, 3 * d, x=y_prev if li else x_in, w=w_in, bias=b_in, y=qkv, **bn_prev)
@@ -131,6 +145,7 @@ class FusedEncoderStackFn(torch.autograd.Function):
                 G2 = abi.ffn_blocks(m)
                 st2 = new(G2, 2, d)
                 abi.ffn_fwd(m, ff, stream, x=y1, w1=w1, b1=bb1, w2=w2, b2=bb2, h=h, y=y2, y_stats=st2, **bn1)
+                st2, G2 = _cap_partials(abi, stream, st2, new)
             else:
                 # F4
                 dsc = abi.rowlin_ex(m, d, ff, relu=True, x=y1, w=w1, bias=bb1, y=h, **bn1)

@@ -254,3 +254,17 @@ def check_attn_block_equals_three_launches(dev, hook, monkeypatch, shape, n_min,
 def test_attn_block_equals_three_launches(emu, monkeypatch, shape, n_min, n_max, tie_qk, pe_on):
     check_attn_block_equals_three_launches(CPU, lambda: _lib.override_for_tests(emu), monkeypatch, shape,
                                            n_min, n_max, tie_qk, pe_on)
+
+
+def test_capped_statistics_partials_give_the_same_result(emu, monkeypatch):
+    """large batches: the per-workgroup BatchNorm partial sums are reduced once before their consumers
+    (fused_stack.MAX_STAT_ROWS); forced here with a cap of 2 rows"""
+    from feta_tmlr_amd import fused_stack
+    model, batch9, cache = _model_case(True, 1, 'spectral', True, bsz=4, d=64, heads=4, layers=2, order=2)
+    hook = lambda: _lib.override_for_tests(emu)
+    a = _stack_run(model, batch9, cache, True, monkeypatch, hook)
+    monkeypatch.setattr(fused_stack, 'MAX_STAT_ROWS', 2)
+    b = _stack_run(model, batch9, cache, True, monkeypatch, hook)
+    KC.assert_close('output', b[0], a[0].double(), tol=2e-6)
+    for k in a[3]:
+        KC.assert_close('grad ' + k, b[3][k], a[3][k].double(), tol=1e-5)

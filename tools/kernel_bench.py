@@ -87,18 +87,6 @@ def main():
     add('attn_bwd (dq + dkdv)', lambda: abi.attn_bwd(q, kk, v, pe, nr, out, dout, stats, delta, dq, dk, dv, sc, st),
         f4 * b * (3 * n * d + 2 * n * d + n * n + 2 * h * n + 3 * n * d + h * n))
 
-    if abi.attn_block_supported(n, d, h) and not bf:
-        xb, w_in, b_in, w_o, b_o = rnd(m, d), rnd(3 * d, d) / d ** 0.5, rnd(3 * d), rnd(d, d) / d ** 0.5, rnd(d)
-        yb1, stb1 = torch.empty(m, d, device=dev), torch.empty(b, 2, d, device=dev)
-        outb = torch.empty(n, b, h, dh, device=dev)
-        deg = torch.rand(m, generator=g).to(dev)
-        for nm, att in (('attn_block_fwd (+attn write)', attn), ('attn_block_fwd (no attn write)', None)):
-            add(nm, lambda att=att: abi.attn_block_fwd(b, n, sc, st, x=xb, w_in=w_in, b_in=b_in, w_out=w_o, b_out=b_o,
-                                                       pe=pe, n_real=nr, rowscale=deg, qkv=qkv, out=outb,
-                                                       attn_stats=stats, attn=att, y=yb1, y_stats=stb1),
-                f4 * (b * (n * d + n * n + 3 * n * d + n * d + 2 * h * n + n * d + (h * n * n if att is not None else 0))
-                      + 4 * d * d))
-
     s = rnd(c)
     gb = rnd(c) * 0.1
     cj = torch.empty(h * b, n, device=dev)
@@ -157,6 +145,11 @@ def main():
     dyb = torch.empty(m, d, device=dev)
     dg, dbt = torch.empty(d, device=dev), torch.empty(d, device=dev)
     add('bn_bwd (reduce + apply)', lambda: abi.bn_bwd(yb, ob, mr, gm, pb, dyb, dg, dbt, st), f4 * 5 * m * d)
+
+    if not bf:   # the kernels of a fused-stack layer in the variants the stack issues
+        from feta_tmlr_amd.benchcases import stack_layer_cases
+        for name, _, fn, nbytes, _ in stack_layer_cases(abi, st, dev, b, n, d, h, 2 * d, pe, nr):
+            add(name, fn, nbytes)
 
     if a.json:
         print(json.dumps({'batch': b, 'mean_nodes': mean_n,

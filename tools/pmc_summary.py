@@ -16,17 +16,25 @@ ROWS = [  # (bench row, kernel-symbol substrings enqueued by one call, in order)
     ('attn_fwd (no attn write)', ['attn_fwd']),
     ('attn_bwd (dq + dkdv)', ['attn_bwd_dq', 'attn_bwd_dkdv']),
     ('coeff_fwd', ['coeff_fwd_kernel']),
-    ('coeff_bwd', ['coeff_bwd_kernel', 'colsum_kernel', 'colsum_kernel']),
+    ('coeff_bwd', ['coeff_bwd_kernel', 'colsum']),
     ('spec_filter_fwd', ['spec_fwd']),
     ('spec_filter_bwd', ['spec_bwd']),
     ('cheb_filter_fwd', ['cheb_fwd']),
     ('cheb_filter_bwd', ['cheb_bwd']),
-    ('rowlin_fwd in_proj', ['rowlin_fwd']), ('rowlin_bwd in_proj', ['rowlin_bwd', 'colsum_kernel']),
-    ('rowlin_fwd out_proj', ['rowlin_fwd']), ('rowlin_bwd out_proj', ['rowlin_bwd', 'colsum_kernel']),
-    ('rowlin_fwd linear1', ['rowlin_fwd']), ('rowlin_bwd linear1', ['rowlin_bwd', 'colsum_kernel']),
-    ('rowlin_fwd linear2', ['rowlin_fwd']), ('rowlin_bwd linear2', ['rowlin_bwd', 'colsum_kernel']),
+    ('rowlin_fwd in_proj', ['rowlin_fwd']), ('rowlin_bwd in_proj', ['rowlin_bwd', 'colsum']),
+    ('rowlin_fwd out_proj', ['rowlin_fwd']), ('rowlin_bwd out_proj', ['rowlin_bwd', 'colsum']),
+    ('rowlin_fwd linear1', ['rowlin_fwd']), ('rowlin_bwd linear1', ['rowlin_bwd', 'colsum']),
+    ('rowlin_fwd linear2', ['rowlin_fwd']), ('rowlin_bwd linear2', ['rowlin_bwd', 'colsum']),
     ('bn_apply_fwd', ['bn_apply_fwd']),
     ('bn_bwd (reduce + apply)', ['bn_bwd_reduce', 'bn_bwd_apply']),
+    # feta_tmlr_amd/benchcases.py: the kernels of one fused-stack layer, in the stack's variants
+    ('attn_block_fwd (no attn write)', ['attn_block_fwd']),
+    ('attn_block_fwd (+attn write)', ['attn_block_fwd']),
+    ('ffn_fwd', ['ffn_fwd']),
+    ('rowlin_bwd linear2 (stack: BN-backward gradient)', ['rowlin_bwd']),
+    ('rowlin_bwd linear1 (stack: relu, add, sums)', ['rowlin_bwd']),
+    ('rowlin_bwd out_proj (stack: BN-backward gradient)', ['rowlin_bwd']),
+    ('rowlin_bwd in_proj (stack: add, sums)', ['rowlin_bwd']),
 ]
 
 
