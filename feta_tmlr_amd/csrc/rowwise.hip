@@ -234,15 +234,23 @@ __device__ unsigned long long feta_rowlin_stamps[32];
 template <int NO>
 __device__ void rowlin_dx_role(const RowLinArgs& a, const RowLinGeom& ge, const float* gv,
                                float* lds_free, int lq, int g) {
+  // A workgroup = 64 rows x up to 4 k tiles.  The gradient tile g[64][NO] is staged ONCE in LDS with all
+  // transforms applied (BatchNorm backward, relu mask, row scale); a wave owns ONE k tile: its weight
+  // column slice W[:, k tile] sits in registers for the whole launch (NO/4 values per lane) and the
+  // wave walks the row tiles with it, reading the gradient rows as 16-byte LDS operands.  Per MFMA that
+  // is 1/4 of an LDS read instead of one, and a wave's columns are its own (no cross-wave sums unless
+  // fewer than 4 k tiles leave waves free to split the rows).
+  constexpr int GP = NO + 4, NJ = Feat<NO>::NJ;
   const int rg = blockIdx.x % ge.G, kg = blockIdx.x / ge.G;
-  const int ks = ge.TG * 16, ldw = ks + 4;
+  const int ks = ge.TG * 16;
   const int k_base = kg * ks;
   const int ntile = min(ge.TG, a.KI / 16 - kg * ge.TG);
-  float* wt = lds_free;                // [NO][ldw]: W[:, k_base : k_base + 16 ntile]
-  float* red = wt + NO * ldw;          // [kRowWaves][2][ks] partial sums for the next BN backward
-  float* ev = red + kRowWaves * 2 * ks;  // [7][ks] epilogue vectors of this k slice:
+  float* gt = lds_free;          // [64][GP]
+  float* ev = gt + 64 * GP;      // [7][ks] epilogue vectors of this k slice:
   // add_bn scale, mean, rstd; add_fin m1, m2; sum_bn mean, rstd
+  float* red = ev + 7 * ks;      // [kRowWaves][2][16] column sums of the waves
   const bool want_sums = a.sum_out != nullptr;
+  const bool gbn = a.g_y != nullptr;
   for (int i = threadIdx.x; i < ks; i += kRowThreads) {
     const int k = k_base + i;
     const bool kok = k < a.KI;
@@ -255,128 +263,115 @@ __device__ void rowlin_dx_role(const RowLinArgs& a, const RowLinGeom& ge, const 
     ev[5 * ks + i] = (want_sums && kok) ? a.sum_bn[2 * a.KI + k] : 0.0f;
     ev[6 * ks + i] = (want_sums && kok) ? a.sum_bn[3 * a.KI + k] : 0.0f;
   }
-  // load batch of a row block (clamped row, unconditional): gradient row, its BatchNorm / relu
-  // companions and every epilogue operand; the first one is issued before the weight staging
-  struct Batch {
-    float rs;
-    Feat<NO> gf, gyf, ryf;
-    float4 pv4[4], dv4[4], ay4[4], sy4[4];
-  };
-  auto load_batch = [&](int rb, Batch& B) {
-    const int row = rb * kRowsPerBlock + wave_id() * 16 + lq;
-    const bool rok = row < a.M;
-    const int rowc = min(row, a.M - 1);
-    B.rs = a.rowscale != nullptr ? a.rowscale[rowc] : 1.0f;
-    load_row_sel<NO>(B.gf, a.dy + (int64_t)rowc * NO, rok, g);
-    if (a.g_y != nullptr) load_row_sel<NO>(B.gyf, a.g_y + (int64_t)rowc * NO, true, g);
-    if (a.relu_y != nullptr) load_row_sel<NO>(B.ryf, a.relu_y + (int64_t)rowc * NO, true, g);
-    const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  // wave -> (k tile, row tiles): 4 tiles: one tile, all 4 row tiles; 2 tiles: 2 row tiles; 1 tile: 1
+  const int w = wave_id();
+  const int groups = kRowWaves / ntile, per = 4 / (groups > 0 ? groups : 1);
+  const bool active = w < groups * ntile;
+  const int t = active ? w % ntile : 0, rt0 = active ? (w / ntile) * per : 0;
+  const int kcol = k_base + 16 * t + lq;
+  float wA[NJ][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      B.pv4[t] = z4; B.dv4[t] = z4; B.ay4[t] = z4; B.sy4[t] = z4;
-      if (t < ntile) {
-        const int64_t off = (int64_t)rowc * a.KI + k_base + 16 * t + 4 * g;
-        if (a.add_plain != nullptr) B.pv4[t] = *reinterpret_cast<const float4*>(a.add_plain + off);
-        if (a.add_dout != nullptr) {
-          B.dv4[t] = *reinterpret_cast<const float4*>(a.add_dout + off);
-          B.ay4[t] = *reinterpret_cast<const float4*>(a.add_y + off);
-        }
-        if (want_sums) B.sy4[t] = *reinterpret_cast<const float4*>(a.sum_y + off);
-      }
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int o = 16 * j + 4 * g + s;
+      const float wv = a.w[(int64_t)(o < NO ? o : 0) * a.KI + (kcol < a.KI ? kcol : 0)];
+      wA[j][s] = (o < NO && kcol < a.KI && active) ? wv : 0.0f;
     }
-  };
   RL_STAMP_X(1);
-  Batch cur;
-  load_batch(rg, cur);
-
-  const int rowvec = ntile * 4;
-  stage_float4(
-      NO * rowvec,
-      [&](int idx) {
-        const int o = idx / rowvec, c4 = idx - o * rowvec;
-        return reinterpret_cast<const float4*>(a.w + (int64_t)o * a.KI + k_base + 4 * c4);
-      },
-      [&](int idx) {
-        const int o = idx / rowvec, c4 = idx - o * rowvec;
-        return reinterpret_cast<float4*>(wt + o * ldw + 4 * c4);
-      });
-  if (want_sums)
-    for (int i = threadIdx.x; i < kRowWaves * 2 * ks; i += kRowThreads) red[i] = 0.0f;
-  __syncthreads();
-  RL_STAMP_X(2);
-  float* my = red + wave_id() * 2 * ks;
+  float sum1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, sum2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   const int nrb = (a.M + kRowsPerBlock - 1) / kRowsPerBlock;
+  constexpr int gq = NO / 4;
   for (int rb = rg; rb < nrb; rb += ge.G) {
-    const int row = rb * kRowsPerBlock + wave_id() * 16 + lq;
-    const bool rok = row < a.M;
-    if (rb != rg) load_batch(rb, cur);
-    const float rs = cur.rs;
-    Feat<NO>& gf = cur.gf;
-    Feat<NO>& gyf = cur.gyf;
-    Feat<NO>& ryf = cur.ryf;
-    float4 (&pv4)[4] = cur.pv4;
-    float4 (&dv4)[4] = cur.dv4;
-    float4 (&ay4)[4] = cur.ay4;
-    float4 (&sy4)[4] = cur.sy4;
-    if (a.g_y != nullptr) {
+    const int r0 = rb * kRowsPerBlock;
+    const int row_last = a.M - 1;
+    if (rb != rg) __syncthreads();  // the previous tile has been consumed
+    // stage the gradient tile: four items per thread per pass, every load of the pass issued first
+    for (int base = threadIdx.x; base < 64 * gq; base += 4 * kRowThreads) {
+      float4 dv[4], yv[4], rv[4];
+      float rsv[4];
 #pragma unroll
-      for (int j = 0; j < Feat<NO>::NJ; ++j) {
-        const int o = 16 * j + 4 * g;
-        if (o < NO) {
+      for (int u = 0; u < 4; ++u) {
+        const int idx = min(base + u * kRowThreads, 64 * gq - 1);
+        const int rr = idx / gq, c4 = idx - rr * gq;
+        const int64_t off = (int64_t)min(r0 + rr, row_last) * NO + 4 * c4;
+        dv[u] = *reinterpret_cast<const float4*>(a.dy + off);
+        if (gbn) yv[u] = *reinterpret_cast<const float4*>(a.g_y + off);
+        if (a.relu_y != nullptr) rv[u] = *reinterpret_cast<const float4*>(a.relu_y + off);
+        rsv[u] = a.rowscale != nullptr ? a.rowscale[min(r0 + rr, row_last)] : 1.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = base + u * kRowThreads;
+        if (idx >= 64 * gq) break;
+        const int rr = idx / gq, c4 = idx - rr * gq;
+        const int o = 4 * c4;
+        float v[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w};
+        if (gbn) {
+          const float yy[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            const float xh = (gyf.f[j][s] - gv[NO + o + s]) * gv[2 * NO + o + s];
-            gf.f[j][s] = gv[o + s] * (gf.f[j][s] - gv[3 * NO + o + s] - xh * gv[4 * NO + o + s]);
+            const float xh = (yy[s] - gv[NO + o + s]) * gv[2 * NO + o + s];
+            v[s] = gv[o + s] * (v[s] - gv[3 * NO + o + s] - xh * gv[4 * NO + o + s]);
           }
         }
+        if (a.relu_y != nullptr) {
+          if (!(rv[u].x > 0.0f)) v[0] = 0.0f;
+          if (!(rv[u].y > 0.0f)) v[1] = 0.0f;
+          if (!(rv[u].z > 0.0f)) v[2] = 0.0f;
+          if (!(rv[u].w > 0.0f)) v[3] = 0.0f;
+        }
+        const bool ok = r0 + rr < a.M;
+        *reinterpret_cast<float4*>(gt + rr * GP + o) =
+            make_float4(ok ? v[0] * rsv[u] : 0.0f, ok ? v[1] * rsv[u] : 0.0f, ok ? v[2] * rsv[u] : 0.0f,
+                        ok ? v[3] * rsv[u] : 0.0f);
       }
     }
-#pragma unroll
-    for (int j = 0; j < Feat<NO>::NJ; ++j)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        float v = rok ? gf.f[j][s] * rs : 0.0f;
-        if (a.relu_y != nullptr && !(ryf.f[j][s] > 0.0f)) v = 0.0f;
-        gf.f[j][s] = v;
-      }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      if (t >= ntile) break;
-      // dX^T tile (k = k_base + 16t + 4g' + r, row): A[k = lq][o = 16j + 4g + s] = W[o][k]
-      f32x4 acc = zero4();
-#pragma unroll
-      for (int j = 0; j < Feat<NO>::NJ; ++j) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int o = 16 * j + 4 * g + s;
-          const float wv = o < NO ? wt[o * ldw + 16 * t + lq] : 0.0f;
-          acc = mfma16(wv, gf.f[j][s], acc);
+    __syncthreads();
+    RL_STAMP_X(2);
+    if (active) {
+      for (int i = 0; i < per; ++i) {
+        const int rt = rt0 + i;
+        const int row = r0 + 16 * rt + lq;
+        const bool rok = row < a.M;
+        const int64_t off = (int64_t)min(row, row_last) * a.KI + k_base + 16 * t + 4 * g;
+        const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float4 pv4 = z4, dv4 = z4, ay4 = z4, sy4 = z4;
+        if (a.add_plain != nullptr) pv4 = *reinterpret_cast<const float4*>(a.add_plain + off);
+        if (a.add_dout != nullptr) {
+          dv4 = *reinterpret_cast<const float4*>(a.add_dout + off);
+          ay4 = *reinterpret_cast<const float4*>(a.add_y + off);
         }
-      }
-      const int kl = 16 * t + 4 * g, k = k_base + kl;
-      float v[4] = {acc[0] + pv4[t].x, acc[1] + pv4[t].y, acc[2] + pv4[t].z, acc[3] + pv4[t].w};
-      if (a.add_dout != nullptr) {  // residual branch: BatchNorm backward of add_dout
-        const float dd[4] = {dv4[t].x, dv4[t].y, dv4[t].z, dv4[t].w};
-        const float yy[4] = {ay4[t].x, ay4[t].y, ay4[t].z, ay4[t].w};
+        if (want_sums) sy4 = *reinterpret_cast<const float4*>(a.sum_y + off);
+        // dX^T tile (k = k_base + 16t + 4g' + r, row): A[k = lq][o = 16j + 4g + s] = W[o][k]
+        Feat<NO> gf;
+        load_row<NO>(gf, gt + (16 * rt + lq) * GP, g);
+        f32x4 acc = zero4();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float xh = (yy[r] - ev[ks + kl + r]) * ev[2 * ks + kl + r];
-          v[r] += ev[kl + r] * (dd[r] - ev[3 * ks + kl + r] - xh * ev[4 * ks + kl + r]);
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc = mfma16(wA[j][s], gf.f[j][s], acc);
+        const int kl = 16 * t + 4 * g, k = k_base + kl;
+        float v[4] = {acc[0] + pv4.x, acc[1] + pv4.y, acc[2] + pv4.z, acc[3] + pv4.w};
+        if (a.add_dout != nullptr) {  // residual branch: BatchNorm backward of add_dout
+          const float dd[4] = {dv4.x, dv4.y, dv4.z, dv4.w};
+          const float yy[4] = {ay4.x, ay4.y, ay4.z, ay4.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float xh = (yy[r] - ev[ks + kl + r]) * ev[2 * ks + kl + r];
+            v[r] += ev[kl + r] * (dd[r] - ev[3 * ks + kl + r] - xh * ev[4 * ks + kl + r]);
+          }
         }
-      }
-      if (rok)
-        *reinterpret_cast<float4*>(dx_at(a, row, k)) = make_float4(v[0], v[1], v[2], v[3]);
-      if (want_sums) {  // sum(dx), sum(dx * xhat) over rows, for the BatchNorm that produced x
-        const float yy[4] = {sy4[t].x, sy4[t].y, sy4[t].z, sy4[t].w};
+        if (rok)
+          *reinterpret_cast<float4*>(dx_at(a, row, k)) = make_float4(v[0], v[1], v[2], v[3]);
+        if (want_sums) {  // sum(dx), sum(dx * xhat) over rows, for the BatchNorm that produced x
+          const float yy[4] = {sy4.x, sy4.y, sy4.z, sy4.w};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float xh = (yy[r] - ev[5 * ks + kl + r]) * ev[6 * ks + kl + r];
-          float s1 = rok ? v[r] : 0.0f, s2 = s1 * xh;
-          s1 = row16_sum(s1);
-          s2 = row16_sum(s2);
-          if (lq == 0) {
-            my[kl + r] += s1;
-            my[ks + kl + r] += s2;
+          for (int r = 0; r < 4; ++r) {
+            const float xh = (yy[r] - ev[5 * ks + kl + r]) * ev[6 * ks + kl + r];
+            const float s1 = rok ? v[r] : 0.0f;
+            sum1[r] += s1;        // lane-local over this lane's rows; reduced over the 16 lanes once
+            sum2[r] += s1 * xh;
           }
         }
       }
@@ -384,13 +379,21 @@ __device__ void rowlin_dx_role(const RowLinArgs& a, const RowLinGeom& ge, const 
   }
   RL_STAMP_X(3);
   if (want_sums) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float s1 = row16_sum(sum1[r]), s2 = row16_sum(sum2[r]);
+      if (lq == 0) {
+        red[(w * 2 + 0) * 16 + 4 * g + r] = active ? s1 : 0.0f;
+        red[(w * 2 + 1) * 16 + 4 * g + r] = active ? s2 : 0.0f;
+      }
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * ks; i += kRowThreads) {
       const int which = i / ks, kl = i - which * ks;
       if (kl < ntile * 16) {
+        const int tile = kl >> 4, c = kl & 15;
         float s = 0.0f;
-#pragma unroll
-        for (int w = 0; w < kRowWaves; ++w) s += red[w * 2 * ks + i];
+        for (int gi = 0; gi < groups; ++gi) s += red[((gi * ntile + tile) * 2 + which) * 16 + c];
         a.sum_out[((int64_t)rg * 2 + which) * a.KI + k_base + kl] = s;
       }
     }
@@ -942,7 +945,7 @@ extern "C" int feta_rowlin_bwd_ex(const feta_rowlin_ex* d, float* dwdb, feta_str
     if (role[0] == 'x') grid = ge.dx_blocks;
     if (role[0] == 'w') { ge.dx_blocks = 0; grid = dw_blocks; }
   }
-  const size_t dx_lds = a.NO * (16 * ge.TG + 4) + (kRowWaves * 2 + 7) * 16 * ge.TG;
+  const size_t dx_lds = 64 * (a.NO + 4) + 7 * 16 * ge.TG + kRowWaves * 2 * 16;
   const size_t dw_lds = a.KI <= 128 ? 64 * (64 + 16) + 64 * (a.KI + 16) : 0;
   const size_t lds = sizeof(float) * ((dx_lds > dw_lds ? dx_lds : dw_lds) +
                                       (a.g_y ? 5 * a.NO + reduce_scratch_floats(a.NO) : 0));
