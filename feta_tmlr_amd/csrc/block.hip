@@ -206,64 +206,92 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
   // ---- attention core per 16-query tile (same arithmetic as attn_fwd_dense_kernel) ---------------
   const int bh = b * kBlkH + h;
   float* stg = scr + h * 16 * KP;
+  // All query tiles advance together through each phase (scores, row max, exp / row sum, P.V): the
+  // tiles are independent, so their MFMA chains and shuffle reductions interleave instead of running
+  // one after the other.  Key tiles beyond n_real are skipped by wave-uniform branches.
+  f32x4 acc[NT][NT];
+#pragma unroll
+  for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+    for (int qb = 0; qb < NT; ++qb) acc[qb][kt] = zero4();
+    if (16 * kt < n) {
+#pragma unroll
+      for (int qb = 0; qb < NT; ++qb) {
+        Feat<DH> qs;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qs.f[0][s] = qf[qb].f[0][s] * a.scale;
+        acc[qb][kt] = dot_rows<DH>(kf[kt], qs, zero4());  // (key 4g+r, query lq)
+      }
+    }
+  }
+  float mx[NT], zs[NT], rinv[NT];
 #pragma unroll
   for (int qb = 0; qb < NT; ++qb) {
-    if (16 * qb >= a.N) break;
-    const int q = 16 * qb + lq;
-    Feat<DH> qs;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) qs.f[0][s] = qf[qb].f[0][s] * a.scale;
-    f32x4 acc[NT];
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt) {
-      acc[kt] = zero4();
-      if (16 * kt < n) acc[kt] = dot_rows<DH>(kf[kt], qs, zero4());  // (key 4g+r, query lq)
-    }
     float m = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (16 * kt + 4 * g + r < n) m = fmaxf(m, acc[kt][r]);
-    m = fmaxf(m, shfl_xor(m, 16));
-    m = fmaxf(m, shfl_xor(m, 32));
-    float z = 0.0f;
+        if (16 * kt + 4 * g + r < n) m = fmaxf(m, acc[qb][kt][r]);
+    mx[qb] = m;
+  }
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt) {
-      if (16 * kt >= n) continue;
+  for (int qb = 0; qb < NT; ++qb) mx[qb] = fmaxf(mx[qb], shfl_xor(mx[qb], 16));
+#pragma unroll
+  for (int qb = 0; qb < NT; ++qb) mx[qb] = fmaxf(mx[qb], shfl_xor(mx[qb], 32));
+#pragma unroll
+  for (int qb = 0; qb < NT; ++qb) zs[qb] = 0.0f;
+#pragma unroll
+  for (int kt = 0; kt < NT; ++kt) {
+    if (16 * kt >= n) continue;
+#pragma unroll
+    for (int qb = 0; qb < NT; ++qb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const bool kok = 16 * kt + 4 * g + r < n;
-        const float e = kok ? fast_exp(acc[kt][r] - m) * pv[qb][kt][r] : 0.0f;
-        acc[kt][r] = e;
-        z += e;
+        const float e = kok ? fast_exp(acc[qb][kt][r] - mx[qb]) * pv[qb][kt][r] : 0.0f;
+        acc[qb][kt][r] = e;
+        zs[qb] += e;
       }
-    }
-    z += shfl_xor(z, 16);
-    z += shfl_xor(z, 32);
-    const float rinv = 1.0f / fmaxf(z, 1e-6f);
+  }
+#pragma unroll
+  for (int qb = 0; qb < NT; ++qb) zs[qb] += shfl_xor(zs[qb], 16);
+#pragma unroll
+  for (int qb = 0; qb < NT; ++qb) zs[qb] += shfl_xor(zs[qb], 32);
+  f32x4 o[NT];
+#pragma unroll
+  for (int qb = 0; qb < NT; ++qb) {
+    rinv[qb] = 1.0f / fmaxf(zs[qb], 1e-6f);
+    o[qb] = zero4();
+    const int q = 16 * qb + lq;
     if (g == 0 && q < a.N) {
       float* st = a.attn_stats + ((int64_t)bh * a.N + q) * 2;
-      st[0] = m;
-      st[1] = z;
+      st[0] = mx[qb];
+      st[1] = zs[qb];
     }
-    f32x4 o = zero4();
+  }
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt) {
-      if (16 * kt >= n) continue;
+  for (int kt = 0; kt < NT; ++kt) {
+    if (16 * kt >= n) continue;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        acc[kt][r] *= rinv;
-        o = mfma16(acc[kt][r], vb[kt][r], o);  // (query 4g+r, c' lq)
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int qb = 0; qb < NT; ++qb) {
+        acc[qb][kt][r] *= rinv[qb];
+        o[qb] = mfma16(acc[qb][kt][r], vb[kt][r], o[qb]);  // (query 4g+r, c' lq)
       }
-    }
+  }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Os[(16 * qb + 4 * g + r) * P + DH * h + lq] = o[r];
-    if (a.attn != nullptr) {
+  for (int qb = 0; qb < NT; ++qb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Os[(16 * qb + 4 * g + r) * P + DH * h + lq] = o[qb][r];
+  if (a.attn != nullptr) {
+#pragma unroll
+    for (int qb = 0; qb < NT; ++qb) {
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) stg[lq * KP + 16 * kt + 4 * g + r] = acc[kt][r];
+        for (int r = 0; r < 4; ++r) stg[lq * KP + 16 * kt + 4 * g + r] = acc[qb][kt][r];
       wave_lds_sync();
       const int rows = min(16, a.N - 16 * qb);
       float* dst = a.attn + ((int64_t)bh * a.N + 16 * qb) * a.N;
