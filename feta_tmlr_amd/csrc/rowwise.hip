@@ -917,10 +917,12 @@ extern "C" int feta_debug_rowlin_stamps(unsigned long long* out32) {
 extern "C" int feta_rowlin_bwd_ex(const feta_rowlin_ex* d, float* dwdb, feta_stream_t stream) {
   FETA_REQUIRE(d != nullptr, "rowlin_bwd_ex: null descriptor");
   const RowLinArgs& a = *d;
-  FETA_REQUIRE(a.x && a.w && a.dy && a.dx && a.partial && a.M > 0, "rowlin_bwd: null pointer / empty");
+  // dx == NULL: weight / bias gradient only (the dX chain ran elsewhere: feta_attn_block_bwd)
+  FETA_REQUIRE(a.x && a.w && a.dy && a.partial && a.M > 0, "rowlin_bwd: null pointer / empty");
+  FETA_REQUIRE(a.dx || (!a.add_plain && !a.add_dout && !a.sum_out && !a.dx2), "rowlin_bwd: dW-only launch with dX epilogue operands");
   FETA_REQUIRE(dwdb || a.partial_ld > 0, "rowlin_bwd: dwdb may only be NULL with a caller-reduced partial_ld");
   FETA_REQUIRE(dim_ok(a.KI) && dim_ok(a.NO), "rowlin_bwd: unsupported dims KI=%d NO=%d", a.KI, a.NO);
-  FETA_REQUIRE(aligned16(a.x) && aligned16(a.w) && aligned16(a.dy) && aligned16(a.dx) &&
+  FETA_REQUIRE(aligned16(a.x) && aligned16(a.w) && aligned16(a.dy) && aligned16(a.dx) &&  /* NULL is aligned */
                    (!a.relu_y || aligned16(a.relu_y)) && (!a.g_y || aligned16(a.g_y)),
                "rowlin_bwd: pointers must be 16-byte aligned");
   FETA_REQUIRE(!a.g_y || (a.g_bn && (a.g_sum || a.g_fin)), "rowlin_bwd: g_y needs g_bn and g_sum|g_fin");
@@ -936,7 +938,7 @@ extern "C" int feta_rowlin_bwd_ex(const feta_rowlin_ex* d, float* dwdb, feta_str
   ge.G = row_blocks(a.M);
   ge.TG = tiles_dx(a.NO);
   const int n_kg = (a.KI / 16 + ge.TG - 1) / ge.TG;
-  ge.dx_blocks = ge.G * n_kg;
+  ge.dx_blocks = a.dx != nullptr ? ge.G * n_kg : 0;
   const int n_ot = a.NO / 16;
   const int dw_blocks = a.KI <= 128 ? ge.RC * ((n_ot + kRowWaves - 1) / kRowWaves)
                                     : (ge.RC * n_ot + kRowWaves - 1) / kRowWaves;

@@ -307,6 +307,46 @@ typedef struct feta_attn_block {
 int feta_attn_block_supported(int N, int d_model, int heads);
 int feta_attn_block_fwd(const feta_attn_block* d, feta_stream_t stream);
 
+/* ---- backward of the attention sub-block, dX chain in ONE launch -------------------------------
+ * (feta_attn_block_bwd_supported: d_model = 64, 4 heads, N <= 48.)  dy is the gradient w.r.t. the
+ * output of BatchNorm 1; the kernel applies that BatchNorm's backward itself (y1, bn1 [4][64], partial
+ * sums g_sum [Gs][2][64] of (dy, dy*xhat)), publishing fin_out [2][64] = (m1, m2), dgamma, dbeta; then
+ * dconcat = rowscale * g0 W_out (+ dout2), the attention backward (dq|dk|dv -> dqkv [M,192]) and
+ * dx = dqkv W_in + g0 [M,64]; sum_out [B][2][64] (optional) = per-graph (sum dx, sum dx * xhat0) with
+ * xhat0 from x0 and bn0, for the BatchNorm-2 backward of the previous layer.
+ * The weight gradients of out_proj / in_proj are computed by dW-only feta_rowlin_bwd_ex launches
+ * (dx = NULL) from dqkv and fin_out.  Rows are addressed as in feta_attn_block. */
+typedef struct feta_attn_block_grad {
+  const float* dy;
+  const float* y1;
+  const float* bn1;
+  const float* g_sum;
+  int Gs;
+  float* fin_out;
+  float* dgamma;
+  float* dbeta;
+  const float* rowscale;
+  const float* w_out;
+  const float* w_in;
+  const float* qkv;
+  const float* out;
+  const float* dout2;
+  const float* pe;
+  const int32_t* n_real;
+  const float* attn_stats;
+  const float* x0;
+  const float* bn0;
+  float* dqkv;
+  float* dx;
+  float* sum_out;
+  float scale;
+  int B, N, M;
+  int64_t row_sb, row_sn;
+} feta_attn_block_grad;
+
+int feta_attn_block_bwd_supported(int N, int d_model, int heads);
+int feta_attn_block_bwd(const feta_attn_block_grad* d, feta_stream_t stream);
+
 /* ---- feed-forward half of one encoder layer in ONE launch -----------------------------------
  * x = BN1(y1) (x_bn | x_stats as in feta_rowlin_ex / feta_attn_block);  h = relu(x W1^T + b1);
  * y = x + h W2^T + b2;  y_stats [feta_ffn_blocks(M)][2][64] per-workgroup (sum, sum of squares).
