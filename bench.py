@@ -235,12 +235,13 @@ def cpu_baseline(args, cpu, enc):
     ei = cpu['edge_index']
     ei = ei[:, ei[0] < n_tot]
 
-    def step():
+    def step(collapsed=False):
         leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
         src = cpu['src'][:, :sub].clone().requires_grad_(True)
         out, _, _ = O.encoder_gengcn(src, cpu['pe'][:sub], ei, cpu['fi'][:n_tot], cpu['batch'][:n_tot],
                                      cpu['degree'][:sub], m, leaves, args.layers, args.heads, args.order,
-                                     batch_norm=not args.layer_norm, heads_share_graph=True)
+                                     batch_norm=not args.layer_norm, heads_share_graph=True,
+                                     collapsed=collapsed)
         (out * cpu['dout'][:, :sub]).sum().backward()
 
     step()
@@ -249,10 +250,19 @@ def cpu_baseline(args, cpu, enc):
     for _ in range(args.cpu_steps):
         step()
     dt = (time.perf_counter() - t0) / args.cpu_steps
+    # the same restatement with the exact GCNConv(ones) = c_j colsum(W) + b collapse, so that
+    # the GPU/CPU ratio is not inflated by the reference's redundant ones @ W product alone
+    step(True)
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_steps):
+        step(True)
+    dt_opt = (time.perf_counter() - t0) / args.cpu_steps
     return {'value': round(sub / dt, 2), 'unit': 'graphs/s', 'cores': cores, 'kind': 'port',
             'sample': '%d steps of fwd+bwd on the first %d graphs of the batch (oracle.encoder_gengcn, '
                       'faithful formulation, exact Chebyshev operator, torch CPU fp32, %d threads)'
-                      % (args.cpu_steps, sub, cores)}
+                      % (args.cpu_steps, sub, cores),
+            'optimised_value': round(sub / dt_opt, 2),
+            'optimised_sample': 'same, with the collapsed coefficient generator (no ones @ W, no dense edge list)'}
 
 
 def main():
