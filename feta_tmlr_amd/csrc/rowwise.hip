@@ -401,69 +401,7 @@ __device__ void rowlin_dx_role(const RowLinArgs& a, const RowLinGeom& ge, const 
   RL_STAMP_X(4);
 }
 
-template <int KI>
-__device__ void rowlin_dw_role(const RowLinArgs& a, const RowLinGeom& ge, const float* gv, int lq,
-                               int g) {
-  constexpr int KT = KI / 16;
-  const int not_ = a.NO / 16;
-  const int item = (blockIdx.x - ge.dx_blocks) * kRowWaves + wave_id();
-  if (item >= ge.RC * not_) return;
-  const int ot = item % not_, rc = item / not_;
-  const int nrb16 = (a.M + 15) / 16;
-  const int per = (nrb16 + ge.RC - 1) / ge.RC;
-  const int o = 16 * ot + lq;
-  const bool gbn = a.g_y != nullptr;
-  float g_sc = 1.0f, g_mu = 0.0f, g_rs = 0.0f, g_m1 = 0.0f, g_m2 = 0.0f;
-  if (gbn) {
-    g_sc = gv[o]; g_mu = gv[a.NO + o]; g_rs = gv[2 * a.NO + o]; g_m1 = gv[3 * a.NO + o]; g_m2 = gv[4 * a.NO + o];
-  }
-  float xs[KT], xh[KT];  // input BatchNorm: x = x_raw * xs + xh
-#pragma unroll
-  for (int kt = 0; kt < KT; ++kt) {
-    xs[kt] = a.x_bn != nullptr ? a.x_bn[16 * kt + lq] : 1.0f;
-    xh[kt] = a.x_bn != nullptr ? a.x_bn[KI + 16 * kt + lq] : 0.0f;
-  }
-  f32x4 acc[KT];
-#pragma unroll
-  for (int kt = 0; kt < KT; ++kt) acc[kt] = zero4();
-  float db = 0.0f;
-  for (int rb = rc * per; rb < min((rc + 1) * per, nrb16); ++rb) {
-    // issue every load of the row block before the first MFMA (one latency per block)
-    float gvr[4], xv[4][KT];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 16 * rb + 4 * g + r;
-      const bool rok = row < a.M;
-      float v = rok ? a.dy[(int64_t)row * a.NO + o] : 0.0f;
-      if (gbn && rok) {
-        const float xhat = (a.g_y[(int64_t)row * a.NO + o] - g_mu) * g_rs;
-        v = g_sc * (v - g_m1 - xhat * g_m2);
-      }
-      if (rok && a.rowscale != nullptr) v *= a.rowscale[row];
-      if (rok && a.relu_y != nullptr && !(a.relu_y[(int64_t)row * a.NO + o] > 0.0f)) v = 0.0f;
-      gvr[r] = v;
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-        xv[r][kt] = rok ? *x_at(a, row, 16 * kt + lq) * xs[kt] + xh[kt] : 0.0f;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      db += gvr[r];
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt) acc[kt] = mfma16(gvr[r], xv[r][kt], acc[kt]);  // (o 4g+r', k lq)
-    }
-  }
-  float* p = a.partial + (int64_t)rc * (a.partial_ld > 0 ? (int64_t)a.partial_ld : (int64_t)a.NO * KI + a.NO);
-#pragma unroll
-  for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) p[(int64_t)(16 * ot + 4 * g + r) * KI + 16 * kt + lq] = acc[kt][r];
-  db += shfl_xor(db, 16);
-  db += shfl_xor(db, 32);
-  if (g == 0) p[(int64_t)a.NO * KI + o] = db;
-}
-
-// dW/db role, LDS-staged (KI <= 128): a workgroup = one row chunk x a group of 4 output tiles
+// dW/db role, LDS-staged: a workgroup = one row chunk x a group of 4 output tiles x one 64-column slice of x
 // (one per wave).  The chunk's gradient slice g[64 rows][64 outputs] (all transforms applied) and
 // x[64 rows][KI] (seen through its BatchNorm) are staged by all 256 threads with 16-byte loads -
 // one memory latency for the whole tile instead of one per 16-row block - and the MFMA operands
@@ -471,12 +409,18 @@ __device__ void rowlin_dw_role(const RowLinArgs& a, const RowLinGeom& ge, const 
 template <int KI>
 __device__ void rowlin_dw_role_lds(const RowLinArgs& a, const RowLinGeom& ge, const float* gv,
                                    float* lds_free, int lq, int g) {
-  constexpr int KT = KI / 16;
-  constexpr int GP = 64 + 16, XP = KI + 16;
+  // a workgroup also takes ONE 64-column slice of x (KS columns): wide inputs are split over more
+  // workgroups instead of lengthening the staging and the MFMA chain of each (the dW role is the long
+  // pole of the launch for KI = 128)
+  constexpr int KS = KI > 64 ? 64 : KI, NKS = KI / KS;
+  constexpr int KT = KS / 16;
+  constexpr int GP = 64 + 16, XP = KS + 16;
   const int not_ = a.NO / 16;
   const int n_og = (not_ + kRowWaves - 1) / kRowWaves;
   const int bi = blockIdx.x - ge.dx_blocks;
-  const int og = bi % n_og, rc = bi / n_og;
+  const int ksi = bi % NKS, bj = bi / NKS;
+  const int k0 = ksi * KS;
+  const int og = bj % n_og, rc = bj / n_og;
   const int o_base = og * 64;
   const int ow = min(64, a.NO - o_base);  // outputs of this group
   float* gt = lds_free;                   // [64][GP]
@@ -537,23 +481,23 @@ __device__ void rowlin_dw_role_lds(const RowLinArgs& a, const RowLinGeom& ge, co
         for (int s = 0; s < 4; ++s) gt[rr * GP + 4 * c4 + s] = ok ? v[s] * rsv[u] : 0.0f;
       }
     }
-    for (int base = threadIdx.x; base < 64 * (KI / 4); base += 4 * kRowThreads) {
+    for (int base = threadIdx.x; base < 64 * (KS / 4); base += 4 * kRowThreads) {
       float4 xv[4], sc[4], sh[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int idx = min(base + u * kRowThreads, 64 * (KI / 4) - 1);
-        const int rr = idx / (KI / 4), k = 4 * (idx - rr * (KI / 4));
-        xv[u] = *reinterpret_cast<const float4*>(x_at(a, min(r0 + rr, row_last), k));
+        const int idx = min(base + u * kRowThreads, 64 * (KS / 4) - 1);
+        const int rr = idx / (KS / 4), k = 4 * (idx - rr * (KS / 4));
+        xv[u] = *reinterpret_cast<const float4*>(x_at(a, min(r0 + rr, row_last), k0 + k));
         if (a.x_bn != nullptr) {
-          sc[u] = *reinterpret_cast<const float4*>(a.x_bn + k);
-          sh[u] = *reinterpret_cast<const float4*>(a.x_bn + KI + k);
+          sc[u] = *reinterpret_cast<const float4*>(a.x_bn + k0 + k);
+          sh[u] = *reinterpret_cast<const float4*>(a.x_bn + KI + k0 + k);
         }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int idx = base + u * kRowThreads;
-        if (idx >= 64 * (KI / 4)) break;
-        const int rr = idx / (KI / 4), k = 4 * (idx - rr * (KI / 4));
+        if (idx >= 64 * (KS / 4)) break;
+        const int rr = idx / (KS / 4), k = 4 * (idx - rr * (KS / 4));
         float v[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
         if (a.x_bn != nullptr) {
           v[0] = v[0] * sc[u].x + sh[u].x;
@@ -587,10 +531,10 @@ __device__ void rowlin_dw_role_lds(const RowLinArgs& a, const RowLinGeom& ge, co
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) p[(int64_t)(16 * ot + 4 * g + r) * KI + 16 * kt + lq] = acc[kt][r];
+    for (int r = 0; r < 4; ++r) p[(int64_t)(16 * ot + 4 * g + r) * KI + k0 + 16 * kt + lq] = acc[kt][r];
   db += shfl_xor(db, 16);
   db += shfl_xor(db, 32);
-  if (g == 0) p[(int64_t)a.NO * KI + 16 * ot + lq] = db;
+  if (g == 0 && ksi == 0) p[(int64_t)a.NO * KI + 16 * ot + lq] = db;
   RL_STAMP_W(5);
 }
 
@@ -632,10 +576,7 @@ __global__ __launch_bounds__(kRowThreads) void rowlin_bwd_kernel(RowLinArgs a, R
   if ((int)blockIdx.x < ge.dx_blocks) {
     rowlin_dx_role<NO>(a, ge, gv, after, lq, g);
   } else {
-    if constexpr (KI <= 128)
-      rowlin_dw_role_lds<KI>(a, ge, gv, after, lq, g);
-    else
-      rowlin_dw_role<KI>(a, ge, gv, lq, g);
+    rowlin_dw_role_lds<KI>(a, ge, gv, after, lq, g);
   }
 }
 
@@ -940,15 +881,15 @@ extern "C" int feta_rowlin_bwd_ex(const feta_rowlin_ex* d, float* dwdb, feta_str
   const int n_kg = (a.KI / 16 + ge.TG - 1) / ge.TG;
   ge.dx_blocks = a.dx != nullptr ? ge.G * n_kg : 0;
   const int n_ot = a.NO / 16;
-  const int dw_blocks = a.KI <= 128 ? ge.RC * ((n_ot + kRowWaves - 1) / kRowWaves)
-                                    : (ge.RC * n_ot + kRowWaves - 1) / kRowWaves;
+  const int n_ks = a.KI > 64 ? a.KI / 64 : 1;   // 64-column slices of x, one per dW workgroup
+  const int dw_blocks = ge.RC * ((n_ot + kRowWaves - 1) / kRowWaves) * n_ks;
   int grid = ge.dx_blocks + dw_blocks;
   if (const char* role = getenv("FETA_ROWLIN_ROLE")) {  // diagnostic: time one role alone (results incomplete)
     if (role[0] == 'x') grid = ge.dx_blocks;
     if (role[0] == 'w') { ge.dx_blocks = 0; grid = dw_blocks; }
   }
   const size_t dx_lds = 64 * (a.NO + 4) + 7 * 16 * ge.TG + kRowWaves * 2 * 16;
-  const size_t dw_lds = a.KI <= 128 ? 64 * (64 + 16) + 64 * (a.KI + 16) : 0;
+  const size_t dw_lds = 64 * (64 + 16) + 64 * ((a.KI > 64 ? 64 : a.KI) + 16);
   const size_t lds = sizeof(float) * ((dx_lds > dw_lds ? dx_lds : dw_lds) +
                                       (a.g_y ? 5 * a.NO + reduce_scratch_floats(a.NO) : 0));
 #define CALL(KV) launch_bwd_ki<KV>(a, ge, grid, lds, (hipStream_t)stream);
