@@ -28,7 +28,7 @@ if ROOT not in sys.path:
 
 from feta_tmlr_amd import _lib                                            # noqa: E402
 from feta_tmlr_amd import functional as FF                                # noqa: E402
-from feta_tmlr_amd.parallel import FlatGradAllReduce                      # noqa: E402
+from feta_tmlr_amd.parallel import FlatBufferAllReduce, FlatGradAllReduce, HybridGradAllReduce                      # noqa: E402
 from feta_tmlr_amd.transformer import data as D                           # noqa: E402
 from feta_tmlr_amd.transformer.layers import DiffTransformerEncoderLayer  # noqa: E402
 from feta_tmlr_amd.transformer.models import DiffTransformerEncoderGenGCN  # noqa: E402
@@ -327,12 +327,15 @@ def main():
         # split backward: the filter-stage gradients (96 % of the bytes) are ready first; their
         # all-reduce runs under the backward of the encoder stack
         enc.keep_stack_boundary = True
-        r_head = FlatGradAllReduce(enc.head_parameters(), world)
-        r_stack = FlatGradAllReduce(enc.stack_parameters(), world)
+        # head: the two 4 MB gradients in place + one small packed bucket, all under the stack backward;
+        # stack: its gradients already live in one flat buffer - one in-place collective, no pack / unpack
+        r_head = HybridGradAllReduce(enc.head_parameters(), world)
+        r_stack = FlatBufferAllReduce(enc.stack_flat_grad, world)
 
         def phase1():
             r_head.zero()
-            r_stack.zero()
+            for p_ in enc.stack_parameters():
+                p_.grad = None
             out, _, _ = enc(*fwd_args, **fwd_kw)
             enc.backward_head(out, gpu['dout'])
 

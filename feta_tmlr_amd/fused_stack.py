@@ -19,6 +19,7 @@ Reference semantics: DiffTransformerEncoderLayer.forward as reconstructed in
 feta_tmlr_amd/transformer/layers.py (contract transformer/models.py:166-167).
 """
 import os
+import weakref
 
 import torch
 
@@ -64,6 +65,10 @@ def stack_supported(layers, d_model):
             return False
     return True
 
+
+# first layer of a stack -> the flat gradient buffer of its last backward (kept off the modules:
+# state_dict / deepcopy / pickle of a model must not see it)
+STACK_FLAT_GRAD = weakref.WeakKeyDictionary()
 
 MAX_STAT_ROWS = 256   # every consumer workgroup re-reduces the partial statistics: keep them few
 
@@ -175,6 +180,7 @@ class FusedEncoderStackFn(torch.autograd.Function):
         ctx.meta = (n, b, d, heads, dh, tie, scale, G, nl)
         ctx.aux = (pe_c, degree_rows, n_real)
         ctx.params = params
+        ctx.owner = layers[0] if len(layers) else None
         if attn is not None:
             ctx.mark_non_differentiable(attn)
         concat_last = saved[-1]['out'].view(n, b, d)
@@ -197,7 +203,11 @@ class FusedEncoderStackFn(torch.autograd.Function):
         per_layer = (3 * d * d + 3 * d) + (d * d + d) + (ff0 * d + ff0) + (d * ff0 + d)
         total = per_layer * nl
         part_all = new(RC, total)
-        dwdb_all = new(total)
+        # ONE flat gradient buffer for the whole stack: [weights and biases (reduced partials) | dgamma,
+        # dbeta of norm1 / norm2 of every layer]; every parameter gradient returned below is a view of it,
+        # so a data-parallel trainer all-reduces it in place (parallel.FlatBufferAllReduce)
+        dwdb_all = new(total + nl * 4 * d)
+        bn_tail = dwdb_all[total:].view(nl, 4, d)
         cursor = [0]
 
         def wslot(no, ki):
@@ -220,7 +230,7 @@ class FusedEncoderStackFn(torch.autograd.Function):
             base = li * PER_LAYER
             # B1: linear2 backward, gradient = BN2 backward of dcur
             dh_ = new(m, ff)
-            fin2, dg2, db2 = new(2, d), new(d), new(d)
+            fin2, dg2, db2 = new(2, d), bn_tail[li, 2], bn_tail[li, 3]
             pp, off = wslot(d, ff)
             slots[base + 8] = (off, d, ff)
             dsc = abi.rowlin_ex(m, ff, d, x=s['h'], w=w2, dy=dcur, dx=dh_, partial_ptr=pp, partial_ld=total,
@@ -238,7 +248,7 @@ class FusedEncoderStackFn(torch.autograd.Function):
             abi.rowlin_bwd_ex(dsc, None, stream)
             if chain:
                 # B3 + B4 + B5 dX chain in one launch; the two weight gradients as dW-only launches
-                fin1, dg1, db1 = new(2, d), new(d), new(d)
+                fin1, dg1, db1 = new(2, d), bn_tail[li, 0], bn_tail[li, 1]
                 dqkv, dx0 = new(m, 3 * d), new(m, d)
                 gs_prev = new(b, 2, d) if li > 0 else None
                 d2 = d_concat_last.contiguous().view(m, d) if (li == nl - 1 and d_concat_last is not None) else None
@@ -266,7 +276,7 @@ class FusedEncoderStackFn(torch.autograd.Function):
             else:
                 # B3: out_proj backward, gradient = degree * BN1 backward of dx1
                 dconcat = new(m, d)
-                fin1, dg1, db1 = new(2, d), new(d), new(d)
+                fin1, dg1, db1 = new(2, d), bn_tail[li, 0], bn_tail[li, 1]
                 pp, off = wslot(d, d)
                 slots[base + 2] = (off, d, d)
                 dsc = abi.rowlin_ex(m, d, d, x=s['out'].view(m, d), w=w_o, dy=dx1, rowscale=degree_rows, dx=dconcat,
@@ -306,7 +316,9 @@ class FusedEncoderStackFn(torch.autograd.Function):
                 Gs_next = G
             dcur, gs, Gs_cur = dx0, gs_prev, Gs_next
         assert cursor[0] == total
-        abi.colsum(part_all, dwdb_all, stream)
+        abi.colsum(part_all, dwdb_all[:total], stream)
+        if ctx.owner is not None:
+            STACK_FLAT_GRAD[ctx.owner] = dwdb_all
         for idx, (off, no, ki) in slots.items():
             grads[idx] = dwdb_all[off:off + no * ki].view(no, ki)
             if params[idx + 1] is not None:

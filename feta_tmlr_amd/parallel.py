@@ -127,3 +127,88 @@ class FlatGradAllReduce:
             self.flat.mul_(1.0 / self.world_size)
         if not self.views:
             self.unpack()
+
+
+class HybridGradAllReduce:
+    """Large gradients are all-reduced IN PLACE, one collective each (no pack / unpack copies of
+    megabytes: ``encoder.linear.weight`` and the dense ``encoder.gcn.weight`` gradient are 4 MB each);
+    everything else goes through one packed FlatGradAllReduce bucket.  Meant for gradients that are
+    ready early in backward (the filter stage), whose collectives run under the rest of backward."""
+
+    def __init__(self, params, world_size=None, process_group=None, big_numel=1 << 18):
+        params = [p for p in params if p.requires_grad]
+        self.big = [p for p in params if p.numel() >= big_numel]
+        small = [p for p in params if p.numel() < big_numel]
+        self.small = FlatGradAllReduce(small, world_size, process_group) if small else None
+        self.group = process_group
+        if world_size is None:
+            world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.world_size = world_size
+        self.avg_in_collective = (dist.is_initialized() and world_size > 1
+                                  and dist.get_backend(process_group) == 'nccl')
+
+    def zero(self):
+        for p in self.big:
+            p.grad = None
+        if self.small is not None:
+            self.small.zero()
+
+    def start(self):
+        if self.world_size == 1:
+            return None
+        op = dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM
+        works = [dist.all_reduce(p.grad, op=op, group=self.group, async_op=True)
+                 for p in self.big if p.grad is not None]
+        return works, (self.small.start() if self.small is not None else None)
+
+    def finish(self, handle):
+        if handle is None:
+            return
+        works, small = handle
+        for w in works:
+            w.wait()
+        if not self.avg_in_collective:
+            for p in self.big:
+                if p.grad is not None:
+                    p.grad.mul_(1.0 / self.world_size)
+        if self.small is not None:
+            self.small.finish(small)
+
+    def all_reduce(self):
+        self.finish(self.start())
+
+
+class FlatBufferAllReduce:
+    """All-reduce of a gradient buffer that is ALREADY flat: the fused encoder stack writes every weight,
+    bias and BatchNorm gradient of its layers into one tensor (fused_stack.py) and hands the parameters
+    views of it, so the collective runs in place - no pack, no unpack.  ``getter()`` returns that tensor
+    (its address is stable across hipGraph replays)."""
+
+    def __init__(self, getter, world_size=None, process_group=None):
+        self.getter = getter
+        self.group = process_group
+        if world_size is None:
+            world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.world_size = world_size
+        self.avg_in_collective = (dist.is_initialized() and world_size > 1
+                                  and dist.get_backend(process_group) == 'nccl')
+
+    def start(self):
+        if self.world_size == 1:
+            return None
+        flat = self.getter()
+        if flat is None:
+            raise RuntimeError('no flat stack gradient: backward has not run through the fused stack')
+        op = dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM
+        return dist.all_reduce(flat, op=op, group=self.group, async_op=True), flat
+
+    def finish(self, handle):
+        if handle is None:
+            return
+        work, flat = handle
+        work.wait()
+        if not self.avg_in_collective:
+            flat.mul_(1.0 / self.world_size)
+
+    def all_reduce(self):
+        self.finish(self.start())

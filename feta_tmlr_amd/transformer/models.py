@@ -178,6 +178,12 @@ class DiffTransformerEncoderGenGCN(nn.Module):
     def stack_parameters(self):
         return [p for p in self.layers.parameters() if p.requires_grad]
 
+    def stack_flat_grad(self):
+        """The flat buffer that holds every gradient of the layer stack after a backward through the
+        fused BatchNorm stack (all stack_parameters().grad are views of it), or None."""
+        from ..fused_stack import STACK_FLAT_GRAD
+        return STACK_FLAT_GRAD.get(self.layers[0]) if len(self.layers) else None
+
     def backward_head(self, out, grad_out):
         """Phase 1 of backward after a fused-stack forward: gradients of head_parameters() (assigned
         to .grad) and of the stack outputs (kept for backward_stack).  A data-parallel trainer starts

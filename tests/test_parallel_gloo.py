@@ -95,3 +95,63 @@ def test_shard_indices_partition():
     for world in (1, 2, 4, 8):
         got = sorted(i for r in range(world) for i in shard_indices(37, r, world))
         assert got == list(range(37))
+
+
+def _build_bn(seed=0):
+    """d_model 64 / 4 heads / BatchNorm: takes the fused stack (flat stack-gradient buffer)"""
+    from feta_tmlr_amd.transformer.models import DiffGraphTransformerGenGCN
+    torch.manual_seed(seed)
+    return DiffGraphTransformerGenGCN(8, 1, 64, 4, dim_feedforward=128, dropout=0.0, nb_layers=2,
+                                      batch_norm=True, filter_order=2, heads_share_graph=True)
+
+
+def _worker_inplace(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import ctypes
+    from feta_tmlr_amd import _abi, _lib
+    from feta_tmlr_amd.parallel import FlatBufferAllReduce, FlatGradAllReduce, HybridGradAllReduce, shard_indices
+    from feta_tmlr_amd.transformer import data as D
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    emu = _abi.bind(ctypes.CDLL(os.path.join(ROOT, 'tools', 'simt', 'libfeta_emu.so')))
+    ds = D.SyntheticGraphDataset('mutag', 4, in_dim=8, seed=5, n_min=4, n_max=12)
+    mine = [ds[i] for i in shard_indices(len(ds), rank, world)]
+    out = {}
+    for mode in ('packed', 'inplace'):
+        model = _build_bn()
+        enc = model.encoder
+        rest = [p for p in model.parameters() if all(p is not q for q in enc.parameters())]
+        with _lib.override_for_tests(emu):
+            model.zero_grad(set_to_none=True)
+            _loss_on(model, mine, 1.0 / len(mine)).backward()
+        if mode == 'packed':
+            FlatGradAllReduce(model.parameters(), world).all_reduce()
+        else:
+            flat = enc.stack_flat_grad()
+            assert flat is not None
+            for p in enc.stack_parameters():      # every stack gradient is a view of the flat buffer
+                assert p.grad is None or (p.grad.data_ptr() >= flat.data_ptr() and
+                                          p.grad.data_ptr() < flat.data_ptr() + 4 * flat.numel())
+            # big_numel lowered so that the in-place branch is exercised at this model size
+            HybridGradAllReduce(enc.head_parameters(), world, big_numel=1 << 12).all_reduce()
+            FlatBufferAllReduce(enc.stack_flat_grad, world).all_reduce()
+            FlatGradAllReduce(rest, world).all_reduce()
+        out[mode] = _full_grads(model)
+    ret[rank] = (out['packed'], out['inplace'])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_inplace_reducers_equal_packed_bucket_world2(emu):
+    """HybridGradAllReduce (big gradients in place) + FlatBufferAllReduce (the fused stack's flat
+    gradient buffer) give the averaged gradients of the packed single bucket"""
+    port = 29500 + (os.getpid() % 400) + 7
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_inplace, args=(2, port, ret), nprocs=2, join=True)
+    for rank in (0, 1):
+        packed, inplace = ret[rank]
+        assert torch.allclose(packed, inplace, rtol=1e-6, atol=1e-7), float((packed - inplace).abs().max())
+    assert torch.allclose(ret[0][1], ret[1][1])
