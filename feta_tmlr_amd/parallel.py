@@ -157,20 +157,26 @@ class HybridGradAllReduce:
         if self.world_size == 1:
             return None
         op = dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM
-        works = [dist.all_reduce(p.grad, op=op, group=self.group, async_op=True)
-                 for p in self.big if p.grad is not None]
+        works = []
+        for p in self.big:
+            g = p.grad
+            if g is None:
+                continue
+            if g.dim() == 2 and g.stride(0) == 0:
+                g = g[0]            # broadcast row (d colsum(W) / dW): the one row IS the whole gradient
+            elif not g.is_contiguous():
+                g = p.grad = g.contiguous()
+            works.append((dist.all_reduce(g, op=op, group=self.group, async_op=True), g))
         return works, (self.small.start() if self.small is not None else None)
 
     def finish(self, handle):
         if handle is None:
             return
         works, small = handle
-        for w in works:
+        for w, g in works:
             w.wait()
-        if not self.avg_in_collective:
-            for p in self.big:
-                if p.grad is not None:
-                    p.grad.mul_(1.0 / self.world_size)
+            if not self.avg_in_collective:
+                g.mul_(1.0 / self.world_size)
         if self.small is not None:
             self.small.finish(small)
 

@@ -116,29 +116,40 @@ def _worker_inplace(rank, world, port, ret):
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     emu = _abi.bind(ctypes.CDLL(os.path.join(ROOT, 'tools', 'simt', 'libfeta_emu.so')))
-    ds = D.SyntheticGraphDataset('mutag', 4, in_dim=8, seed=5, n_min=4, n_max=12)
+    ds = D.SyntheticGraphDataset('mutag', 4, in_dim=64, seed=5, n_min=4, n_max=12)
     mine = [ds[i] for i in shard_indices(len(ds), rank, world)]
+    batch9, cache = D.collate(mine)
+    x, mask, pe, _, degree, _, edge_index, batch, fi = batch9
+    src = x.permute(1, 0, 2).contiguous()
+    g = torch.Generator().manual_seed(100 + rank)
+    dout = torch.randn(src.shape, generator=g)
     out = {}
     for mode in ('packed', 'inplace'):
-        model = _build_bn()
-        enc = model.encoder
-        rest = [p for p in model.parameters() if all(p is not q for q in enc.parameters())]
+        enc = _build_bn().encoder
+        enc.train()
+        kw = dict(degree=degree, src_key_padding_mask=mask, graph_cache=cache)
         with _lib.override_for_tests(emu):
-            model.zero_grad(set_to_none=True)
-            _loss_on(model, mine, 1.0 / len(mine)).backward()
-        if mode == 'packed':
-            FlatGradAllReduce(model.parameters(), world).all_reduce()
-        else:
-            flat = enc.stack_flat_grad()
-            assert flat is not None
-            for p in enc.stack_parameters():      # every stack gradient is a view of the flat buffer
-                assert p.grad is None or (p.grad.data_ptr() >= flat.data_ptr() and
-                                          p.grad.data_ptr() < flat.data_ptr() + 4 * flat.numel())
-            # big_numel lowered so that the in-place branch is exercised at this model size
-            HybridGradAllReduce(enc.head_parameters(), world, big_numel=1 << 12).all_reduce()
-            FlatBufferAllReduce(enc.stack_flat_grad, world).all_reduce()
-            FlatGradAllReduce(rest, world).all_reduce()
-        out[mode] = _full_grads(model)
+            if mode == 'packed':      # one backward, one packed bucket
+                o, _, _ = enc(src, pe, edge_index, fi, batch, **kw)
+                o.backward(gradient=dout)
+                FlatGradAllReduce(enc.parameters(), world).all_reduce()
+            else:                     # the flow of bench.py --gpus N
+                enc.keep_stack_boundary = True
+                r_head = HybridGradAllReduce(enc.head_parameters(), world, big_numel=1 << 12)
+                r_stack = FlatBufferAllReduce(enc.stack_flat_grad, world)
+                o, _, _ = enc(src, pe, edge_index, fi, batch, **kw)
+                enc.backward_head(o, dout)
+                assert enc.gcn.weight.grad.stride(0) == 0     # the broadcast row: only it travels
+                w1 = r_head.start()
+                enc.backward_stack()
+                flat = enc.stack_flat_grad()
+                for p in enc.stack_parameters():   # every stack gradient is a view of the flat buffer
+                    assert p.grad is None or (flat.data_ptr() <= p.grad.data_ptr() <
+                                              flat.data_ptr() + 4 * flat.numel())
+                w2 = r_stack.start()
+                r_head.finish(w1)
+                r_stack.finish(w2)
+        out[mode] = _full_grads(enc)
     ret[rank] = (out['packed'], out['inplace'])
     dist.barrier()
     dist.destroy_process_group()
