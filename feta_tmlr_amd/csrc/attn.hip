@@ -17,6 +17,8 @@
 #include <cmath>
 
 #include "feta_abi_common.h"
+#include <cstdlib>
+
 #include "feta_tiles.h"
 
 namespace feta {
@@ -689,8 +691,252 @@ int launch_fwd(const AttnArgs& a, int kt_max, hipStream_t stream) {
   return check_launch("feta_attn_fwd");
 }
 
+// ---- backward, one workgroup per graph (4 heads x dh 16, N <= 64) -------------------------------
+// 8 waves: wave = (head, role); role 0 computes dq over the head's query tiles, role 1 dk / dv over its
+// key tiles (the arithmetic of the dense roles above).  What the per-(head, tile) kernels fetch again
+// and again - every key tile re-reads q / dout / stats of all queries, every query tile K and V of all
+// keys, 64 bytes at a time - is fetched ONCE per graph here: the 256-byte node rows of q, k, v, out and
+// dout (+ dout2), pe_b and the statistics go to LDS with 16-byte requests, both roles take their
+// operands (either layout) from there, and dq | dk | dv leave through the same tiles as whole rows.
+constexpr int kGbP = 64 + 4;   // pitch of a staged 64-float row
+
+__host__ __device__ inline int attn_bwd_graph_lds_floats(int nt) {
+  const int nr = 16 * nt;
+  return 5 * nr * kGbP + nr * (nr + 1) + 4 * nr * 2;
+}
+
+template <int NT>
+__global__ __launch_bounds__(512) void attn_bwd_graph_kernel(AttnArgs a) {
+  constexpr int DH = 16, H = 4, P = kGbP, NR = 16 * NT, PEP = NR + 1;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lq = lane & 15, g = lane >> 4;
+  const int h = wv & 3, role = wv >> 2;
+  const int b = blockIdx.x;
+  const int n = a.n_real[b];
+  float* Qs = feta_lds;        // [NR][P] q, later dq
+  float* Ks = Qs + NR * P;     // k, later dk
+  float* Vs = Ks + NR * P;     // v, later dv
+  float* Ds = Vs + NR * P;     // dout (+ dout2)
+  float* Os = Ds + NR * P;     // out
+  float* PE = Os + NR * P;     // [NR][PEP]
+  float* ST = PE + NR * PEP;   // [H][NR][2]
+  const bool has_pe = a.pe != nullptr;
+  const int nm1 = a.N - 1;
+
+  // ---- cooperative loads: NT * 16 * 16 float4 per tensor, 512 threads ------------------------------------
+  constexpr int RI = (NR * 16 + 511) / 512;
+  float4 qv[RI], kv[RI], vv[RI], dv_[RI], ov[RI];
+#pragma unroll
+  for (int i = 0; i < RI; ++i) {
+    const int idx = min(tid + 512 * i, NR * 16 - 1), node = min(idx >> 4, nm1), c4 = 4 * (idx & 15);
+    qv[i] = *reinterpret_cast<const float4*>(tok_row(a.q, a.qsb, a.qsn, b, node, 0, DH) + c4);
+    kv[i] = *reinterpret_cast<const float4*>(tok_row(a.k, a.qsb, a.qsn, b, node, 0, DH) + c4);
+    vv[i] = *reinterpret_cast<const float4*>(tok_row(a.v, a.qsb, a.qsn, b, node, 0, DH) + c4);
+    ov[i] = *reinterpret_cast<const float4*>(tok_row(a.out, a.osb, a.osn, b, node, 0, DH) + c4);
+    float4 d1 = *reinterpret_cast<const float4*>(tok_row(a.dout, a.osb, a.osn, b, node, 0, DH) + c4);
+    if (a.dout2 != nullptr) {
+      const float4 d2 = *reinterpret_cast<const float4*>(tok_row(a.dout2, a.osb, a.osn, b, node, 0, DH) + c4);
+      d1 = make_float4(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z, d1.w + d2.w);
+    }
+    dv_[i] = d1;
+  }
+  constexpr int PEI = (NR * NR + 511) / 512;
+  float pev[PEI];
+#pragma unroll
+  for (int i = 0; i < PEI; ++i) {
+    const int idx = tid + 512 * i, qq = idx / NR, kk = idx - qq * NR;
+    const float v = has_pe ? a.pe[((int64_t)b * a.N + min(qq, nm1)) * a.N + min(kk, nm1)] : 1.0f;
+    pev[i] = (idx < NR * NR && qq < a.N && kk < a.N) ? v : 0.0f;
+  }
+  {
+    const int hh = tid / (NR * 2), rem = tid - hh * NR * 2;   // H * NR * 2 <= 512
+    const float sv = a.stats_in[(((int64_t)b * H + min(hh, H - 1)) * a.N + min(rem >> 1, nm1)) * 2 + (rem & 1)];
+    if (tid < H * NR * 2) ST[tid] = sv;
+  }
+#pragma unroll
+  for (int i = 0; i < RI; ++i) {
+    const int idx = tid + 512 * i;
+    if (idx < NR * 16) {
+      const int off = (idx >> 4) * P + 4 * (idx & 15);
+      *reinterpret_cast<float4*>(Qs + off) = qv[i];
+      *reinterpret_cast<float4*>(Ks + off) = kv[i];
+      *reinterpret_cast<float4*>(Vs + off) = vv[i];
+      *reinterpret_cast<float4*>(Ds + off) = dv_[i];
+      *reinterpret_cast<float4*>(Os + off) = ov[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < PEI; ++i) {
+    const int idx = tid + 512 * i;
+    if (idx < NR * NR) PE[(idx / NR) * PEP + idx % NR] = pev[i];
+  }
+  __syncthreads();
+
+  const int co = DH * h;
+  const int bh = b * H + h;
+  f32x4 r0[NT], r1[NT];   // role 0: dq tiles; role 1: dk, dv tiles
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    r0[t] = zero4();
+    r1[t] = zero4();
+  }
+  if (role == 0) {
+    // dq: S^T orientation (key 4g+r, query lq)
+    Feat<DH> kf[NT], vf[NT];
+    float kb[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int rowl = 16 * t + lq;
+      load_row<DH>(kf[t], Ks + rowl * P + co, g);
+      load_row<DH>(vf[t], Vs + rowl * P + co, g);
+      if (rowl >= n) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kf[t].f[0][s] = vf[t].f[0][s] = 0.0f;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = 16 * t + 4 * g + r;
+        kb[t][r] = rr < n ? Ks[rr * P + co + lq] : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int qb = 0; qb < NT; ++qb) {
+      const int q = 16 * qb + lq;
+      const bool qok = q < a.N;
+      Feat<DH> qf, dof, of;
+      load_row<DH>(qf, Qs + q * P + co, g, a.scale);
+      load_row<DH>(dof, Ds + q * P + co, g);
+      load_row<DH>(of, Os + q * P + co, g);
+      if (!qok) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf.f[0][s] = dof.f[0][s] = 0.0f;
+      }
+      float delta = dof.f[0][0] * of.f[0][0] + dof.f[0][1] * of.f[0][1] + dof.f[0][2] * of.f[0][2] +
+                    dof.f[0][3] * of.f[0][3];
+      delta += shfl_xor(delta, 16);
+      delta += shfl_xor(delta, 32);
+      if (g == 0 && qok) a.delta[(int64_t)bh * a.N + q] = delta;
+      const float m = ST[(h * NR + q) * 2], z = ST[(h * NR + q) * 2 + 1];
+      const float rinv = 1.0f / fmaxf(z, 1e-6f);
+      if (z < 1e-6f) delta = 0.0f;
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) {
+        if (16 * kt >= n) continue;
+        const f32x4 s = dot_rows<DH>(kf[kt], qf, zero4());
+        const f32x4 da = dot_rows<DH>(vf[kt], dof, zero4());
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = 16 * kt + 4 * g + r;
+          const float p = key < n ? fast_exp(s[r] - m) * PE[q * PEP + key] * rinv : 0.0f;
+          r0[qb] = mfma16(p * (da[r] - delta), kb[kt][r], r0[qb]);  // (query 4g+r, c lq)
+        }
+      }
+    }
+  } else {
+    // dk, dv: S orientation (query 4g+r, key lq)
+    Feat<DH> qf[NT], dof[NT];
+    float qb4[NT][4], dob[NT][4], sd[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int rowl = 16 * t + lq;
+      load_row<DH>(qf[t], Qs + rowl * P + co, g, a.scale);
+      load_row<DH>(dof[t], Ds + rowl * P + co, g);
+      if (rowl >= a.N) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[t].f[0][s] = dof[t].f[0][s] = 0.0f;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = 16 * t + 4 * g + r;
+        const bool ok = rr < a.N;
+        const float dvv = Ds[rr * P + co + lq];
+        qb4[t][r] = ok ? Qs[rr * P + co + lq] * a.scale : 0.0f;
+        dob[t][r] = ok ? dvv : 0.0f;
+        sd[t][r] = row16_sum(ok ? dvv * Os[rr * P + co + lq] : 0.0f);   // delta[q = 4g + r]
+      }
+    }
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      if (16 * kt >= n) continue;
+      const int key = 16 * kt + lq;
+      Feat<DH> kf, vf;
+      load_row<DH>(kf, Ks + key * P + co, g);
+      load_row<DH>(vf, Vs + key * P + co, g);
+      if (key >= n) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kf.f[0][s] = vf.f[0][s] = 0.0f;
+      }
+#pragma unroll
+      for (int qb = 0; qb < NT; ++qb) {
+        const f32x4 s = dot_rows<DH>(qf[qb], kf, zero4());
+        const f32x4 da = dot_rows<DH>(dof[qb], vf, zero4());
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = 16 * qb + 4 * g + r;
+          const float m = ST[(h * NR + q) * 2], z = ST[(h * NR + q) * 2 + 1];
+          const bool ok = q < a.N && key < n;
+          const float p = ok ? fast_exp(s[r] - m) * PE[q * PEP + key] * (1.0f / fmaxf(z, 1e-6f)) : 0.0f;
+          const float ds = p * (da[r] - (z < 1e-6f ? 0.0f : sd[qb][r]));
+          r1[kt] = mfma16(p, dob[qb][r], r1[kt]);    // dv (key 4g+r, c lq)
+          r0[kt] = mfma16(ds, qb4[qb][r], r0[kt]);   // dk
+        }
+      }
+    }
+  }
+  __syncthreads();   // every wave has taken its operands: the q / k / v tiles become dq / dk / dv
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = 16 * t + 4 * g + r;
+      if (role == 0) {
+        Qs[rr * P + co + lq] = r0[t][r] * a.scale;
+      } else {
+        Ks[rr * P + co + lq] = r0[t][r];
+        Vs[rr * P + co + lq] = r1[t][r];
+      }
+    }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < RI; ++i) {
+    const int idx = tid + 512 * i, node = idx >> 4, c4 = 4 * (idx & 15);
+    if (idx < NR * 16 && node < a.N) {
+      const int off = node * P + c4;
+      *reinterpret_cast<float4*>(tok_row(a.dq, a.qsb, a.qsn, b, node, 0, DH) + c4) = *reinterpret_cast<const float4*>(Qs + off);
+      *reinterpret_cast<float4*>(tok_row(a.dk, a.qsb, a.qsn, b, node, 0, DH) + c4) = *reinterpret_cast<const float4*>(Ks + off);
+      *reinterpret_cast<float4*>(tok_row(a.dv, a.qsb, a.qsn, b, node, 0, DH) + c4) = *reinterpret_cast<const float4*>(Vs + off);
+    }
+  }
+}
+
+template <int NT>
+void launch_bwd_graph_t(const AttnArgs& a, hipStream_t stream) {
+  const size_t lds = sizeof(float) * attn_bwd_graph_lds_floats(NT);
+  auto kern = attn_bwd_graph_kernel<NT>;
+  static size_t lds_seen = 0;
+  allow_dynamic_lds(kern, lds, lds_seen);
+  hipLaunchKernelGGL(kern, dim3(a.B), dim3(512), lds, stream, a);
+}
+
+// -> true if the one-workgroup-per-graph backward was launched (4 heads x dh 16, N <= 64)
+bool try_bwd_graph(const AttnArgs& a, int dh, hipStream_t stream) {
+  if (a.H != 4 || dh != 16 || a.N > 64) return false;
+  // measured (MI355X, N = 37): per-(head, tile) waves win while a batch cannot fill the chip (12.6 vs 13.1 us
+  // at 128 graphs), one workgroup per graph wins from 256 graphs up (13.7 vs 17.4 us; 460 vs 880 us at
+  // 16384).  FETA_ATTN_BWD_GRAPH=0 / 1 forces the choice (tests).
+  const char* e = getenv("FETA_ATTN_BWD_GRAPH");
+  if (e != nullptr ? e[0] == '0' : a.B < 192) return false;
+  switch (a.NB) {
+    case 1: launch_bwd_graph_t<1>(a, stream); break;
+    case 2: launch_bwd_graph_t<2>(a, stream); break;
+    case 3: launch_bwd_graph_t<3>(a, stream); break;
+    default: launch_bwd_graph_t<4>(a, stream); break;
+  }
+  return true;
+}
+
 template <int DH>
 int launch_bwd(const AttnArgs& a, hipStream_t stream) {
+  if (try_bwd_graph(a, DH, stream)) return check_launch("feta_attn_bwd");
   if constexpr (DH <= 16) {
     if (a.NB <= 3) { launch_bwd_dense_t<DH, 3>(a, stream); return check_launch("feta_attn_bwd"); }
     if (a.NB <= 4) { launch_bwd_dense_t<DH, 4>(a, stream); return check_launch("feta_attn_bwd"); }

@@ -13,6 +13,8 @@ CPU = torch.device('cpu')
     (3, 20, 2, 16, True, True),
     (2, 37, 4, 16, False, True),
     (2, 37, 4, 16, True, False),
+    (2, 64, 4, 16, True, True),        # 4 heads x 16: one workgroup per graph in backward, 4 row tiles
+    (3, 12, 4, 16, False, False),
     (2, 50, 2, 8, True, True),
     (2, 33, 1, 32, True, False),
     (1, 70, 1, 64, True, True),
@@ -28,6 +30,7 @@ def test_attn_no_attn_write(emu):
 
 def test_attn_clamped_rows(emu):
     KC.check_attn(emu, CPU, None, 2, 19, 2, 16, True, clamp_case=True)
+    KC.check_attn(emu, CPU, None, 2, 19, 4, 16, True, clamp_case=True)
 
 
 @pytest.mark.parametrize('bsz,n,h,c', [(3, 12, 2, 64), (2, 37, 4, 256), (1, 5, 1, 16)])
@@ -99,3 +102,12 @@ def test_batchnorm(emu, m, d):
 @pytest.mark.parametrize('r,c', [(19, 4096 + 64), (3, 8192), (64, 4100), (74, 4096), (300, 4096), (200, 48), (1, 16)])
 def test_colsum_shapes(emu, r, c):
     KC.check_colsum(emu, CPU, None, r, c)
+
+
+@pytest.mark.parametrize('bsz,n,use_pe,seq_first,clamp', [
+    (3, 37, True, True, False), (2, 64, True, False, False), (4, 9, False, True, False), (2, 19, True, True, True),
+])
+def test_attn_bwd_one_workgroup_per_graph(emu, monkeypatch, bsz, n, use_pe, seq_first, clamp):
+    """4 heads x dh 16: attn_bwd_graph_kernel (chosen by itself from 192 graphs up; forced here)"""
+    monkeypatch.setenv('FETA_ATTN_BWD_GRAPH', '1')
+    KC.check_attn(emu, CPU, None, bsz, n, 4, 16, use_pe, seq_first, clamp_case=clamp)

@@ -12,6 +12,8 @@ pytestmark = pytest.mark.gpu
     (3, 20, 2, 16, True, True),
     (2, 37, 4, 16, False, True),
     (2, 37, 4, 16, True, False),
+    (2, 64, 4, 16, True, True),        # 4 heads x 16: one workgroup per graph in backward, 4 row tiles
+    (3, 12, 4, 16, False, False),
     (2, 50, 2, 8, True, True),
     (2, 33, 1, 32, True, False),
     (1, 70, 1, 64, True, True),
@@ -128,3 +130,12 @@ def test_batchnorm(hip, m, d):
 @pytest.mark.parametrize('r,c', [(19, 4096 + 64), (3, 8192), (64, 4100), (74, 4096), (300, 4096), (200, 48), (1, 16)])
 def test_colsum_shapes(hip, r, c):
     KC.check_colsum(*hip, r, c)
+
+
+@pytest.mark.parametrize('bsz,n,use_pe,seq_first,clamp', [
+    (3, 37, True, True, False), (2, 64, True, False, False), (4, 9, False, True, False), (2, 19, True, True, True),
+])
+def test_attn_bwd_one_workgroup_per_graph(hip, monkeypatch, bsz, n, use_pe, seq_first, clamp):
+    """4 heads x dh 16: attn_bwd_graph_kernel (chosen by itself from 192 graphs up; forced here)"""
+    monkeypatch.setenv('FETA_ATTN_BWD_GRAPH', '1')
+    KC.check_attn(*hip, bsz, n, 4, 16, use_pe, seq_first, clamp_case=clamp)
