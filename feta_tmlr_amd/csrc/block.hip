@@ -16,6 +16,8 @@
 //     owns output columns 16w .. 16w+15, so the column statistics need no cross-wave reduction.
 // q, k, v, the per-head output and the softmax statistics are still written to HBM: the backward
 // pass (attn.hip, rowwise.hip) and the spectral filter read them.
+#include <cstdlib>
+
 #include "feta_abi_common.h"
 #include "feta_rowops.h"
 
@@ -25,6 +27,7 @@ typedef feta_attn_block BlockArgs;  // include/feta_hip.h
 
 constexpr int kBlkD = 64, kBlkH = 4, kBlkDH = 16;
 constexpr int kBlkP = kBlkD + 4;  // LDS pitch of every staged 64-float row
+constexpr int kBlkMaxGrid = 256;  // workgroups of a launch (MI355X: 256 CUs, one such workgroup each)
 
 __host__ __device__ inline int block_lds_floats(int nt, bool attn) {
   const int nr = 16 * nt;
@@ -46,8 +49,6 @@ template <int NT>
 __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a) {
   constexpr int D = kBlkD, DH = kBlkDH, P = kBlkP, NR = 16 * NT, KP = NR + 1;
   const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6, lq = lane & 15, g = lane >> 4;
-  const int b = blockIdx.x;
-  const int n = a.n_real[b];
   float* Wi = feta_lds;              // [192][P]
   float* Wo = Wi + 3 * D * P;        // [64][P]
   float* Xs = Wo + D * P;            // [NR][P]  layer input, BatchNorm applied
@@ -57,29 +58,9 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
   const bool x_norm = a.x_stats != nullptr || a.x_bn != nullptr;
   FETA_STAMP(0);
 
-  // ---- requests first: node rows, then the weights ------------------------------------------------
-  float4 xv[NT];
-#pragma unroll
-  for (int i = 0; i < NT; ++i) {
-    const int idx = tid + kRowThreads * i, node = idx >> 4, q = idx & 15;
-    const int64_t row = (int64_t)b * a.row_sb + (int64_t)min(node, a.N - 1) * a.row_sn;
-    xv[i] = *reinterpret_cast<const float4*>(a.x + row * D + 4 * q);
-  }
-  // pe values of this lane's (query, key) pairs, degree scale and biases: requested now, used after the
-  // projections (stores to qkv / attn_stats in between would otherwise pin these loads behind them)
-  const bool has_pe = a.pe != nullptr;
-  float pv[NT][NT][4];
-  float rsv[NT];
-#pragma unroll
-  for (int qb = 0; qb < NT; ++qb) {
-    const int qc = min(16 * qb + lq, a.N - 1);
-    rsv[qb] = a.rowscale != nullptr ? a.rowscale[(int64_t)b * a.row_sb + (int64_t)qc * a.row_sn] : 1.0f;
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        pv[qb][kt][r] = has_pe ? a.pe[((int64_t)b * a.N + qc) * a.N + min(16 * kt + 4 * g + r, a.N - 1)] : 1.0f;
-  }
+  // ---- once per workgroup: biases, W_in / W_out into LDS, BatchNorm of the input finalized; the
+  // workgroup then walks its graphs (b, b + gridDim.x, ...) with the weights in place - at large
+  // batches the 64 KB of weights per graph would otherwise be the largest stream of the kernel
   float4 bin4[3], bo = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   float bin1 = 0.0f;
 #pragma unroll
@@ -115,7 +96,7 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
       const float shift = a.x_beta[c] - mean * scale;
       xss[c] = scale;
       xss[D + c] = shift;
-      if (b == 0) {
+      if (blockIdx.x == 0) {
         a.x_bn_out[c] = scale;
         a.x_bn_out[D + c] = shift;
         a.x_bn_out[2 * D + c] = mean;
@@ -129,6 +110,34 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
     }
   } else if (a.x_bn != nullptr) {
     for (int c = tid; c < 2 * D; c += kRowThreads) xss[c] = a.x_bn[c];
+  }
+  bool first = true;
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+  const int n = a.n_real[b];
+  if (!first) __syncthreads();   // the tiles of the previous graph have been consumed
+  first = false;
+  // ---- requests of this graph: node rows, pe, degree -------------------------------------------------------
+  float4 xv[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int idx = tid + kRowThreads * i, node = idx >> 4, q = idx & 15;
+    const int64_t row = (int64_t)b * a.row_sb + (int64_t)min(node, a.N - 1) * a.row_sn;
+    xv[i] = *reinterpret_cast<const float4*>(a.x + row * D + 4 * q);
+  }
+  // pe values of this lane's (query, key) pairs, degree scale and biases: requested now, used after the
+  // projections (stores to qkv / attn_stats in between would otherwise pin these loads behind them)
+  const bool has_pe = a.pe != nullptr;
+  float pv[NT][NT][4];
+  float rsv[NT];
+#pragma unroll
+  for (int qb = 0; qb < NT; ++qb) {
+    const int qc = min(16 * qb + lq, a.N - 1);
+    rsv[qb] = a.rowscale != nullptr ? a.rowscale[(int64_t)b * a.row_sb + (int64_t)qc * a.row_sn] : 1.0f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        pv[qb][kt][r] = has_pe ? a.pe[((int64_t)b * a.N + qc) * a.N + min(16 * kt + 4 * g + r, a.N - 1)] : 1.0f;
   }
   __syncthreads();
 #pragma unroll
@@ -347,6 +356,7 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
       *reinterpret_cast<float4*>(st + D + o0) = make_float4(s2[0], s2[1], s2[2], s2[3]);
     }
   }
+  }  // graphs of this workgroup
   FETA_STAMP(5);
 }
 
@@ -356,7 +366,10 @@ int launch_block_fwd(const BlockArgs& a, hipStream_t stream) {
   auto kern = attn_block_fwd_kernel<NT>;
   static size_t lds_seen = 0;
   allow_dynamic_lds(kern, lds, lds_seen);
-  hipLaunchKernelGGL(kern, dim3(a.B), dim3(kRowThreads), lds, stream, a);
+  int cap = kBlkMaxGrid;   // one resident workgroup per CU (LDS); FETA_BLOCK_MAX_GRID: tests force the loop
+  if (const char* e = getenv("FETA_BLOCK_MAX_GRID")) cap = atoi(e) > 0 ? atoi(e) : cap;
+  const int grid = a.B < cap ? a.B : cap;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kRowThreads), lds, stream, a);
   return check_launch("feta_attn_block_fwd");
 }
 

@@ -11,6 +11,8 @@
 // BASELINE batch sizes: 4736 rows).  The two halves exchange their partial y2 tiles through LDS and
 // each finishes two of the four output tiles; the residual BN1(y1) is the wave's own x operand.
 // h is still written to HBM: backward needs it (relu mask, dW2).
+#include <cstdlib>
+
 #include "feta_abi_common.h"
 #include "feta_rowops.h"
 
@@ -28,6 +30,15 @@ __host__ __device__ inline int ffn_lds_floats(int ff) {
          + 4 * 2 * 4 * 64;                      // exchange [wave][2 tiles][4 regs][64 lanes]
 }
 
+// workgroups of a launch = partial rows of y_stats: every 32-row block up to 512 of them (two resident
+// per CU), beyond that the workgroups loop.  FETA_FFN_MAX_GRID: tests force the loop.
+inline int ffn_grid(int M) {
+  int cap = 512;
+  if (const char* e = getenv("FETA_FFN_MAX_GRID")) cap = atoi(e) > 0 ? atoi(e) : cap;
+  const int nblk = (M + kFfnRows - 1) / kFfnRows;
+  return nblk < cap ? nblk : cap;
+}
+
 template <int FF>
 __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a) {
   constexpr int D = kFfnD, P1 = D + 4, P2 = FF + 4, HT = FF / 32;  // HT hidden tiles per half
@@ -38,11 +49,14 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a) {
   float* xss = W2 + D * P2;        // [2][64]
   float* scr = xss + 2 * D;        // finalize scratch
   float* xch = scr + reduce_scratch_floats(D);  // [4 waves][2][4][64]
-  const int row = blockIdx.x * kFfnRows + 16 * rt + lq;
-  const bool rok = row < a.M;
-  const int rowc = min(row, a.M - 1);
+  const int nblk = (a.M + kFfnRows - 1) / kFfnRows;
+  // a workgroup stages the weights ONCE and walks its row blocks (blockIdx.x, + gridDim.x, ...): at large
+  // batches the 64 KB of weights per 32 rows would otherwise be the largest stream of the kernel
+  int row = blockIdx.x * kFfnRows + 16 * rt + lq;
+  bool rok = row < a.M;
+  int rowc = min(row, a.M - 1);
 
-  // ---- requests: the wave's x rows, biases, then the weights ------------------------------------------
+  // ---- requests: the wave's first x rows, biases, then the weights ----------------------------------------
   Feat<D> xf;
   load_row_sel<D>(xf, a.x + (int64_t)rowc * D, true, g);
   float4 b1v[HT], b2v[2];
@@ -100,6 +114,16 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a) {
     for (int c = tid; c < 2 * D; c += kRowThreads) xss[c] = a.x_bn != nullptr ? a.x_bn[c] : (c < D ? 1.0f : 0.0f);
   }
   __syncthreads();
+  const bool want_stats = a.y_stats != nullptr;
+  float tot1[1] = {0.0f};   // thread tid < 128: one entry of the workgroup's [2][64] (sum, sum of squares)
+  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+  if (blk != (int)blockIdx.x) {
+    __syncthreads();   // exchange / reduction scratch of the previous row block consumed
+    row = blk * kFfnRows + 16 * rt + lq;
+    rok = row < a.M;
+    rowc = min(row, a.M - 1);
+    load_row_sel<D>(xf, a.x + (int64_t)rowc * D, true, g);
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const float4 sc = *reinterpret_cast<const float4*>(xss + 16 * j + 4 * g);
@@ -151,7 +175,6 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a) {
   __syncthreads();
   const float* theirs = xch + (wv ^ 1) * (2 * 4 * 64);
   float* red = scr;  // [2 row tiles][2][64] column sums, reduced below
-  const bool want_stats = a.y_stats != nullptr;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int t2 = 2 * hh + t, o2 = 16 * t2 + 4 * g;
@@ -174,9 +197,10 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a) {
   }
   if (want_stats) {
     __syncthreads();
-    for (int i = tid; i < 2 * D; i += kRowThreads)
-      a.y_stats[(int64_t)blockIdx.x * 2 * D + i] = red[i] + red[2 * D + i];
+    if (tid < 2 * D) tot1[0] += red[tid] + red[2 * D + tid];
   }
+  }  // row blocks of this workgroup
+  if (want_stats && tid < 2 * D) a.y_stats[(int64_t)blockIdx.x * 2 * D + tid] = tot1[0];
 }
 
 template <int FF>
@@ -185,8 +209,7 @@ int launch_ffn_fwd(const FfnArgs& a, hipStream_t stream) {
   auto kern = ffn_fwd_kernel<FF>;
   static size_t lds_seen = 0;
   allow_dynamic_lds(kern, lds, lds_seen);
-  const int grid = (a.M + kFfnRows - 1) / kFfnRows;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kRowThreads), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3(ffn_grid(a.M)), dim3(kRowThreads), lds, stream, a);
   return check_launch("feta_ffn_fwd");
 }
 
@@ -198,7 +221,7 @@ extern "C" int feta_ffn_supported(int d_model, int ff) {
   return (d_model == kFfnD && (ff == 64 || ff == 128 || ff == 256)) ? 1 : 0;
 }
 
-extern "C" int feta_ffn_blocks(int M) { return (M + kFfnRows - 1) / kFfnRows; }
+extern "C" int feta_ffn_blocks(int M) { return ffn_grid(M); }
 
 extern "C" int feta_ffn_fwd(const feta_ffn* d, feta_stream_t stream) {
   FETA_REQUIRE(d != nullptr, "ffn_fwd: null descriptor");

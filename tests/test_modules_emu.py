@@ -269,3 +269,12 @@ def test_capped_statistics_partials_give_the_same_result(emu, monkeypatch):
     KC.assert_close('output', b[0], a[0].double(), tol=2e-6)
     for k in a[3]:
         KC.assert_close('grad ' + k, b[3][k], a[3][k].double(), tol=1e-5)
+
+
+def test_attn_block_walks_several_graphs_per_workgroup(emu, monkeypatch):
+    """large batches: a workgroup of the fused attention block stages the weights once and loops over its
+    graphs; forced here with 2 workgroups for 5 graphs"""
+    monkeypatch.setenv('FETA_BLOCK_MAX_GRID', '2')
+    monkeypatch.setenv('FETA_FFN_MAX_GRID', '3')
+    check_attn_block_equals_three_launches(CPU, lambda: _lib.override_for_tests(emu), monkeypatch, 'zinc',
+                                           9, 30, False, True, bsz=5)
