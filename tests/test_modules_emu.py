@@ -278,3 +278,11 @@ def test_attn_block_walks_several_graphs_per_workgroup(emu, monkeypatch):
     monkeypatch.setenv('FETA_FFN_MAX_GRID', '3')
     check_attn_block_equals_three_launches(CPU, lambda: _lib.override_for_tests(emu), monkeypatch, 'zinc',
                                            9, 30, False, True, bsz=5)
+
+
+@pytest.mark.parametrize('n_min,n_max,bsz', [(2, 3, 1), (1, 2, 2), (16, 16, 2), (17, 17, 1), (48, 48, 1)])
+def test_fused_kernels_edge_shapes(emu, monkeypatch, n_min, n_max, bsz):
+    """tiny graphs, a single graph, node counts on the tile boundaries (16, 17, 48): fused kernels ==
+    the unfused launch sequence"""
+    check_attn_block_equals_three_launches(CPU, lambda: _lib.override_for_tests(emu), monkeypatch, 'mutag',
+                                           n_min, n_max, False, True, bsz=bsz)

@@ -67,3 +67,13 @@ def test_attn_block_equals_three_launches(monkeypatch, shape, n_min, n_max, tie_
     from test_modules_emu import check_attn_block_equals_three_launches
     check_attn_block_equals_three_launches(torch.device('cuda:0'), contextlib.nullcontext, monkeypatch, shape,
                                            n_min, n_max, tie_qk, pe_on, bsz=bsz)
+
+
+@pytest.mark.parametrize('n_min,n_max,bsz', [(2, 3, 1), (1, 2, 2), (16, 16, 2), (17, 17, 1), (48, 48, 1), (9, 37, 300)])
+def test_fused_kernels_edge_shapes(monkeypatch, n_min, n_max, bsz):
+    """tiny graphs, one graph, tile-boundary node counts, and a batch above the per-graph attention
+    backward threshold and above the resident-workgroup caps (workgroups walk several graphs)"""
+    import contextlib
+    from test_modules_emu import check_attn_block_equals_three_launches
+    check_attn_block_equals_three_launches(torch.device('cuda:0'), contextlib.nullcontext, monkeypatch, 'zinc' if bsz > 100 else 'mutag',
+                                           n_min, n_max, False, True, bsz=bsz)
