@@ -63,8 +63,12 @@ __global__ __launch_bounds__(64 * kWaves) void attn_fwd_kernel(AttnArgs a) {
   const int KT = (n + 15) >> 4;
   const int q = q0 + lq;  // this lane's query (column of the transposed tile)
 
+  // every load below is UNCONDITIONAL (row indices clamped into the tensor, validity applied by selects):
+  // a branch around a load serialises the memory round trips of the unrolled loops, without it the loads
+  // of a phase go out back to back and the wave pays one latency per phase
+  const int nm1 = max(n - 1, 0), qc = min(q, a.N - 1);
   Feat<DH> qf;
-  load_row<DH>(qf, q < a.N ? tok_row(a.q, a.qsb, a.qsn, b, q, h, DH) : nullptr, g, a.scale);
+  load_row_sel<DH>(qf, tok_row(a.q, a.qsb, a.qsn, b, qc, h, DH), q < a.N, g, a.scale);
 
   // S^T tiles: acc[kt][r] <-> key 16kt + 4g + r, query q
   f32x4 acc[KT_MAX];
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(64 * kWaves) void attn_fwd_kernel(AttnArgs a) {
     if (kt < KT) {
       const int key = 16 * kt + lq;
       Feat<DH> kf;
-      load_row<DH>(kf, key < n ? tok_row(a.k, a.qsb, a.qsn, b, key, h, DH) : nullptr, g);
+      load_row_sel<DH>(kf, tok_row(a.k, a.qsb, a.qsn, b, min(key, nm1), h, DH), key < n, g);
       acc[kt] = dot_rows<DH>(kf, qf, zero4());
     }
   }
@@ -90,19 +94,19 @@ __global__ __launch_bounds__(64 * kWaves) void attn_fwd_kernel(AttnArgs a) {
   m = fmaxf(m, shfl_xor(m, 16));
   m = fmaxf(m, shfl_xor(m, 32));
 
-  const float* pe_row = (a.pe != nullptr && q < a.N) ? a.pe + ((int64_t)b * a.N + q) * a.N : nullptr;
+  const bool has_pe = a.pe != nullptr;
+  const float* pe_row = has_pe ? a.pe + ((int64_t)b * a.N + qc) * a.N : nullptr;
   float z = 0.0f;
 #pragma unroll
   for (int kt = 0; kt < KT_MAX; ++kt) {
     if (kt < KT) {
+      float pv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pv[r] = has_pe ? pe_row[min(16 * kt + 4 * g + r, nm1)] : 1.0f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = 16 * kt + 4 * g + r;
-        float e = 0.0f;
-        if (key < n) {
-          e = fast_exp(acc[kt][r] - m);
-          if (pe_row != nullptr) e *= pe_row[key];
-        }
+        const float e = key < n ? fast_exp(acc[kt][r] - m) * pv[r] : 0.0f;
         acc[kt][r] = e;
         z += e;
       }
@@ -128,12 +132,12 @@ __global__ __launch_bounds__(64 * kWaves) void attn_fwd_kernel(AttnArgs a) {
       for (int r = 0; r < 4; ++r) {
         acc[kt][r] *= rinv;
         const int key = 16 * kt + 4 * g + r;
-        const float* vrow = key < n ? tok_row(a.v, a.qsb, a.qsn, b, key, h, DH) : nullptr;
+        const float* vrow = tok_row(a.v, a.qsb, a.qsn, b, min(key, nm1), h, DH);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
           const int c = 16 * ct + lq;
-          const float vb = (vrow != nullptr && c < DH) ? vrow[c] : 0.0f;
-          o[ct] = mfma16(acc[kt][r], vb, o[ct]);
+          const float vv = vrow[c < DH ? c : 0];
+          o[ct] = mfma16(acc[kt][r], (key < n && c < DH) ? vv : 0.0f, o[ct]);
         }
       }
     }
@@ -215,37 +219,53 @@ __global__ __launch_bounds__(64 * kWaves) void attn_bwd_dq_kernel(AttnArgs a) {
   }
   const float rinv = 1.0f / fmaxf(z, 1e-6f);
   if (z < 1e-6f) delta = 0.0f;  // clamp active: the normaliser is a constant
-  const float* pe_row = (a.pe != nullptr && qok) ? a.pe + ((int64_t)b * a.N + q) * a.N : nullptr;
-
   f32x4 dq[CT];
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) dq[ct] = zero4();
 
-  for (int kt = 0; kt < KT; ++kt) {
-    const int krow = 16 * kt + lq;
+  // one batch of unconditional, clamped loads per key tile (K and V rows in both operand layouts, pe);
+  // the batch of tile kt + 1 is requested before tile kt is computed
+  struct Tile {
     Feat<DH> kf, vf;
-    load_row<DH>(kf, krow < n ? tok_row(a.k, a.qsb, a.qsn, b, krow, h, DH) : nullptr, g);
-    load_row<DH>(vf, krow < n ? tok_row(a.v, a.qsb, a.qsn, b, krow, h, DH) : nullptr, g);
-    f32x4 s = dot_rows<DH>(kf, qf, zero4());    // scores^T
-    f32x4 da = dot_rows<DH>(vf, dof, zero4());  // (dout . v^T)^T
+    float pv[4], kb[4][CT];
+  };
+  const int nm1 = max(n - 1, 0);
+  const bool has_pe = a.pe != nullptr;
+  const float* pe_c = has_pe ? a.pe + ((int64_t)b * a.N + min(q, a.N - 1)) * a.N : nullptr;
+  auto load_tile = [&](int kt, Tile& T) {
+    const int krow = 16 * kt + lq;
+    load_row_sel<DH>(T.kf, tok_row(a.k, a.qsb, a.qsn, b, min(krow, nm1), h, DH), krow < n, g);
+    load_row_sel<DH>(T.vf, tok_row(a.v, a.qsb, a.qsn, b, min(krow, nm1), h, DH), krow < n, g);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int key = 16 * kt + 4 * g + r;
-      float p = 0.0f;
-      if (key < n) {
-        p = fast_exp(s[r] - m);
-        if (pe_row != nullptr) p *= pe_row[key];
-        p *= rinv;
-      }
-      const float ds = p * (da[r] - delta);
-      const float* krow_p = key < n ? tok_row(a.k, a.qsb, a.qsn, b, key, h, DH) : nullptr;
+      const int kc = min(key, nm1);
+      T.pv[r] = has_pe ? pe_c[kc] : 1.0f;
+      const float* kr = tok_row(a.k, a.qsb, a.qsn, b, kc, h, DH);
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
         const int c = 16 * ct + lq;
-        const float kb = (krow_p != nullptr && c < DH) ? krow_p[c] : 0.0f;
-        dq[ct] = mfma16(ds, kb, dq[ct]);
+        const float kv = kr[c < DH ? c : 0];
+        T.kb[r][ct] = (key < n && c < DH) ? kv : 0.0f;
       }
     }
+  };
+  Tile cur;
+  if (KT > 0) load_tile(0, cur);
+  for (int kt = 0; kt < KT; ++kt) {
+    Tile nxt;
+    load_tile(min(kt + 1, KT - 1), nxt);
+    f32x4 s = dot_rows<DH>(cur.kf, qf, zero4());    // scores^T
+    f32x4 da = dot_rows<DH>(cur.vf, dof, zero4());  // (dout . v^T)^T
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = 16 * kt + 4 * g + r;
+      const float p = (key < n && qok) ? fast_exp(s[r] - m) * cur.pv[r] * rinv : 0.0f;
+      const float ds = p * (da[r] - delta);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) dq[ct] = mfma16(ds, cur.kb[r][ct], dq[ct]);
+    }
+    cur = nxt;
   }
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
@@ -283,37 +303,57 @@ __global__ __launch_bounds__(64 * kWaves) void attn_bwd_dkdv_kernel(AttnArgs a) 
     Feat<DH> kf, vf;
     load_row<DH>(kf, kok ? tok_row(a.k, a.qsb, a.qsn, b, key, h, DH) : nullptr, g);
     load_row<DH>(vf, kok ? tok_row(a.v, a.qsb, a.qsn, b, key, h, DH) : nullptr, g);
-    for (int qb = 0; qb < a.NB; ++qb) {
-      const int q0 = 16 * qb;
-      const int qrow = q0 + lq;
+    // one batch of unconditional, clamped loads per query tile; the next tile's batch is requested first
+    struct Tile {
       Feat<DH> qf, dof;
-      load_row<DH>(qf, qrow < a.N ? tok_row(a.q, a.qsb, a.qsn, b, qrow, h, DH) : nullptr, g, a.scale);
-      load_row<DH>(dof, qrow < a.N ? tok_row(a.dout, a.osb, a.osn, b, qrow, h, DH) : nullptr, g);
-      f32x4 s = dot_rows<DH>(qf, kf, zero4());    // scores: row = query 4g+r, col = key
-      f32x4 da = dot_rows<DH>(dof, vf, zero4());  // dout . v^T
+      float sm[4], sz[4], sd[4], pv[4], dob[4][CT], qbv[4][CT];
+    };
+    const int keyc = min(key, max(n - 1, 0));
+    const bool has_pe = a.pe != nullptr;
+    auto load_tile = [&](int qb, Tile& T) {
+      const int qrow = 16 * qb + lq, qrc = min(qrow, a.N - 1);
+      load_row_sel<DH>(T.qf, tok_row(a.q, a.qsb, a.qsn, b, qrc, h, DH), qrow < a.N, g, a.scale);
+      load_row_sel<DH>(T.dof, tok_row(a.dout, a.osb, a.osn, b, qrc, h, DH), qrow < a.N, g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int qq = q0 + 4 * g + r;
-        float p = 0.0f, ds = 0.0f;
-        if (qq < a.N && kok) {
-          const float* st = a.stats_in + ((int64_t)bh * a.N + qq) * 2;
-          const float m = st[0], z = st[1];
-          p = fast_exp(s[r] - m);
-          if (a.pe != nullptr) p *= a.pe[((int64_t)b * a.N + qq) * a.N + key];
-          p *= 1.0f / fmaxf(z, 1e-6f);
-          const float delta = z < 1e-6f ? 0.0f : a.delta[(int64_t)bh * a.N + qq];
-          ds = p * (da[r] - delta);
-        }
-        const float* dorow = qq < a.N ? tok_row(a.dout, a.osb, a.osn, b, qq, h, DH) : nullptr;
-        const float* qrow_p = qq < a.N ? tok_row(a.q, a.qsb, a.qsn, b, qq, h, DH) : nullptr;
+        const int qq = 16 * qb + 4 * g + r, qqc = min(qq, a.N - 1);
+        const float* st = a.stats_in + ((int64_t)bh * a.N + qqc) * 2;
+        T.sm[r] = st[0];
+        T.sz[r] = st[1];
+        T.sd[r] = a.delta[(int64_t)bh * a.N + qqc];
+        T.pv[r] = has_pe ? a.pe[((int64_t)b * a.N + qqc) * a.N + keyc] : 1.0f;
+        const float* dorow = tok_row(a.dout, a.osb, a.osn, b, qqc, h, DH);
+        const float* qrow_p = tok_row(a.q, a.qsb, a.qsn, b, qqc, h, DH);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-          const int c = 16 * ct + lq;
-          const bool ok = dorow != nullptr && c < DH;
-          dv[ct] = mfma16(p, ok ? dorow[c] : 0.0f, dv[ct]);
-          dk[ct] = mfma16(ds, ok ? qrow_p[c] * a.scale : 0.0f, dk[ct]);
+          const int c = 16 * ct + lq, cc = c < DH ? c : 0;
+          const bool ok = qq < a.N && c < DH;
+          const float dv_ = dorow[cc], qv_ = qrow_p[cc];
+          T.dob[r][ct] = ok ? dv_ : 0.0f;
+          T.qbv[r][ct] = ok ? qv_ * a.scale : 0.0f;
         }
       }
+    };
+    Tile cur;
+    load_tile(0, cur);
+    for (int qb = 0; qb < a.NB; ++qb) {
+      Tile nxt;
+      load_tile(min(qb + 1, a.NB - 1), nxt);
+      f32x4 s = dot_rows<DH>(cur.qf, kf, zero4());    // scores: row = query 4g+r, col = key
+      f32x4 da = dot_rows<DH>(cur.dof, vf, zero4());  // dout . v^T
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qq = 16 * qb + 4 * g + r;
+        const float zz = cur.sz[r];
+        const float p = (qq < a.N && kok) ? fast_exp(s[r] - cur.sm[r]) * cur.pv[r] * (1.0f / fmaxf(zz, 1e-6f)) : 0.0f;
+        const float ds = p * (da[r] - (zz < 1e-6f ? 0.0f : cur.sd[r]));
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          dv[ct] = mfma16(p, cur.dob[r][ct], dv[ct]);
+          dk[ct] = mfma16(ds, cur.qbv[r][ct], dk[ct]);
+        }
+      }
+      cur = nxt;
     }
   }
 #pragma unroll
