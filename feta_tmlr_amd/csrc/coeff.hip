@@ -83,7 +83,21 @@ __global__ __launch_bounds__(kCoeffThreads) void coeff_fwd_kernel(
   } else {
     const float* src = a;
     if (stage) {
-      for (int idx = threadIdx.x; idx < n * N; idx += kCoeffThreads) tile[idx] = a[idx];
+      // eight requests in flight per thread (a plain copy loop pays one memory latency per 256 floats)
+      const int cnt = n * N;
+      for (int base = threadIdx.x; base < cnt; base += 8 * kCoeffThreads) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int idx = base + u * kCoeffThreads;
+          v[u] = a[idx < cnt ? idx : cnt - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int idx = base + u * kCoeffThreads;
+          if (idx < cnt) tile[idx] = v[u];
+        }
+      }
       __syncthreads();
       src = tile;
     }
