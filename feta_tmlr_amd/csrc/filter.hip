@@ -1079,7 +1079,7 @@ bool try_spec_dense_dh(const FilterArgs& a, bool bwd, hipStream_t stream, int* r
   return true;
 }
 
-// ---- eigenbasis form, one workgroup per graph (d = 64: 4 heads x dh 16, N <= 64, K <= 32, K % 4 = 0) --
+// ---- eigenbasis form, one workgroup per graph (d = 64: 4 heads x dh 16, N <= 192, K <= 32, K % 4 = 0) --
 // The 4 waves of a workgroup are the 4 heads of ONE graph, so everything the heads share is fetched
 // from HBM once and with 16-byte accesses: the eigenvector tile U_b [N, K] and lambda_b (the per-head
 // kernels above read U eight times per graph: 4 heads x 2 operand orientations), and the node rows of
@@ -1119,9 +1119,18 @@ __global__ __launch_bounds__(256) void spec_fwd_graph_kernel(FilterArgs a) {
     const float4 v = *reinterpret_cast<const float4*>(U + (int64_t)min(node, nm1) * a.K + min(e, a.K - 4));
     uv[i] = keep4(node < n && e < a.K, v);
   }
-  float4 wv[PP];
+  // this head's W_k: requested first and written to LDS first (with 12 row tiles in flight the compiler
+  // would otherwise park these registers in private memory)
+  {
+    float4 wv[PP];
 #pragma unroll
-  for (int i = 0; i < PP; ++i) wv[i] = reinterpret_cast<const float4*>(w)[lane + 64 * i];
+    for (int i = 0; i < PP; ++i) wv[i] = reinterpret_cast<const float4*>(w)[lane + 64 * i];
+#pragma unroll
+    for (int i = 0; i < PP; ++i) {
+      const int idx = lane + 64 * i;
+      *reinterpret_cast<float4*>(Ws + (idx >> 2) * WP + 4 * (idx & 3)) = wv[i];
+    }
+  }
   const float lv = a.lam[(int64_t)b * a.K + min(tid, a.K - 1)];
   const float bv = (a.bias != nullptr) ? a.bias[lq] : 0.0f;
 #pragma unroll
@@ -1133,11 +1142,6 @@ __global__ __launch_bounds__(256) void spec_fwd_graph_kernel(FilterArgs a) {
   for (int i = 0; i < UI; ++i) {
     const int idx = tid + 256 * i;
     if (idx < NR * UQ) *reinterpret_cast<float4*>(Us + (idx / UQ) * UP + 4 * (idx % UQ)) = uv[i];
-  }
-#pragma unroll
-  for (int i = 0; i < PP; ++i) {
-    const int idx = lane + 64 * i;
-    *reinterpret_cast<float4*>(Ws + (idx >> 2) * WP + 4 * (idx & 3)) = wv[i];
   }
   if (tid < 16 * ET_MAX) lams[tid] = tid < a.K ? lv : 0.0f;
   __syncthreads();
@@ -1363,10 +1367,14 @@ int launch_spec_graph_p(const FilterArgs& a, bool bwd, hipStream_t stream) {
   if (bwd) {
     const size_t lds = sizeof(float) * (2 * NR * kGraphXP + NR * UP + 16 * ET_MAX);
     auto kern = spec_bwd_graph_kernel<NT_MAX, ET_MAX, PP>;
+    static size_t lds_seen = 0;
+    allow_dynamic_lds(kern, lds, lds_seen);
     hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
   } else {
     const size_t lds = sizeof(float) * (NR * kGraphXP + NR * UP + 16 * ET_MAX + 4 * PP * 16 * kGraphWP);
     auto kern = spec_fwd_graph_kernel<NT_MAX, ET_MAX, PP>;
+    static size_t lds_seen = 0;
+    allow_dynamic_lds(kern, lds, lds_seen);
     hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
   }
   return check_launch(bwd ? "feta_spec_filter_bwd" : "feta_spec_filter_fwd");
@@ -1386,8 +1394,19 @@ int launch_spec_graph(const FilterArgs& a, bool bwd, hipStream_t stream) {
 // (heads_share_graph), 4 heads x dh 16 stored as one 64-float row per node, 16-byte aligned rows of U.
 bool try_spec_graph(const FilterArgs& a, int dh, bool bwd, hipStream_t stream, int* rc) {
   const int nt = (a.N + 15) / 16, et = (a.K + 15) / 16;
-  if (!a.share || a.H != 4 || dh != 16 || nt > 4 || et > 2 || (a.K & 3) != 0 || a.P < 2 || a.P > 5) return false;
+  if (!a.share || a.H != 4 || dh != 16 || nt > 12 || et > 2 || (a.K & 3) != 0 || a.P < 2 || a.P > 5) return false;
   if (!aligned16(a.u)) return false;
+  if (nt > 4) {
+    // large graphs (N <= 192, the PATTERN shape): the node rows of X / dY and the eigenvector tile U_b still
+    // fit in LDS (100 KB forward, 132 KB backward) - the "LDS-tiled U^T X" of BASELINE config 4.  Only the
+    // default filter order is instantiated at these sizes; other orders take the per-head kernels.
+    if (a.P != 4) return false;
+    if (nt <= 8 && et <= 1) *rc = launch_spec_graph_p<8, 1, 4>(a, bwd, stream);
+    else if (nt <= 8) *rc = launch_spec_graph_p<8, 2, 4>(a, bwd, stream);
+    else if (et <= 1) *rc = launch_spec_graph_p<12, 1, 4>(a, bwd, stream);
+    else *rc = launch_spec_graph_p<12, 2, 4>(a, bwd, stream);
+    return true;
+  }
   if (nt <= 3 && et <= 1) *rc = launch_spec_graph<3, 1>(a, bwd, stream);
   else if (et <= 1) *rc = launch_spec_graph<4, 1>(a, bwd, stream);
   else if (nt <= 3) *rc = launch_spec_graph<3, 2>(a, bwd, stream);

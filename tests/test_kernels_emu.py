@@ -75,6 +75,8 @@ def test_spec_truncated(emu, k_eig):
     (8, 'mutag', None, None, 4, False),
     (32, 'pattern', 44, 64, 3, True),         # 4 row tiles, 2 eigen tiles
     (None, 'zinc', 12, 32, 5, True),          # exact operator, K = N_pad = 32
+    (32, 'pattern', 100, 188, 4, True),       # large graphs: 12 row tiles, LDS-tiled U^T X
+    (16, 'pattern', 70, 120, 4, False),       # 8 row tiles
 ])
 def test_spec_one_workgroup_per_graph(emu, k_eig, shape, n_min, n_max, order, seq_first):
     """4 heads x dh 16, all heads on the graph: the LDS-staged kernels (spec_*_graph_kernel)."""

@@ -90,6 +90,8 @@ def test_spec_truncated(hip, k_eig, bsz):
     (8, 'mutag', None, None, 4, False, 5),
     (32, 'pattern', 44, 64, 3, True, 9),
     (None, 'zinc', 12, 32, 5, True, 4),
+    (32, 'pattern', 100, 188, 4, True, 9),
+    (16, 'pattern', 70, 120, 4, False, 5),
 ])
 def test_spec_one_workgroup_per_graph(hip, k_eig, shape, n_min, n_max, order, seq_first, bsz):
     abi, dev, stream = hip
