@@ -193,3 +193,64 @@ class GraphedTrainStep:
                 dst.copy_(graph_cache.extra[key], non_blocking=True)
         self.graph.replay()
         return self.loss
+
+
+def rocauc(scores, labels):
+    """Binary ROC-AUC over the labeled graphs (what ogb's Evaluator('ogbg-molhiv') reports,
+    experiments/run_transformer_gengcn_molhiv.py:213-218): rank statistic with ties averaged."""
+    keep = ~torch.isnan(labels)
+    s, y = scores[keep].double().cpu(), labels[keep].double().cpu()
+    pos, neg = int((y > 0.5).sum()), int((y <= 0.5).sum())
+    if pos == 0 or neg == 0:
+        return float('nan')
+    order = torch.argsort(s)
+    ranks = torch.empty_like(s)
+    ranks[order] = torch.arange(1, len(s) + 1, dtype=torch.float64)
+    vals, inv, counts = torch.unique(s, return_inverse=True, return_counts=True)
+    sums = torch.zeros_like(vals).scatter_add_(0, inv, ranks)
+    ranks = (sums / counts)[inv]                        # average rank of tied scores
+    return float((ranks[y > 0.5].sum() - pos * (pos + 1) / 2.0) / (pos * neg))
+
+
+@torch.no_grad()
+def evaluate(task, model, criterion, batches):
+    """The reference's eval_epoch for one split: ``batches`` yields (batch9, graph_cache).  Returns a dict:
+    'loss' (sample-weighted mean, as running_loss / n_sample) plus 'mae' and 'mse' (zinc,
+    run_transformer_gengcn.py:167-209), 'acc' (tu: fraction of graphs; sbm: mean per-class recall in
+    percent averaged over batches, ..._SBM_cv.py:221-266) or 'rocauc' (molhiv).  The model is put in eval
+    mode (BatchNorm running statistics) and restored."""
+    was_training = model.training
+    model.eval()
+    tot = {'loss': 0.0, 'mae': 0.0, 'mse': 0.0, 'hit': 0.0, 'acc_sum': 0.0}
+    n_sample, n_batch = 0, 0
+    scores, labels_all = [], []
+    for batch9, cache in batches:
+        loss, out = task_loss(task, model, criterion, batch9, cache)
+        labels = batch9[5]
+        bsz = batch9[0].shape[0]
+        tot['loss'] += float(loss) * bsz
+        n_sample += bsz
+        n_batch += 1
+        if task == 'zinc':
+            lab = labels.view(out.shape)
+            tot['mae'] += float(F.l1_loss(out, lab)) * bsz
+            tot['mse'] += float(F.mse_loss(out, lab)) * bsz
+        elif task == 'tu':
+            pred = out.argmax(dim=1) if out.dim() == 2 and out.shape[1] > 1 else (out.view(-1) > 0).long()
+            tot['hit'] += float((pred == labels.view(-1)).sum())
+        elif task == 'sbm':
+            tot['acc_sum'] += accuracy_SBM(out, labels.view(-1))
+        elif task == 'molhiv':
+            scores.append(out.view(-1).detach())
+            labels_all.append(labels.view(-1))
+    model.train(was_training)
+    res = {'loss': tot['loss'] / max(n_sample, 1)}
+    if task == 'zinc':
+        res.update(mae=tot['mae'] / n_sample, mse=tot['mse'] / n_sample)
+    elif task == 'tu':
+        res['acc'] = tot['hit'] / n_sample
+    elif task == 'sbm':
+        res['acc'] = tot['acc_sum'] / max(n_batch, 1)
+    elif task == 'molhiv':
+        res['rocauc'] = rocauc(torch.cat(scores), torch.cat(labels_all))
+    return res

@@ -61,3 +61,39 @@ def test_regularisation_matches_oracle():
     from feta_tmlr_amd.transformer.models import regularisation_max_cos
     c = torch.randn(3, 4, 16, dtype=torch.float64)
     assert abs(float(regularisation_max_cos(c)) - float(O.regularisation_max_cos(c))) < 1e-12
+
+
+def test_rocauc_matches_sklearn():
+    from sklearn.metrics import roc_auc_score
+    g = torch.Generator().manual_seed(0)
+    s = torch.randn(200, generator=g).round(decimals=1)          # ties on purpose
+    y = (torch.rand(200, generator=g) < 0.3).float()
+    y[::17] = float('nan')
+    keep = ~torch.isnan(y)
+    assert abs(T.rocauc(s, y) - roc_auc_score(y[keep].numpy(), s[keep].numpy())) < 1e-12
+
+
+@pytest.mark.parametrize('task', ['zinc', 'tu', 'molhiv', 'sbm'])
+def test_evaluate_metrics(emu, task):
+    """eval-mode metrics of one split (running BatchNorm statistics, no gradient) against the same
+    quantities computed from the model outputs by hand"""
+    model, batch9, cache = TC.build_case(task, torch.device('cpu'), batch_norm=(task == 'zinc'))
+    crit = T.make_criterion(task, nb_class=3 if task in ('tu', 'sbm') else 1)
+    with _lib.override_for_tests(emu):
+        res = T.evaluate(task, model, crit, [(batch9, cache), (batch9, cache)])
+        model.eval()
+        with torch.no_grad():
+            loss, out = T.task_loss(task, model, crit, batch9, cache)
+        model.train()
+    assert model.training
+    assert abs(res['loss'] - float(loss)) < 1e-6
+    labels = batch9[5]
+    if task == 'zinc':
+        assert abs(res['mae'] - float((out - labels.view(out.shape)).abs().mean())) < 1e-6
+        assert abs(res['mse'] - float(((out - labels.view(out.shape)) ** 2).mean())) < 1e-6
+    elif task == 'tu':
+        assert abs(res['acc'] - float((out.argmax(1) == labels).float().mean())) < 1e-9
+    elif task == 'sbm':
+        assert abs(res['acc'] - T.accuracy_SBM(out, labels)) < 1e-9
+    else:
+        assert res['rocauc'] == T.rocauc(torch.cat([out.view(-1)] * 2), torch.cat([labels] * 2))

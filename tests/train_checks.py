@@ -21,6 +21,8 @@ def build_case(task, dev, seed=0, bsz=4, d=32, heads=2, layers=2, order=3, batch
                                      labels='binary', nan_label_frac=0.3)
         ds.samples[0].y = float('nan')      # at least one unlabeled graph
         ds.samples[1].y = 1.0
+        if len(ds.samples) > 2:
+            ds.samples[2].y = 0.0           # both classes present
     elif task == 'sbm':
         model = M.DiffGraphTransformerGenGCNSBM(5, nb_class, d, heads, **kw)
         ds = D.SyntheticGraphDataset('pattern', bsz, in_dim=5, seed=seed, n_min=6, n_max=21,
