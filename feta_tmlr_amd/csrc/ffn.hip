@@ -39,6 +39,11 @@ inline int ffn_grid(int M) {
   return nblk < cap ? nblk : cap;
 }
 
+#ifdef FETA_TIMING
+__device__ unsigned long long feta_ffn_stamps[16];
+#endif
+#define FFN_STAMP(i) FETA_STAMP_TO(feta_ffn_stamps, i, blockIdx.x == 0 && threadIdx.x == 0)
+
 template <int FF>
 __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a) {
   constexpr int D = kFfnD, P1 = D + 4, P2 = FF + 4, HT = FF / 32;  // HT hidden tiles per half
@@ -49,6 +54,7 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a) {
   float* xss = W2 + D * P2;        // [2][64]
   float* scr = xss + 2 * D;        // finalize scratch
   float* xch = scr + reduce_scratch_floats(D);  // [4 waves][2][4][64]
+  FFN_STAMP(0);
   const int nblk = (a.M + kFfnRows - 1) / kFfnRows;
   // a workgroup stages the weights ONCE and walks its row blocks (blockIdx.x, + gridDim.x, ...): at large
   // batches the 64 KB of weights per 32 rows would otherwise be the largest stream of the kernel
@@ -68,6 +74,10 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a) {
   for (int t = 0; t < 2; ++t)
     b2v[t] = a.b2 != nullptr ? *reinterpret_cast<const float4*>(a.b2 + 16 * (2 * hh + t) + 4 * g)
                              : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  PartialRows<16> pre;   // the BatchNorm-1 partial sums: requested with the weights, reduced after them
+  // (unconditional: a conditionally-filled float4 array is lowered to private memory; without statistics
+  // the first rows of W1 are read and never used)
+  partials_issue<16>(a.x_stats != nullptr ? a.x_stats : a.w1, a.x_stats != nullptr ? a.Gx : 1, D, pre);
   {
     constexpr int NV = 2 * FF * D / 4 / kRowThreads;  // float4 per thread: W1 then W2
     float4 wv4[NV];
@@ -88,8 +98,9 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a) {
       }
     }
   }
+  FFN_STAMP(1);
   if (a.x_stats != nullptr) {
-    reduce_partials(a.x_stats, a.Gx, D, scr + 2 * D, scr);
+    partials_finish<16>(a.x_stats, a.Gx, D, scr + 2 * D, scr, pre);
     for (int c = tid; c < D; c += kRowThreads) {
       const float mean = scr[c] / (float)a.M;
       const float var = fmaxf(scr[D + c] / (float)a.M - mean * mean, 0.0f);
@@ -114,6 +125,7 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a) {
     for (int c = tid; c < 2 * D; c += kRowThreads) xss[c] = a.x_bn != nullptr ? a.x_bn[c] : (c < D ? 1.0f : 0.0f);
   }
   __syncthreads();
+  FFN_STAMP(2);
   const bool want_stats = a.y_stats != nullptr;
   float tot1[1] = {0.0f};   // thread tid < 128: one entry of the workgroup's [2][64] (sum, sum of squares)
   for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
@@ -149,6 +161,7 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a) {
     hacc[t] = v;
     if (rok) *reinterpret_cast<float4*>(a.h + (int64_t)row * FF + o + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
   }
+  FFN_STAMP(3);
   // ---- partial y2^T tiles over this half: (output 4g+r, row lq) --------------------------------------
   f32x4 yp[4];
 #pragma unroll
@@ -164,13 +177,15 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a) {
     }
     yp[t2] = acc;
   }
+  FFN_STAMP(4);
   // ---- exchange: this wave finishes output tiles 2hh, 2hh+1; the partner gets the other two -----------
   {
     float* mine = xch + wv * (2 * 4 * 64);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) mine[(t * 4 + r) * 64 + lane] = yp[2 * (1 - hh) + t][r];
+      for (int r = 0; r < 4; ++r)   // (selects, not a runtime index: that would put yp in private memory)
+        mine[(t * 4 + r) * 64 + lane] = hh ? yp[t][r] : yp[2 + t][r];
   }
   __syncthreads();
   const float* theirs = xch + (wv ^ 1) * (2 * 4 * 64);
@@ -181,7 +196,15 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a) {
     const float bb[4] = {b2v[t].x, b2v[t].y, b2v[t].z, b2v[t].w};
     float v[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = yp[t2][r] + theirs[(t * 4 + r) * 64 + lane] + bb[r] + xf.f[t2][r];
+    for (int r = 0; r < 4; ++r) {
+      const float own = hh ? yp[2 + t][r] : yp[t][r];
+      // (the empty asm makes both candidates plain register values: a select between two LOADS of xf is
+      // folded into one load at a selected address, which puts xf in private memory)
+      float x_hi = xf.f[2 + t][r], x_lo = xf.f[t][r];
+      asm volatile("" : "+v"(x_hi), "+v"(x_lo));
+      const float res = hh ? x_hi : x_lo;
+      v[r] = own + theirs[(t * 4 + r) * 64 + lane] + bb[r] + res;
+    }
     if (rok) *reinterpret_cast<float4*>(a.y + (int64_t)row * D + o2) = make_float4(v[0], v[1], v[2], v[3]);
     if (want_stats) {
 #pragma unroll
@@ -199,6 +222,7 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a) {
     __syncthreads();
     if (tid < 2 * D) tot1[0] += red[tid] + red[2 * D + tid];
   }
+  FFN_STAMP(5);
   }  // row blocks of this workgroup
   if (want_stats && tid < 2 * D) a.y_stats[(int64_t)blockIdx.x * 2 * D + tid] = tot1[0];
 }
@@ -216,6 +240,12 @@ int launch_ffn_fwd(const FfnArgs& a, hipStream_t stream) {
 }  // namespace feta
 
 using namespace feta;
+
+#ifdef FETA_TIMING
+extern "C" int feta_debug_ffn_stamps(unsigned long long* out16) {
+  return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(feta_ffn_stamps), sizeof(unsigned long long) * 16);
+}
+#endif
 
 extern "C" int feta_ffn_supported(int d_model, int ff) {
   return (d_model == kFfnD && (ff == 64 || ff == 128 || ff == 256)) ? 1 : 0;
