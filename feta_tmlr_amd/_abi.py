@@ -48,6 +48,11 @@ SIGNATURES = {
     'feta_bn_bwd': ([_F, _F, _F, _F, _F, _F, _F, _F, C.c_int, C.c_int, _S], C.c_int),
     'feta_lhat_from_edges': ([_I, C.c_int64, _I, _I, _F, _F, C.c_int, C.c_int, C.c_int64, _S],
                              C.c_int),
+    'feta_eigh_sym_supported': ([C.c_int], C.c_int),
+    'feta_eigh_sym': ([_F, _I, C.c_float, _F, _F, _I, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _S],
+                      C.c_int),
+    'feta_spectral_kernel': ([_F, _F, _I, C.c_int, C.c_float, C.c_int, C.c_float, C.c_int, _F,
+                              C.c_int, C.c_int, C.c_int, _S], C.c_int),
 }
 
 class RowLinEx(C.Structure):
@@ -132,7 +137,7 @@ SIGNATURES.update({
     'feta_ffn_fwd': ([C.POINTER(Ffn), _S], C.c_int),
 })
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class FetaError(RuntimeError):
@@ -389,6 +394,20 @@ class Abi:
                                                   _p(node_graph), _p(node_off), _p(deg), _p(lhat),
                                                   b, n, node_graph.shape[0], stream),
                     'feta_lhat_from_edges')
+
+    def eigh_sym_supported(self, n):
+        return bool(self.lib.feta_eigh_sym_supported(n))
+
+    def eigh_sym(self, a, n_real, shift, u, lam, sweeps, max_sweeps, tol, stream):
+        b, n, k = u.shape
+        self._check(self.lib.feta_eigh_sym(_p(a), _p(n_real), shift, _p(u), _p(lam), _p(sweeps), b, n, k,
+                                           max_sweeps, tol, stream), 'feta_eigh_sym')
+
+    def spectral_kernel(self, u, lam, n_real, mode, beta, p, lam_offset, zero_diag, out, stream):
+        b, n, k = u.shape
+        self._check(self.lib.feta_spectral_kernel(_p(u), _p(lam), _p(n_real), mode, beta, p, lam_offset,
+                                                  int(zero_diag), _p(out), b, n, k, stream),
+                    'feta_spectral_kernel')
 
 
 def bind(cdll):

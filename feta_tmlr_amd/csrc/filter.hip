@@ -129,7 +129,7 @@ __device__ __forceinline__ float cheb_at_zero(int k) {
 // ---- heads without a graph (Lhat = 0): y = X sum_k T_k(0) W_k + bias ---------------------
 
 template <int DH>
-__device__ void nograph_fwd(const FilterArgs& a, int b, int h, int n, const float* w, int lq, int g) {
+__device__ __forceinline__ void nograph_fwd(const FilterArgs& a, int b, int h, int n, const float* w, int lq, int g) {
   constexpr int CT = Feat<DH>::CT;
   const int NTall = (a.N + 15) >> 4;
   for (int nt = 0; nt < NTall; ++nt) {

@@ -345,3 +345,37 @@ def lhat_from_edges(edge_index, node_graph, node_off, num_graphs, n_pad):
     abi.lhat_from_edges(edge_index.contiguous(), node_graph.contiguous(), node_off.contiguous(),
                         deg, lhat, stream)
     return lhat
+
+
+def eigh_sym(a, n_real, shift, k=None, max_sweeps=0, tol=0.0, return_sweeps=False):
+    """Batched symmetric eigendecomposition on the device (feta_eigh_sym): a [B,N,N] (lower triangle
+    read, a + shift*I positive definite), n_real [B] int32 -> u [B,N,K] (ascending, zero-padded),
+    lam [B,K].  Replaces the per-graph host eig of transformer/position_encoding.py:127-161."""
+    abi, stream = _lib.backend(a)
+    b, n, _ = a.shape
+    k = n if k is None else int(k)
+    if not abi.eigh_sym_supported(n):
+        raise ValueError('eigh_sym: N = %d does not fit one workgroup (N <= 192); decompose on the host' % n)
+    u = torch.empty((b, n, k), dtype=torch.float32, device=a.device)
+    lam = torch.empty((b, k), dtype=torch.float32, device=a.device)
+    sweeps = torch.empty((b,), dtype=torch.int32, device=a.device) if return_sweeps else None
+    abi.eigh_sym(a.contiguous(), n_real.contiguous(), float(shift), u, lam, sweeps, int(max_sweeps),
+                 float(tol), stream)
+    return (u, lam, sweeps) if return_sweeps else (u, lam)
+
+
+SPECTRAL_MODES = {'diffusion': 0, 'pstep': 1}
+
+
+def spectral_kernel(u, lam, n_real, kind='diffusion', beta=1.0, p=1, lam_offset=0.0, zero_diag=False):
+    """out [B,N,N] = U f(lam + lam_offset) U^T on the real block (feta_spectral_kernel):
+    'diffusion' f = exp(-beta x) (transformer/position_encoding.py:65-72), 'pstep' f = (1 - beta x)^p
+    (:83-93)."""
+    if kind not in SPECTRAL_MODES:
+        raise ValueError('unknown spectral kernel %r' % (kind,))
+    abi, stream = _lib.backend(u, lam)
+    b, n, _ = u.shape
+    out = torch.empty((b, n, n), dtype=torch.float32, device=u.device)
+    abi.spectral_kernel(u.contiguous(), lam.contiguous(), n_real.contiguous(), SPECTRAL_MODES[kind],
+                        float(beta), int(p), float(lam_offset), bool(zero_diag), out, stream)
+    return out

@@ -229,6 +229,31 @@ def collate(samples, k_eig=None, n_pad=None, device='cpu', seq_first_degree=True
     return batch9, cache
 
 
+def attach_device_spectrum(batch9, cache, k_eig=None, pos_enc=None, beta=1.0, p=1, zero_diag=False,
+                           lap_dim=None):
+    """Fill the spectral inputs of a collated batch ON THE DEVICE instead of per graph on the host
+    (SURVEY 8f N2-N4): ``cache.lhat``, ``cache.u`` [B,N,K], ``cache.lam`` [B,K] from the batch's edge
+    list (position_encoding.device_spectrum), and optionally the relative kernel ``pos_enc``
+    ('diffusion' | 'pstep', 'sym' normalisation) and ``lap_dim`` Laplacian eigenvector features, which
+    replace entries 2 / 3 of the 9-tuple.  The batch must already live on the GPU
+    (``collate(..., device=...)``; graphs need no ``u`` / ``lam`` / ``pe`` of their own)."""
+    from . import position_encoding as PE
+    x, mask, pe, lap, deg, labels, edge_index, batch, fi = batch9
+    n = cache.n_pad
+    full = pos_enc is not None or lap_dim is not None
+    lhat, u, lam = PE.device_spectrum(edge_index, batch, cache.node_off, cache.n_real, n,
+                                      None if full else k_eig)
+    if pos_enc is not None:
+        pe = PE.device_kernel_pe(u, lam, cache.n_real, pos_enc, beta=beta, p=p, zero_diag=zero_diag)
+    if lap_dim is not None:
+        lap = PE.device_lap_encoding(u, cache.n_real, lap_dim)
+    cache.lhat = lhat
+    k = n if k_eig is None else min(k_eig, n)
+    cache.u = u if k == u.shape[2] else u[:, :, :k].contiguous()
+    cache.lam = lam if k == lam.shape[1] else lam[:, :k].contiguous()
+    return (x, mask, pe, lap, deg, labels, edge_index, batch, fi), cache
+
+
 BUCKETS = (16, 32, 48, 64, 128, 256)
 
 

@@ -135,7 +135,7 @@ class PStepRWEncoding(PositionEncoding):
 
     def compute_pe(self, graph):
         lam, v, vinv = decompose(graph.edge_index, graph.num_nodes, self.normalization)
-        return ((v * (1.0 - self.beta * lam) ** self.p) @ vinv).astype(np.float32)
+        return ((v * (1.0 - self.beta * lam) ** max(self.p, 1)) @ vinv).astype(np.float32)   # :89-92: p - 1 products
 
 
 class AdjEncoding(PositionEncoding):
@@ -208,3 +208,40 @@ POSENCODINGS = {
     'pstep': PStepRWEncoding,
     'adj': AdjEncoding,
 }
+
+
+# ---- the same encodings for a whole padded batch, on the device ---------------------------------
+
+
+def device_spectrum(edge_index, batch, node_off, n_real, n_pad, k_eig=None):
+    """Batch producer of the spectral inputs: edge list of the collated batch ->
+    (lhat [B,N,N], u [B,N,K], lam [B,K]) with K = k_eig or N, all on the device of the inputs.
+    Two launches: feta_lhat_from_edges (ChebConvDynamic.__norm__ semantics) and feta_eigh_sym, one
+    workgroup per graph; the reference decomposes graph by graph on the host (:127-161).  The
+    spectrum is that of Lhat = L_sym - I, which is what ``filter_mode='spectral'`` consumes."""
+    from .. import functional as FF
+    lhat = FF.lhat_from_edges(edge_index, batch, node_off, n_real.shape[0], n_pad)
+    u, lam = FF.eigh_sym(lhat, n_real, shift=2.0, k=k_eig)
+    return lhat, u, lam
+
+
+def device_kernel_pe(u, lam, n_real, kind='diffusion', beta=1.0, p=1, zero_diag=False):
+    """pe [B,N,N] of the batch from the FULL spectrum (K = N) of Lhat: the 'sym'-normalised
+    DiffusionEncoding / PStepRWEncoding (:55-93) as U f(lam + 1) U^T - one launch for the batch."""
+    from .. import functional as FF
+    if u.shape[2] != u.shape[1]:
+        raise ValueError('a kernel of the whole Laplacian needs the full spectrum: K = %d, N = %d'
+                         % (u.shape[2], u.shape[1]))
+    return FF.spectral_kernel(u, lam, n_real, kind, beta=beta, p=p, lam_offset=1.0, zero_diag=zero_diag)
+
+
+def device_lap_encoding(u, n_real, dim):
+    """lap_pe [B,N,dim]: eigenvector columns 1..dim (ascending, the first dropped, zero columns when
+    the graph has fewer: LapEncoding.compute_pe, :137-161) from the device decomposition."""
+    import torch
+    b, n, k = u.shape
+    out = torch.zeros((b, n, dim), dtype=u.dtype, device=u.device)
+    take = min(dim, k - 1)
+    if take > 0:
+        out[:, :, :take] = u[:, :, 1:1 + take]
+    return out

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FETA_ABI_VERSION 3
+#define FETA_ABI_VERSION 4
 
 #define FETA_OK 0
 #define FETA_E_ARG (-1)     /* bad shape / stride / alignment / unsupported size */
@@ -390,6 +390,37 @@ int feta_lhat_from_edges(const int64_t* edge_index, int64_t E,
                          const int64_t* node_graph, const int32_t* node_off,
                          float* deg, float* lhat, int B, int N, int64_t n_tot,
                          feta_stream_t stream);
+
+/* ---- spectrum producer ------------------------------------------------
+ * Batched symmetric eigendecomposition, one workgroup per graph, the matrix in LDS (N <= 192):
+ *   a [B,N,N]: the real n_b x n_b block of graph b is decomposed; as numpy.linalg.eigh does, only
+ *   the LOWER triangle is read.  a + shift*I must be positive definite (Lhat = -D^-1/2 A D^-1/2 has
+ *   its spectrum in [-1,1]: shift 2; L_sym: shift 1) - the one-sided Jacobi iteration runs on that
+ *   matrix and the shift is taken off the eigenvalues again.
+ *   u [B,N,K]: eigenvectors of the K smallest eigenvalues as columns, ascending; rows >= n_b and
+ *   columns >= n_b are zero; the entry of largest magnitude of every column is positive.
+ *   lam [B,K]: eigenvalues (0 for columns >= n_b).  sweeps [B] (may be NULL): Jacobi sweeps used.
+ *   max_sweeps <= 0: 16.  tol <= 0: 1e-6 (a pair is rotated while |g_p.g_q| > tol |g_p||g_q|).
+ * Replaces the per-graph host eigendecomposition of transformer/position_encoding.py:127-161 and
+ * feeds feta_spec_filter_fwd/bwd (u, lam) directly.
+ */
+int feta_eigh_sym_supported(int N);
+int feta_eigh_sym(const float* a, const int32_t* n_real, float shift, float* u, float* lam,
+                  int32_t* sweeps, int B, int N, int K, int max_sweeps, float tol,
+                  feta_stream_t stream);
+
+/* Kernel function of the spectrum on the real block, zero elsewhere:
+ *   out_b = U_b f(lam_b + lam_offset) U_b^T,   out [B,N,N], u [B,N,K], lam [B,K]
+ *   FETA_SPECTRAL_DIFFUSION: f(x) = exp(-beta x)     (DiffusionEncoding, position_encoding.py:65-72)
+ *   FETA_SPECTRAL_PSTEP:     f(x) = (1 - beta x)^max(p,1)   (PStepRWEncoding, :83-93: p - 1 products)
+ * zero_diag: the diagonal is cleared (PositionEncoding.apply_to, position_encoding.py:25-27).
+ * With (u, lam) of Lhat pass lam_offset = 1 for the kernels of L_sym = I + Lhat.
+ */
+#define FETA_SPECTRAL_DIFFUSION 0
+#define FETA_SPECTRAL_PSTEP 1
+int feta_spectral_kernel(const float* u, const float* lam, const int32_t* n_real, int mode,
+                         float beta, int p, float lam_offset, int zero_diag, float* out,
+                         int B, int N, int K, feta_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -194,6 +194,24 @@ def eig_basis(lhat, k_eig, n_pad=None):
     return torch.from_numpy(uu), torch.from_numpy(ll)
 
 
+def diffusion_pe(lap, beta):
+    """expm(-beta L) of one graph (DiffusionEncoding.compute_pe, transformer/position_encoding.py:65-72:
+    scipy.sparse.linalg.expm of the sparse Laplacian; dense scipy expm here, same Pade algorithm)."""
+    import scipy.linalg
+    return torch.from_numpy(scipy.linalg.expm(-float(beta) * np.asarray(lap, dtype=np.float64)))
+
+
+def pstep_pe(lap, beta, p):
+    """(I - beta L)^p by p - 1 products (PStepRWEncoding.compute_pe, transformer/position_encoding.py:83-93;
+    p = 0 gives the first power as well: the reference loop runs max(p - 1, 0) times)."""
+    lap = np.asarray(lap, dtype=np.float64)
+    m = np.eye(lap.shape[0]) - float(beta) * lap
+    tmp = m
+    for _ in range(int(p) - 1):
+        tmp = tmp @ m
+    return torch.from_numpy(tmp)
+
+
 # ---------------------------------------------------------------------------
 # A2: filter-coefficient generator
 # ---------------------------------------------------------------------------

@@ -357,3 +357,99 @@ def check_colsum(abi, dev, stream, r, c, seed=0):
     out = torch.full((c,), float('nan'), device=dev)
     abi.colsum(x.to(dev), out, stream)
     assert_close('colsum %dx%d' % (r, c), out, x.double().sum(0))
+
+
+# ---- spectrum producer ------------------------------------------------------
+
+
+def _lhat_batch(shape, bsz, seed, n_min, n_max, n_pad=None, special=True):
+    """-> lhat [B,N,N] fp64 (zero outside the real blocks), n_real list.  With ``special`` the first
+    graphs are replaced by an edgeless graph (Lhat = 0: one n-fold eigenvalue), a single node and a
+    2-node graph when the batch is large enough."""
+    ds = D.SyntheticGraphDataset(shape, bsz, in_dim=2, seed=seed, n_min=n_min, n_max=n_max,
+                                 pos_enc=False, with_eig=False)
+    ns = [g.num_nodes for g in ds.samples]
+    mats = [D.lhat_numpy(g.edge_index, g.num_nodes) for g in ds.samples]
+    if special and bsz >= 4:
+        mats[1] = np.zeros_like(mats[1])
+        mats[2], ns[2] = np.zeros((1, 1)), 1
+        mats[3], ns[3] = np.array([[0.0, -1.0], [-1.0, 0.0]]), 2
+    n = max(ns) if n_pad is None else n_pad
+    lhat = np.zeros((bsz, n, n))
+    for b, m in enumerate(mats):
+        lhat[b, :ns[b], :ns[b]] = m
+    return torch.from_numpy(lhat), ns
+
+
+def check_eigh(abi, dev, stream, shape='zinc', bsz=6, seed=0, n_min=None, n_max=None, n_pad=None, k=None,
+               tol_val=5e-6):
+    """feta_eigh_sym on Lhat blocks against numpy.linalg.eigh (fp64): eigenvalues, the defining
+    relations (residual, orthonormality - eigenvectors themselves are unique only up to sign and a
+    rotation inside degenerate eigenspaces, which molecule graphs have), order, padding, sign rule."""
+    lhat64, ns = _lhat_batch(shape, bsz, seed, n_min, n_max, n_pad)
+    n = lhat64.shape[1]
+    k = n if k is None else k
+    a = lhat64.float().to(dev)
+    # only the lower triangle may be read: poison the strict upper triangle
+    a = torch.tril(a) + torch.triu(torch.full_like(a, 7.0), diagonal=1)
+    n_real = torch.tensor(ns, dtype=torch.int32, device=dev)
+    u = torch.full((bsz, n, k), float('nan'), device=dev)
+    lam = torch.full((bsz, k), float('nan'), device=dev)
+    sweeps = torch.zeros(bsz, dtype=torch.int32, device=dev)
+    abi.eigh_sym(a, n_real, 2.0, u, lam, sweeps, 0, 0.0, stream)
+    u, lam, sweeps = u.cpu().double(), lam.cpu().double(), sweeps.cpu()
+    worst = {'lam': 0.0, 'res': 0.0, 'orth': 0.0}
+    for b in range(bsz):
+        nb = ns[b]
+        kk = min(k, nb)
+        ref = np.linalg.eigvalsh(lhat64[b, :nb, :nb].numpy())
+        assert float(u[b, nb:, :].abs().max() if nb < n else 0.0) == 0.0, 'padded rows'
+        assert float(u[b, :, kk:].abs().max() if kk < k else 0.0) == 0.0, 'padded columns'
+        assert float(lam[b, kk:].abs().max() if kk < k else 0.0) == 0.0, 'padded eigenvalues'
+        lb, ub = lam[b, :kk], u[b, :nb, :kk]
+        assert bool((lb[1:] >= lb[:-1]).all()), 'ascending'
+        worst['lam'] = max(worst['lam'], float((lb - torch.from_numpy(ref[:kk])).abs().max()))
+        res = lhat64[b, :nb, :nb] @ ub - ub * lb
+        worst['res'] = max(worst['res'], float(res.abs().max()))
+        worst['orth'] = max(worst['orth'], float((ub.T @ ub - torch.eye(kk, dtype=torch.float64)).abs().max()))
+        # sign rule: the entry of largest magnitude is positive (up to rounding when +x and -x tie)
+        assert bool((ub.max(0).values >= ub.abs().max(0).values - 1e-6).all()), 'sign rule'
+        assert int(sweeps[b]) < 16, 'not converged: %d sweeps with rotations' % int(sweeps[b])
+    assert worst['lam'] < tol_val and worst['res'] < tol_val and worst['orth'] < tol_val, worst
+    worst['sweeps'] = int(sweeps.max())
+    return worst, u, lam, lhat64, ns
+
+
+def check_eigh_truncated_equals_full(abi, dev, stream):
+    """K < N writes the first K columns of the full decomposition, bit for bit."""
+    _, u_full, lam_full, lhat64, ns = check_eigh(abi, dev, stream, bsz=5, seed=3)
+    _, u_k, lam_k, _, _ = check_eigh(abi, dev, stream, bsz=5, seed=3, k=8)
+    assert torch.equal(u_k, u_full[:, :, :8]) and torch.equal(lam_k, lam_full[:, :8])
+
+
+def check_spectral_kernel(abi, dev, stream, kind, shape='zinc', bsz=5, seed=1, n_min=None, n_max=None,
+                          beta=0.7, p=3, zero_diag=False, from_device_eigh=True):
+    """feta_spectral_kernel on (U, lam) of Lhat with lam_offset 1 against the reference's direct
+    evaluation on L_sym = I + Lhat (oracle.diffusion_pe: expm; oracle.pstep_pe: matrix powers)."""
+    lhat64, ns = _lhat_batch(shape, bsz, seed, n_min, n_max)
+    n = lhat64.shape[1]
+    n_real = torch.tensor(ns, dtype=torch.int32, device=dev)
+    if from_device_eigh:
+        u = torch.empty((bsz, n, n), device=dev)
+        lam = torch.empty((bsz, n), device=dev)
+        abi.eigh_sym(lhat64.float().to(dev), n_real, 2.0, u, lam, None, 0, 0.0, stream)
+    else:
+        uu, ll = zip(*[O.eig_basis(lhat64[b, :ns[b], :ns[b]], n, n) for b in range(bsz)])
+        u, lam = torch.stack(uu).float().to(dev), torch.stack(ll).float().to(dev)
+    out = torch.full((bsz, n, n), float('nan'), device=dev)
+    abi.spectral_kernel(u, lam, n_real, {'diffusion': 0, 'pstep': 1}[kind], beta, p, 1.0, zero_diag, out, stream)
+    ref = torch.zeros(bsz, n, n, dtype=torch.float64)
+    for b in range(bsz):
+        nb = ns[b]
+        lap = np.eye(nb) + lhat64[b, :nb, :nb].numpy()
+        r = O.diffusion_pe(lap, beta) if kind == 'diffusion' else O.pstep_pe(lap, beta, p)
+        if zero_diag:
+            r = r.clone()
+            r.diagonal()[:] = 0            # PositionEncoding.apply_to, transformer/position_encoding.py:25-27
+        ref[b, :nb, :nb] = r
+    return assert_close('spectral kernel ' + kind, out, ref, tol=2e-5)

@@ -113,3 +113,42 @@ def test_attn_bwd_one_workgroup_per_graph(emu, monkeypatch, bsz, n, use_pe, seq_
     """4 heads x dh 16: attn_bwd_graph_kernel (chosen by itself from 192 graphs up; forced here)"""
     monkeypatch.setenv('FETA_ATTN_BWD_GRAPH', '1')
     KC.check_attn(emu, CPU, None, bsz, n, 4, 16, use_pe, seq_first, clamp_case=clamp)
+
+
+# ---- spectrum producer (SURVEY 8f N2 / N4) ----
+
+
+@pytest.mark.parametrize('shape,bsz,n_min,n_max,n_pad', [
+    ('zinc', 6, None, None, None),     # N <= 37, one 64-row chunk, edgeless / 1-node / 2-node graphs mixed in
+    ('mutag', 5, 3, 16, 16),           # 256-thread launch (N <= 32), odd and even n
+    ('pattern', 2, 66, 70, None),      # two 64-row chunks
+])
+def test_eigh_sym(emu, shape, bsz, n_min, n_max, n_pad):
+    KC.check_eigh(emu, CPU, None, shape, bsz, 0, n_min, n_max, n_pad)
+
+
+def test_eigh_sym_three_chunks(emu):
+    KC.check_eigh(emu, CPU, None, 'pattern', 1, 0, 130, 130)
+
+
+def test_eigh_sym_truncated_equals_full(emu):
+    KC.check_eigh_truncated_equals_full(emu, CPU, None)
+
+
+def test_eigh_sym_rejects_large_n(emu):
+    assert emu.eigh_sym_supported(192) and not emu.eigh_sym_supported(193)
+    a = torch.zeros(1, 200, 200)
+    with pytest.raises(ValueError, match='192'):
+        emu.eigh_sym(a, torch.tensor([200], dtype=torch.int32), 2.0, torch.zeros(1, 200, 200), torch.zeros(1, 200),
+                     None, 0, 0.0, None)
+
+
+@pytest.mark.parametrize('kind,zero_diag,from_device', [('diffusion', False, True), ('pstep', True, True),
+                                                        ('pstep', False, False)])
+def test_spectral_kernel(emu, kind, zero_diag, from_device):
+    KC.check_spectral_kernel(emu, CPU, None, kind, zero_diag=zero_diag, from_device_eigh=from_device)
+
+
+def test_spectral_kernel_pstep_exponents(emu):
+    KC.check_spectral_kernel(emu, CPU, None, 'pstep', p=1, bsz=4, from_device_eigh=False)
+    KC.check_spectral_kernel(emu, CPU, None, 'pstep', p=0, bsz=4, from_device_eigh=False)   # first power as well

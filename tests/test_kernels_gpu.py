@@ -141,3 +141,37 @@ def test_attn_bwd_one_workgroup_per_graph(hip, monkeypatch, bsz, n, use_pe, seq_
     """4 heads x dh 16: attn_bwd_graph_kernel (chosen by itself from 192 graphs up; forced here)"""
     monkeypatch.setenv('FETA_ATTN_BWD_GRAPH', '1')
     KC.check_attn(*hip, bsz, n, 4, 16, use_pe, seq_first, clamp_case=clamp)
+
+
+# ---- spectrum producer (SURVEY 8f N2 / N4) ----
+
+
+@pytest.mark.parametrize('shape,bsz,n_min,n_max,n_pad', [
+    ('zinc', 128, None, None, None),
+    ('mutag', 32, 3, 16, 16),
+    ('pattern', 16, 66, 128, None),
+    ('pattern', 8, 150, 188, None),     # BASELINE PATTERN shape: three 64-row chunks, 141 KB of LDS
+    ('molhiv', 64, None, 64, 64),
+])
+def test_eigh_sym(hip, shape, bsz, n_min, n_max, n_pad):
+    abi, dev, stream = hip
+    KC.check_eigh(abi, dev, stream, shape, bsz, 0, n_min, n_max, n_pad)
+
+
+def test_eigh_sym_max_n(hip):
+    abi, dev, stream = hip
+    KC.check_eigh(abi, dev, stream, 'pattern', 4, 1, 180, 192, 192)
+
+
+def test_eigh_sym_truncated_equals_full(hip):
+    abi, dev, stream = hip
+    KC.check_eigh_truncated_equals_full(abi, dev, stream)
+
+
+@pytest.mark.parametrize('kind,zero_diag,from_device', [('diffusion', False, True), ('pstep', True, True),
+                                                        ('diffusion', True, False), ('pstep', False, False)])
+@pytest.mark.parametrize('shape,n_min,n_max', [('zinc', None, None), ('pattern', 100, 188)])
+def test_spectral_kernel(hip, kind, zero_diag, from_device, shape, n_min, n_max):
+    abi, dev, stream = hip
+    KC.check_spectral_kernel(abi, dev, stream, kind, shape=shape, bsz=8, n_min=n_min, n_max=n_max,
+                             zero_diag=zero_diag, from_device_eigh=from_device)

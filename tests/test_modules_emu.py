@@ -286,3 +286,53 @@ def test_fused_kernels_edge_shapes(emu, monkeypatch, n_min, n_max, bsz):
     the unfused launch sequence"""
     check_attn_block_equals_three_launches(CPU, lambda: _lib.override_for_tests(emu), monkeypatch, 'mutag',
                                            n_min, n_max, False, True, bsz=bsz)
+
+
+def check_device_spectrum_feeds_the_model(dev, hook, shape='mutag', bsz=4, n_min=5, n_max=19, d=32, heads=2):
+    """data.attach_device_spectrum (edge list -> Lhat -> eigh -> diffusion kernel / Laplacian features,
+    all on the device) against the host producers: the relative kernel equals expm(-L_sym); with the
+    full basis (K = N) the filtered model output does not depend on which eigenbasis was found, so
+    the model fed from the device spectrum agrees with the model fed from numpy's."""
+    torch.manual_seed(2)
+    model = DiffGraphTransformerGenGCN(7, 1, d, heads, dim_feedforward=2 * d, dropout=0.0, nb_layers=2,
+                                       batch_norm=False, filter_order=3, heads_share_graph=True,
+                                       filter_mode='spectral').to(dev)
+    ds = D.SyntheticGraphDataset(shape, bsz, in_dim=7, seed=4, pos_enc=True, n_min=n_min, n_max=n_max)
+    n_pad = max(g.num_nodes for g in ds.samples)
+    host9, host_cache = D.collate(ds.samples, k_eig=n_pad, device=dev)
+    for g in ds.samples:          # the device path needs nothing per graph
+        g.pe = g.u = g.lam = None
+    dev9, dev_cache = D.collate(ds.samples, device=dev)
+    assert dev9[2] is None and dev_cache.u is None
+    with hook():
+        dev9, dev_cache = D.attach_device_spectrum(dev9, dev_cache, pos_enc='diffusion', beta=1.0, lap_dim=6)
+        outs = []
+        for b9, cache in ((host9, host_cache), (dev9, dev_cache)):
+            x, mask, pe, _, degree, labels, edge_index, batch, fi = b9
+            out, _, coeff = model(x, edge_index, batch, fi, mask, pe, degree=degree,
+                                  return_filter_coeff=True, graph_cache=cache)
+            outs.append((out.detach().cpu().double(), coeff.detach().cpu().double()))
+    KC.assert_close('relative kernel', dev9[2].cpu(), host9[2].cpu().double(), tol=2e-5)
+    assert dev_cache.u.shape == host_cache.u.shape and dev_cache.lam.shape == host_cache.lam.shape
+    KC.assert_close('eigenvalues', dev_cache.lam.cpu(), host_cache.lam.cpu().double(), tol=2e-5)
+    KC.assert_close('model output', outs[1][0], outs[0][0], tol=1e-4)
+    KC.assert_close('coefficients', outs[1][1], outs[0][1], tol=1e-4)
+    # Laplacian features: columns 1..6 are eigenvectors of Lhat for eigenvalues lam[1..6]
+    lap, lhat, lam = dev9[3].cpu().double(), dev_cache.lhat.cpu().double(), dev_cache.lam.cpu().double()
+    assert lap.shape == (bsz, n_pad, 6)
+    for b in range(bsz):
+        nb = int(dev_cache.n_real[b])
+        take = min(6, nb - 1)
+        res = lhat[b] @ lap[b, :, :take] - lap[b, :, :take] * lam[b, 1:1 + take]
+        assert float(res.abs().max()) < 2e-5
+        assert float(lap[b, :, take:].abs().max() if take < 6 else 0.0) == 0.0
+
+
+def test_device_spectrum_feeds_the_model(emu):
+    check_device_spectrum_feeds_the_model(CPU, lambda: _lib.override_for_tests(emu))
+
+
+def test_device_kernel_pe_needs_full_spectrum(emu):
+    from feta_tmlr_amd.transformer import position_encoding as PE
+    with pytest.raises(ValueError):
+        PE.device_kernel_pe(torch.zeros(1, 8, 4), torch.zeros(1, 4), torch.tensor([8], dtype=torch.int32))

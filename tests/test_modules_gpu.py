@@ -77,3 +77,12 @@ def test_fused_kernels_edge_shapes(monkeypatch, n_min, n_max, bsz):
     from test_modules_emu import check_attn_block_equals_three_launches
     check_attn_block_equals_three_launches(torch.device('cuda:0'), contextlib.nullcontext, monkeypatch, 'zinc' if bsz > 100 else 'mutag',
                                            n_min, n_max, False, True, bsz=bsz)
+
+
+@pytest.mark.parametrize('shape,bsz,n_min,n_max,d,heads', [('mutag', 8, 5, 19, 32, 2), ('zinc', 64, None, None, 64, 4),
+                                                            ('pattern', 6, 100, 188, 64, 4)])
+def test_device_spectrum_feeds_the_model(shape, bsz, n_min, n_max, d, heads):
+    import contextlib
+    from test_modules_emu import check_device_spectrum_feeds_the_model
+    check_device_spectrum_feeds_the_model(torch.device('cuda:0'), contextlib.nullcontext, shape, bsz, n_min, n_max,
+                                          d, heads)
