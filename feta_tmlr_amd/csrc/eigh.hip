@@ -41,8 +41,10 @@ __device__ __forceinline__ void tournament_pair(int step, int k, int m, int& p, 
     p = m - 1;
     q = step;
   } else {
-    p = (step + k) % (m - 1);
-    q = (step - k + (m - 1)) % (m - 1);
+    p = step + k;             // both in [0, 2 (m - 1)): one conditional subtraction instead of a division
+    q = step - k + (m - 1);
+    if (p >= m - 1) p -= m - 1;
+    if (q >= m - 1) q -= m - 1;
   }
 }
 
@@ -98,9 +100,11 @@ __global__ __launch_bounds__(512) void eigh_jacobi_kernel(EighArgs a) {
         be = row16_sum(be);
         ga = row16_sum(ga);
         if (live && ga * ga > tol2 * al * be) {   // same value on the 16 lanes of the pair
-          const float zeta = (be - al) / (2.0f * ga);
-          const float t = copysignf(1.0f, zeta) / (fabsf(zeta) + sqrtf(1.0f + zeta * zeta));
-          const float cs = rsqrtf(1.0f + t * t), sn = cs * t;
+          // (hardware reciprocal / square root: the angle only steers convergence, and the scale of
+          // (c, s) is repaired below)
+          const float zeta = 0.5f * (be - al) * fast_rcp(ga);
+          const float t = copysignf(fast_rcp(fabsf(zeta) + fast_sqrt(1.0f + zeta * zeta)), zeta);
+          const float cs = fast_rsqrt(1.0f + t * t), sn = cs * t;
           // c^2 + s^2 = 1 only to a few ulp, and that scale error is common to every element of both
           // columns: over the ~n * sweeps rotations a column goes through it would drift the norms
           // (= the eigenvalues) by tens of ulp.  The defect e = 1 - c^2 - s^2 is evaluated exactly

@@ -50,4 +50,10 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x));  // v_rcp_f32: 1 ulp
 }
 
+// 1-ulp hardware approximations (v_rcp_f32 / v_sqrt_f32 / v_rsq_f32), for values whose last bits do not
+// reach the result (rotation angles of the Jacobi sweeps)
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+
 }  // namespace feta

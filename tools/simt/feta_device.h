@@ -78,5 +78,8 @@ inline void wave_lds_sync() { simt::wave_barrier(); }
 
 inline float fast_exp(float x) { return expf(x); }
 inline float fast_tanh(float x) { return 1.0f - 2.0f / (1.0f + expf(2.0f * x)); }
+inline float fast_rcp(float x) { return 1.0f / x; }
+inline float fast_sqrt(float x) { return sqrtf(x); }
+inline float fast_rsqrt(float x) { return 1.0f / sqrtf(x); }
 
 }  // namespace feta
