@@ -48,6 +48,9 @@ SIGNATURES = {
     'feta_bn_bwd': ([_F, _F, _F, _F, _F, _F, _F, _F, C.c_int, C.c_int, _S], C.c_int),
     'feta_lhat_from_edges': ([_I, C.c_int64, _I, _I, _F, _F, C.c_int, C.c_int, C.c_int64, _S],
                              C.c_int),
+    'feta_layernorm_blocks': ([C.c_int], C.c_int),
+    'feta_layernorm_fwd': ([_F, _F, _F, C.c_float, _F, _F, C.c_int, C.c_int, _S], C.c_int),
+    'feta_layernorm_bwd': ([_F, _F, _F, _F, _F, _F, _F, C.c_int, C.c_int, _S], C.c_int),
     'feta_eigh_sym_supported': ([C.c_int], C.c_int),
     'feta_eigh_sym': ([_F, _I, C.c_float, _F, _F, _I, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _S],
                       C.c_int),
@@ -394,6 +397,19 @@ class Abi:
                                                   _p(node_graph), _p(node_off), _p(deg), _p(lhat),
                                                   b, n, node_graph.shape[0], stream),
                     'feta_lhat_from_edges')
+
+    def layernorm_blocks(self, m):
+        return self.lib.feta_layernorm_blocks(m)
+
+    def layernorm_fwd(self, y, gamma, beta, eps, out, stats, stream):
+        m, d = y.shape
+        self._check(self.lib.feta_layernorm_fwd(_p(y), _p(gamma), _p(beta), eps, _p(out), _p(stats), m, d, stream),
+                    'feta_layernorm_fwd')
+
+    def layernorm_bwd(self, dout, y, stats, gamma, dy, partial, dgdb, stream):
+        m, d = y.shape
+        self._check(self.lib.feta_layernorm_bwd(_p(dout), _p(y), _p(stats), _p(gamma), _p(dy), _p(partial),
+                                                _p(dgdb), m, d, stream), 'feta_layernorm_bwd')
 
     def eigh_sym_supported(self, n):
         return bool(self.lib.feta_eigh_sym_supported(n))

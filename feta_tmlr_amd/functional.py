@@ -318,6 +318,41 @@ def batch_norm_train(y, stats, gamma, beta, running_mean, running_var, momentum,
     return BatchNormTrainFn.apply(y, stats, gamma, beta, running_mean, running_var, momentum, eps)
 
 
+class LayerNormRowsFn(torch.autograd.Function):
+    """nn.LayerNorm over the last dimension of [M, D] rows (feta_layernorm_fwd/bwd): norm1 / norm2 of
+    the encoder layer when batch_norm=False."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, eps):
+        abi, stream = _lib.backend(y, gamma)
+        y = y.contiguous()
+        m, d = y.shape
+        out = torch.empty_like(y)
+        stats = torch.empty((m, 2), dtype=torch.float32, device=y.device)
+        abi.layernorm_fwd(y, gamma.contiguous(), beta.contiguous(), float(eps), out, stats, stream)
+        ctx.save_for_backward(y, stats, gamma)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, stats, gamma = ctx.saved_tensors
+        abi, stream = _lib.backend(dout)
+        m, d = y.shape
+        dy = torch.empty_like(y)
+        partial = torch.empty((abi.layernorm_blocks(m), 2, d), dtype=torch.float32, device=y.device)
+        dgdb = torch.empty((2, d), dtype=torch.float32, device=y.device)
+        abi.layernorm_bwd(dout.contiguous(), y, stats, gamma.contiguous(), dy, partial, dgdb, stream)
+        return dy, dgdb[0], dgdb[1], None
+
+
+def layer_norm_rows_supported(d):
+    return d % 4 == 0 and 4 <= d <= 256
+
+
+def layer_norm_rows(y, gamma, beta, eps):
+    return LayerNormRowsFn.apply(y, gamma, beta, eps)
+
+
 def attention_core(qkv, pe, n_real, num_heads, need_attn=True, tie_qk=False, batch_first=False):
     return AttentionCoreFn.apply(qkv, pe, n_real, num_heads, need_attn, tie_qk, batch_first)
 

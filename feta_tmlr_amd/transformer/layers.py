@@ -134,6 +134,9 @@ class DiffTransformerEncoderLayer(nn.Module):
         """y [M, d] -> normalised [M, d].  BatchNorm statistics run over all N*B rows, padded ones
         included, exactly as nn.BatchNorm1d on the [N*B, d] view does."""
         if not self.batch_norm:
+            if (isinstance(mod, nn.LayerNorm) and mod.elementwise_affine and y.dim() == 2
+                    and FF.layer_norm_rows_supported(y.shape[1])):
+                return FF.layer_norm_rows(y, mod.weight, mod.bias, mod.eps)
             return mod(y)
         if mod.training and mod.momentum is not None and y.shape[1] % 4 == 0 and y.shape[1] <= 256:
             # num_batches_tracked is not advanced (only read when momentum is None)

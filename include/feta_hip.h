@@ -391,6 +391,20 @@ int feta_lhat_from_edges(const int64_t* edge_index, int64_t E,
                          float* deg, float* lhat, int B, int N, int64_t n_tot,
                          feta_stream_t stream);
 
+/* ---- LayerNorm over the feature dimension (norm1 / norm2 of DiffTransformerEncoderLayer with
+ * batch_norm=False, contract transformer/models.py:505-506; the default of the TU / molhiv / SBM
+ * scripts, experiments/run_transformer_gengcn_cv.py:56) --------------------------------------
+ * y, out, dout, dy [M,D] row-major, D a multiple of 4, <= 256; stats [M,2] = (mean, rstd) per row
+ * (biased variance, eps inside the root, as torch.nn.LayerNorm).  Backward also returns
+ * dgamma_dbeta [2,D]; partial [feta_layernorm_blocks(M), 2, D] is caller-provided scratch.
+ */
+int feta_layernorm_blocks(int M);
+int feta_layernorm_fwd(const float* y, const float* gamma, const float* beta, float eps, float* out,
+                       float* stats, int M, int D, feta_stream_t stream);
+int feta_layernorm_bwd(const float* dout, const float* y, const float* stats, const float* gamma,
+                       float* dy, float* partial, float* dgamma_dbeta, int M, int D,
+                       feta_stream_t stream);
+
 /* ---- spectrum producer ------------------------------------------------
  * Batched symmetric eigendecomposition, one workgroup per graph, the matrix in LDS (N <= 192):
  *   a [B,N,N]: the real n_b x n_b block of graph b is decomposed; as numpy.linalg.eigh does, only

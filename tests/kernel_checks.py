@@ -453,3 +453,31 @@ def check_spectral_kernel(abi, dev, stream, kind, shape='zinc', bsz=5, seed=1, n
             r.diagonal()[:] = 0            # PositionEncoding.apply_to, transformer/position_encoding.py:25-27
         ref[b, :nb, :nb] = r
     return assert_close('spectral kernel ' + kind, out, ref, tol=2e-5)
+
+
+def check_layernorm(abi, dev, stream, m, d, seed=0, eps=1e-5):
+    """feta_layernorm_fwd/bwd against torch.nn.functional.layer_norm in fp64 (what oracle._norm applies
+    for batch_norm=False): output, (mean, rstd), dy, dgamma, dbeta."""
+    g = torch.Generator().manual_seed(seed)
+    y64 = (torch.randn(m, d, generator=g, dtype=torch.float64) * 1.7 + 0.3).requires_grad_(True)
+    gamma64 = (1.0 + 0.3 * torch.randn(d, generator=g, dtype=torch.float64)).requires_grad_(True)
+    beta64 = (0.2 * torch.randn(d, generator=g, dtype=torch.float64)).requires_grad_(True)
+    dout64 = torch.randn(m, d, generator=g, dtype=torch.float64)
+    ref = torch.nn.functional.layer_norm(y64, (d,), gamma64, beta64, eps)
+    ref.backward(dout64)
+    y, gamma, beta, dout = (t.detach().float().to(dev) for t in (y64, gamma64, beta64, dout64))
+    out = torch.full((m, d), float('nan'), device=dev)
+    stats = torch.full((m, 2), float('nan'), device=dev)
+    abi.layernorm_fwd(y, gamma, beta, eps, out, stats, stream)
+    dy = torch.full((m, d), float('nan'), device=dev)
+    partial = torch.full((abi.layernorm_blocks(m), 2, d), float('nan'), device=dev)
+    dgdb = torch.full((2, d), float('nan'), device=dev)
+    abi.layernorm_bwd(dout, y, stats, gamma, dy, partial, dgdb, stream)
+    mean = y64.detach().mean(1)
+    rstd = 1.0 / torch.sqrt(y64.detach().var(1, unbiased=False) + eps)
+    return {'out': assert_close('layernorm out', out, ref.detach()),
+            'mean': assert_close('layernorm mean', stats[:, 0], mean),
+            'rstd': assert_close('layernorm rstd', stats[:, 1], rstd),
+            'dy': assert_close('layernorm dy', dy, y64.grad),
+            'dgamma': assert_close('layernorm dgamma', dgdb[0], gamma64.grad, tol=2e-5),
+            'dbeta': assert_close('layernorm dbeta', dgdb[1], beta64.grad, tol=2e-5)}

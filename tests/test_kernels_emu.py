@@ -152,3 +152,14 @@ def test_spectral_kernel(emu, kind, zero_diag, from_device):
 def test_spectral_kernel_pstep_exponents(emu):
     KC.check_spectral_kernel(emu, CPU, None, 'pstep', p=1, bsz=4, from_device_eigh=False)
     KC.check_spectral_kernel(emu, CPU, None, 'pstep', p=0, bsz=4, from_device_eigh=False)   # first power as well
+
+
+@pytest.mark.parametrize('m,d', [(37, 64), (5, 32), (100, 128), (16, 4), (33, 200), (1, 256)])
+def test_layernorm(emu, m, d):
+    KC.check_layernorm(emu, CPU, None, m, d)
+
+
+def test_layernorm_rejects_unsupported_width(emu):
+    y = torch.zeros(4, 6)
+    with pytest.raises(ValueError):
+        emu.layernorm_fwd(y, torch.ones(6), torch.zeros(6), 1e-5, torch.empty_like(y), torch.empty(4, 2), None)

@@ -175,3 +175,9 @@ def test_spectral_kernel(hip, kind, zero_diag, from_device, shape, n_min, n_max)
     abi, dev, stream = hip
     KC.check_spectral_kernel(abi, dev, stream, kind, shape=shape, bsz=8, n_min=n_min, n_max=n_max,
                              zero_diag=zero_diag, from_device_eigh=from_device)
+
+
+@pytest.mark.parametrize('m,d', [(4736, 64), (37, 64), (5, 32), (7000, 128), (33, 200), (100000, 64), (1, 256)])
+def test_layernorm(hip, m, d):
+    abi, dev, stream = hip
+    KC.check_layernorm(abi, dev, stream, m, d)
