@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench   # noqa: E402
 
-sys.argv = ['bench.py']
+sys.argv = ['bench.py'] + sys.argv[1:]   # bench.py flags select the configuration (--shape, --layer-norm, ...)
 args = bench.parse()
 dev = torch.device('cuda:0')
 cpu, gpu = bench.make_batch(args, 0, dev)
