@@ -50,7 +50,7 @@ SIGNATURES = {
                              C.c_int),
     'feta_layernorm_blocks': ([C.c_int], C.c_int),
     'feta_layernorm_fwd': ([_F, _F, _F, C.c_float, _F, _F, C.c_int, C.c_int, _S], C.c_int),
-    'feta_layernorm_bwd': ([_F, _F, _F, _F, _F, _F, _F, C.c_int, C.c_int, _S], C.c_int),
+    'feta_layernorm_bwd': ([_F, _F, _F, _F, _F, _F, C.c_int, _F, C.c_int, C.c_int, _S], C.c_int),
     'feta_eigh_sym_supported': ([C.c_int], C.c_int),
     'feta_eigh_sym': ([_F, _I, C.c_float, _F, _F, _I, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _S],
                       C.c_int),
@@ -406,9 +406,12 @@ class Abi:
         self._check(self.lib.feta_layernorm_fwd(_p(y), _p(gamma), _p(beta), eps, _p(out), _p(stats), m, d, stream),
                     'feta_layernorm_fwd')
 
-    def layernorm_bwd(self, dout, y, stats, gamma, dy, partial, dgdb, stream):
+    def layernorm_bwd(self, dout, y, stats, gamma, dy, partial, dgdb, stream, partial_ld=0, partial_ptr=None):
+        """partial_ptr / partial_ld: this LayerNorm's columns inside a shared [blocks, total] partial buffer
+        (dgdb None: the caller reduces it)."""
         m, d = y.shape
-        self._check(self.lib.feta_layernorm_bwd(_p(dout), _p(y), _p(stats), _p(gamma), _p(dy), _p(partial),
+        pp = _p(partial) if partial_ptr is None else C.c_void_p(partial_ptr)
+        self._check(self.lib.feta_layernorm_bwd(_p(dout), _p(y), _p(stats), _p(gamma), _p(dy), pp, partial_ld,
                                                 _p(dgdb), m, d, stream), 'feta_layernorm_bwd')
 
     def eigh_sym_supported(self, n):

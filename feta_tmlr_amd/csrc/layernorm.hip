@@ -25,9 +25,9 @@ struct LnArgs {
   float* stats;         // [M, 2] mean, rstd
   const float* dout;    // [M, D]
   float* dy;            // [M, D]
-  float* partial;       // [gridDim.x, 2, D] dgamma | dbeta partial sums
+  float* partial;       // [gridDim.x, 2, D] dgamma | dbeta partial sums (row pitch partial_ld)
   float eps;
-  int M, D;
+  int M, D, partial_ld;
 };
 
 template <int NV>
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kLnThreads) void ln_bwd_kernel(LnArgs a) {
   for (int i = threadIdx.x; i < 2 * a.D; i += kLnThreads) {
     float s = 0.0f;
     for (int r = 0; r < kLnRows; ++r) s += red[r * 2 * a.D + i];
-    a.partial[(int64_t)blockIdx.x * 2 * a.D + i] = s;
+    a.partial[(int64_t)blockIdx.x * a.partial_ld + i] = s;
   }
 }
 
@@ -198,9 +198,11 @@ extern "C" int feta_layernorm_fwd(const float* y, const float* gamma, const floa
 }
 
 extern "C" int feta_layernorm_bwd(const float* dout, const float* y, const float* stats, const float* gamma,
-                                  float* dy, float* partial, float* dgamma_dbeta, int M, int D,
+                                  float* dy, float* partial, int partial_ld, float* dgamma_dbeta, int M, int D,
                                   feta_stream_t stream) {
-  FETA_REQUIRE(dout && y && stats && gamma && dy && partial && dgamma_dbeta && M > 0, "layernorm_bwd: bad arguments");
+  FETA_REQUIRE(dout && y && stats && gamma && dy && partial && M > 0, "layernorm_bwd: bad arguments");
+  FETA_REQUIRE(partial_ld == 0 || partial_ld >= 2 * D, "layernorm_bwd: partial_ld = %d < 2 D", partial_ld);
+  FETA_REQUIRE(dgamma_dbeta || partial_ld > 0, "layernorm_bwd: dgamma_dbeta may only be NULL with a caller-reduced partial_ld");
   FETA_REQUIRE(ln_dim_ok(D), "layernorm_bwd: D = %d (multiple of 4, <= 256)", D);
   FETA_REQUIRE(aligned16(dout) && aligned16(y) && aligned16(gamma) && aligned16(dy),
                "layernorm_bwd: pointers must be 16-byte aligned");
@@ -211,6 +213,7 @@ extern "C" int feta_layernorm_bwd(const float* dout, const float* y, const float
   a.dout = dout;
   a.dy = dy;
   a.partial = partial;
+  a.partial_ld = partial_ld > 0 ? partial_ld : 2 * D;
   a.M = M;
   a.D = D;
   const int G = ln_blocks(M);
@@ -219,6 +222,7 @@ extern "C" int feta_layernorm_bwd(const float* dout, const float* y, const float
   FETA_LN_SWITCH((D + 63) / 64, CALL)
 #undef CALL
   const int rc = check_launch("feta_layernorm_bwd");
-  if (rc != FETA_OK) return rc;
+  if (rc != FETA_OK || dgamma_dbeta == nullptr) return rc;   // NULL: the caller reduces all its partials at once
+  FETA_REQUIRE(partial_ld == 0, "layernorm_bwd: dgamma_dbeta with partial_ld is not supported");
   return feta_colsum(partial, dgamma_dbeta, G, 2 * D, stream);
 }

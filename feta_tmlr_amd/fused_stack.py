@@ -51,15 +51,28 @@ def layer_params(layer):
             layer.linear2.weight, layer.linear2.bias, layer.norm2.weight, layer.norm2.bias]
 
 
+USE_LN_STACK = os.environ.get('FETA_LN_STACK', '1') != '0'   # 0: LayerNorm layers run op by op (A/B timing)
+
+
 def stack_supported(layers, d_model):
-    from .functional import ROWLIN_DIMS
+    """BatchNorm stack (training mode: batch statistics) or LayerNorm stack (any mode), no dropout."""
+    from .functional import ROWLIN_DIMS, layer_norm_rows_supported
+    if not len(layers):
+        return False
+    bn = layers[0].batch_norm
     for l in layers:
-        if not l.batch_norm or not l.training:
+        if l.batch_norm != bn:
             return False
-        if l.dropout1.p > 0.0 or l.dropout.p > 0.0 or l.dropout2.p > 0.0 or l.self_attn.dropout > 0.0:
+        if l.training and (l.dropout1.p > 0.0 or l.dropout.p > 0.0 or l.dropout2.p > 0.0 or l.self_attn.dropout > 0.0):
             return False
-        if l.norm1.momentum is None or l.norm2.momentum is None:
-            return False
+        if bn:
+            if not l.training or l.norm1.momentum is None or l.norm2.momentum is None:
+                return False
+        else:
+            if not USE_LN_STACK or not isinstance(l.norm1, torch.nn.LayerNorm):
+                return False
+            if not (l.norm1.elementwise_affine and l.norm2.elementwise_affine and layer_norm_rows_supported(d_model)):
+                return False
         ff = l.linear1.out_features
         if not all(c in ROWLIN_DIMS for c in (d_model, 3 * d_model, ff)):
             return False
@@ -326,9 +339,191 @@ class FusedEncoderStackFn(torch.autograd.Function):
         return (dcur.view(n, b, d), None, None, None, None, None) + tuple(grads)
 
 
+class FusedLayerNormStackFn(torch.autograd.Function):
+    """The LayerNorm variant (batch_norm=False: the default of the reference's TU / molhiv / SBM scripts,
+    experiments/run_transformer_gengcn_cv.py:56).  LayerNorm is row-local, so the normalised activations
+    ARE materialised (feta_layernorm_fwd after each sub-layer) and every kernel reads plain operands.
+    Per layer, forward (4 launches where csrc/block.hip and csrc/ffn.hip take the shape, else 7):
+        y1 = x0 + degree * out_proj(attention(in_proj(x0)))     feta_attn_block_fwd
+        x1 = LN1(y1)                                             feta_layernorm_fwd
+        y2 = x1 + linear2(relu(linear1(x1)))                     feta_ffn_fwd
+        x2 = LN2(y2)                                             feta_layernorm_fwd
+    backward (7 launches): LN2, linear2, linear1 (+ residual dy2 in its dX epilogue), LN1, out_proj,
+    attention, in_proj (+ residual dy1); the weight / bias partials of the whole stack share one
+    [chunks, total] buffer and the LayerNorm partials another: two reductions per stack, into the same
+    flat gradient buffer layout as the BatchNorm stack (parallel.FlatBufferAllReduce)."""
+
+    @staticmethod
+    def forward(ctx, src, pe, degree_rows, n_real, layers, need_attn, *params):
+        abi, stream = _lib.backend(src, pe, n_real)
+        ctx.set_materialize_grads(False)
+        n, b, d = src.shape
+        m = n * b
+        nl = len(layers)
+        heads = layers[0].self_attn.num_heads
+        dh = d // heads
+        tie = layers[0].self_attn.tie_qk
+        scale = float(dh) ** -0.5
+        dev = src.device
+        new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        x_in = src.contiguous().view(m, d)
+        pe_c = None if pe is None else pe.contiguous()
+        block = USE_ATTN_BLOCK and abi.attn_block_supported(n, d, heads)
+        saved = []
+        attn = None
+        for li, layer in enumerate(layers):
+            (w_in, b_in, w_o, b_o, g1, be1, w1, bb1, w2, bb2, g2, be2) = params[li * PER_LAYER:(li + 1) * PER_LAYER]
+            ff = w1.shape[0]
+            want = need_attn and li == nl - 1
+            attn = new(b, heads, n, n) if want else None
+            ast = new(b, heads, n, 2)
+            qkv = new(m, 3 * d)
+            out = torch.empty((n, b, heads, dh), dtype=torch.float32, device=dev)
+            y1 = new(m, d)
+            if block:
+                abi.attn_block_fwd(b, n, scale, stream, tie_qk=tie, x=x_in, w_in=w_in, b_in=b_in, w_out=w_o,
+                                   b_out=b_o, pe=pe_c, n_real=n_real, rowscale=degree_rows, qkv=qkv, out=out,
+                                   attn_stats=ast, attn=attn, y=y1, y_stats=new(b, 2, d))   # (statistics unused)
+            else:
+                dsc = abi.rowlin_ex(m, d, 3 * d, x=x_in, w=w_in, bias=b_in, y=qkv)
+                abi.rowlin_fwd_ex(dsc, stream)
+                q, k, v = _views(qkv, n, b, heads, dh)
+                if tie:
+                    k = q
+                abi.attn_fwd(q, k, v, pe_c, n_real, out.permute(1, 0, 2, 3), attn, ast, scale, stream)
+                dsc = abi.rowlin_ex(m, d, d, x=out.view(m, d), w=w_o, bias=b_o, rowscale=degree_rows,
+                                    residual=x_in, y=y1)
+                abi.rowlin_fwd_ex(dsc, stream)
+            x1, lst1 = new(m, d), new(m, 2)
+            abi.layernorm_fwd(y1, g1, be1, float(layer.norm1.eps), x1, lst1, stream)
+            h, y2 = new(m, ff), new(m, d)
+            if USE_FFN_FUSED and abi.ffn_supported(d, ff):
+                abi.ffn_fwd(m, ff, stream, x=x1, w1=w1, b1=bb1, w2=w2, b2=bb2, h=h, y=y2)
+            else:
+                dsc = abi.rowlin_ex(m, d, ff, relu=True, x=x1, w=w1, bias=bb1, y=h)
+                abi.rowlin_fwd_ex(dsc, stream)
+                dsc = abi.rowlin_ex(m, ff, d, x=h, w=w2, bias=bb2, residual=x1, y=y2)
+                abi.rowlin_fwd_ex(dsc, stream)
+            x2, lst2 = new(m, d), new(m, 2)
+            abi.layernorm_fwd(y2, g2, be2, float(layer.norm2.eps), x2, lst2, stream)
+            saved.append(dict(x0=x_in, qkv=qkv, out=out, ast=ast, y1=y1, lst1=lst1, x1=x1, h=h, y2=y2, lst2=lst2))
+            x_in = x2
+        ctx.saved_state = saved
+        ctx.meta = (n, b, d, heads, dh, tie, scale, nl)
+        ctx.aux = (pe_c, degree_rows, n_real)
+        ctx.params = params
+        ctx.owner = layers[0] if len(layers) else None
+        if attn is not None:
+            ctx.mark_non_differentiable(attn)
+        concat_last = saved[-1]['out'].view(n, b, d)
+        # (a fresh tensor object for the output: the saved x2 of the last layer is not handed out)
+        return x_in.view(n, b, d), concat_last, attn
+
+    @staticmethod
+    def backward(ctx, d_final, d_concat_last, _d_attn):
+        saved, params = ctx.saved_state, ctx.params
+        n, b, d, heads, dh, tie, scale, nl = ctx.meta
+        pe_c, degree_rows, n_real = ctx.aux
+        abi, stream = _lib.backend(saved[0]['qkv'])
+        m = n * b
+        dev = saved[0]['qkv'].device
+        new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        RC = abi.rowlin_chunks(m)
+        GL = abi.layernorm_blocks(m)
+        grads = [None] * len(params)
+        ff0 = params[6].shape[0]
+        per_layer = (3 * d * d + 3 * d) + (d * d + d) + (ff0 * d + ff0) + (d * ff0 + d)
+        total = per_layer * nl
+        part_all = new(RC, total)
+        ln_part = new(GL, nl * 4 * d)
+        dwdb_all = new(total + nl * 4 * d)          # same layout as the BatchNorm stack's flat buffer
+        ln_tail = dwdb_all[total:].view(nl, 4, d)   # dgamma1, dbeta1, dgamma2, dbeta2 per layer
+        cursor = [0]
+
+        def wslot(no, ki):
+            off = cursor[0]
+            cursor[0] += no * ki + no
+            return part_all.data_ptr() + 4 * off, off
+
+        def ln_bwd(dout, y, stats, gamma, li, which):
+            dy = new(m, d)
+            abi.layernorm_bwd(dout, y, stats, gamma, dy, None, None, stream, partial_ld=nl * 4 * d,
+                              partial_ptr=ln_part.data_ptr() + 4 * (li * 4 + 2 * which) * d)
+            return dy
+
+        slots = {}
+        if d_final is None:
+            d_final = torch.zeros(n, b, d, dtype=torch.float32, device=dev)
+        dcur = d_final.contiguous().view(m, d)
+        for li in range(nl - 1, -1, -1):
+            s = saved[li]
+            (w_in, b_in, w_o, b_o, g1, be1, w1, bb1, w2, bb2, g2, be2) = params[li * PER_LAYER:(li + 1) * PER_LAYER]
+            ff = w1.shape[0]
+            base = li * PER_LAYER
+            dy2 = ln_bwd(dcur, s['y2'], s['lst2'], g2, li, 1)
+            grads[base + 10], grads[base + 11] = ln_tail[li, 2], ln_tail[li, 3]
+            # linear2, then linear1 with the residual gradient dy2 added in its dX epilogue
+            dh_ = new(m, ff)
+            pp, off = wslot(d, ff)
+            slots[base + 8] = (off, d, ff)
+            dsc = abi.rowlin_ex(m, ff, d, x=s['h'], w=w2, dy=dy2, dx=dh_, partial_ptr=pp, partial_ld=total)
+            abi.rowlin_bwd_ex(dsc, None, stream)
+            dx1 = new(m, d)
+            pp, off = wslot(ff, d)
+            slots[base + 6] = (off, ff, d)
+            dsc = abi.rowlin_ex(m, d, ff, x=s['x1'], w=w1, dy=dh_, relu_y=s['h'], dx=dx1, partial_ptr=pp,
+                                partial_ld=total, add_plain=dy2)
+            abi.rowlin_bwd_ex(dsc, None, stream)
+            dy1 = ln_bwd(dx1, s['y1'], s['lst1'], g1, li, 0)
+            grads[base + 4], grads[base + 5] = ln_tail[li, 0], ln_tail[li, 1]
+            # out_proj (gradient scaled by degree), attention, in_proj with the residual gradient dy1
+            dconcat = new(m, d)
+            pp, off = wslot(d, d)
+            slots[base + 2] = (off, d, d)
+            dsc = abi.rowlin_ex(m, d, d, x=s['out'].view(m, d), w=w_o, dy=dy1, rowscale=degree_rows, dx=dconcat,
+                                partial_ptr=pp, partial_ld=total)
+            abi.rowlin_bwd_ex(dsc, None, stream)
+            dout2 = None
+            if li == nl - 1 and d_concat_last is not None:
+                if abi.attn_bwd_takes_dout2(n, dh):
+                    dout2 = d_concat_last.contiguous().view(n, b, heads, dh).permute(1, 0, 2, 3)
+                else:
+                    dconcat = dconcat + d_concat_last.contiguous().view(m, d)
+            q, k, v = _views(s['qkv'], n, b, heads, dh)
+            if tie:
+                k = q
+            dqkv = new(m, 3 * d)
+            dq, dk, dv = _views(dqkv, n, b, heads, dh)
+            delta = new(b, heads, n)
+            abi.attn_bwd(q, k, v, pe_c, n_real, s['out'].permute(1, 0, 2, 3),
+                         dconcat.view(n, b, heads, dh).permute(1, 0, 2, 3), s['ast'], delta, dq, dk, dv, scale,
+                         stream, dout2=dout2)
+            if tie:
+                dqkv[:, :d] += dqkv[:, d:2 * d]
+                dqkv[:, d:2 * d] = 0
+            dx0 = new(m, d)
+            pp, off = wslot(3 * d, d)
+            slots[base + 0] = (off, 3 * d, d)
+            dsc = abi.rowlin_ex(m, d, 3 * d, x=s['x0'], w=w_in, dy=dqkv, dx=dx0, partial_ptr=pp, partial_ld=total,
+                                add_plain=dy1)
+            abi.rowlin_bwd_ex(dsc, None, stream)
+            dcur = dx0
+        assert cursor[0] == total
+        abi.colsum(part_all, dwdb_all[:total], stream)
+        abi.colsum(ln_part, dwdb_all[total:], stream)
+        if ctx.owner is not None:
+            STACK_FLAT_GRAD[ctx.owner] = dwdb_all
+        for idx, (off, no, ki) in slots.items():
+            grads[idx] = dwdb_all[off:off + no * ki].view(no, ki)
+            if params[idx + 1] is not None:
+                grads[idx + 1] = dwdb_all[off + no * ki:off + no * ki + no]
+        return (dcur.view(n, b, d), None, None, None, None, None) + tuple(grads)
+
+
 def fused_encoder_stack(src, pe, degree_rows, n_real, layers, need_attn=True):
     """-> (output [N,B,d] of the last layer, concat heads of the last layer [N,B,d], attn or None)"""
     params = []
     for l in layers:
         params += layer_params(l)
-    return FusedEncoderStackFn.apply(src, pe, degree_rows, n_real, list(layers), need_attn, *params)
+    fn = FusedEncoderStackFn if layers[0].batch_norm else FusedLayerNormStackFn
+    return fn.apply(src, pe, degree_rows, n_real, list(layers), need_attn, *params)

@@ -397,12 +397,15 @@ int feta_lhat_from_edges(const int64_t* edge_index, int64_t E,
  * y, out, dout, dy [M,D] row-major, D a multiple of 4, <= 256; stats [M,2] = (mean, rstd) per row
  * (biased variance, eps inside the root, as torch.nn.LayerNorm).  Backward also returns
  * dgamma_dbeta [2,D]; partial [feta_layernorm_blocks(M), 2, D] is caller-provided scratch.
+ * partial_ld > 0: row pitch of partial, so that several LayerNorms share one
+ * [feta_layernorm_blocks(M), total] buffer which the caller reduces with ONE feta_colsum
+ * (dgamma_dbeta = NULL then), as feta_rowlin_ex.partial_ld does for the weight gradients.
  */
 int feta_layernorm_blocks(int M);
 int feta_layernorm_fwd(const float* y, const float* gamma, const float* beta, float eps, float* out,
                        float* stats, int M, int D, feta_stream_t stream);
 int feta_layernorm_bwd(const float* dout, const float* y, const float* stats, const float* gamma,
-                       float* dy, float* partial, float* dgamma_dbeta, int M, int D,
+                       float* dy, float* partial, int partial_ld, float* dgamma_dbeta, int M, int D,
                        feta_stream_t stream);
 
 /* ---- spectrum producer ------------------------------------------------

@@ -336,3 +336,44 @@ def test_device_kernel_pe_needs_full_spectrum(emu):
     from feta_tmlr_amd.transformer import position_encoding as PE
     with pytest.raises(ValueError):
         PE.device_kernel_pe(torch.zeros(1, 8, 4), torch.zeros(1, 4), torch.tensor([8], dtype=torch.int32))
+
+
+def check_layernorm_stack_equals_per_op(dev, hook, monkeypatch, shape, n_min, n_max, d, heads, tie_qk, bsz=3,
+                                        use_block=True):
+    """LayerNorm layers as one autograd node (fused_stack.FusedLayerNormStackFn: block / ffn kernels,
+    residual gradients in the dX epilogues, two reductions per stack) == the layers run op by op"""
+    from feta_tmlr_amd import fused_stack
+    torch.manual_seed(6)
+    model = DiffGraphTransformerGenGCN(9, 1, d, heads, dim_feedforward=2 * d, dropout=0.0, nb_layers=2,
+                                       batch_norm=False, filter_order=2, heads_share_graph=True,
+                                       filter_mode='spectral', tie_qk=tie_qk)
+    with torch.no_grad():
+        for l in model.encoder.layers:
+            l.self_attn.out_proj.bias.normal_(0, 0.1)
+            l.norm1.weight.normal_(1.0, 0.2)
+            l.norm2.bias.normal_(0, 0.1)
+    ds = D.SyntheticGraphDataset(shape, bsz, in_dim=9, seed=3, pos_enc=True, n_min=n_min, n_max=n_max)
+    n_pad = max(g.num_nodes for g in ds.samples)
+    batch9, cache = D.collate(ds.samples, k_eig=n_pad, device=dev)
+    model = model.to(dev)
+    monkeypatch.setattr(fused_stack, 'USE_LN_STACK', True)
+    a = _stack_run(model, batch9, cache, use_block, monkeypatch, hook)
+    assert fused_stack.STACK_FLAT_GRAD.get(model.encoder.layers[0]) is not None   # the fused node ran
+    monkeypatch.setattr(fused_stack, 'USE_LN_STACK', False)
+    b = _stack_run(model, batch9, cache, use_block, monkeypatch, hook)
+    KC.assert_close('output', a[0], b[0].double(), tol=2e-6)
+    KC.assert_close('coefficients', a[1], b[1].double(), tol=2e-6)
+    KC.assert_close('dx', a[2], b[2].double(), tol=1e-5)
+    assert a[3].keys() == b[3].keys()
+    for k in a[3]:
+        KC.assert_close('grad ' + k, a[3][k], b[3][k].double(), tol=1e-5)
+
+
+@pytest.mark.parametrize('shape,n_min,n_max,d,heads,tie_qk,use_block', [
+    ('zinc', 20, 37, 64, 4, False, True),      # csrc/block.hip + csrc/ffn.hip
+    ('mutag', 5, 19, 64, 4, True, False),      # row-wise launches, K tied to Q
+    ('mutag', 5, 19, 64, 2, False, True),      # two heads: no attention block kernel, fused FFN
+])
+def test_layernorm_stack_equals_per_op(emu, monkeypatch, shape, n_min, n_max, d, heads, tie_qk, use_block):
+    check_layernorm_stack_equals_per_op(CPU, lambda: _lib.override_for_tests(emu), monkeypatch, shape, n_min, n_max,
+                                        d, heads, tie_qk, use_block=use_block)

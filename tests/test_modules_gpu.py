@@ -86,3 +86,17 @@ def test_device_spectrum_feeds_the_model(shape, bsz, n_min, n_max, d, heads):
     from test_modules_emu import check_device_spectrum_feeds_the_model
     check_device_spectrum_feeds_the_model(torch.device('cuda:0'), contextlib.nullcontext, shape, bsz, n_min, n_max,
                                           d, heads)
+
+
+@pytest.mark.parametrize('shape,n_min,n_max,d,heads,tie_qk,use_block,bsz', [
+    ('zinc', 9, 37, 64, 4, False, True, 32),
+    ('mutag', 5, 19, 64, 4, True, False, 8),
+    ('mutag', 5, 19, 64, 2, False, True, 8),
+    ('pattern', 70, 120, 64, 4, False, True, 4),    # N > 64: general attention kernels inside the stack
+    ('molhiv', None, 64, 64, 4, False, True, 300),  # more graphs than workgroups: persistent loops
+])
+def test_layernorm_stack_equals_per_op(monkeypatch, shape, n_min, n_max, d, heads, tie_qk, use_block, bsz):
+    import contextlib
+    from test_modules_emu import check_layernorm_stack_equals_per_op
+    check_layernorm_stack_equals_per_op(torch.device('cuda:0'), contextlib.nullcontext, monkeypatch, shape, n_min, n_max,
+                                        d, heads, tie_qk, bsz=bsz, use_block=use_block)
