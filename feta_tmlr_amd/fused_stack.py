@@ -1,5 +1,6 @@
-"""The whole stack of DiffTransformerEncoderLayers (BatchNorm variant) as ONE autograd node with a
-hand-scheduled forward and backward over the C ABI.
+"""The whole stack of DiffTransformerEncoderLayers as ONE autograd node with a hand-scheduled forward
+and backward over the C ABI: FusedEncoderStackFn (BatchNorm layers, described here) and
+FusedLayerNormStackFn (LayerNorm layers, described at the class).
 
 Per layer, forward (5 launches):
     F1  qkv  = BN2_prev(y2_prev) W_in^T                       feta_rowlin_fwd_ex (finalizes BN2_prev)

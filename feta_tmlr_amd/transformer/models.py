@@ -99,7 +99,7 @@ class DiffTransformerEncoderGenGCN(nn.Module):
         self.use_skip_conn = use_skip_conn
         self.heads_share_graph = heads_share_graph
         self.filter_mode = filter_mode
-        self.fused_stack = True   # BatchNorm stacks run as one autograd node when the dims allow
+        self.fused_stack = True   # layer stacks (BatchNorm or LayerNorm) run as one autograd node when the dims allow
         self.keep_stack_boundary = False   # set by trainers that use backward_head / backward_stack
         self.coeff_side_stream = False     # second-stream coefficient generator: measured SLOWER (0.505 vs 0.488 ms/step:
                                            # the fork/join edges of the hipGraph cost more than the overlap buys)
