@@ -86,59 +86,6 @@ __device__ __forceinline__ void reduce_partials(const float* part, int G, int D,
   __syncthreads();
 }
 
-// reduce_partials in two halves, so that the loads of the partial sums travel together with the other
-// requests of a kernel's prologue (weights, first operand rows) instead of costing a memory latency of
-// their own: partials_issue() requests the first NPRE rows of each slice into registers (clamped,
-// unconditional), partials_finish() adds any further rows and does the LDS reduction of reduce_partials.
-template <int NPRE>
-struct PartialRows {
-  float4 v[NPRE];
-};
-
-template <int NPRE>
-__device__ __forceinline__ void partials_issue(const float* part, int G, int D, PartialRows<NPRE>& P) {
-  const int nq = 2 * D / 4;
-  const int slices = kRowThreads / nq > 0 ? kRowThreads / nq : 1;
-  const int q = threadIdx.x % nq, slice = threadIdx.x / nq;
-  const float4* p4 = reinterpret_cast<const float4*>(part);
-#pragma unroll
-  for (int u = 0; u < NPRE; ++u) {
-    const int gi = slice + u * slices;
-    P.v[u] = p4[(int64_t)(gi < G ? gi : G - 1) * nq + q];
-  }
-}
-
-template <int NPRE>
-__device__ __forceinline__ void partials_finish(const float* part, int G, int D, float* red, float* tot,
-                                                const PartialRows<NPRE>& P) {
-  const int nq = 2 * D / 4;
-  const int slices = kRowThreads / nq > 0 ? kRowThreads / nq : 1;
-  const int q = threadIdx.x % nq, slice = threadIdx.x / nq;
-  if ((int)threadIdx.x < slices * nq) {
-    const float4* p4 = reinterpret_cast<const float4*>(part);
-    float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll
-    for (int u = 0; u < NPRE; ++u) {
-      if (slice + u * slices < G) {
-        s.x += P.v[u].x; s.y += P.v[u].y; s.z += P.v[u].z; s.w += P.v[u].w;
-      }
-    }
-    for (int gi = slice + NPRE * slices; gi < G; gi += slices) {
-      const float4 v = p4[(int64_t)gi * nq + q];
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    }
-    float* r = red + (slice * nq + q) * 4;
-    r[0] = s.x; r[1] = s.y; r[2] = s.z; r[3] = s.w;
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < 2 * D; c += kRowThreads) {
-    float t = 0.0f;
-    for (int sl = 0; sl < slices; ++sl) t += red[sl * 2 * D + c];
-    tot[c] = t;
-  }
-  __syncthreads();
-}
-
 __host__ __device__ inline int reduce_red_floats(int D) {
   const int nq = 2 * D / 4;
   const int slices = kRowThreads / nq > 0 ? kRowThreads / nq : 1;

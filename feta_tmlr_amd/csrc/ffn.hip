@@ -74,10 +74,6 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a) {
   for (int t = 0; t < 2; ++t)
     b2v[t] = a.b2 != nullptr ? *reinterpret_cast<const float4*>(a.b2 + 16 * (2 * hh + t) + 4 * g)
                              : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  PartialRows<16> pre;   // the BatchNorm-1 partial sums: requested with the weights, reduced after them
-  // (unconditional: a conditionally-filled float4 array is lowered to private memory; without statistics
-  // the first rows of W1 are read and never used)
-  partials_issue<16>(a.x_stats != nullptr ? a.x_stats : a.w1, a.x_stats != nullptr ? a.Gx : 1, D, pre);
   {
     constexpr int NV = 2 * FF * D / 4 / kRowThreads;  // float4 per thread: W1 then W2
     float4 wv4[NV];
@@ -100,7 +96,10 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a) {
   }
   FFN_STAMP(1);
   if (a.x_stats != nullptr) {
-    partials_finish<16>(a.x_stats, a.Gx, D, scr + 2 * D, scr, pre);
+    // (requesting the partial sums together with the weights was measured SLOWER, 18.0 k vs 15.0 k cycles:
+    // every workgroup asks for the same rows at the same moment, and the in-order return of loads parks the
+    // weights behind that hot spot)
+    reduce_partials(a.x_stats, a.Gx, D, scr + 2 * D, scr);
     for (int c = tid; c < D; c += kRowThreads) {
       const float mean = scr[c] / (float)a.M;
       const float var = fmaxf(scr[D + c] / (float)a.M - mean * mean, 0.0f);
