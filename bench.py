@@ -75,7 +75,7 @@ def parse():
                     help='force the split backward (default for --gpus > 1: overlaps the all-reduce of the '
                          'filter-stage gradients with the backward of the encoder stack)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-steps', type=int, default=5)
+    ap.add_argument('--cpu-steps', type=int, default=10)
     ap.add_argument('--kernel-iters', type=int, default=200)
     ap.add_argument('--stream-batch', type=int, default=16384,
                     help='graphs in the streaming-batch run of the north-star kernel (roofline_streaming); 0 = skip')
