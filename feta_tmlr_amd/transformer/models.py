@@ -99,6 +99,7 @@ class DiffTransformerEncoderGenGCN(nn.Module):
         self.use_skip_conn = use_skip_conn
         self.heads_share_graph = heads_share_graph
         self.filter_mode = filter_mode
+        self.spectral_k = None    # eigenpairs kept when the eigenbasis is computed here (None: all N_pad)
         self.fused_stack = True   # layer stacks (BatchNorm or LayerNorm) run as one autograd node when the dims allow
         self.keep_stack_boundary = False   # set by trainers that use backward_head / backward_stack
         self.coeff_side_stream = False     # second-stream coefficient generator: measured SLOWER (0.505 vs 0.488 ms/step:
@@ -166,6 +167,13 @@ class DiffTransformerEncoderGenGCN(nn.Module):
         if self.filter_mode == 'cheb' and graph_cache.lhat is None:
             graph_cache.lhat = FF.lhat_from_edges(edge_index, batch, graph_cache.node_off,
                                                   graph_cache.n_real.shape[0], n_pad)
+        if self.filter_mode == 'spectral' and graph_cache.u is None:
+            # no eigenbasis came with the batch: decompose Lhat of every graph on the device (edge list ->
+            # Lhat -> feta_eigh_sym, two launches per batch; spectral_k = None keeps the full basis, which
+            # makes the filter the exact Chebyshev operator)
+            from . import position_encoding as PE
+            graph_cache.lhat, graph_cache.u, graph_cache.lam = PE.device_spectrum(
+                edge_index, batch, graph_cache.node_off, graph_cache.n_real, n_pad, self.spectral_k)
         return graph_cache
 
     # -- two-phase backward (data-parallel overlap) ---------------------------------------------

@@ -377,3 +377,37 @@ def check_layernorm_stack_equals_per_op(dev, hook, monkeypatch, shape, n_min, n_
 def test_layernorm_stack_equals_per_op(emu, monkeypatch, shape, n_min, n_max, d, heads, tie_qk, use_block):
     check_layernorm_stack_equals_per_op(CPU, lambda: _lib.override_for_tests(emu), monkeypatch, shape, n_min, n_max,
                                         d, heads, tie_qk, use_block=use_block)
+
+
+def check_spectral_mode_without_eigenbasis(dev, hook, spectral_k=None):
+    """filter_mode='spectral' fed only with the edge list: the encoder decomposes Lhat on the device
+    (models._graph_cache -> position_encoding.device_spectrum) and agrees with the same model fed with
+    numpy's eigenbasis; spectral_k truncates the device basis like collate(k_eig=) truncates the host one
+    (compared through the eigenvalues: a truncated basis is not unique inside degenerate eigenspaces)."""
+    torch.manual_seed(3)
+    model = DiffGraphTransformerGenGCN(7, 1, 32, 2, dim_feedforward=64, dropout=0.0, nb_layers=1,
+                                       batch_norm=False, filter_order=3, heads_share_graph=True,
+                                       filter_mode='spectral').to(dev)
+    ds = D.SyntheticGraphDataset('mutag', 4, in_dim=7, seed=5, pos_enc=True, n_min=5, n_max=17)
+    n_pad = max(g.num_nodes for g in ds.samples)
+    host9, host_cache = D.collate(ds.samples, k_eig=spectral_k or n_pad, device=dev)
+    for g in ds.samples:
+        g.u = g.lam = None
+    dev9, dev_cache = D.collate(ds.samples, device=dev)
+    model.encoder.spectral_k = spectral_k
+    outs = []
+    with hook():
+        for b9, cache in ((host9, host_cache), (dev9, dev_cache)):
+            x, mask, pe, _, degree, labels, edge_index, batch, fi = b9
+            out, _, _ = model(x, edge_index, batch, fi, mask, pe, degree=degree, return_filter_coeff=True,
+                              graph_cache=cache)
+            outs.append(out.detach().cpu().double())
+    assert dev_cache.u.shape == host_cache.u.shape
+    KC.assert_close('eigenvalues', dev_cache.lam.cpu(), host_cache.lam.cpu().double(), tol=2e-5)
+    if spectral_k is None:
+        KC.assert_close('model output', outs[1], outs[0], tol=1e-4)
+
+
+def test_spectral_mode_without_eigenbasis(emu):
+    check_spectral_mode_without_eigenbasis(CPU, lambda: _lib.override_for_tests(emu))
+    check_spectral_mode_without_eigenbasis(CPU, lambda: _lib.override_for_tests(emu), spectral_k=6)

@@ -100,3 +100,10 @@ def test_layernorm_stack_equals_per_op(monkeypatch, shape, n_min, n_max, d, head
     from test_modules_emu import check_layernorm_stack_equals_per_op
     check_layernorm_stack_equals_per_op(torch.device('cuda:0'), contextlib.nullcontext, monkeypatch, shape, n_min, n_max,
                                         d, heads, tie_qk, bsz=bsz, use_block=use_block)
+
+
+@pytest.mark.parametrize('spectral_k', [None, 6])
+def test_spectral_mode_without_eigenbasis(spectral_k):
+    import contextlib
+    from test_modules_emu import check_spectral_mode_without_eigenbasis
+    check_spectral_mode_without_eigenbasis(torch.device('cuda:0'), contextlib.nullcontext, spectral_k)
