@@ -97,15 +97,15 @@ def test_shard_indices_partition():
         assert got == list(range(37))
 
 
-def _build_bn(seed=0):
-    """d_model 64 / 4 heads / BatchNorm: takes the fused stack (flat stack-gradient buffer)"""
+def _build_bn(seed=0, batch_norm=True):
+    """d_model 64 / 4 heads: takes the fused stack, BatchNorm or LayerNorm (flat stack-gradient buffer)"""
     from feta_tmlr_amd.transformer.models import DiffGraphTransformerGenGCN
     torch.manual_seed(seed)
     return DiffGraphTransformerGenGCN(8, 1, 64, 4, dim_feedforward=128, dropout=0.0, nb_layers=2,
-                                      batch_norm=True, filter_order=2, heads_share_graph=True)
+                                      batch_norm=batch_norm, filter_order=2, heads_share_graph=True)
 
 
-def _worker_inplace(rank, world, port, ret):
+def _worker_inplace(rank, world, port, ret, batch_norm):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import ctypes
@@ -125,7 +125,7 @@ def _worker_inplace(rank, world, port, ret):
     dout = torch.randn(src.shape, generator=g)
     out = {}
     for mode in ('packed', 'inplace'):
-        enc = _build_bn().encoder
+        enc = _build_bn(batch_norm=batch_norm).encoder
         enc.train()
         kw = dict(degree=degree, src_key_padding_mask=mask, graph_cache=cache)
         with _lib.override_for_tests(emu):
@@ -155,13 +155,14 @@ def _worker_inplace(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_inplace_reducers_equal_packed_bucket_world2(emu):
+@pytest.mark.parametrize('batch_norm', [True, False])
+def test_inplace_reducers_equal_packed_bucket_world2(emu, batch_norm):
     """HybridGradAllReduce (big gradients in place) + FlatBufferAllReduce (the fused stack's flat
     gradient buffer) give the averaged gradients of the packed single bucket"""
-    port = 29500 + (os.getpid() % 400) + 7
+    port = 29500 + (os.getpid() % 400) + 7 + (0 if batch_norm else 11)
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker_inplace, args=(2, port, ret), nprocs=2, join=True)
+    mp.spawn(_worker_inplace, args=(2, port, ret, batch_norm), nprocs=2, join=True)
     for rank in (0, 1):
         packed, inplace = ret[rank]
         assert torch.allclose(packed, inplace, rtol=1e-6, atol=1e-7), float((packed - inplace).abs().max())
