@@ -212,6 +212,8 @@ POSENCODINGS = {
 
 # ---- the same encodings for a whole padded batch, on the device ---------------------------------
 
+DEVICE_EIGH_MAX_N = 192   # feta_eigh_sym_supported: the matrix lives in one workgroup's LDS
+
 
 def device_spectrum(edge_index, batch, node_off, n_real, n_pad, k_eig=None):
     """Batch producer of the spectral inputs: edge list of the collated batch ->
@@ -221,8 +223,24 @@ def device_spectrum(edge_index, batch, node_off, n_real, n_pad, k_eig=None):
     spectrum is that of Lhat = L_sym - I, which is what ``filter_mode='spectral'`` consumes."""
     from .. import functional as FF
     lhat = FF.lhat_from_edges(edge_index, batch, node_off, n_real.shape[0], n_pad)
-    u, lam = FF.eigh_sym(lhat, n_real, shift=2.0, k=k_eig)
-    return lhat, u, lam
+    if n_pad <= DEVICE_EIGH_MAX_N:
+        u, lam = FF.eigh_sym(lhat, n_real, shift=2.0, k=k_eig)
+        return lhat, u, lam
+    # the largest molhiv bucket (N_pad = 256): the matrix does not fit one workgroup's LDS - these batches are
+    # decomposed graph by graph on the host, as the reference does for every graph (:137)
+    import torch
+    k = n_pad if k_eig is None else int(k_eig)
+    lh, ns = lhat.cpu().double().numpy(), n_real.cpu().tolist()
+    u = np.zeros((len(ns), n_pad, k), np.float32)
+    lam = np.zeros((len(ns), k), np.float32)
+    for b, nb in enumerate(ns):
+        w, v = np.linalg.eigh(lh[b, :nb, :nb])
+        kk = min(k, nb)
+        piv = np.abs(v[:, :kk]).argmax(0)
+        sign = np.where(v[piv, np.arange(kk)] < 0, -1.0, 1.0)     # the sign rule of feta_eigh_sym
+        u[b, :nb, :kk] = v[:, :kk] * sign
+        lam[b, :kk] = w[:kk]
+    return lhat, torch.from_numpy(u).to(lhat.device), torch.from_numpy(lam).to(lhat.device)
 
 
 def device_kernel_pe(u, lam, n_real, kind='diffusion', beta=1.0, p=1, zero_diag=False):

@@ -1,5 +1,6 @@
 """Host logic (autograd Functions + nn.Modules mirroring the reference API) against the oracle,
 with the kernels running in the host SIMT emulation (test hook _lib.override_for_tests)."""
+import numpy as np
 import pytest
 import torch
 
@@ -411,3 +412,19 @@ def check_spectral_mode_without_eigenbasis(dev, hook, spectral_k=None):
 def test_spectral_mode_without_eigenbasis(emu):
     check_spectral_mode_without_eigenbasis(CPU, lambda: _lib.override_for_tests(emu))
     check_spectral_mode_without_eigenbasis(CPU, lambda: _lib.override_for_tests(emu), spectral_k=6)
+
+
+def test_device_spectrum_falls_back_to_the_host_beyond_192_nodes(emu):
+    from feta_tmlr_amd.transformer import position_encoding as PE
+    ds = D.SyntheticGraphDataset('molhiv', 2, in_dim=2, seed=0, pos_enc=False, with_eig=False, n_min=30, n_max=40)
+    b9, cache = D.collate(ds.samples, n_pad=200)
+    with _lib.override_for_tests(emu):
+        lhat, u, lam = PE.device_spectrum(b9[6], b9[7], cache.node_off, cache.n_real, 200, k_eig=16)
+    assert u.shape == (2, 200, 16) and lam.shape == (2, 16)
+    for b, g in enumerate(ds.samples):
+        nb = g.num_nodes
+        ref = np.linalg.eigvalsh(D.lhat_numpy(g.edge_index, nb))
+        assert np.abs(lam[b].numpy() - ref[:16]).max() < 1e-6
+        res = lhat[b].double() @ u[b].double() - u[b].double() * lam[b].double()
+        assert float(res.abs().max()) < 1e-5
+        assert float(u[b, nb:].abs().max()) == 0.0
