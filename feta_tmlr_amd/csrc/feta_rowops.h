@@ -44,32 +44,47 @@ __device__ __forceinline__ void stage_float4(int count, Src src, Dst dst) {
 
 // sums the G partial pairs [G][2][D] with all 256 threads; on return tot[c], tot[D + c] (LDS)
 // hold the totals.  red: [slices][2][D] scratch.
+#ifndef FETA_PARTIAL_UNROLL
+#define FETA_PARTIAL_UNROLL 8
+#endif
+constexpr int kPartialUnroll = FETA_PARTIAL_UNROLL;   // 16-byte loads in flight per thread in reduce_partials
+
 __device__ __forceinline__ void reduce_partials(const float* part, int G, int D, float* red,
                                                 float* tot) {
-  // one partial = 2D contiguous floats = nq float4; thread -> (float4 column q, slice); the
-  // loop is unrolled x4 with independent accumulators so that four 16-byte loads are in flight
-  // per thread (the dependent-latency chain of a scalar loop cost ~10 us per consumer)
+  // one partial = 2D contiguous floats = nq float4; thread -> (float4 column q, slice); rows are
+  // requested kPartialUnroll at a time (independent accumulators), the tail as one clamped batch: every
+  // batch is one memory round trip per consumer workgroup (a scalar loop cost ~10 us per consumer)
   const int nq = 2 * D / 4;
   const int slices = kRowThreads / nq > 0 ? kRowThreads / nq : 1;
   const int q = threadIdx.x % nq, slice = threadIdx.x / nq;
   if ((int)threadIdx.x < slices * nq) {
     const float4* p4 = reinterpret_cast<const float4*>(part);
+    constexpr int U = kPartialUnroll;
     float4 s[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) s[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     int gi = slice;
-    for (; gi + 3 * slices < G; gi += 4 * slices) {
-      float4 v[4];
+    for (; gi + (U - 1) * slices < G; gi += U * slices) {
+      float4 v[U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = p4[(int64_t)(gi + u * slices) * nq + q];
+      for (int u = 0; u < U; ++u) v[u] = p4[(int64_t)(gi + u * slices) * nq + q];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        s[u].x += v[u].x; s[u].y += v[u].y; s[u].z += v[u].z; s[u].w += v[u].w;
+      for (int u = 0; u < U; ++u) {
+        s[u & 3].x += v[u].x; s[u & 3].y += v[u].y; s[u & 3].z += v[u].z; s[u & 3].w += v[u].w;
       }
     }
-    for (; gi < G; gi += slices) {
-      const float4 v = p4[(int64_t)gi * nq + q];
-      s[0].x += v.x; s[0].y += v.y; s[0].z += v.z; s[0].w += v.w;
+    if (gi < G) {   // the remaining (fewer than U) rows of this slice: one more batch, clamped and masked
+      float4 v[U - 1];
+#pragma unroll
+      for (int u = 0; u < U - 1; ++u) {
+        const int gr = gi + u * slices;
+        v[u] = p4[(int64_t)(gr < G ? gr : G - 1) * nq + q];
+      }
+#pragma unroll
+      for (int u = 0; u < U - 1; ++u) {
+        const float m = gi + u * slices < G ? 1.0f : 0.0f;
+        s[u & 3].x += m * v[u].x; s[u & 3].y += m * v[u].y; s[u & 3].z += m * v[u].z; s[u & 3].w += m * v[u].w;
+      }
     }
     float* r = red + (slice * nq + q) * 4;
     r[0] = (s[0].x + s[1].x) + (s[2].x + s[3].x);
