@@ -64,6 +64,10 @@ def main():
         for i, (row, _) in enumerate(ROWS):
             if row.startswith('attn_bwd'):
                 ROWS[i] = (row, ['attn_bwd_dense'])
+    if any('attn_bwd_graph' in name for name, _ in f):   # large batches: one workgroup per graph
+        for i, (row, _) in enumerate(ROWS):
+            if row.startswith('attn_bwd'):
+                ROWS[i] = (row, ['attn_bwd_graph'])
     calls = int(sys.argv[3]) + 3
     fk, wk = walk(f, calls), walk(w, calls)
     res = {name: {'FETCH_SIZE_KB': round(fk[name], 1), 'WRITE_SIZE_KB': round(wk[name], 1),
