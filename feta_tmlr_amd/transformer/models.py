@@ -291,6 +291,32 @@ class GlobalAvg1D(nn.Module):
         return (x * m).sum(dim=1) / m.sum(dim=1)
 
 
+class _InputEmbeddingFn(torch.autograd.Function):
+    """y = x W^T for the node-feature embedding ``nn.Linear(in_size, d_model, bias=False)`` of the task shells
+    (transformer/models.py:521-522) when x is data (no gradient).  Plain library GEMMs; the point is the weight
+    gradient: dW = dy^T x contracts over all N*B rows into a d_model x in_size result, which the BLAS heuristics
+    run as ONE workgroup (38 us at the ZINC batch) - here it is split over the leading (node) dimension as a
+    batched GEMM plus one small sum (10 us)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x)
+        return torch.matmul(x, w.t())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        dw = torch.bmm(dy.transpose(1, 2), x).sum(0)     # [S, d, B] x [S, B, f] -> [S, d, f] -> [d, f]
+        return None, dw
+
+
+def input_embedding(linear, x):
+    """x [S, B, in_size] -> [S, B, d_model] through ``linear`` (an nn.Linear)."""
+    if linear.bias is None and x.dim() == 3 and not x.requires_grad and torch.is_grad_enabled() and linear.weight.requires_grad:
+        return _InputEmbeddingFn.apply(x, linear.weight)
+    return linear(x)
+
+
 class DiffGraphTransformerGenGCN(nn.Module):
     """transformer/models.py:487-551 (graph-level regression / classification shell)."""
 
@@ -321,7 +347,7 @@ class DiffGraphTransformerGenGCN(nn.Module):
 
     def forward(self, x, edge_index, batch, feature_indices, masks, pe, x_lap_pos_enc=None,
                 degree=None, regularization=0.0, return_filter_coeff=False, graph_cache=None):
-        output = self.embedding(x.permute(1, 0, 2))                              # :521-522
+        output = input_embedding(self.embedding, x.permute(1, 0, 2))                              # :521-522
         if self.lap_pos_enc and x_lap_pos_enc is not None:
             output = output + self.embedding_lap_pos_enc(x_lap_pos_enc.transpose(0, 1))   # :523-526
         output, attn, filter_coeff = self.encoder(output, pe, edge_index, feature_indices, batch,
@@ -485,7 +511,7 @@ class DiffGraphTransformerGenGCNSBM(nn.Module):
                 padded_logits=False):
         """padded_logits=True returns the logits of every position [B, N_pad, nb_class] instead of
         the boolean gather of the real nodes (whose length differs per batch: not capturable)."""
-        output = self.embedding(x.permute(1, 0, 2))                              # :1042-1043
+        output = input_embedding(self.embedding, x.permute(1, 0, 2))                              # :1042-1043
         if self.lap_pos_enc and x_lap_pos_enc is not None:
             output = output + self.embedding_lap_pos_enc(x_lap_pos_enc.transpose(0, 1))
         output, attn, filter_coeff = self.encoder(output, pe, edge_index, feature_indices, batch,
