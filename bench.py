@@ -3,19 +3,27 @@ padded-graph batches (BASELINE.json configs[1]: B=128, N_pad=37, d=64, 4 heads, 
 fp32), one process per GPU, weak scaling.
 
     python bench.py --gpus 1 --steps 50 --warmup 10
+    python bench.py --gpus 4 --steps 50 --warmup 10        # starts its own 4 ranks (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A step = zero grads, forward and backward of DiffTransformerEncoderGenGCN (all layers, attention
 -> coefficient generator -> spectral filter on the last layer -> linear_cat) on one batch that is
 already resident in HBM, plus, for N > 1, the RCCL all-reduce of the flat gradient bucket.
-Rank 0 prints ONE JSON line (contract in the task description) with two extra objects:
-  roofline      the dominant hand-written kernel of the step, timed live with HIP events
-  cpu_baseline  the reference-faithful CPU restatement (oracle/) timed on the host cores
+Rank 0 prints ONE JSON line (contract in the task description) with these extra objects:
+  roofline           the dominant hand-written kernel SYMBOL of the step (largest launches x time), timed
+                     live with HIP events in the variants the stack issues
+  roofline_streaming the north-star kernel (U^T X -> g(Lambda) -> U) at a batch beyond the Infinity Cache
+  cpu_baseline       the CPU restatement (oracle/) of the SAME operator as the timed GPU leg
+  reference_literal  the reference-literal operator (filter_mode='cheb': order-P Chebyshev recursion,
+                     heads_share_graph=False: transformer/models.py:186) timed the same way, with its own
+                     cpu_baseline (the reference-faithful restatement)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,11 +35,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from feta_tmlr_amd import _lib                                            # noqa: E402
-from feta_tmlr_amd import functional as FF                                # noqa: E402
 from feta_tmlr_amd.parallel import FlatBufferAllReduce, FlatGradAllReduce, HybridGradAllReduce                      # noqa: E402
 from feta_tmlr_amd.transformer import data as D                           # noqa: E402
 from feta_tmlr_amd.transformer.layers import DiffTransformerEncoderLayer  # noqa: E402
 from feta_tmlr_amd.transformer.models import DiffTransformerEncoderGenGCN  # noqa: E402
+
 
 def log(msg):
     sys.stderr.write('[bench %.1fs] %s\n' % (time.perf_counter() - _T0, msg))
@@ -55,7 +63,7 @@ _T0 = time.perf_counter()
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
@@ -69,18 +77,58 @@ def parse():
     ap.add_argument('--n-pad', type=int, default=37)
     ap.add_argument('--shape', default='zinc', choices=['mutag', 'zinc', 'pattern', 'molhiv'],
                     help='synthetic graph-size distribution (SURVEY 8d); the headline metric is zinc')
+    ap.add_argument('--filter-mode', default='spectral', choices=['spectral', 'cheb'],
+                    help="operator of the timed leg: 'spectral' = K-eigenpair eigenbasis filter (the BASELINE "
+                         "metric's K=16), 'cheb' = the reference's order-P Chebyshev recursion")
+    ap.add_argument('--no-share-graph', action='store_true',
+                    help='heads_share_graph=False: the reference-literal un-replicated edge_index '
+                         '(transformer/models.py:186), heads >= 1 filtered with L_hat = 0')
+    ap.add_argument('--no-literal', action='store_true', help='skip the reference_literal leg')
     ap.add_argument('--layer-norm', action='store_true', help='LayerNorm instead of the ZINC default BatchNorm')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of one hipGraph per step')
     ap.add_argument('--two-phase', action='store_true',
                     help='force the split backward (default for --gpus > 1: overlaps the all-reduce of the '
                          'filter-stage gradients with the backward of the encoder stack)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-steps', type=int, default=10)
+    ap.add_argument('--cpu-steps', type=int, default=8)
     ap.add_argument('--kernel-iters', type=int, default=200)
     ap.add_argument('--stream-batch', type=int, default=16384,
                     help='graphs in the streaming-batch run of the north-star kernel (roofline_streaming); 0 = skip')
-    return ap.parse_args()
+    ap.add_argument('--dry-cpu', action='store_true',
+                    help='LAUNCHER REHEARSAL, not a measurement: the same step() on CPU tensors through the host '
+                         'SIMT emulation of the kernels (tools/simt, test hook) with the gloo backend; the line it '
+                         'prints carries "invalid"')
+    return ap.parse_args(argv)
 
+
+# ---------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` starts its own ranks
+# ---------------------------------------------------------------------------------------------------
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args, argv):
+    """One child process per GPU through torch.distributed.run (which sets RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_*), started BEFORE this process makes any GPU call; the children are fresh processes, nothing
+    is exec'd over a process that has touched the GPU.  Rank 0's JSON line goes to our stdout unchanged;
+    the exit code is the launcher's (non-zero if any rank failed)."""
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, host_cores() // max(1, args.gpus))))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+           os.path.abspath(__file__)] + list(argv)
+    log('starting %d ranks: %s' % (args.gpus, ' '.join(cmd[2:])))
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ---------------------------------------------------------------------------------------------------
 
 def make_batch(args, rank, dev):
     n_max = min(args.n_pad, D.SHAPES[args.shape][1])
@@ -97,13 +145,141 @@ def make_batch(args, rank, dev):
     return cpu, gpu
 
 
-def build_encoder(args):
+def build_encoder(args, filter_mode=None, share=None):
     torch.manual_seed(0)
     layer = DiffTransformerEncoderLayer(args.dim, args.heads, 2 * args.dim, 0.0,
                                         batch_norm=not args.layer_norm)
     return DiffTransformerEncoderGenGCN(args.dim, args.heads, layer, args.layers,
-                                        num_coefficients=args.order, heads_share_graph=True,
-                                        filter_mode='spectral')
+                                        num_coefficients=args.order,
+                                        heads_share_graph=(not args.no_share_graph) if share is None else share,
+                                        filter_mode=args.filter_mode if filter_mode is None else filter_mode)
+
+
+def _sync(dev):
+    if dev.type == 'cuda':
+        torch.cuda.synchronize()
+
+
+def make_step(args, enc, gpu, world, dev):
+    """-> step(): one forward + backward (+ gradient all-reduce for world > 1) of `enc` on the resident batch,
+    as one hipGraph replay (two for the split backward) unless --no-graph / --dry-cpu."""
+    params = [p for p in enc.parameters()]
+    two_phase = args.two_phase or world > 1
+    fwd_args = (gpu['src'], gpu['pe'], gpu['edge_index'], gpu['fi'], gpu['batch'])
+    fwd_kw = dict(degree=gpu['degree'], src_key_padding_mask=gpu['mask'], graph_cache=gpu['cache'])
+    use_graph = not args.no_graph and dev.type == 'cuda'
+
+    def capture(fn):
+        """hipGraph of fn() (after warm-up on a side stream), or fn itself with --no-graph."""
+        if not use_graph:
+            return fn
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                fn()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        return g.replay
+
+    if not two_phase:
+        reducer = FlatGradAllReduce(params, world)   # fresh .grad per step, one flat bucket for RCCL
+
+        held = {}
+
+        def fwd_bwd():
+            reducer.zero()
+            out, _, _ = enc(*fwd_args, **fwd_kw)
+            held['out'] = out                    # (static address across replays: read by the parity test)
+            out.backward(gradient=gpu['dout'])   # upstream gradient dOut ~ N(0,1) injected directly (SURVEY 8d)
+
+        fwd_bwd()
+        _sync(dev)
+        run = capture(fwd_bwd)
+
+        def step():
+            run()
+            if world > 1:
+                reducer.all_reduce()
+        step.held = held
+        return step, two_phase, use_graph
+
+    # split backward: the filter-stage gradients (96 % of the bytes) are ready first; their
+    # all-reduce runs under the backward of the encoder stack
+    enc.keep_stack_boundary = True
+    # head: the two 4 MB gradients in place + one small packed bucket, all under the stack backward;
+    # stack: its gradients already live in one flat buffer - one in-place collective, no pack / unpack
+    r_head = HybridGradAllReduce(enc.head_parameters(), world)
+    r_stack = FlatBufferAllReduce(enc.stack_flat_grad, world, params=enc.stack_parameters())
+
+    held = {}
+
+    def phase1():
+        r_head.zero()
+        for p_ in enc.stack_parameters():
+            p_.grad = None
+        out, _, _ = enc(*fwd_args, **fwd_kw)
+        held['out'] = out
+        enc.backward_head(out, gpu['dout'])
+
+    def both():
+        phase1()
+        enc.backward_stack()
+
+    both()
+    _sync(dev)
+    if use_graph:   # warm-up runs whole steps; the two graphs share one memory pool
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                both()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            phase1()
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2, pool=g1.pool()):
+            enc.backward_stack()
+        run1, run2 = g1.replay, g2.replay
+    else:
+        run1, run2 = phase1, enc.backward_stack
+
+    def step():
+        run1()
+        w1 = r_head.start()
+        run2()
+        w2 = r_stack.start()
+        r_head.finish(w1)
+        r_stack.finish(w2)
+    step.held = held
+    return step, two_phase, use_graph
+
+
+def time_steps(step, args, world, dev):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
+    for _ in range(args.warmup):
+        step()
+    _sync(dev)
+    if world > 1:
+        dist.barrier()
+    _sync(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    _sync(dev)
+    if world > 1:
+        dist.barrier()
+    _sync(dev)
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    return float(tmax.item())
 
 
 def time_kernel(fn, iters):
@@ -119,13 +295,38 @@ def time_kernel(fn, iters):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
+def spec_bytes(b, n, h, dh, k_eig, p, sum_n, backward):
+    """Algorithmic HBM bytes of one launch of the eigenbasis filter kernels: operand rows
+    of REAL nodes only (the kernels clamp their loads to n_real; sum_n = sum of node counts), whole padded
+    rows for the result (padded rows are written as zeros)."""
+    d, c = h * dh, p * dh * dh
+    if not backward:     # read x, U, lambda, W; write y
+        return 4 * (sum_n * d + sum_n * k_eig + b * k_eig + b * h * c + b * n * d)
+    # read x, dy, U, lambda, W; write dx, dW (+ per-block bias partials)
+    return 4 * (2 * sum_n * d + sum_n * k_eig + b * k_eig + b * h * c + b * n * d + b * h * c + b * h * dh)
+
+
+def _load_json(*names):
+    for nm in names:
+        p = os.path.join(ROOT, 'profiles', nm)
+        if os.path.exists(p):
+            try:
+                return json.load(open(p))
+            except Exception:
+                pass
+    return {}
+
+
 def roofline(args, gpu, dev):
     """Times the hand-written kernels of one step in isolation, in exactly the variants the fused stack
     issues (feta_tmlr_amd/benchcases.py; HIP events on the stream they are launched on - torch's
-    current stream), picks the DOMINANT one = largest launches-per-step x launch time, and prices it
-    against the HBM roofline with its algorithmic bytes.  `traffic` = HBM bytes
-    per launch from the rocprofv3 PMC passes committed in profiles/traffic.json (FETCH_SIZE x2 +
-    WRITE_SIZE, tools/pmc_summary.py), null if absent."""
+    current stream), groups the variants by KERNEL SYMBOL (what rocprofv3 --stats reports: e.g. the two
+    attention-block variants, with and without the attn write, are one symbol), picks the DOMINANT symbol =
+    largest sum over variants of launches-per-step x launch time, and prices its average launch against the
+    HBM roofline with its average algorithmic bytes.  `traffic` = HBM bytes per launch
+    from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE,
+    tools/pmc_summary.py), `mfma_busy` = MFMA-pipe busy share of that symbol (tools/pmc_mfma.py); null if
+    absent."""
     from feta_tmlr_amd.benchcases import stack_layer_cases
     abi, st = _lib.abi(), _lib.stream_handle()
     b, n, h, d = args.batch, args.n_pad, args.heads, args.dim
@@ -133,18 +334,22 @@ def roofline(args, gpu, dev):
     c = p * dh * dh
     L = args.layers
     nr = gpu['cache'].n_real
+    sum_n = int(nr.sum().item())
     rnd = lambda *s: torch.randn(*s, device=dev)
-    cand = []   # (name, launches per step, fn, algorithmic bytes)
-    for name, per_layer, fn, nbytes, _ in stack_layer_cases(abi, st, dev, b, n, d, h, 2 * d, gpu['pe'], nr):
+    cand = []   # (variant name, symbol, launches per step, fn, algorithmic bytes)
+    for name, per_layer, fn, nbytes, syms in stack_layer_cases(abi, st, dev, b, n, d, h, 2 * d, gpu['pe'], nr):
         if name == 'attn_block_fwd (no attn write)':
             cnt = L - 1
         elif name == 'attn_block_fwd (+attn write)':
             cnt = 1
         elif 'linear2' in name:
-            cnt = L + 1      # + linear_cat backward (same shape class)
+            cnt = L + 1      # + linear_cat backward (same instantiation: KI = 2d, NO = d)
         else:
             cnt = L
-        cand.append((name, cnt, fn, nbytes))
+        sym = syms[0]
+        if sym == 'rowlin_bwd':   # one template instantiation (= one symbol) per (KI, NO)
+            sym = 'rowlin_bwd<%s>' % name.split()[1]
+        cand.append((name, sym, cnt, fn, nbytes))
     qkv = rnd(n, b, 3 * d)
     v5 = qkv.view(n, b, 3, h, dh)
     q, k, v = (v5[:, :, i].permute(1, 0, 2, 3) for i in range(3))
@@ -156,52 +361,71 @@ def roofline(args, gpu, dev):
     g5 = dqkv.view(n, b, 3, h, dh)
     dq, dk, dv = (g5[:, :, i].permute(1, 0, 2, 3) for i in range(3))
     sc = dh ** -0.5
-    cand.append(('attn_bwd (dq + dkdv)', L,
+    cand.append(('attn_bwd (dq + dkdv)', 'attn_bwd', L,
                  lambda: abi.attn_bwd(q, k, v, gpu['pe'], nr, out, dout, stats, delta, dq, dk, dv, sc, st),
                  4 * b * (3 * n * d + 2 * n * d + n * n + 2 * h * n + 3 * n * d + h * n)))
-    xs, dys = rnd(n, b, h, dh).permute(1, 0, 2, 3), rnd(n, b, h, dh).permute(1, 0, 2, 3)
-    ys, dxs = tok(), tok()
-    coeff, bias = rnd(h * b, c), rnd(dh)
-    dcoeff, dbp = torch.empty_like(coeff), torch.empty(b * h, dh, device=dev)
-    u, lam = gpu['cache'].u, gpu['cache'].lam
-    cand.append(('spec_filter_fwd', 1, lambda: abi.spec_filter_fwd(xs, u, lam, coeff, bias, nr, ys, p, 1, st),
-                 4 * b * (n * d + n * k_eig + k_eig + h * c + n * d)))
-    cand.append(('spec_filter_bwd', 1,
-                 lambda: abi.spec_filter_bwd(xs, u, lam, coeff, nr, dys, dxs, dcoeff, dbp, p, 1, st),
-                 4 * b * (2 * n * d + n * k_eig + k_eig + h * c + n * d + h * c)))
-    rows = []
-    for name, cnt, fn, nbytes in cand:
+    if args.filter_mode == 'spectral' and not args.no_share_graph:
+        xs, dys = rnd(n, b, h, dh).permute(1, 0, 2, 3), rnd(n, b, h, dh).permute(1, 0, 2, 3)
+        ys, dxs = tok(), tok()
+        coeff, bias = rnd(h * b, c), rnd(dh)
+        dcoeff, dbp = torch.empty_like(coeff), torch.empty(b * h, dh, device=dev)
+        u, lam = gpu['cache'].u, gpu['cache'].lam
+        cand.append(('spec_filter_fwd', 'spec_fwd', 1,
+                     lambda: abi.spec_filter_fwd(xs, u, lam, coeff, bias, nr, ys, p, 1, st),
+                     spec_bytes(b, n, h, dh, k_eig, p, sum_n, False)))
+        cand.append(('spec_filter_bwd', 'spec_bwd', 1,
+                     lambda: abi.spec_filter_bwd(xs, u, lam, coeff, nr, dys, dxs, dcoeff, dbp, p, 1, st),
+                     spec_bytes(b, n, h, dh, k_eig, p, sum_n, True)))
+    traffic = _load_json('r02_traffic_b128.json', 'traffic.json')
+    mfma = _load_json('r02_pmc_mfma_b128.json', 'r01_pmc_mfma_b128.json')
+    groups = {}
+    for name, sym, cnt, fn, nbytes in cand:
         t = time_kernel(fn, args.kernel_iters)
-        rows.append({'kernel': name, 'launches_per_step': cnt, 'launch_us': round(t * 1e6, 3),
-                     'algorithmic_bytes': nbytes, 'achieved': round(nbytes / t / 1e9, 2),
-                     'frac': round(nbytes / t / 1e9 / HBM_PEAK_GBS, 5)})
-    traffic = {}
-    tp = os.path.join(ROOT, 'profiles', 'traffic.json')
-    if os.path.exists(tp):
-        try:
-            traffic = json.load(open(tp))
-        except Exception:
-            traffic = {}
-    for r in rows:
-        r['traffic'] = (traffic.get(r['kernel']) or {}).get('hbm_bytes')
-    dom = max(rows, key=lambda r: r['launches_per_step'] * r['launch_us'])
+        tr = (traffic.get(name) or {}).get('hbm_bytes')
+        row = {'variant': name, 'launches_per_step': cnt, 'launch_us': round(t * 1e6, 3),
+               'algorithmic_bytes': nbytes, 'traffic': tr}
+        groups.setdefault(sym, []).append(row)
+    out_rows = []
+    for sym, rows in groups.items():
+        launches = sum(r['launches_per_step'] for r in rows)
+        t_step = sum(r['launches_per_step'] * r['launch_us'] for r in rows)          # us of this symbol per step
+        bytes_step = sum(r['launches_per_step'] * r['algorithmic_bytes'] for r in rows)
+        tr = None
+        if all(r['traffic'] is not None for r in rows):
+            tr = int(sum(r['launches_per_step'] * r['traffic'] for r in rows) / launches)
+        busy = None
+        for key, val in mfma.items():
+            if sym.split('<')[0] in key:
+                busy = val.get('mfma_busy_pct')
+                break
+        ach = bytes_step / t_step / 1e3       # bytes / us -> GB/s
+        out_rows.append({'kernel': sym, 'launches_per_step': launches, 'launch_us': round(t_step / launches, 3),
+                         'us_per_step': round(t_step, 2), 'algorithmic_bytes': int(bytes_step / launches),
+                         'achieved': round(ach, 2), 'frac': round(ach / HBM_PEAK_GBS, 5), 'traffic': tr,
+                         'mfma_busy_pct': busy, 'variants': rows})
+    dom = max(out_rows, key=lambda r: r['us_per_step'])
     res = {'kernel': dom['kernel'], 'bound': 'hbm', 'achieved': dom['achieved'], 'peak': HBM_PEAK_GBS,
            'unit': 'GB/s', 'frac': dom['frac'], 'traffic': dom['traffic'],
            'algorithmic_bytes': dom['algorithmic_bytes'], 'launch_us': dom['launch_us'],
-           'launches_per_step': dom['launches_per_step'], 'other_kernels': [r for r in rows if r is not dom]}
+           'launches_per_step': dom['launches_per_step'], 'us_per_step': dom['us_per_step'],
+           'mfma_busy_pct': dom['mfma_busy_pct'], 'variants': dom['variants'],
+           'other_kernels': [{k_: v_ for k_, v_ in r.items() if k_ != 'variants'} for r in out_rows if r is not dom]}
     return res
 
 
 def roofline_streaming(args, dev):
     """The north-star kernel (eigenbasis filter: U^T X -> g(Lambda) -> U) at a batch whose working
     set (~0.6 GB) does not fit the 256 MB Infinity Cache, so that HBM is what is measured; same
-    kernel, same shape per graph as the BASELINE batch.  HIP events on the launch stream."""
+    kernel, same shape per graph as the BASELINE batch.  HIP events on the launch stream; algorithmic bytes
+    count operand rows of real nodes only (spec_bytes)."""
     abi, st = _lib.abi(), _lib.stream_handle()
     b, n, h, d = args.stream_batch, args.n_pad, args.heads, args.dim
     dh, k_eig, p = d // h, args.k_eig, args.order
     c = p * dh * dh
     g = torch.Generator(device='cpu').manual_seed(1)
-    nr = torch.randint(9, n + 1, (b,), generator=g, dtype=torch.int32).to(dev)
+    nr_cpu = torch.randint(9, n + 1, (b,), generator=g, dtype=torch.int32)
+    sum_n = int(nr_cpu.sum())
+    nr = nr_cpu.to(dev)
     rnd = lambda *s: torch.randn(*s, device=dev)
     xs, dys = (rnd(n, b, h, dh).permute(1, 0, 2, 3) for _ in range(2))
     ys, dxs = (torch.empty(n, b, h, dh, device=dev).permute(1, 0, 2, 3) for _ in range(2))
@@ -211,9 +435,9 @@ def roofline_streaming(args, dev):
     out = []
     for name, fn, nbytes in (
             ('spec_filter_fwd', lambda: abi.spec_filter_fwd(xs, u, lam, coeff, bias, nr, ys, p, 1, st),
-             4 * b * (n * d + n * k_eig + k_eig + h * c + n * d)),
+             spec_bytes(b, n, h, dh, k_eig, p, sum_n, False)),
             ('spec_filter_bwd', lambda: abi.spec_filter_bwd(xs, u, lam, coeff, nr, dys, dxs, dcoeff, dbp, p, 1, st),
-             4 * b * (2 * n * d + n * k_eig + k_eig + h * c + n * d + h * c))):
+             spec_bytes(b, n, h, dh, k_eig, p, sum_n, True))):
         t = time_kernel(fn, 20)
         out.append({'kernel': name, 'batch': b, 'bound': 'hbm', 'launch_us': round(t * 1e6, 2),
                     'algorithmic_bytes': nbytes, 'achieved': round(nbytes / t / 1e9, 1), 'peak': HBM_PEAK_GBS,
@@ -221,9 +445,13 @@ def roofline_streaming(args, dev):
     return out
 
 
-def cpu_baseline(args, cpu, enc):
-    """Reference-faithful CPU restatement (edge-list recursion, per-node weight copies, the
-    un-collapsed GCNConv on ones, Python loop over H*B blocks), PyTorch CPU fp32, all host cores."""
+def cpu_baseline(args, cpu, enc, spectral, share):
+    """CPU restatement of the SAME operator as the GPU leg it is reported beside, PyTorch CPU fp32, all host
+    cores: the reference's algorithm for everything the reference has text for (attention layer as
+    reconstructed, the un-collapsed GCNConv on ones with its Python loop over the H*B blocks, head stacking,
+    linear_cat) and, for the filter stage, either the reference's edge-list recursion with per-node weight
+    copies (spectral=False: the reference-literal operator) or the K-eigenpair eigenbasis form the GPU leg
+    computes (spectral=True; not a reference operator unless K spans the graph)."""
     from oracle import feta_oracle as O
     cores = host_cores()
     torch.set_num_threads(cores)
@@ -234,167 +462,90 @@ def cpu_baseline(args, cpu, enc):
     n_tot = int(nb.sum())
     ei = cpu['edge_index']
     ei = ei[:, ei[0] < n_tot]
+    eig = (cpu['cache'].u[:sub], cpu['cache'].lam[:sub]) if spectral else None
 
     def step(collapsed=False):
         leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
         src = cpu['src'][:, :sub].clone().requires_grad_(True)
         out, _, _ = O.encoder_gengcn(src, cpu['pe'][:sub], ei, cpu['fi'][:n_tot], cpu['batch'][:n_tot],
                                      cpu['degree'][:sub], m, leaves, args.layers, args.heads, args.order,
-                                     batch_norm=not args.layer_norm, heads_share_graph=True,
-                                     collapsed=collapsed)
+                                     batch_norm=not args.layer_norm, heads_share_graph=share,
+                                     collapsed=collapsed, eig=eig)
         (out * cpu['dout'][:, :sub]).sum().backward()
 
-    step()
-    log('cpu baseline warm-up step done')
-    t0 = time.perf_counter()
-    for _ in range(args.cpu_steps):
-        step()
-    dt = (time.perf_counter() - t0) / args.cpu_steps
+    def timed(collapsed):
+        step(collapsed)
+        t0 = time.perf_counter()
+        for _ in range(args.cpu_steps):
+            step(collapsed)
+        return (time.perf_counter() - t0) / args.cpu_steps
+
+    dt = timed(False)
+    log('cpu baseline (%s) timed' % ('eigenbasis K=%d' % args.k_eig if spectral else 'edge-list recursion'))
     # the same restatement with the exact GCNConv(ones) = c_j colsum(W) + b collapse, so that
     # the GPU/CPU ratio is not inflated by the reference's redundant ones @ W product alone
-    step(True)
-    t0 = time.perf_counter()
-    for _ in range(args.cpu_steps):
-        step(True)
-    dt_opt = (time.perf_counter() - t0) / args.cpu_steps
+    dt_opt = timed(True)
+    op = ('K=%d eigenbasis filter, every head on the graph' % args.k_eig) if spectral else \
+        'order-%d Chebyshev edge-list recursion' % args.order
+    if not spectral or not share:
+        op += ', heads_share_graph=%s' % share
     return {'value': round(sub / dt, 2), 'unit': 'graphs/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d steps of fwd+bwd on the first %d graphs of the batch (oracle.encoder_gengcn, '
-                      'faithful formulation, exact Chebyshev operator, torch CPU fp32, %d threads)'
-                      % (args.cpu_steps, sub, cores),
+            'sample': '%d steps of fwd+bwd on the %d graphs of the batch (oracle.encoder_gengcn: %s; un-collapsed '
+                      'coefficient generator; torch CPU fp32, %d threads)' % (args.cpu_steps, sub, op, cores),
             'optimised_value': round(sub / dt_opt, 2),
             'optimised_sample': 'same, with the collapsed coefficient generator (no ones @ W, no dense edge list)'}
 
 
-def main():
-    args = parse()
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args, argv))       # nothing above touches a GPU
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
-    if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
-    _lib.abi()
-
+    assert world == args.gpus, 'WORLD_SIZE=%d but --gpus %d' % (world, args.gpus)
+    hook = None
+    if args.dry_cpu:
+        import ctypes
+        from feta_tmlr_amd import _abi
+        dev = torch.device('cpu')
+        hook = _lib.override_for_tests(_abi.bind(ctypes.CDLL(os.path.join(ROOT, 'tools', 'simt', 'libfeta_emu.so'))))
+        hook.__enter__()
+        if world > 1:
+            dist.init_process_group('gloo')
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device('cuda', local)
+        if world > 1:
+            dist.init_process_group('nccl', device_id=dev)
+        _lib.abi()
     log('library loaded')
     cpu, gpu = make_batch(args, rank, dev)
     log('batch built')
     enc = build_encoder(args).to(dev)
     enc.train()
-    params = [p for p in enc.parameters()]
-    two_phase = args.two_phase or world > 1
-    fwd_args = (gpu['src'], gpu['pe'], gpu['edge_index'], gpu['fi'], gpu['batch'])
-    fwd_kw = dict(degree=gpu['degree'], src_key_padding_mask=gpu['mask'], graph_cache=gpu['cache'])
-    use_graph = not args.no_graph
+    step, two_phase, use_graph = make_step(args, enc, gpu, world, dev)
+    log('graph captured' if use_graph else 'eager mode')
+    dt = time_steps(step, args, world, dev)
+    log('timed region done: %.3f ms/step' % (dt / args.steps * 1e3))
 
-    def capture(fn):
-        """hipGraph of fn() (after warm-up on a side stream), or fn itself with --no-graph."""
-        if not use_graph:
-            return fn
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(3):
-                fn()
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=capture.pool):
-            fn()
-        capture.pool = g.pool()
-        return g.replay
-    capture.pool = None
-
-    if not two_phase:
-        reducer = FlatGradAllReduce(params, world)   # fresh .grad per step, one flat bucket for RCCL
-
-        def fwd_bwd():
-            reducer.zero()
-            out, _, _ = enc(*fwd_args, **fwd_kw)
-            out.backward(gradient=gpu['dout'])   # upstream gradient dOut ~ N(0,1) injected directly (SURVEY 8d)
-
-        fwd_bwd()
-        torch.cuda.synchronize()
-        log('first eager step done')
-        run = capture(fwd_bwd)
-
-        def step():
-            run()
-            if world > 1:
-                reducer.all_reduce()
-    else:
-        # split backward: the filter-stage gradients (96 % of the bytes) are ready first; their
-        # all-reduce runs under the backward of the encoder stack
-        enc.keep_stack_boundary = True
-        # head: the two 4 MB gradients in place + one small packed bucket, all under the stack backward;
-        # stack: its gradients already live in one flat buffer - one in-place collective, no pack / unpack
-        r_head = HybridGradAllReduce(enc.head_parameters(), world)
-        r_stack = FlatBufferAllReduce(enc.stack_flat_grad, world)
-
-        def phase1():
-            r_head.zero()
-            for p_ in enc.stack_parameters():
-                p_.grad = None
-            out, _, _ = enc(*fwd_args, **fwd_kw)
-            enc.backward_head(out, gpu['dout'])
-
-        def both():
-            phase1()
-            enc.backward_stack()
-
-        both()
-        torch.cuda.synchronize()
-        log('first eager step done')
-        if use_graph:   # warm-up runs whole steps; the two graphs share one memory pool
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                for _ in range(3):
-                    both()
-            torch.cuda.current_stream().wait_stream(s)
-            torch.cuda.synchronize()
-            g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
-                phase1()
-            g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, pool=g1.pool()):
-                enc.backward_stack()
-            run1, run2 = g1.replay, g2.replay
-        else:
-            run1, run2 = phase1, enc.backward_stack
-
-        def step():
-            run1()
-            w1 = r_head.start()
-            run2()
-            w2 = r_stack.start()
-            r_head.finish(w1)
-            r_stack.finish(w2)
-
-    graph = use_graph
-    log('graph captured' if graph else 'eager mode')
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    literal = None
+    if not args.no_literal and not args.dry_cpu and not (args.filter_mode == 'cheb' and args.no_share_graph):
+        # the reference-literal operator on the same batch, same parameters, timed the same way
+        enc_lit = build_encoder(args, filter_mode='cheb', share=False).to(dev)
+        enc_lit.train()
+        step_lit, _, _ = make_step(args, enc_lit, gpu, world, dev)
+        dt_lit = time_steps(step_lit, args, world, dev)
+        log('reference-literal operator: %.3f ms/step' % (dt_lit / args.steps * 1e3))
+        literal = {'value': round(args.batch * world * args.steps / dt_lit, 2), 'unit': 'graphs/s',
+                   'ms_per_step': round(dt_lit / args.steps * 1e3, 4),
+                   'operator': "filter_mode='cheb' (order-%d Chebyshev recursion, transformer/ChebNetDynamic.py:157-187), "
+                               'heads_share_graph=False (un-replicated edge_index, transformer/models.py:186)' % args.order}
 
     if rank == 0:
         total_graphs = args.batch * world * args.steps
+        share = not args.no_share_graph
         res = {
             'metric': 'graphs/sec fwd+bwd, ZINC batch (N<=37,d=64,K=16)',
             'value': round(total_graphs / dt, 2), 'unit': 'graphs/s', 'n_gpus': world,
@@ -405,23 +556,34 @@ def main():
                                    '(attention + coefficient generator + spectral filter), fwd+bwd',
                        'graphs_per_gpu': args.batch, 'global_batch': args.batch * world,
                        'n_pad': args.n_pad, 'd_model': args.dim, 'heads': args.heads,
-                       'filter_order': args.order, 'k_eig': args.k_eig, 'layers': args.layers,
+                       'filter_order': args.order, 'k_eig': args.k_eig if args.filter_mode == 'spectral' else None,
+                       'filter_mode': args.filter_mode, 'layers': args.layers,
                        'norm': 'layer' if args.layer_norm else 'batch(per-rank stats)',
-                       'heads_share_graph': True, 'hip_graph': bool(use_graph),
+                       'heads_share_graph': share, 'hip_graph': bool(use_graph),
                        'backward': 'two-phase (head all-reduce under stack backward)' if two_phase else 'single',
                        'parallelism': 'dp%d' % world},
         }
-        log('timed region done: %.3f ms/step' % (dt / args.steps * 1e3))
-        res['roofline'] = roofline(args, gpu, dev)
-        if args.stream_batch > 0:
-            res['roofline_streaming'] = roofline_streaming(args, dev)
-        log('roofline kernel timed')
-        if world == 1 and not args.no_cpu_baseline:
-            res['cpu_baseline'] = cpu_baseline(args, cpu, enc)
+        if args.dry_cpu:
+            res['invalid'] = 'dry-cpu launcher rehearsal on the host emulation of the kernels: not a measurement'
+            res['data'] = 'synthetic (dry-cpu)'
+        else:
+            res['roofline'] = roofline(args, gpu, dev)
+            if args.stream_batch > 0:
+                res['roofline_streaming'] = roofline_streaming(args, dev)
+            log('roofline kernels timed')
+            if world == 1 and not args.no_cpu_baseline:
+                res['cpu_baseline'] = cpu_baseline(args, cpu, enc, args.filter_mode == 'spectral', share)
+            if literal is not None:
+                if world == 1 and not args.no_cpu_baseline:
+                    literal['cpu_baseline'] = cpu_baseline(args, cpu, enc, False, False)
+                res['reference_literal'] = literal
         print(json.dumps(res))
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if hook is not None:
+        hook.__exit__(None, None, None)
 
 
 if __name__ == '__main__':

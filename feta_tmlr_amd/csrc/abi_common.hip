@@ -7,6 +7,7 @@
 // the one dynamic-LDS array every kernel carves (declared in feta_device.h)
 namespace {
 thread_local char g_err[512] = "";
+thread_local char g_attr[160] = "";   // a refused hipFuncSetAttribute, reported with the launch that follows
 }
 
 namespace feta {
@@ -16,10 +17,16 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+void note_attr_error(const char* what) { snprintf(g_attr, sizeof(g_attr), "%s", what); }
 int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess) {
-    set_error("%s: %s", what, hipGetErrorString(e));
+  if (e != hipSuccess || g_attr[0] != 0) {
+    if (g_attr[0] != 0)
+      set_error("%s: %s (raising the dynamic-LDS limit of the kernel on this device failed: %s)", what,
+                hipGetErrorString(e), g_attr);
+    else
+      set_error("%s: %s", what, hipGetErrorString(e));
+    g_attr[0] = 0;
     return FETA_E_LAUNCH;
   }
   return FETA_OK;

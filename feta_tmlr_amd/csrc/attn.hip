@@ -713,7 +713,7 @@ void launch_fwd_t(const AttnArgs& a, hipStream_t stream) {
   // per-wave staging block of the probability tile: 16 rows x (16 KT_MAX + 1) floats
   const size_t lds = a.attn != nullptr ? sizeof(float) * kWaves * 16 * (16 * KT_MAX + 1) : 0;
   auto kern = attn_fwd_kernel<DH, KT_MAX>;
-  static size_t lds_seen = 0;  // KT_MAX = 16: 65.8 KB, above the 64 KB default dynamic-LDS cap
+  static LdsSeen lds_seen;  // KT_MAX = 16: 65.8 KB, above the 64 KB default dynamic-LDS cap
   allow_dynamic_lds(kern, lds, lds_seen);
   hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
 }
@@ -952,7 +952,7 @@ template <int NT>
 void launch_bwd_graph_t(const AttnArgs& a, hipStream_t stream) {
   const size_t lds = sizeof(float) * attn_bwd_graph_lds_floats(NT);
   auto kern = attn_bwd_graph_kernel<NT>;
-  static size_t lds_seen = 0;
+  static LdsSeen lds_seen;
   allow_dynamic_lds(kern, lds, lds_seen);
   hipLaunchKernelGGL(kern, dim3(a.B), dim3(512), lds, stream, a);
 }

@@ -364,7 +364,7 @@ template <int NT>
 int launch_block_fwd(const BlockArgs& a, hipStream_t stream) {
   const size_t lds = sizeof(float) * block_lds_floats(NT, a.attn != nullptr);
   auto kern = attn_block_fwd_kernel<NT>;
-  static size_t lds_seen = 0;
+  static LdsSeen lds_seen;
   allow_dynamic_lds(kern, lds, lds_seen);
   int cap = kBlkMaxGrid;   // one resident workgroup per CU (LDS); FETA_BLOCK_MAX_GRID: tests force the loop
   if (const char* e = getenv("FETA_BLOCK_MAX_GRID")) cap = atoi(e) > 0 ? atoi(e) : cap;

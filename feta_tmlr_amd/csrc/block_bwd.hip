@@ -340,7 +340,7 @@ template <int NT>
 int launch_block_bwd(const BwdArgs& a, hipStream_t stream) {
   const size_t lds = sizeof(float) * block_bwd_lds_floats(NT);
   auto kern = attn_block_bwd_kernel<NT>;
-  static size_t lds_seen = 0;
+  static LdsSeen lds_seen;
   allow_dynamic_lds(kern, lds, lds_seen);
   hipLaunchKernelGGL(kern, dim3(a.B), dim3(kRowThreads), lds, stream, a);
   return check_launch("feta_attn_block_bwd");

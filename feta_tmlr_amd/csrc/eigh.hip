@@ -300,7 +300,7 @@ extern "C" int feta_eigh_sym(const float* a, const int32_t* n_real, float shift,
 #define FETA_EIGH_CASE(nc)                                                           \
   case nc: {                                                                         \
     auto kern = eigh_jacobi_kernel<nc>;                                              \
-    static size_t seen = 0;                                                          \
+    static LdsSeen seen;                                                          \
     allow_dynamic_lds(kern, lds, seen);                                              \
     hipLaunchKernelGGL(kern, grid, block, lds, (hipStream_t)stream, args);           \
   } break;
@@ -335,7 +335,7 @@ extern "C" int feta_spectral_kernel(const float* u, const float* lam, const int3
   args.N = N;
   args.K = K;
   auto kern = spectral_fn_kernel;
-  static size_t seen = 0;
+  static LdsSeen seen;
   allow_dynamic_lds(kern, lds, seen);
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, (hipStream_t)stream, args);
   return check_launch("feta_spectral_kernel");

@@ -230,7 +230,7 @@ template <int FF>
 int launch_ffn_fwd(const FfnArgs& a, hipStream_t stream) {
   const size_t lds = sizeof(float) * ffn_lds_floats(FF);
   auto kern = ffn_fwd_kernel<FF>;
-  static size_t lds_seen = 0;
+  static LdsSeen lds_seen;
   allow_dynamic_lds(kern, lds, lds_seen);
   hipLaunchKernelGGL(kern, dim3(ffn_grid(a.M)), dim3(kRowThreads), lds, stream, a);
   return check_launch("feta_ffn_fwd");

@@ -1367,13 +1367,13 @@ int launch_spec_graph_p(const FilterArgs& a, bool bwd, hipStream_t stream) {
   if (bwd) {
     const size_t lds = sizeof(float) * (2 * NR * kGraphXP + NR * UP + 16 * ET_MAX);
     auto kern = spec_bwd_graph_kernel<NT_MAX, ET_MAX, PP>;
-    static size_t lds_seen = 0;
+    static LdsSeen lds_seen;
     allow_dynamic_lds(kern, lds, lds_seen);
     hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
   } else {
     const size_t lds = sizeof(float) * (NR * kGraphXP + NR * UP + 16 * ET_MAX + 4 * PP * 16 * kGraphWP);
     auto kern = spec_fwd_graph_kernel<NT_MAX, ET_MAX, PP>;
-    static size_t lds_seen = 0;
+    static LdsSeen lds_seen;
     allow_dynamic_lds(kern, lds, lds_seen);
     hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
   }

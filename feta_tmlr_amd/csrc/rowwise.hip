@@ -808,7 +808,7 @@ void launch_bwd_ki(const RowLinArgs& a, const RowLinGeom& ge, int grid, size_t l
 #define CALL(NOV)                                                                   \
   {                                                                                 \
     auto kern = rowlin_bwd_kernel<KI, NOV>;                                         \
-    static size_t lds_seen = 0;                                                     \
+    static LdsSeen lds_seen;                                                     \
     allow_dynamic_lds(kern, lds, lds_seen);                                         \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kRowThreads), lds, stream, a, ge);    \
   }

@@ -103,6 +103,8 @@ class FusedEncoderStackFn(torch.autograd.Function):
     def forward(ctx, src, pe, degree_rows, n_real, layers, need_attn, *params):
         abi, stream = _lib.backend(src, pe, n_real)
         ctx.set_materialize_grads(False)   # no zero tensor for the (non-differentiable) attn output
+        if len(layers):
+            STACK_FLAT_GRAD.pop(layers[0], None)   # the buffer of an earlier backward is stale from here on
         n, b, d = src.shape
         m = n * b
         nl = len(layers)
@@ -190,6 +192,10 @@ class FusedEncoderStackFn(torch.autograd.Function):
                              final, prm2, last.running_mean, last.running_var, float(last.momentum),
                              float(last.eps), stream)
         saved[-1]['prm2'] = prm2
+        # nn.BatchNorm1d advances num_batches_tracked once per training forward: one multi-tensor add
+        nbt = [t for l in layers for t in (l.norm1.num_batches_tracked, l.norm2.num_batches_tracked) if t is not None]
+        if nbt:
+            torch._foreach_add_(nbt, 1)
         ctx.saved_state = saved
         ctx.meta = (n, b, d, heads, dh, tie, scale, G, nl)
         ctx.aux = (pe_c, degree_rows, n_real)
@@ -358,6 +364,8 @@ class FusedLayerNormStackFn(torch.autograd.Function):
     def forward(ctx, src, pe, degree_rows, n_real, layers, need_attn, *params):
         abi, stream = _lib.backend(src, pe, n_real)
         ctx.set_materialize_grads(False)
+        if len(layers):
+            STACK_FLAT_GRAD.pop(layers[0], None)
         n, b, d = src.shape
         m = n * b
         nl = len(layers)

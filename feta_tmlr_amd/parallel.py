@@ -190,8 +190,12 @@ class FlatBufferAllReduce:
     views of it, so the collective runs in place - no pack, no unpack.  ``getter()`` returns that tensor
     (its address is stable across hipGraph replays)."""
 
-    def __init__(self, getter, world_size=None, process_group=None):
+    def __init__(self, getter, world_size=None, process_group=None, params=None):
+        """params (optional): the parameters whose gradients must live in the flat buffer; start() then
+        verifies that every .grad is a view of it (gradient accumulation or zero_grad(set_to_none=False)
+        make AccumulateGrad add into an OLDER buffer, which this collective would silently miss)."""
         self.getter = getter
+        self.params = None if params is None else [p for p in params if p.requires_grad]
         self.group = process_group
         if world_size is None:
             world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -205,8 +209,23 @@ class FlatBufferAllReduce:
         flat = self.getter()
         if flat is None:
             raise RuntimeError('no flat stack gradient: backward has not run through the fused stack')
+        self.check_views(flat)
         op = dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM
         return dist.all_reduce(flat, op=op, group=self.group, async_op=True), flat
+
+    def check_views(self, flat):
+        if not self.params:
+            return
+        lo = flat.data_ptr()
+        hi = lo + flat.numel() * flat.element_size()
+        for p in self.params:
+            g = p.grad
+            if g is None:
+                continue
+            if not (lo <= g.data_ptr() and g.data_ptr() + g.numel() * g.element_size() <= hi):
+                raise RuntimeError('a stack gradient does not live in the flat buffer of the last backward (was '
+                                   '.grad kept across steps? use set_to_none=True / p.grad = None, or reduce it with '
+                                   'FlatGradAllReduce)')
 
     def finish(self, handle):
         if handle is None:

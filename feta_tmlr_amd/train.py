@@ -141,7 +141,13 @@ class GraphedTrainStep:
     of ``data.bucket_batches``); the variable-length members of the tuple (edge_index, batch,
     feature_indices) are consumed before the graph by ``prepare_cache`` / ``pad_node_labels``.
     The learning rate lives in a device scalar (capturable optimiser), so the warm-up schedule does
-    not re-capture."""
+    not re-capture.
+
+    Construction does not advance training: the warm-up iterations and the capture run REAL steps on
+    the example batch, so the parameters, the module buffers (BatchNorm running statistics,
+    num_batches_tracked) and the optimiser state (moments and step counters) are snapshotted before
+    and restored, in place, afterwards - an instance created mid-training (one per padded-size bucket)
+    leaves the trajectory exactly where the reference loop would have it."""
 
     def __init__(self, task, model, criterion, optimizer, batch9, graph_cache=None, warmup_iters=3):
         self.task, self.model, self.criterion, self.optimizer = task, model, criterion, optimizer
@@ -158,6 +164,7 @@ class GraphedTrainStep:
                                        clone(graph_cache.lam), clone(graph_cache.lhat),
                                        {k: (v.clone() if torch.is_tensor(v) else v)
                                         for k, v in graph_cache.extra.items()})
+        snap = self._snapshot()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -167,6 +174,34 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = self._body()
+        self._restore(snap)
+
+    def _snapshot(self):
+        """Copies of everything a step mutates; optimiser state that does not exist yet (lazily created
+        by the first step) is recorded as absent and zeroed on restore."""
+        tensors = list(self.model.parameters()) + list(self.model.buffers())
+        opt = {}
+        for p, st in self.optimizer.state.items():
+            opt[p] = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+        return [t.detach().clone() for t in tensors], opt
+
+    @torch.no_grad()
+    def _restore(self, snap):
+        """In place: the captured graph holds the addresses of these tensors."""
+        saved, opt = snap
+        tensors = list(self.model.parameters()) + list(self.model.buffers())
+        for t, s in zip(tensors, saved):
+            t.copy_(s)
+        for p, st in self.optimizer.state.items():
+            before = opt.get(p)
+            for k, v in st.items():
+                if torch.is_tensor(v):
+                    if before is not None and k in before:
+                        v.copy_(before[k])
+                    else:
+                        v.zero_()
+                elif before is not None and k in before:
+                    st[k] = before[k]
 
     def _fixed(self, batch9):
         x, mask, pe, lap_pe, degree, labels, edge_index, batch, feature_indices = batch9

@@ -139,7 +139,8 @@ class DiffTransformerEncoderLayer(nn.Module):
                 return FF.layer_norm_rows(y, mod.weight, mod.bias, mod.eps)
             return mod(y)
         if mod.training and mod.momentum is not None and y.shape[1] % 4 == 0 and y.shape[1] <= 256:
-            # num_batches_tracked is not advanced (only read when momentum is None)
+            if mod.num_batches_tracked is not None:
+                mod.num_batches_tracked.add_(1)
             return FF.batch_norm_train(y, stats, mod.weight, mod.bias, mod.running_mean,
                                        mod.running_var, mod.momentum, mod.eps)
         return mod(y)

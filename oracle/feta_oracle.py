@@ -395,12 +395,41 @@ def filter_stage_faithful(out_each_head, coeff_all_heads, edge_index, feature_in
     return out.index_put((feature_indices[:, 1], feature_indices[:, 0]), filt)  # :202
 
 
+def filter_stage_eigenbasis(out_each_head, coeff_all_heads, u, lam, key_padding_mask, bias, order,
+                            heads_share_graph=False):
+    """The filter stage in the eigenbasis of a TRUNCATED spectrum: per (head, graph) block
+    ``Y = U_K [sum_k diag(t_k(lam_K)) (U_K^T X) W_k] + bias`` with the K eigenpairs handed in
+    (u [B,N,K], lam [B,K]; SURVEY Appendix A, eigen form).  NOT the reference operator unless K spans
+    the graph: this is the oracle of BASELINE.json's "K eigenpairs" benchmark shapes, whose
+    glue (block index h*B+b, weight reshape, head-major features, zero padded rows) follows
+    transformer/models.py:178-186,200-202,357 like filter_stage_faithful.  heads_share_graph=False keeps
+    the reference's quirk of :186: heads >= 1 see no edges, L_hat = 0."""
+    bsz, n, h, dh = out_each_head.shape
+    coeff = coeff_all_heads.reshape(h * bsz, -1)                             # :178
+    nb = (~key_padding_mask).sum(-1).tolist()
+    out = torch.zeros(n, bsz, h * dh, dtype=out_each_head.dtype)
+    for hh in range(h):
+        for bb in range(bsz):
+            m = nb[bb]
+            w = coeff[hh * bsz + bb].reshape(order, dh, dh)                  # :357
+            x = out_each_head[bb, :m, hh]
+            if heads_share_graph or hh == 0:
+                y = spec_filter_eig(x, u[bb, :m], lam[bb], w, bias)
+            else:
+                y = cheb_filter_dense(x, torch.zeros(m, m, dtype=x.dtype), w, bias)
+            out = out.index_put((torch.arange(m), torch.tensor(bb),
+                                 torch.arange(hh * dh, (hh + 1) * dh).unsqueeze(1)), y.t())
+    return out
+
+
 def encoder_gengcn(src, pe, edge_index, feature_indices, batch, degree, key_padding_mask,
                    p, num_layers, num_heads, order, batch_norm=False, tie_qk=False,
                    heads_share_graph=False, last_layer_filter=True, collapsed=False,
-                   prefix=''):
+                   prefix='', eig=None):
     """DiffTransformerEncoderGenGCN.forward, transformer/models.py:155-238
     (gnn_type='ChebConvDynamic', use_skip_conn=True).
+    ``eig=(u [B,N,K], lam [B,K])``: the filter stage runs in that (possibly truncated) eigenbasis
+    (filter_stage_eigenbasis) instead of the reference's edge-list recursion.
     Returns (output [N,B,d], attn [B,H,N,N], coefficients [B, H*n_filtered, C])."""
     out = src
     allf = None
@@ -414,9 +443,13 @@ def encoder_gengcn(src, pe, edge_index, feature_indices, batch, degree, key_padd
             continue
         c = getc(attn, key_padding_mask, p[prefix + 'gcn.weight'], p[prefix + 'gcn.bias'],
                  p[prefix + 'linear.weight'], p[prefix + 'linear.bias'])      # :173
-        f = filter_stage_faithful(oh, c, edge_index, feature_indices, batch,
-                                  p[prefix + 'spectral_gnns.bias'], order, out.shape,
-                                  heads_share_graph)
+        if eig is not None:
+            f = filter_stage_eigenbasis(oh, c, eig[0], eig[1], key_padding_mask,
+                                        p[prefix + 'spectral_gnns.bias'], order, heads_share_graph)
+        else:
+            f = filter_stage_faithful(oh, c, edge_index, feature_indices, batch,
+                                      p[prefix + 'spectral_gnns.bias'], order, out.shape,
+                                      heads_share_graph)
         coeffs.append(c)
         allf = f if allf is None else allf + f                               # :209-213
     if allf is not None:
@@ -432,10 +465,34 @@ def global_avg_1d(x, mask):
     return (x * m).sum(dim=1) / m.sum(dim=1)
 
 
+def lap_pos_embedding(out, x_lap_pos_enc, p):
+    """``output + embedding_lap_pos_enc(x_lap_pos_enc.transpose(0, 1))``, transformer/models.py:523-526
+    (same lines in the MolHiv / SBM shells, :670-673, :1044-1047).  x_lap_pos_enc [B,N,lap_dim]."""
+    if x_lap_pos_enc is None:
+        return out
+    return out + F.linear(x_lap_pos_enc.transpose(0, 1), p['embedding_lap_pos_enc.weight'],
+                          p['embedding_lap_pos_enc.bias'])
+
+
+def lap_encoding(edge_index, n, dim):
+    """LapEncoding.compute_pe (normalization='sym'), transformer/position_encoding.py:127-161: sorted
+    eigenvectors of L_sym, the first (constant-direction) one dropped, `dim` columns, zero-padded columns
+    when the graph has fewer.  (np.linalg.eigh here instead of the general np.linalg.eig of :136 - the
+    matrix is symmetric; eigenvectors are unique only up to sign / rotation in degenerate eigenspaces,
+    which the reference's random sign flip, experiments/run_transformer_gengcn.py:126-131, ignores too.)"""
+    lap = np.eye(n) + lhat_dense(torch.as_tensor(edge_index), n, torch.float64).numpy()
+    lam, vec = np.linalg.eigh(lap)
+    pe = vec[:, 1:dim + 1]
+    if pe.shape[1] < dim:
+        pe = np.concatenate([pe, np.zeros((n, dim - pe.shape[1]))], axis=1)
+    return torch.from_numpy(pe).float()
+
+
 def graph_transformer_gengcn(x, edge_index, batch, feature_indices, masks, pe, degree, p,
-                             num_layers, num_heads, order, **kw):
-    """DiffGraphTransformerGenGCN.forward, transformer/models.py:518-551 (no lap PE)."""
+                             num_layers, num_heads, order, x_lap_pos_enc=None, **kw):
+    """DiffGraphTransformerGenGCN.forward, transformer/models.py:518-551."""
     out = F.linear(x.permute(1, 0, 2), p['embedding.weight'])                # :521-522
+    out = lap_pos_embedding(out, x_lap_pos_enc, p)                           # :523-526
     out, attn, coeff = encoder_gengcn(out, pe, edge_index, feature_indices, batch, degree,
                                       masks, p, num_layers, num_heads, order,
                                       prefix='encoder.', **kw)               # :527
@@ -473,12 +530,13 @@ def regularisation_pairwise(coeff):
 
 
 def graph_transformer_gengcn_molhiv(x_int, edge_index, batch, feature_indices, masks, pe, degree, p,
-                                    num_layers, num_heads, order, **kw):
+                                    num_layers, num_heads, order, x_lap_pos_enc=None, **kw):
     """DiffGraphTransformerGenGCNMolHiv.forward, transformer/models.py:642-725.
     ``nn.LeakyReLU(True)`` (:637) is LeakyReLU(negative_slope=1.0): the identity, kept as written."""
     bsz, n = x_int.shape[0], x_int.shape[1]
     emb = atom_encoder(x_int.reshape(-1, x_int.shape[-1]).long(), p)          # :645-646
     out = emb.reshape(bsz, n, -1).permute(1, 0, 2)                            # :648,667
+    out = lap_pos_embedding(out, x_lap_pos_enc, p)                            # :670-673
     out, attn, coeff = encoder_gengcn(out, pe, edge_index, feature_indices, batch, degree,
                                       masks, p, num_layers, num_heads, order,
                                       prefix='encoder.', **kw)                # :674
@@ -489,10 +547,11 @@ def graph_transformer_gengcn_molhiv(x_int, edge_index, batch, feature_indices, m
 
 
 def graph_transformer_gengcn_sbm(x, edge_index, batch, feature_indices, masks, pe, degree, p,
-                                 num_layers, num_heads, order, **kw):
+                                 num_layers, num_heads, order, x_lap_pos_enc=None, **kw):
     """DiffGraphTransformerGenGCNSBM.forward, transformer/models.py:1039-1076: node-level logits of
     the real nodes, graph-major ([N_tot, nb_class])."""
     out = F.linear(x.permute(1, 0, 2), p['embedding.weight'])                 # :1042-1043
+    out = lap_pos_embedding(out, x_lap_pos_enc, p)                            # :1044-1047
     out, attn, coeff = encoder_gengcn(out, pe, edge_index, feature_indices, batch, degree,
                                       masks, p, num_layers, num_heads, order,
                                       prefix='encoder.', **kw)                # :1048

@@ -1,0 +1,44 @@
+"""Parity of EXACTLY what bench.py times: the encoder bench.build_encoder builds, on the batch
+bench.make_batch builds, through the step bench.make_step captures (one hipGraph replay per step on the
+MI355X), against the fp64 oracle of the same operator - output and every parameter gradient.  Shared by
+the emulation suite (small shapes, CPU) and the MI355X suite (the BASELINE configuration)."""
+import torch
+
+import bench
+import kernel_checks as KC
+from oracle import feta_oracle as O
+
+
+def check_bench_step(dev, run_ctx, argv, filter_mode=None, share=None, replays=2, two_phase=False,
+                     out_tol=KC.TOL, grad_tol=3e-5):
+    args = bench.parse(list(argv) + (['--two-phase'] if two_phase else []))
+    cpu, gpu = bench.make_batch(args, 0, dev)
+    enc = bench.build_encoder(args, filter_mode=filter_mode, share=share).to(dev)
+    enc.train()
+    with torch.no_grad():   # the zero-initialised biases would hide errors in their paths
+        enc.spectral_gnns.bias.normal_(0, 0.1)
+        enc.gcn.bias.normal_(0, 0.1)
+    p64 = {k: v.detach().cpu().double().clone().requires_grad_(True) for k, v in enc.state_dict().items()
+           if v.dtype.is_floating_point}
+    with run_ctx():
+        step, _, used_graph = bench.make_step(args, enc, gpu, 1, dev)
+        for _ in range(replays):
+            step()
+        if dev.type == 'cuda':
+            torch.cuda.synchronize()
+    out = step.held['out'].detach().cpu()
+    mode = enc.filter_mode
+    eig = (cpu['cache'].u.double(), cpu['cache'].lam.double()) if mode == 'spectral' else None
+    ref, _, _ = O.encoder_gengcn(cpu['src'].double(), cpu['pe'].double(), cpu['edge_index'], cpu['fi'],
+                                 cpu['batch'], cpu['degree'].double(), cpu['mask'], p64, args.layers, args.heads,
+                                 args.order, batch_norm=not args.layer_norm, heads_share_graph=enc.heads_share_graph,
+                                 collapsed=True, eig=eig)
+    (ref * cpu['dout'].double()).sum().backward()
+    errs = {'out': KC.assert_close('encoder output', out, ref, tol=out_tol)}
+    for name, p in enc.named_parameters():
+        g_ref = p64[name].grad
+        if p.grad is None:
+            assert g_ref is None or float(g_ref.abs().max()) == 0.0, name
+            continue
+        errs[name] = KC.assert_close('grad ' + name, p.grad.detach().cpu(), g_ref, tol=grad_tol)
+    return errs, used_graph

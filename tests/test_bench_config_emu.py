@@ -1,0 +1,47 @@
+"""What bench.py times, at small shapes, on the host emulation of the kernels: truncated-K eigenbasis
+operator (the timed default), the reference-literal operator, the split backward; and the self-launcher
+(`python bench.py --gpus 2` with no external torchrun) with gloo on the CPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+import bench_checks as BC
+from feta_tmlr_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CPU = torch.device('cpu')
+SMALL = ['--batch', '5', '--n-pad', '14', '--k-eig', '6', '--layers', '2', '--no-graph']
+
+
+@pytest.mark.parametrize('mode,share,two_phase', [('spectral', True, False), ('cheb', False, False),
+                                                  ('spectral', False, True)])
+def test_bench_step_matches_oracle(emu, mode, share, two_phase):
+    BC.check_bench_step(CPU, lambda: _lib.override_for_tests(emu), SMALL, filter_mode=mode, share=share,
+                        replays=1, two_phase=two_phase)
+
+
+def test_bench_starts_its_own_ranks(emu):
+    """python bench.py --gpus 2 (no WORLD_SIZE in the environment) spawns two ranks, prints ONE JSON line
+    for the whole job and exits 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-cpu', '--batch', '3',
+                        '--n-pad', '12', '--k-eig', '6', '--layers', '1', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['config']['global_batch'] == 6 and res['config']['parallelism'] == 'dp2'
+    assert 'invalid' in res     # a rehearsal, not a measurement
+
+
+def test_bench_launcher_propagates_failure():
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-cpu', '--shape', 'zinc',
+                        '--batch', '0', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode != 0

@@ -1,0 +1,24 @@
+"""The EXACT configuration bench.py times (BASELINE.json configs[1]: B=128, N_pad=37, d=64, 4 heads, K=16,
+3 layers, BatchNorm, every head on the graph, eigenbasis filter) through the captured hipGraph, against the
+fp64 oracle of the same truncated-K operator; and the reference-literal operator bench.py reports beside it."""
+import contextlib
+
+import pytest
+import torch
+
+import bench_checks as BC
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('mode,share,two_phase', [
+    (None, None, False),           # bench.py defaults: spectral, K = 16, heads_share_graph = True
+    (None, None, True),            # the split backward bench.py uses for --gpus > 1
+    ('cheb', False, False),        # reference_literal leg
+    ('spectral', False, False),
+])
+def test_timed_configuration_matches_oracle(hip, mode, share, two_phase):
+    errs, used_graph = BC.check_bench_step(hip[1], contextlib.nullcontext, [], filter_mode=mode, share=share,
+                                           replays=3, two_phase=two_phase)
+    assert used_graph
+    print('max abs errors:', {k: '%.2e' % v for k, v in errs.items()})

@@ -25,6 +25,35 @@ def test_one_optimisation_step_matches_oracle(emu, task, batch_norm, mode):
     TC.check_task_step(task, torch.device('cpu'), _ctx(emu), batch_norm=batch_norm, mode=mode)
 
 
+@pytest.mark.parametrize('task,batch_norm,mode', [('molhiv', False, 'spectral'), ('zinc', True, 'cheb')])
+def test_lap_pos_enc_step_matches_oracle(emu, task, batch_norm, mode):
+    """--lappe --lap-dim 8 (BASELINE config 5): the embedding_lap_pos_enc branch of the shells."""
+    TC.check_task_step(task, torch.device('cpu'), _ctx(emu), batch_norm=batch_norm, mode=mode, lap_dim=8)
+
+
+def test_oracle_lap_encoding_matches_product():
+    """LapEncoding (transformer/position_encoding.py:127-161): product and oracle agree up to the sign of
+    each column on graphs with simple low eigenvalues; zero-padded columns for graphs smaller than dim."""
+    import numpy as np
+    from feta_tmlr_amd.transformer import data as D
+    from feta_tmlr_amd.transformer.position_encoding import LapEncoding, laplacian_dense
+    ds = D.SyntheticGraphDataset('mutag', 6, in_dim=4, seed=3, n_min=3, n_max=15)
+    enc = LapEncoding(8, normalization='sym')
+    for g in ds.samples:
+        got = enc.compute_pe(g)
+        ref = O.lap_encoding(g.edge_index, g.num_nodes, 8).numpy()
+        assert got.shape == ref.shape == (g.num_nodes, 8)
+        lam = np.linalg.eigvalsh(laplacian_dense(g.edge_index, g.num_nodes, 'sym'))
+        for c in range(8):
+            k = c + 1
+            if k >= g.num_nodes:
+                assert not got[:, c].any() and not ref[:, c].any()
+                continue
+            gap = min(lam[k] - lam[k - 1], (lam[k + 1] - lam[k]) if k + 1 < g.num_nodes else 1.0)
+            if gap > 1e-6:      # a simple eigenvalue: the column is unique up to its sign
+                assert min(np.abs(got[:, c] - ref[:, c]).max(), np.abs(got[:, c] + ref[:, c]).max()) < 1e-5
+
+
 def test_molhiv_shell_outputs(emu):
     TC.check_molhiv_outputs(torch.device('cpu'), _ctx(emu))
 

@@ -25,6 +25,13 @@ def test_one_optimisation_step_matches_oracle(hip, task, batch_norm, mode):
     TC.check_task_step(task, hip[1], contextlib.nullcontext, batch_norm=batch_norm, mode=mode)
 
 
+@pytest.mark.parametrize('task,batch_norm,mode', [('molhiv', False, 'spectral'), ('zinc', True, 'cheb'),
+                                                  ('sbm', False, 'cheb')])
+def test_lap_pos_enc_step_matches_oracle(hip, task, batch_norm, mode):
+    """--lappe --lap-dim 8 (BASELINE config 5): the embedding_lap_pos_enc branch of the three shells."""
+    TC.check_task_step(task, hip[1], contextlib.nullcontext, batch_norm=batch_norm, mode=mode, lap_dim=8)
+
+
 def test_molhiv_shell_outputs(hip):
     TC.check_molhiv_outputs(hip[1], contextlib.nullcontext)
 
@@ -48,12 +55,13 @@ def test_graphed_train_step_equals_eager_steps(hip, task):
     opt_b = T.make_optimizer(task, model_b.parameters(), lr=1e-3, capturable=True)
     start = {k: v.clone() for k, v in model_b.state_dict().items()}
     graphed = T.GraphedTrainStep(task, model_b, crit, opt_b, batch9, cache)
-    # capture ran warm-up steps: restore weights, BatchNorm buffers and optimiser state
-    model_b.load_state_dict(start)
+    # construction (warm-up steps + capture) leaves weights, buffers and optimiser state untouched
+    for k, v in model_b.state_dict().items():
+        assert torch.equal(v, start[k]), k
     for st in opt_b.state.values():
         for v in st.values():
             if torch.is_tensor(v):
-                v.zero_()
+                assert float(v.abs().max()) == 0.0
     lrs = [1e-3, 5e-4, 2e-3]
     for lr in lrs:
         la = T.train_step(task, model_a, crit, opt_a, batch9, T.prepare_cache(model_a, batch9, cache), lr=lr)

@@ -10,11 +10,14 @@ from oracle import feta_oracle as O
 
 
 def build_case(task, dev, seed=0, bsz=4, d=32, heads=2, layers=2, order=3, batch_norm=False,
-               share=1, mode='cheb', nb_class=3):
-    """-> model (on dev), batch9, cache (on dev), oracle forward closure."""
+               share=1, mode='cheb', nb_class=3, lap_dim=0):
+    """-> model (on dev), batch9, cache (on dev), oracle forward closure.
+    lap_dim > 0: Laplacian eigenvector node features (``--lappe --lap-dim``, BASELINE config 5) through the
+    shells' ``embedding_lap_pos_enc`` branch (transformer/models.py:523-526)."""
     torch.manual_seed(seed)
     kw = dict(dim_feedforward=2 * d, dropout=0.0, nb_layers=layers, batch_norm=batch_norm,
-              filter_order=order, heads_share_graph=bool(share), filter_mode=mode)
+              filter_order=order, heads_share_graph=bool(share), filter_mode=mode,
+              lap_pos_enc=lap_dim > 0, lap_pos_enc_dim=lap_dim)
     if task == 'molhiv':
         model = M.DiffGraphTransformerGenGCNMolHiv(9, 1, d, heads, **kw)
         ds = D.SyntheticGraphDataset('mutag', bsz, seed=seed, n_min=4, n_max=17, features='atom',
@@ -39,6 +42,11 @@ def build_case(task, dev, seed=0, bsz=4, d=32, heads=2, layers=2, order=3, batch
     with torch.no_grad():
         model.encoder.spectral_gnns.bias.normal_(0, 0.1)
         model.encoder.gcn.bias.normal_(0, 0.1)
+    if lap_dim > 0:
+        from feta_tmlr_amd.transformer.position_encoding import LapEncoding
+        LapEncoding(lap_dim, normalization='sym').apply_to(ds)
+        with torch.no_grad():
+            model.embedding_lap_pos_enc.bias.normal_(0, 0.1)
     n_pad = max(g.num_nodes for g in ds.samples)
     batch9, cache = D.collate(ds.samples, k_eig=n_pad if mode == 'spectral' else None, device=dev)
     model = model.to(dev)
@@ -46,9 +54,10 @@ def build_case(task, dev, seed=0, bsz=4, d=32, heads=2, layers=2, order=3, batch
 
 
 def oracle_forward(task, model, batch9, p64, batch_norm=False, share=1):
-    x, mask, pe, _, degree, labels, edge_index, batch, fi = (None if t is None else t.cpu() for t in batch9)
+    x, mask, pe, lap, degree, labels, edge_index, batch, fi = (None if t is None else t.cpu() for t in batch9)
     kw = dict(num_layers=len(model.encoder.layers), num_heads=model.encoder.num_heads,
-              order=model.encoder.order, batch_norm=batch_norm, heads_share_graph=bool(share))
+              order=model.encoder.order, batch_norm=batch_norm, heads_share_graph=bool(share),
+              x_lap_pos_enc=None if lap is None else lap.double())
     pe64 = None if pe is None else pe.double()
     dg64 = None if degree is None else degree.double()
     if task == 'molhiv':
@@ -70,10 +79,10 @@ def params64(model):
             for k, v in model.state_dict().items() if v.dtype.is_floating_point}
 
 
-def check_task_step(task, dev, run_ctx, batch_norm=False, mode='cheb', lr=1e-3):
+def check_task_step(task, dev, run_ctx, batch_norm=False, mode='cheb', lr=1e-3, lap_dim=0):
     """forward output, loss, every parameter gradient and the parameters after ONE optimiser step
     (Adam / AdamW as the reference scripts configure them) against the fp64 oracle."""
-    model, batch9, cache = build_case(task, dev, batch_norm=batch_norm, mode=mode)
+    model, batch9, cache = build_case(task, dev, batch_norm=batch_norm, mode=mode, lap_dim=lap_dim)
     p64 = params64(model)
     crit = T.make_criterion(task, nb_class=3 if task in ('tu', 'sbm') else 1)
     opt = T.make_optimizer(task, model.parameters(), lr=lr)
