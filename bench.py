@@ -193,7 +193,7 @@ def make_step(args, enc, gpu, world, dev):
         def fwd_bwd():
             reducer.zero()
             out, _, _ = enc(*fwd_args, **fwd_kw)
-            held['out'] = out                    # (static address across replays: read by the parity test)
+            held['out'] = out.detach()           # (static address across replays: read by the parity test)
             out.backward(gradient=gpu['dout'])   # upstream gradient dOut ~ N(0,1) injected directly
 
         fwd_bwd()
@@ -222,7 +222,7 @@ def make_step(args, enc, gpu, world, dev):
         for p_ in enc.stack_parameters():
             p_.grad = None
         out, _, _ = enc(*fwd_args, **fwd_kw)
-        held['out'] = out
+        held['out'] = out.detach()
         enc.backward_head(out, gpu['dout'])
 
     def both():

@@ -35,10 +35,21 @@ def check_bench_step(dev, run_ctx, argv, filter_mode=None, share=None, replays=2
                                  collapsed=True, eig=eig)
     (ref * cpu['dout'].double()).sum().backward()
     errs = {'out': KC.assert_close('encoder output', out, ref, tol=out_tol)}
+    m_rows = cpu['src'].shape[0] * cpu['src'].shape[1]
     for name, p in enc.named_parameters():
         g_ref = p64[name].grad
         if p.grad is None:
             assert g_ref is None or float(g_ref.abs().max()) == 0.0, name
+            continue
+        if not args.layer_norm and name.endswith('linear2.bias'):
+            # linear2.bias sits directly in front of BatchNorm 2 (out_proj.bias does not: it is scaled by the degree
+            # first): its gradient is EXACTLY zero (the batch mean is subtracted right
+            # after it), computed as a sum of M = N*B O(1) terms that cancel - what any fp32 implementation
+            # returns is rounding noise of size ~ eps * sqrt(M) * |terms|, so only that bound is checked
+            assert float(g_ref.abs().max()) < 1e-10, name
+            noise = float(p.grad.detach().abs().max())
+            assert noise <= 64 * 6e-8 * m_rows ** 0.5, '%s: %.3e' % (name, noise)
+            errs[name] = noise
             continue
         errs[name] = KC.assert_close('grad ' + name, p.grad.detach().cpu(), g_ref, tol=grad_tol)
     return errs, used_graph
