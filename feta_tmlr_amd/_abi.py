@@ -43,7 +43,7 @@ SIGNATURES = {
     'feta_rowlin_fwd': ([_F, _F, _F, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, _S], C.c_int),
     'feta_rowlin_bwd': ([_F, _F, _F, _F, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int, _S], C.c_int),
     'feta_bn_stats': ([_F, _F, C.c_int, C.c_int, _S], C.c_int),
-    'feta_bn_apply_fwd': ([_F, _F, _F, _F, _F, _F, _F, _F, C.c_float, C.c_float, C.c_int, C.c_int, _S],
+    'feta_bn_apply_fwd': ([_F, _F, _F, _F, _F, _F, _F, _F, _I, C.c_float, C.c_float, C.c_int, C.c_int, _S],
                           C.c_int),
     'feta_bn_bwd': ([_F, _F, _F, _F, _F, _F, _F, _F, C.c_int, C.c_int, _S], C.c_int),
     'feta_lhat_from_edges': ([_I, C.c_int64, _I, _I, _F, _F, C.c_int, C.c_int, C.c_int64, _S],
@@ -65,7 +65,7 @@ class RowLinEx(C.Structure):
         ('M', C.c_int), ('KI', C.c_int), ('NO', C.c_int), ('relu', C.c_int),
         ('residual', _F), ('res_bn', _F), ('y', _F), ('stats', _F),
         ('x_bn', _F), ('x_stats', _F), ('Gx', C.c_int),
-        ('x_gamma', _F), ('x_beta', _F), ('x_bn_out', _F), ('x_rmean', _F), ('x_rvar', _F),
+        ('x_gamma', _F), ('x_beta', _F), ('x_bn_out', _F), ('x_rmean', _F), ('x_rvar', _F), ('x_nbt', _I),
         ('momentum', C.c_float), ('eps', C.c_float),
         ('dy', _F), ('relu_y', _F), ('dx', _F), ('partial', _F), ('partial_ld', C.c_int),
         ('g_y', _F), ('g_bn', _F), ('g_sum', _F), ('Gs', C.c_int),
@@ -79,7 +79,7 @@ class RowLinEx(C.Structure):
 SIGNATURES.update({
     'feta_rowlin_fwd_ex': ([C.POINTER(RowLinEx), _S], C.c_int),
     'feta_rowlin_bwd_ex': ([C.POINTER(RowLinEx), _F, _S], C.c_int),
-    'feta_bn_apply_fwd_prm': ([_F, _F, _F, _F, _F, _F, _F, _F, C.c_float, C.c_float, C.c_int, C.c_int,
+    'feta_bn_apply_fwd_prm': ([_F, _F, _F, _F, _F, _F, _F, _F, _I, C.c_float, C.c_float, C.c_int, C.c_int,
                                C.c_int, _S], C.c_int),
     'feta_bn_bwd_reduce': ([_F, _F, _F, _F, C.c_int, C.c_int, _S], C.c_int),
 })
@@ -90,7 +90,7 @@ class AttnBlock(C.Structure):
     """struct feta_attn_block (include/feta_hip.h) - field order must match the header."""
     _fields_ = [
         ('x', _F), ('x_bn', _F), ('x_stats', _F), ('Gx', C.c_int),
-        ('x_gamma', _F), ('x_beta', _F), ('x_bn_out', _F), ('x_rmean', _F), ('x_rvar', _F),
+        ('x_gamma', _F), ('x_beta', _F), ('x_bn_out', _F), ('x_rmean', _F), ('x_rvar', _F), ('x_nbt', _I),
         ('momentum', C.c_float), ('eps', C.c_float),
         ('w_in', _F), ('b_in', _F), ('w_out', _F), ('b_out', _F), ('pe', _F), ('n_real', _I),
         ('rowscale', _F), ('qkv', _F), ('out', _F), ('attn_stats', _F), ('attn', _F), ('y', _F),
@@ -127,7 +127,7 @@ class Ffn(C.Structure):
     """struct feta_ffn (include/feta_hip.h) - field order must match the header."""
     _fields_ = [
         ('x', _F), ('x_bn', _F), ('x_stats', _F), ('Gx', C.c_int),
-        ('x_gamma', _F), ('x_beta', _F), ('x_bn_out', _F), ('x_rmean', _F), ('x_rvar', _F),
+        ('x_gamma', _F), ('x_beta', _F), ('x_bn_out', _F), ('x_rmean', _F), ('x_rvar', _F), ('x_nbt', _I),
         ('momentum', C.c_float), ('eps', C.c_float),
         ('w1', _F), ('b1', _F), ('w2', _F), ('b2', _F), ('h', _F), ('y', _F), ('y_stats', _F),
         ('M', C.c_int), ('FF', C.c_int),
@@ -140,7 +140,7 @@ SIGNATURES.update({
     'feta_ffn_fwd': ([C.POINTER(Ffn), _S], C.c_int),
 })
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class FetaError(RuntimeError):
@@ -289,10 +289,10 @@ class Abi:
         self._check(self.lib.feta_bn_stats(_p(y), _p(stats), m, d, stream), 'feta_bn_stats')
 
     def bn_apply_fwd(self, y, stats, gamma, beta, out, mean_rstd, running_mean, running_var, momentum,
-                     eps, stream):
+                     eps, stream, nbt=None):
         m, d = y.shape
         self._check(self.lib.feta_bn_apply_fwd(_p(y), _p(stats), _p(gamma), _p(beta), _p(out),
-                                               _p(mean_rstd), _p(running_mean), _p(running_var),
+                                               _p(mean_rstd), _p(running_mean), _p(running_var), _p(nbt),
                                                momentum, eps, m, d, stream), 'feta_bn_apply_fwd')
 
     def bn_bwd(self, y, dout, mean_rstd, gamma, partial, dy, dgamma, dbeta, stream):
@@ -379,10 +379,10 @@ class Abi:
         self._check(self.lib.feta_ffn_fwd(C.byref(desc), stream), 'feta_ffn_fwd')
 
     def bn_apply_fwd_prm(self, y, stats, gamma, beta, out, bn_prm, running_mean, running_var, momentum,
-                         eps, stream):
+                         eps, stream, nbt=None):
         m, d = y.shape
         self._check(self.lib.feta_bn_apply_fwd_prm(_p(y), _p(stats), _p(gamma), _p(beta), _p(out),
-                                                   _p(bn_prm), _p(running_mean), _p(running_var),
+                                                   _p(bn_prm), _p(running_mean), _p(running_var), _p(nbt),
                                                    momentum, eps, m, d, stats.shape[0], stream),
                     'feta_bn_apply_fwd_prm')
 

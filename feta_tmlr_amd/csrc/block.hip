@@ -106,6 +106,7 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
           a.x_rmean[c] = (1.0f - a.momentum) * a.x_rmean[c] + a.momentum * mean;
           a.x_rvar[c] = (1.0f - a.momentum) * a.x_rvar[c] + a.momentum * unbiased;
         }
+        if (c == 0 && a.x_nbt != nullptr) *a.x_nbt += 1;
       }
     }
   } else if (a.x_bn != nullptr) {

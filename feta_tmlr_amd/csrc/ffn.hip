@@ -118,6 +118,7 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a) {
           a.x_rmean[c] = (1.0f - a.momentum) * a.x_rmean[c] + a.momentum * mean;
           a.x_rvar[c] = (1.0f - a.momentum) * a.x_rvar[c] + a.momentum * unbiased;
         }
+        if (c == 0 && a.x_nbt != nullptr) *a.x_nbt += 1;
       }
     }
   } else {

@@ -144,6 +144,7 @@ __global__ __launch_bounds__(kRowThreads) void rowlin_fwd_kernel(RowLinArgs a, R
           a.x_rmean[c] = (1.0f - a.momentum) * a.x_rmean[c] + a.momentum * mean;
           a.x_rvar[c] = (1.0f - a.momentum) * a.x_rvar[c] + a.momentum * unbiased;
         }
+        if (c == 0 && a.x_nbt != nullptr) *a.x_nbt += 1;
       }
     }
   } else if (a.x_bn != nullptr) {
@@ -598,6 +599,7 @@ struct BnArgs {
   float* mean_rstd;     // [2, D]
   float* running_mean;  // [D] or null
   float* running_var;   // [D] or null
+  int64_t* nbt;         // num_batches_tracked or null
   float* partial;       // [G, 2, D] backward partial sums
   float* dy;
   float* dgamma;
@@ -672,6 +674,7 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(BnArgs a) {
         a.running_mean[c] = (1.0f - a.momentum) * a.running_mean[c] + a.momentum * mean;
         a.running_var[c] = (1.0f - a.momentum) * a.running_var[c] + a.momentum * unbiased;
       }
+      if (c == 0 && a.nbt != nullptr) *a.nbt += 1;
     }
   }
   __syncthreads();
@@ -946,28 +949,30 @@ static int bn_apply_launch(BnArgs& a, feta_stream_t stream) {
 
 extern "C" int feta_bn_apply_fwd(const float* y, const float* stats, const float* gamma,
                                  const float* beta, float* out, float* mean_rstd, float* running_mean,
-                                 float* running_var, float momentum, float eps, int M, int D,
-                                 feta_stream_t stream) {
+                                 float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
+                                 int M, int D, feta_stream_t stream) {
   FETA_REQUIRE(y && stats && gamma && beta && out && mean_rstd, "bn_apply_fwd: null pointer");
   FETA_REQUIRE(M > 0 && D > 0 && D <= 256 && (D % 4) == 0, "bn_apply_fwd: need D %% 4 == 0, D <= 256");
   FETA_REQUIRE(aligned16(y) && aligned16(out), "bn_apply_fwd: pointers must be 16-byte aligned");
   BnArgs a{};
   a.y = y; a.stats = stats; a.gamma = gamma; a.beta = beta; a.out = out; a.mean_rstd = mean_rstd;
   a.running_mean = running_mean; a.running_var = running_var; a.momentum = momentum; a.eps = eps;
+  a.nbt = num_batches_tracked;
   a.M = M; a.D = D; a.G = row_blocks(M);
   return bn_apply_launch(a, stream);
 }
 
 extern "C" int feta_bn_apply_fwd_prm(const float* y, const float* stats, const float* gamma,
                                      const float* beta, float* out, float* bn_prm, float* running_mean,
-                                     float* running_var, float momentum, float eps, int M, int D,
-                                     int G_stats, feta_stream_t stream) {
+                                     float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
+                                     int M, int D, int G_stats, feta_stream_t stream) {
   FETA_REQUIRE(y && stats && gamma && beta && out && bn_prm, "bn_apply_fwd_prm: null pointer");
   FETA_REQUIRE(M > 0 && D > 0 && D <= 256 && (D % 4) == 0, "bn_apply_fwd_prm: need D %% 4 == 0, D <= 256");
   FETA_REQUIRE(aligned16(y) && aligned16(out), "bn_apply_fwd_prm: pointers must be 16-byte aligned");
   BnArgs a{};
   a.y = y; a.stats = stats; a.gamma = gamma; a.beta = beta; a.out = out; a.mean_rstd = bn_prm;
   a.running_mean = running_mean; a.running_var = running_var; a.momentum = momentum; a.eps = eps;
+  a.nbt = num_batches_tracked;
   a.M = M; a.D = D; a.G = row_blocks(M); a.Gs = G_stats; a.prm4 = 1;
   return bn_apply_launch(a, stream);
 }

@@ -269,7 +269,7 @@ class BatchNormTrainFn(torch.autograd.Function):
     C ABI: feta_bn_stats (when the producer did not emit them), feta_bn_apply_fwd, feta_bn_bwd."""
 
     @staticmethod
-    def forward(ctx, y, stats, gamma, beta, running_mean, running_var, momentum, eps):
+    def forward(ctx, y, stats, gamma, beta, running_mean, running_var, momentum, eps, nbt=None):
         abi, stream = _lib.backend(y)
         y = y.contiguous()
         m, d = y.shape
@@ -279,7 +279,7 @@ class BatchNormTrainFn(torch.autograd.Function):
         out = torch.empty_like(y)
         mean_rstd = torch.empty((2, d), dtype=torch.float32, device=y.device)
         abi.bn_apply_fwd(y, stats, gamma, beta, out, mean_rstd, running_mean, running_var,
-                         float(momentum), float(eps), stream)
+                         float(momentum), float(eps), stream, nbt=nbt)
         ctx.save_for_backward(y, mean_rstd, gamma)
         return out
 
@@ -294,7 +294,7 @@ class BatchNormTrainFn(torch.autograd.Function):
         dgamma = torch.empty(d, dtype=torch.float32, device=y.device)
         dbeta = torch.empty(d, dtype=torch.float32, device=y.device)
         abi.bn_bwd(y, dout, mean_rstd, gamma, partial, dy, dgamma, dbeta, stream)
-        return dy, None, dgamma, dbeta, None, None, None, None
+        return dy, None, dgamma, dbeta, None, None, None, None, None
 
 
 ROWLIN_DIMS = (16, 32, 64, 128, 192, 256)
@@ -314,8 +314,9 @@ def row_linear_cat(x1, x2, w, bias=None):
     return RowLinearCatFn.apply(x1, x2, w, bias)
 
 
-def batch_norm_train(y, stats, gamma, beta, running_mean, running_var, momentum, eps):
-    return BatchNormTrainFn.apply(y, stats, gamma, beta, running_mean, running_var, momentum, eps)
+def batch_norm_train(y, stats, gamma, beta, running_mean, running_var, momentum, eps, num_batches_tracked=None):
+    return BatchNormTrainFn.apply(y, stats, gamma, beta, running_mean, running_var, momentum, eps,
+                                  num_batches_tracked)
 
 
 class LayerNormRowsFn(torch.autograd.Function):

@@ -136,7 +136,7 @@ class FusedEncoderStackFn(torch.autograd.Function):
                 prm_prev = new(4, d)
                 bn_prev = dict(x_stats=st_prev, Gx=G2_prev, x_gamma=params[(li - 1) * PER_LAYER + 10],
                                x_beta=params[(li - 1) * PER_LAYER + 11], x_bn_out=prm_prev,
-                               x_rmean=pl.running_mean, x_rvar=pl.running_var,
+                               x_rmean=pl.running_mean, x_rvar=pl.running_var, x_nbt=pl.num_batches_tracked,
                                momentum=float(pl.momentum), eps=float(pl.eps))
                 saved[li - 1]['prm2'] = prm_prev
             if block:
@@ -165,7 +165,7 @@ class FusedEncoderStackFn(torch.autograd.Function):
             h, prm1 = new(m, ff), new(4, d)
             n1 = layer.norm1
             bn1 = dict(x_stats=st1, Gx=G1, x_gamma=g1, x_beta=be1, x_bn_out=prm1, x_rmean=n1.running_mean,
-                       x_rvar=n1.running_var, momentum=float(n1.momentum), eps=float(n1.eps))
+                       x_rvar=n1.running_var, x_nbt=n1.num_batches_tracked, momentum=float(n1.momentum), eps=float(n1.eps))
             y2 = new(m, d)
             if USE_FFN_FUSED and abi.ffn_supported(d, ff):
                 # F4 + F5 in one launch: the hidden activations stay in registers (csrc/ffn.hip)
@@ -190,12 +190,8 @@ class FusedEncoderStackFn(torch.autograd.Function):
         prm2 = new(4, d)
         abi.bn_apply_fwd_prm(y_prev, st_prev, params[(nl - 1) * PER_LAYER + 10], params[(nl - 1) * PER_LAYER + 11],
                              final, prm2, last.running_mean, last.running_var, float(last.momentum),
-                             float(last.eps), stream)
+                             float(last.eps), stream, nbt=last.num_batches_tracked)
         saved[-1]['prm2'] = prm2
-        # nn.BatchNorm1d advances num_batches_tracked once per training forward: one multi-tensor add
-        nbt = [t for l in layers for t in (l.norm1.num_batches_tracked, l.norm2.num_batches_tracked) if t is not None]
-        if nbt:
-            torch._foreach_add_(nbt, 1)
         ctx.saved_state = saved
         ctx.meta = (n, b, d, heads, dh, tie, scale, G, nl)
         ctx.aux = (pe_c, degree_rows, n_real)

@@ -139,10 +139,8 @@ class DiffTransformerEncoderLayer(nn.Module):
                 return FF.layer_norm_rows(y, mod.weight, mod.bias, mod.eps)
             return mod(y)
         if mod.training and mod.momentum is not None and y.shape[1] % 4 == 0 and y.shape[1] <= 256:
-            if mod.num_batches_tracked is not None:
-                mod.num_batches_tracked.add_(1)
             return FF.batch_norm_train(y, stats, mod.weight, mod.bias, mod.running_mean,
-                                       mod.running_var, mod.momentum, mod.eps)
+                                       mod.running_var, mod.momentum, mod.eps, mod.num_batches_tracked)
         return mod(y)
 
     def forward(self, src, pe=None, degree=None, src_mask=None, src_key_padding_mask=None,

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FETA_ABI_VERSION 4
+#define FETA_ABI_VERSION 5
 
 #define FETA_OK 0
 #define FETA_E_ARG (-1)     /* bad shape / stride / alignment / unsupported size */
@@ -202,6 +202,7 @@ typedef struct feta_rowlin_ex {
   float* x_bn_out;
   float* x_rmean;
   float* x_rvar;
+  int64_t* x_nbt;         /* num_batches_tracked of that BatchNorm (+1 by block 0), or NULL */
   float momentum, eps;
   /* backward:  g = BNbwd?(dy) * rowscale? * [relu_y > 0]? ;  dx = g W (+ adds) ;  dW = g^T BN?(x) */
   const float* dy;        /* [M,NO] */
@@ -241,7 +242,8 @@ int feta_rowlin_bwd_ex(const feta_rowlin_ex* d, float* dwdb, feta_stream_t strea
  * feta_rowlin_fwd*; feta_ffn_blocks(M) after feta_ffn_fwd; B after feta_attn_block_fwd). */
 int feta_bn_apply_fwd_prm(const float* y, const float* stats, const float* gamma, const float* beta,
                           float* out, float* bn_prm, float* running_mean, float* running_var,
-                          float momentum, float eps, int M, int D, int G_stats, feta_stream_t stream);
+                          int64_t* num_batches_tracked, float momentum, float eps, int M, int D, int G_stats,
+                          feta_stream_t stream);
 /* partial [feta_rowlin_blocks(M),2,D] = per-block (sum dout, sum dout*xhat), bn_prm [4][D]. */
 int feta_bn_bwd_reduce(const float* y, const float* dout, const float* bn_prm, float* partial,
                        int M, int D, feta_stream_t stream);
@@ -249,11 +251,11 @@ int feta_bn_bwd_reduce(const float* y, const float* dout, const float* bn_prm, f
 /* Training-mode BatchNorm1d over the M rows (padded rows included, as nn.BatchNorm1d on the
  * [N*B, d] view does).  stats [feta_rowlin_blocks(M), 2, D] from feta_rowlin_fwd or feta_bn_stats.
  * mean_rstd [2, D] is saved for backward; running_* (nullable) are updated with momentum and the
- * unbiased variance. */
+ * unbiased variance, num_batches_tracked (nullable, int64) is advanced by one, as nn.BatchNorm1d does. */
 int feta_bn_stats(const float* y, float* stats, int M, int D, feta_stream_t stream);
 int feta_bn_apply_fwd(const float* y, const float* stats, const float* gamma, const float* beta,
                       float* out, float* mean_rstd, float* running_mean, float* running_var,
-                      float momentum, float eps, int M, int D, feta_stream_t stream);
+                      int64_t* num_batches_tracked, float momentum, float eps, int M, int D, feta_stream_t stream);
 /* partial: scratch [feta_rowlin_blocks(M), 2, D]; dgamma, dbeta [D]. */
 int feta_bn_bwd(const float* y, const float* dout, const float* mean_rstd, const float* gamma,
                 float* partial, float* dy, float* dgamma, float* dbeta,
@@ -284,6 +286,7 @@ typedef struct feta_attn_block {
   float* x_bn_out;
   float* x_rmean;
   float* x_rvar;
+  int64_t* x_nbt;      /* num_batches_tracked of that BatchNorm (+1 by workgroup 0), or NULL */
   float momentum, eps;
   const float* w_in;   /* [192,64] */
   const float* b_in;   /* [192] or NULL */
@@ -362,6 +365,7 @@ typedef struct feta_ffn {
   float* x_bn_out;
   float* x_rmean;
   float* x_rvar;
+  int64_t* x_nbt;
   float momentum, eps;
   const float* w1;  /* [FF,64] */
   const float* b1;  /* [FF] or NULL */

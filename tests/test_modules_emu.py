@@ -175,6 +175,12 @@ def test_fused_stack_updates_running_statistics(emu):
         for nm in ('norm1', 'norm2'):
             KC.assert_close(nm + '.running_mean', getattr(l, nm).running_mean, getattr(lr, nm).running_mean)
             KC.assert_close(nm + '.running_var', getattr(l, nm).running_var, getattr(lr, nm).running_var)
+            # nn.BatchNorm1d advances num_batches_tracked once per training forward: both paths do (in the
+            # kernel that finalizes the statistics), so state dicts stay interchangeable with PyTorch's
+            assert int(getattr(l, nm).num_batches_tracked) == 1 and int(getattr(lr, nm).num_batches_tracked) == 1
+    with _lib.override_for_tests(emu):
+        model(x, edge_index, batch, fi, mask, pe, degree=degree, graph_cache=cache)
+    assert all(int(getattr(l, nm).num_batches_tracked) == 2 for l in model.encoder.layers for nm in ('norm1', 'norm2'))
 
 
 def test_two_phase_backward_equals_single_backward(emu):
