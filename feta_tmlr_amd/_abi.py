@@ -24,7 +24,7 @@ SIGNATURES = {
                       C.c_int),
     'feta_coeff_fwd': ([_F, _I, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, _S], C.c_int),
     'feta_coeff_bwd_groups': ([C.c_int, C.c_int], C.c_int),
-    'feta_coeff_bwd': ([_F, _I, _F, _F, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, _S],
+    'feta_coeff_bwd': ([_F, _I, _F, _F, _F, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _S],
                        C.c_int),
     'feta_colsum': ([_F, _F, C.c_int, C.c_int, _S], C.c_int),
     'feta_cheb_filter_fwd': ([_F, C.c_int64, C.c_int64, _F, _F, _F, _I, _F, C.c_int64, C.c_int64,
@@ -57,6 +57,15 @@ SIGNATURES = {
     'feta_spectral_kernel': ([_F, _F, _I, C.c_int, C.c_float, C.c_int, C.c_float, C.c_int, _F,
                               C.c_int, C.c_int, C.c_int, _S], C.c_int),
 }
+
+class ColsumSeg(C.Structure):
+    """struct feta_colsum_seg (include/feta_hip.h)."""
+    _fields_ = [('in_', _F), ('out', _F), ('R', C.c_int), ('C', C.c_int), ('ld', C.c_int),
+                ('bcast_out', _F), ('bcast_rows', C.c_int)]
+
+
+SIGNATURES['feta_colsum_multi'] = ([C.POINTER(ColsumSeg), C.c_int, _S], C.c_int)
+
 
 class RowLinEx(C.Structure):
     """struct feta_rowlin_ex (include/feta_hip.h) - field order must match the header."""
@@ -104,23 +113,6 @@ SIGNATURES.update({
     'feta_attn_block_fwd': ([C.POINTER(AttnBlock), _S], C.c_int),
 })
 
-
-
-class AttnBlockBwd(C.Structure):
-    """struct feta_attn_block_grad (include/feta_hip.h) - field order must match the header."""
-    _fields_ = [
-        ('dy', _F), ('y1', _F), ('bn1', _F), ('g_sum', _F), ('Gs', C.c_int),
-        ('fin_out', _F), ('dgamma', _F), ('dbeta', _F), ('rowscale', _F), ('w_out', _F), ('w_in', _F),
-        ('qkv', _F), ('out', _F), ('dout2', _F), ('pe', _F), ('n_real', _I), ('attn_stats', _F),
-        ('x0', _F), ('bn0', _F), ('dqkv', _F), ('dx', _F), ('sum_out', _F), ('scale', C.c_float),
-        ('B', C.c_int), ('N', C.c_int), ('M', C.c_int), ('row_sb', C.c_int64), ('row_sn', C.c_int64),
-    ]
-
-
-SIGNATURES.update({
-    'feta_attn_block_bwd_supported': ([C.c_int, C.c_int, C.c_int], C.c_int),
-    'feta_attn_block_bwd': ([C.POINTER(AttnBlockBwd), _S], C.c_int),
-})
 
 
 class Ffn(C.Structure):
@@ -213,11 +205,19 @@ class Abi:
     def coeff_bwd_groups(self, b, h):
         return self.lib.feta_coeff_bwd_groups(b, h)
 
-    def coeff_bwd(self, cj, n_real, s, gcn_bias, dpooled, partial, ds, dbias, b, n, h, stream):
+    def coeff_bwd(self, cj, n_real, s, gcn_bias, dpooled, partial, ds, dbias, b, n, h, stream, dw_dense=None):
         c = s.shape[0]
         self._check(self.lib.feta_coeff_bwd(_p(cj), _p(n_real), _p(s), _p(gcn_bias), _p(dpooled),
-                                            _p(partial), _p(ds), _p(dbias), b, n, h, c, stream),
+                                            _p(partial), _p(ds), _p(dbias), _p(dw_dense),
+                                            0 if dw_dense is None else dw_dense.shape[0], b, n, h, c, stream),
                     'feta_coeff_bwd')
+
+    def colsum_multi(self, pairs, stream):
+        """pairs: [(in [R, C], out [C])] - all reduced by one launch."""
+        segs = (ColsumSeg * len(pairs))()
+        for sg, (x, out) in zip(segs, pairs):
+            sg.in_, sg.out, sg.R, sg.C, sg.ld = x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], x.stride(0)
+        self._check(self.lib.feta_colsum_multi(segs, len(pairs), stream), 'feta_colsum_multi')
 
     def colsum(self, x, out, stream):
         r, c = x.shape
@@ -341,21 +341,6 @@ class Abi:
 
     def attn_block_launch(self, desc, stream):
         self._check(self.lib.feta_attn_block_fwd(C.byref(desc), stream), 'feta_attn_block_fwd')
-
-    def attn_block_bwd_supported(self, n, d_model, heads):
-        return bool(self.lib.feta_attn_block_bwd_supported(n, d_model, heads))
-
-    def attn_block_bwd_desc(self, b, n, scale, Gs, seq_first=True, **ptrs):
-        d = AttnBlockBwd()
-        d.B, d.N, d.M, d.scale, d.Gs = b, n, b * n, scale, Gs
-        d.row_sb, d.row_sn = (1, b) if seq_first else (n, 1)
-        for k, t in ptrs.items():
-            if t is not None:
-                setattr(d, k, t.data_ptr())
-        return d
-
-    def attn_block_bwd(self, desc, stream):
-        self._check(self.lib.feta_attn_block_bwd(C.byref(desc), stream), 'feta_attn_block_bwd')
 
     def ffn_supported(self, d_model, ff):
         return bool(self.lib.feta_ffn_supported(d_model, ff))

@@ -244,6 +244,57 @@ int launch_colsum(const float* in, float* out, int R, int C, hipStream_t stream)
   return launch_colsum_strided(in, out, R, C, C, stream);
 }
 
+// Several independent column sums in ONE launch (every launch of a captured step costs ~4.5 us, whatever
+// its size): workgroup -> (segment, 16-column tile) through the prefix of tile counts; same tree as
+// colsum_kernel.  A segment may also write its result to every row of a dense [bcast_rows][C] matrix: the
+// gradient of a parameter that only ever multiplies an all-ones input (every row equal).
+struct ColsumSegs {
+  feta_colsum_seg seg[FETA_COLSUM_MAX_SEGS];
+  int tile_end[FETA_COLSUM_MAX_SEGS];   // exclusive prefix end of each segment's tiles
+  int nseg;
+};
+
+__global__ __launch_bounds__(kCsCols * kCsSlices) void colsum_multi_kernel(ColsumSegs a) {
+  float* red = feta_lds;  // [slices][cols]
+  int si = 0;
+  while (si + 1 < a.nseg && (int)blockIdx.x >= a.tile_end[si]) ++si;
+  const feta_colsum_seg sg = a.seg[si];
+  const int tile = (int)blockIdx.x - (si > 0 ? a.tile_end[si - 1] : 0);
+  const int lc = threadIdx.x & (kCsCols - 1);
+  const int slice = threadIdx.x / kCsCols;
+  const int col = tile * kCsCols + lc;
+  const int ld = sg.ld > 0 ? sg.ld : sg.C;
+  float acc = 0.0f;
+  if (col < sg.C)
+    for (int r = slice; r < sg.R; r += kCsSlices) acc += sg.in[(int64_t)r * ld + col];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int half = kCsSlices / 2; half >= 1; half >>= 1) {
+    if (slice < half) red[threadIdx.x] += red[threadIdx.x + half * kCsCols];
+    __syncthreads();
+  }
+  if (col < sg.C) {
+    const float v = red[lc];
+    if (slice == 0) sg.out[col] = v;
+    if (sg.bcast_out != nullptr)
+      for (int r = slice; r < sg.bcast_rows; r += kCsSlices) sg.bcast_out[(int64_t)r * sg.C + col] = v;
+  }
+}
+
+int launch_colsum_multi(const feta_colsum_seg* segs, int nseg, hipStream_t stream) {
+  ColsumSegs a{};
+  a.nseg = nseg;
+  int tiles = 0;
+  for (int i = 0; i < nseg; ++i) {
+    a.seg[i] = segs[i];
+    tiles += (segs[i].C + kCsCols - 1) / kCsCols;
+    a.tile_end[i] = tiles;
+  }
+  auto kern = colsum_multi_kernel;
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(kCsCols * kCsSlices), kCsCols * kCsSlices * sizeof(float), stream, a);
+  return check_launch("feta_colsum_multi");
+}
+
 }  // namespace feta
 
 using namespace feta;
@@ -268,9 +319,19 @@ extern "C" int feta_coeff_bwd_groups(int B, int H) {
   return t < kCoeffGroupsMax ? t : kCoeffGroupsMax;
 }
 
+extern "C" int feta_colsum_multi(const feta_colsum_seg* segs, int nseg, feta_stream_t stream) {
+  FETA_REQUIRE(segs != nullptr && nseg >= 1 && nseg <= FETA_COLSUM_MAX_SEGS, "colsum_multi: 1..%d segments",
+               FETA_COLSUM_MAX_SEGS);
+  for (int i = 0; i < nseg; ++i)
+    FETA_REQUIRE(segs[i].in && segs[i].out && segs[i].R > 0 && segs[i].C > 0 && (segs[i].ld == 0 || segs[i].ld >= segs[i].C) &&
+                 (segs[i].bcast_out == nullptr || segs[i].bcast_rows > 0), "colsum_multi: bad segment %d", i);
+  return launch_colsum_multi(segs, nseg, (hipStream_t)stream);
+}
+
 extern "C" int feta_coeff_bwd(const float* cj, const int32_t* n_real, const float* s,
                               const float* gcn_bias, const float* dpooled, float* partial, float* ds,
-                              float* dbias, int B, int N, int H, int C, feta_stream_t stream) {
+                              float* dbias, float* dw_dense, int dw_rows, int B, int N, int H, int C,
+                              feta_stream_t stream) {
   FETA_REQUIRE(cj && n_real && s && gcn_bias && dpooled && partial && ds && dbias,
                "coeff_bwd: null pointer");
   FETA_REQUIRE(B > 0 && H > 0 && C > 0 && N > 0, "coeff_bwd: empty shape");
@@ -281,6 +342,12 @@ extern "C" int feta_coeff_bwd(const float* cj, const int32_t* n_real, const floa
                      gcn_bias, dpooled, partial, B, N, H, C, G);
   int rc = check_launch("feta_coeff_bwd");
   if (rc != FETA_OK) return rc;
+  if (dw_dense != nullptr) {
+    // one launch: ds (also written to every row of the dense [dw_rows][C] weight gradient) and dbias
+    FETA_REQUIRE(dw_rows > 0, "coeff_bwd: dw_dense needs dw_rows");
+    feta_colsum_seg segs[2] = {{partial, ds, G, C, 2 * C, dw_dense, dw_rows}, {partial + C, dbias, G, C, 2 * C, nullptr, 0}};
+    return launch_colsum_multi(segs, 2, (hipStream_t)stream);
+  }
   if (dbias == ds + C)  // contiguous outputs: one reduction launch for both
     return launch_colsum(partial, ds, G, 2 * C, (hipStream_t)stream);
   // separate outputs: reduce the two interleaved halves one after the other

@@ -865,7 +865,7 @@ extern "C" int feta_debug_rowlin_stamps(unsigned long long* out32) {
 extern "C" int feta_rowlin_bwd_ex(const feta_rowlin_ex* d, float* dwdb, feta_stream_t stream) {
   FETA_REQUIRE(d != nullptr, "rowlin_bwd_ex: null descriptor");
   const RowLinArgs& a = *d;
-  // dx == NULL: weight / bias gradient only (the dX chain ran elsewhere: feta_attn_block_bwd)
+  // dx == NULL: weight / bias gradient only (the dX chain ran elsewhere)
   FETA_REQUIRE(a.x && a.w && a.dy && a.partial && a.M > 0, "rowlin_bwd: null pointer / empty");
   FETA_REQUIRE(a.dx || (!a.add_plain && !a.add_dout && !a.sum_out && !a.dx2), "rowlin_bwd: dW-only launch with dX epilogue operands");
   FETA_REQUIRE(dwdb || a.partial_ld > 0, "rowlin_bwd: dwdb may only be NULL with a caller-reduced partial_ld");

@@ -120,9 +120,11 @@ class FilterCoefficientsFn(torch.autograd.Function):
         partial = torch.empty((groups, 2, c), dtype=torch.float32, device=cj.device)
         dsdb = torch.empty((2, c), dtype=torch.float32, device=cj.device)   # contiguous: one reduction
         ds, db = dsdb[0], dsdb[1]
-        abi.coeff_bwd(cj, n_real, s, gb, dpooled.contiguous(), partial, ds, db, b, n, h, stream)
-        # s = 1^T W  =>  every row of dW equals ds
-        return None, None, ds.unsqueeze(0).expand(rows, c), db
+        # s = 1^T W  =>  every row of dW equals ds: the reduction launch writes the dense rows itself (an
+        # expanded view would be copied into a dense .grad by autograd: one more 4 MB kernel per step)
+        dw = torch.empty((rows, c), dtype=torch.float32, device=cj.device)
+        abi.coeff_bwd(cj, n_real, s, gb, dpooled.contiguous(), partial, ds, db, b, n, h, stream, dw_dense=dw)
+        return None, None, dw, db
 
 
 class DenseLinearFn(torch.autograd.Function):
@@ -187,6 +189,69 @@ class _FilterFn(torch.autograd.Function):
             dbias = torch.empty(dh, dtype=torch.float32, device=xs.device)
             abi.colsum(dbp, dbias, stream)
         return dx, dcoeff, dbias, None, None, None, None, None, None, None
+
+
+class FilterFromPooledFn(torch.autograd.Function):
+    """``self.linear`` of the coefficient generator (transformer/models.py:284) and the dynamic filter
+    (transformer/models.py:346-360, transformer/ChebNetDynamic.py:132-189) as ONE autograd node:
+    coeff = pooled W_lin^T + b_lin (rocBLAS), y = filter(x; coeff).  -> (y, coeff [H*B, C]).
+    Same kernels as DenseLinearFn + _FilterFn; what the merge buys is one reduction launch for both bias
+    gradients (colsum of the per-block filter-bias partials and colsum of dcoeff = the gradient of b_lin become
+    available together) instead of two, and no dcoeff hand-over through autograd."""
+
+    @staticmethod
+    def forward(ctx, x, pooled, lin_w, lin_b, bias, n_real, g0, g1, mode, order, share, batch_first):
+        abi, stream = _lib.backend(x, pooled)
+        b, n, h, dh = x.shape
+        xs = _dense_like(x, batch_first)
+        coeff = torch.addmm(lin_b, pooled, lin_w.t())
+        y = _new_token(b, n, h, dh, batch_first, x)
+        if mode == 'cheb':
+            abi.cheb_filter_fwd(xs, g0, coeff, bias, n_real, y, order, share, stream)
+        else:
+            abi.spec_filter_fwd(xs, g0, g1, coeff, bias, n_real, y, order, share, stream)
+        ctx.save_for_backward(xs, coeff, pooled, lin_w, n_real, g0, g1)
+        ctx.cfg = (mode, order, share, batch_first, bias is not None)
+        ctx.set_materialize_grads(False)
+        return y, coeff
+
+    @staticmethod
+    def backward(ctx, dy, dcoeff_ext):
+        xs, coeff, pooled, lin_w, n_real, g0, g1 = ctx.saved_tensors
+        mode, order, share, batch_first, has_bias = ctx.cfg
+        abi, stream = _lib.backend(xs)
+        b, n, h, dh = xs.shape
+        if dy is None:      # only the coefficients were used downstream
+            dx, dbias = None, None
+            dcoeff = dcoeff_ext.contiguous()
+            db_lin = torch.empty(dcoeff.shape[1], dtype=torch.float32, device=xs.device)
+            abi.colsum(dcoeff, db_lin, stream)
+        else:
+            dys = _dense_like(dy, batch_first)
+            dx = _new_token(b, n, h, dh, batch_first, xs)
+            dcoeff = torch.empty_like(coeff)
+            dbp = torch.empty((b * h, dh), dtype=torch.float32, device=xs.device)
+            if mode == 'cheb':
+                abi.cheb_filter_bwd(xs, g0, coeff, n_real, dys, dx, dcoeff, dbp, order, share, stream)
+            else:
+                abi.spec_filter_bwd(xs, g0, g1, coeff, n_real, dys, dx, dcoeff, dbp, order, share, stream)
+            if dcoeff_ext is not None:   # a regulariser on the coefficients (transformer/models.py:554-584)
+                dcoeff += dcoeff_ext
+            both = torch.empty(dh + dcoeff.shape[1], dtype=torch.float32, device=xs.device)
+            dbias, db_lin = both[:dh], both[dh:]
+            abi.colsum_multi([(dbp, dbias), (dcoeff, db_lin)], stream)
+            if not has_bias:
+                dbias = None
+        return (dx, dcoeff.mm(lin_w), dcoeff.t().mm(pooled), db_lin, dbias) + (None,) * 7
+
+
+def filter_from_pooled(x, pooled, lin_w, lin_b, bias, n_real, graph, mode, order, heads_share_graph=False,
+                       batch_first=False):
+    """x [B,N,H,dh] view, pooled [H*B, C] -> (y, coeff [H*B, C]); graph = (lhat,) | (u, lam)."""
+    g0 = graph[0].contiguous()
+    g1 = graph[1].contiguous() if len(graph) > 1 else None
+    return FilterFromPooledFn.apply(x, pooled, lin_w, lin_b, bias, n_real, g0, g1, mode, order,
+                                    bool(heads_share_graph), batch_first)
 
 
 class RowLinearFn(torch.autograd.Function):

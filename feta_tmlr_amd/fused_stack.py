@@ -37,13 +37,6 @@ PER_LAYER = 12  # tensors per layer in the flat parameter list
 # FETA_ATTN_BLOCK=0 keeps the three-launch sequence (A/B timing, fallback for other shapes)
 USE_ATTN_BLOCK = os.environ.get('FETA_ATTN_BLOCK', '1') != '0'
 USE_FFN_FUSED = os.environ.get('FETA_FFN_FUSED', '1') != '0'
-# backward of the attention sub-block: dX chain (BN1 backward -> out_proj -> attention -> in_proj) in one
-# launch + two dW-only launches (csrc/block_bwd.hip) instead of three dX+dW launches.  OFF by default:
-# measured slower at every batch size (0.412 vs 0.385 ms/step at B=128, -2 % at B=8192) - one wave per
-# head serialises 3.4 k VALU + 444 MFMA instructions that the three-launch path spreads over the chip,
-# and the dW-only launches lose the overlap with the dX roles.  Kept, tested, for a wider decomposition.
-USE_ATTN_BLOCK_BWD = os.environ.get('FETA_ATTN_BLOCK_BWD', '0') != '0'
-
 
 def layer_params(layer):
     a = layer.self_attn
@@ -237,7 +230,6 @@ class FusedEncoderStackFn(torch.autograd.Function):
             d_final = torch.zeros(n, b, d, dtype=torch.float32, device=dev)
         dcur = d_final.contiguous().view(m, d)
         gs, Gs_cur = new(G, 2, d), G
-        chain = USE_ATTN_BLOCK_BWD and not tie and abi.attn_block_bwd_supported(n, d, heads)
         abi.bn_bwd_reduce(saved[-1]['y2'], dcur, saved[-1]['prm2'], gs, stream)
         for li in range(nl - 1, -1, -1):
             s = saved[li]
@@ -262,74 +254,46 @@ class FusedEncoderStackFn(torch.autograd.Function):
                                 partial_ptr=pp, partial_ld=total, add_dout=dcur, add_y=s['y2'],
                                 add_bn=s['prm2'], add_fin=fin2, sum_y=s['y1'], sum_bn=s['prm1'], sum_out=gs1)
             abi.rowlin_bwd_ex(dsc, None, stream)
-            if chain:
-                # B3 + B4 + B5 dX chain in one launch; the two weight gradients as dW-only launches
-                fin1, dg1, db1 = new(2, d), bn_tail[li, 0], bn_tail[li, 1]
-                dqkv, dx0 = new(m, 3 * d), new(m, d)
-                gs_prev = new(b, 2, d) if li > 0 else None
-                d2 = d_concat_last.contiguous().view(m, d) if (li == nl - 1 and d_concat_last is not None) else None
-                dsc = abi.attn_block_bwd_desc(b, n, scale, G, dy=dx1, y1=s['y1'], bn1=s['prm1'], g_sum=gs1,
-                                              fin_out=fin1, dgamma=dg1, dbeta=db1, rowscale=degree_rows,
-                                              w_out=w_o, w_in=w_in, qkv=s['qkv'], out=s['out'], dout2=d2,
-                                              pe=pe_c, n_real=n_real, attn_stats=s['ast'],
-                                              x0=(s['x0'] if li > 0 else None), bn0=s['prm0'], dqkv=dqkv,
-                                              dx=dx0, sum_out=gs_prev)
-                abi.attn_block_bwd(dsc, stream)
-                grads[base + 4], grads[base + 5] = dg1, db1
-                pp, off = wslot(d, d)
-                slots[base + 2] = (off, d, d)
-                dsc = abi.rowlin_ex(m, d, d, x=s['out'].view(m, d), w=w_o, dy=dx1, rowscale=degree_rows,
-                                    partial_ptr=pp, partial_ld=total, g_y=s['y1'], g_bn=s['prm1'], g_fin=fin1)
-                abi.rowlin_bwd_ex(dsc, None, stream)
-                pp, off = wslot(3 * d, d)
-                slots[base + 0] = (off, 3 * d, d)
-                dsc = abi.rowlin_ex(m, d, 3 * d, x=s['x0'], x_bn=s['prm0'], w=w_in, dy=dqkv,
-                                    partial_ptr=pp, partial_ld=total)
-                abi.rowlin_bwd_ex(dsc, None, stream)
-                Gs_next = b
-                if gs_prev is not None:
-                    gs_prev, Gs_next = _cap_partials(abi, stream, gs_prev, new)
-            else:
-                # B3: out_proj backward, gradient = degree * BN1 backward of dx1
-                dconcat = new(m, d)
-                fin1, dg1, db1 = new(2, d), bn_tail[li, 0], bn_tail[li, 1]
-                pp, off = wslot(d, d)
-                slots[base + 2] = (off, d, d)
-                dsc = abi.rowlin_ex(m, d, d, x=s['out'].view(m, d), w=w_o, dy=dx1, rowscale=degree_rows, dx=dconcat,
-                                    partial_ptr=pp, partial_ld=total, g_y=s['y1'], g_bn=s['prm1'], g_sum=gs1, Gs=G,
-                                    g_fin_out=fin1, dgamma=dg1, dbeta=db1)
-                abi.rowlin_bwd_ex(dsc, None, stream)
-                grads[base + 4], grads[base + 5] = dg1, db1
-                dout2 = None
-                if li == nl - 1 and d_concat_last is not None:
-                    if abi.attn_bwd_takes_dout2(n, dh):   # added inside the kernel's loads
-                        dout2 = d_concat_last.contiguous().view(n, b, heads, dh).permute(1, 0, 2, 3)
-                    else:
-                        dconcat = dconcat + d_concat_last.contiguous().view(m, d)
-                # B4: attention backward
-                q, k, v = _views(s['qkv'], n, b, heads, dh)
-                if tie:
-                    k = q
-                dqkv = new(m, 3 * d)
-                dq, dk, dv = _views(dqkv, n, b, heads, dh)
-                delta = new(b, heads, n)
-                abi.attn_bwd(q, k, v, pe_c, n_real, s['out'].permute(1, 0, 2, 3),
-                             dconcat.view(n, b, heads, dh).permute(1, 0, 2, 3), s['ast'], delta, dq, dk, dv, scale,
-                             stream, dout2=dout2)
-                if tie:
-                    dqkv[:, :d] += dqkv[:, d:2 * d]
-                    dqkv[:, d:2 * d] = 0
-                # B5: in_proj backward (+ residual BN1 backward, + sums for the previous layer's BN2)
-                dx0 = new(m, d)
-                pp, off = wslot(3 * d, d)
-                slots[base + 0] = (off, 3 * d, d)
-                gs_prev = new(G, 2, d) if li > 0 else None
-                dsc = abi.rowlin_ex(m, d, 3 * d, x=s['x0'], x_bn=s['prm0'], w=w_in, dy=dqkv, dx=dx0,
-                                    partial_ptr=pp, partial_ld=total, add_dout=dx1, add_y=s['y1'],
-                                    add_bn=s['prm1'], add_fin=fin1, sum_y=(s['x0'] if li > 0 else None),
-                                    sum_bn=s['prm0'], sum_out=gs_prev)
-                abi.rowlin_bwd_ex(dsc, None, stream)
-                Gs_next = G
+            # B3: out_proj backward, gradient = degree * BN1 backward of dx1
+            dconcat = new(m, d)
+            fin1, dg1, db1 = new(2, d), bn_tail[li, 0], bn_tail[li, 1]
+            pp, off = wslot(d, d)
+            slots[base + 2] = (off, d, d)
+            dsc = abi.rowlin_ex(m, d, d, x=s['out'].view(m, d), w=w_o, dy=dx1, rowscale=degree_rows, dx=dconcat,
+                                partial_ptr=pp, partial_ld=total, g_y=s['y1'], g_bn=s['prm1'], g_sum=gs1, Gs=G,
+                                g_fin_out=fin1, dgamma=dg1, dbeta=db1)
+            abi.rowlin_bwd_ex(dsc, None, stream)
+            grads[base + 4], grads[base + 5] = dg1, db1
+            dout2 = None
+            if li == nl - 1 and d_concat_last is not None:
+                if abi.attn_bwd_takes_dout2(n, dh):   # added inside the kernel's loads
+                    dout2 = d_concat_last.contiguous().view(n, b, heads, dh).permute(1, 0, 2, 3)
+                else:
+                    dconcat = dconcat + d_concat_last.contiguous().view(m, d)
+            # B4: attention backward
+            q, k, v = _views(s['qkv'], n, b, heads, dh)
+            if tie:
+                k = q
+            dqkv = new(m, 3 * d)
+            dq, dk, dv = _views(dqkv, n, b, heads, dh)
+            delta = new(b, heads, n)
+            abi.attn_bwd(q, k, v, pe_c, n_real, s['out'].permute(1, 0, 2, 3),
+                         dconcat.view(n, b, heads, dh).permute(1, 0, 2, 3), s['ast'], delta, dq, dk, dv, scale,
+                         stream, dout2=dout2)
+            if tie:
+                dqkv[:, :d] += dqkv[:, d:2 * d]
+                dqkv[:, d:2 * d] = 0
+            # B5: in_proj backward (+ residual BN1 backward, + sums for the previous layer's BN2)
+            dx0 = new(m, d)
+            pp, off = wslot(3 * d, d)
+            slots[base + 0] = (off, 3 * d, d)
+            gs_prev = new(G, 2, d) if li > 0 else None
+            dsc = abi.rowlin_ex(m, d, 3 * d, x=s['x0'], x_bn=s['prm0'], w=w_in, dy=dqkv, dx=dx0,
+                                partial_ptr=pp, partial_ld=total, add_dout=dx1, add_y=s['y1'],
+                                add_bn=s['prm1'], add_fin=fin1, sum_y=(s['x0'] if li > 0 else None),
+                                sum_bn=s['prm0'], sum_out=gs_prev)
+            abi.rowlin_bwd_ex(dsc, None, stream)
+            Gs_next = G
             dcur, gs, Gs_cur = dx0, gs_prev, Gs_next
         assert cursor[0] == total
         abi.colsum(part_all, dwdb_all[:total], stream)

@@ -162,21 +162,28 @@ class HybridGradAllReduce:
             g = p.grad
             if g is None:
                 continue
+            full = None
             if g.dim() == 2 and g.stride(0) == 0:
                 g = g[0]            # broadcast row (d colsum(W) / dW): the one row IS the whole gradient
+            elif g.dim() == 2 and getattr(p, '_feta_row_constant', False) and g.shape[0] > 1:
+                if not g.is_contiguous():
+                    g = p.grad = g.contiguous()
+                full, g = g, g[0]   # dense gradient with identical rows: row 0 travels, finish() rewrites the rest
             elif not g.is_contiguous():
                 g = p.grad = g.contiguous()
-            works.append((dist.all_reduce(g, op=op, group=self.group, async_op=True), g))
+            works.append((dist.all_reduce(g, op=op, group=self.group, async_op=True), g, full))
         return works, (self.small.start() if self.small is not None else None)
 
     def finish(self, handle):
         if handle is None:
             return
         works, small = handle
-        for w, g in works:
+        for w, g, full in works:
             w.wait()
             if not self.avg_in_collective:
                 g.mul_(1.0 / self.world_size)
+            if full is not None:
+                full[1:].copy_(g.unsqueeze(0).expand(full.shape[0] - 1, -1))
         if self.small is not None:
             self.small.finish(small)
 

@@ -28,9 +28,6 @@ from .data import GraphBatchCache
 from .layers import DiffTransformerEncoderLayer, clone_layers, linear_rows, n_real_from_mask
 
 
-_SIDE_STREAMS = {}   # one auxiliary HIP stream per device (kept out of the modules: not picklable)
-
-
 class DenseGCNParams(nn.Module):
     """Parameters of the reference's ``self.gcn = GCNConv(C, C)`` (transformer/models.py:144):
     ``weight [in, out]`` glorot, ``bias [out]`` zeros (vendored text transformer/GenGCN.py:340-356).
@@ -102,8 +99,6 @@ class DiffTransformerEncoderGenGCN(nn.Module):
         self.spectral_k = None    # eigenpairs kept when the eigenbasis is computed here (None: all N_pad)
         self.fused_stack = True   # layer stacks (BatchNorm or LayerNorm) run as one autograd node when the dims allow
         self.keep_stack_boundary = False   # set by trainers that use backward_head / backward_stack
-        self.coeff_side_stream = False     # second-stream coefficient generator: measured SLOWER (0.505 vs 0.488 ms/step:
-                                           # the fork/join edges of the hipGraph cost more than the overlap buys)
         self._stack_boundary = None
         self._stack_grads = None
 
@@ -114,8 +109,6 @@ class DiffTransformerEncoderGenGCN(nn.Module):
         ignored there as well, :248-249)."""
         if n_real is None:
             n_real = n_real_from_mask(masks)
-        if self.coeff_side_stream and attn_weights.is_cuda:
-            return self._coefficients_on_side_stream(attn_weights, n_real)
         return self._coefficients(attn_weights, n_real)
 
     def _coefficients(self, attn_weights, n_real):
@@ -123,22 +116,22 @@ class DiffTransformerEncoderGenGCN(nn.Module):
         coeff = FF.dense_linear(pooled, self.linear.weight, self.linear.bias)    # :284
         return coeff.reshape(self.num_heads, attn_weights.shape[0], -1)          # :285
 
-    def _coefficients_on_side_stream(self, attn_weights, n_real):
-        """Same arithmetic on a second HIP stream.  Autograd runs a node's backward on the stream of
-        its forward, so the whole parameter-gradient chain of the generator (C x C GEMMs, the tanh
-        recompute, their reductions: ~60 us per step) leaves the critical path of backward and runs
-        beside the backward of the layer stack; under hipGraph capture the fork/join becomes two
-        branches of the graph."""
-        main = torch.cuda.current_stream()
-        side = _SIDE_STREAMS.get(attn_weights.device)
-        if side is None:
-            side = _SIDE_STREAMS[attn_weights.device] = torch.cuda.Stream(device=attn_weights.device)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            coeff = self._coefficients(attn_weights, n_real)
-        main.wait_stream(side)
-        coeff.record_stream(main)
-        return coeff
+    def _coefficients_and_filter(self, attn_weights, out_each_head, cache):
+        """get_filter_coefficients + filter of one layer (:173, :186-202) with ``self.linear`` folded into the
+        filter's autograd node (functional.FilterFromPooledFn).  -> (coeff [H,B,C], out_filtered [N,B,d])"""
+        bsz, n, h, dh = out_each_head.shape
+        pooled = FF.filter_coefficients(attn_weights.detach(), cache.n_real, self.gcn.weight, self.gcn.bias)
+        if self.filter_mode == 'cheb':
+            graph, mode = (cache.lhat,), 'cheb'
+        else:
+            if cache.u is None:
+                raise ValueError("filter_mode='spectral' needs graph_cache.u / graph_cache.lam "
+                                 '(collate(..., k_eig=K))')
+            graph, mode = (cache.u, cache.lam), 'spec'
+        y, coeff = FF.filter_from_pooled(out_each_head, pooled, self.linear.weight, self.linear.bias,
+                                         self.spectral_gnns.bias, cache.n_real, graph, mode, self.order,
+                                         self.heads_share_graph)
+        return coeff.reshape(h, bsz, -1), y.permute(1, 0, 2, 3).reshape(n, bsz, h * dh)
 
     # -- A3 ---------------------------------------------------------------------------------
     def filter(self, coeff_all_heads, out_each_head, cache):
@@ -251,9 +244,12 @@ class DiffTransformerEncoderGenGCN(nn.Module):
                                                   need_weights=filt, degree_rows=degree_rows)
             if not filt:
                 continue
-            coeff_all_heads = self.get_filter_coefficients(attn, masks=src_key_padding_mask,
-                                                           n_real=cache.n_real)   # :173
-            out_filtered = self.filter(coeff_all_heads, out_each_head, cache)     # :186-202
+            if self.learn_only_filter_order_coeff or self.linear.bias is None:
+                coeff_all_heads = self.get_filter_coefficients(attn, masks=src_key_padding_mask,
+                                                               n_real=cache.n_real)   # :173
+                out_filtered = self.filter(coeff_all_heads, out_each_head, cache)     # :186-202
+            else:
+                coeff_all_heads, out_filtered = self._coefficients_and_filter(attn, out_each_head, cache)
             coefficients.append(coeff_all_heads)                                  # :198
             if self.use_skip_conn and allout_filtered is not None:
                 allout_filtered = allout_filtered + out_filtered                  # :209-213

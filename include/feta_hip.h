@@ -98,15 +98,29 @@ int feta_coeff_fwd(const float* attn, const int32_t* n_real,
 
 /* ds[c] = sum_{blk,j} dpooled*(1-z^2)*c_j/n ; dbias[c] likewise without c_j.
  * partial [G, 2, C] scratch with G = feta_coeff_bwd_groups(B,H); when dbias == ds + C both are
- * reduced by one launch. */
+ * reduced by one launch.  dw_dense (nullable) [dw_rows, C]: the gradient of gcn.weight itself - s = 1^T W,
+ * so every row of dW equals ds; the reduction launch writes the rows (no broadcast copy afterwards). */
 int feta_coeff_bwd_groups(int B, int H);
 int feta_coeff_bwd(const float* cj, const int32_t* n_real,
                    const float* s, const float* gcn_bias, const float* dpooled,
-                   float* partial, float* ds, float* dbias,
+                   float* partial, float* ds, float* dbias, float* dw_dense, int dw_rows,
                    int B, int N, int H, int C, feta_stream_t stream);
 
 /* out[c] = sum_r in[r, c]  (s = colsum(gcn.weight); also reduces per-block partials) */
 int feta_colsum(const float* in, float* out, int R, int C, feta_stream_t stream);
+
+/* Several independent column sums in one launch (bias gradients that become available together):
+ * out[c] = sum_r in[r*ld + c], r < R, c < C (ld = 0: C); bcast_out (nullable) [bcast_rows, C] additionally
+ * receives the result in every row. */
+#define FETA_COLSUM_MAX_SEGS 8
+typedef struct feta_colsum_seg {
+  const float* in;
+  float* out;
+  int R, C, ld;
+  float* bcast_out;
+  int bcast_rows;
+} feta_colsum_seg;
+int feta_colsum_multi(const feta_colsum_seg* segs, int nseg, feta_stream_t stream);
 
 /* ---- A3: dynamic Chebyshev filter, direct recursion on a dense scaled Laplacian ----
  * Replaces ChebConvDynamic.forward + __norm__ (transformer/ChebNetDynamic.py:108-189)
@@ -309,46 +323,6 @@ typedef struct feta_attn_block {
 
 int feta_attn_block_supported(int N, int d_model, int heads);
 int feta_attn_block_fwd(const feta_attn_block* d, feta_stream_t stream);
-
-/* ---- backward of the attention sub-block, dX chain in ONE launch -------------------------------
- * (feta_attn_block_bwd_supported: d_model = 64, 4 heads, N <= 48.)  dy is the gradient w.r.t. the
- * output of BatchNorm 1; the kernel applies that BatchNorm's backward itself (y1, bn1 [4][64], partial
- * sums g_sum [Gs][2][64] of (dy, dy*xhat)), publishing fin_out [2][64] = (m1, m2), dgamma, dbeta; then
- * dconcat = rowscale * g0 W_out (+ dout2), the attention backward (dq|dk|dv -> dqkv [M,192]) and
- * dx = dqkv W_in + g0 [M,64]; sum_out [B][2][64] (optional) = per-graph (sum dx, sum dx * xhat0) with
- * xhat0 from x0 and bn0, for the BatchNorm-2 backward of the previous layer.
- * The weight gradients of out_proj / in_proj are computed by dW-only feta_rowlin_bwd_ex launches
- * (dx = NULL) from dqkv and fin_out.  Rows are addressed as in feta_attn_block. */
-typedef struct feta_attn_block_grad {
-  const float* dy;
-  const float* y1;
-  const float* bn1;
-  const float* g_sum;
-  int Gs;
-  float* fin_out;
-  float* dgamma;
-  float* dbeta;
-  const float* rowscale;
-  const float* w_out;
-  const float* w_in;
-  const float* qkv;
-  const float* out;
-  const float* dout2;
-  const float* pe;
-  const int32_t* n_real;
-  const float* attn_stats;
-  const float* x0;
-  const float* bn0;
-  float* dqkv;
-  float* dx;
-  float* sum_out;
-  float scale;
-  int B, N, M;
-  int64_t row_sb, row_sn;
-} feta_attn_block_grad;
-
-int feta_attn_block_bwd_supported(int N, int d_model, int heads);
-int feta_attn_block_bwd(const feta_attn_block_grad* d, feta_stream_t stream);
 
 /* ---- feed-forward half of one encoder layer in ONE launch -----------------------------------
  * x = BN1(y1) (x_bn | x_stats as in feta_rowlin_ex / feta_attn_block);  h = relu(x W1^T + b1);

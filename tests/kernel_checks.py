@@ -156,6 +156,21 @@ def check_coeff(abi, dev, stream, bsz, n, h, c, seed=0, zero_diag=True, faithful
     assert maxdiff(gw.grad, gw.grad[0:1].expand_as(gw.grad)) < 1e-12
     errs['ds'] = assert_close('ds', ds, gw.grad[0])
     errs['dbias'] = assert_close('dgcn_bias', db, gb.grad)
+    # the same call writing the dense gradient of gcn.weight (every row = ds) in its reduction launch
+    ds2 = torch.full((c,), float('nan'), device=dev)
+    db2 = torch.full((c,), float('nan'), device=dev)
+    dw = torch.full((c + 3, c), float('nan'), device=dev)
+    abi.coeff_bwd(cj, nbd, s, gb32, dp.float().to(dev), partial, ds2, db2, bsz, n, h, stream, dw_dense=dw)
+    assert torch.equal(ds2, ds) and torch.equal(db2, db)
+    assert torch.equal(dw, ds.unsqueeze(0).expand_as(dw))
+    # several column sums in one launch
+    a1 = torch.randn(37, 16, generator=g).to(dev)
+    a2 = torch.randn(11, c, generator=g).to(dev)
+    a3 = torch.randn(70, 2 * c, generator=g).to(dev)[:, :c]      # strided rows
+    o1, o2, o3 = (torch.full((t.shape[1],), float('nan'), device=dev) for t in (a1, a2, a3))
+    abi.colsum_multi([(a1, o1), (a2, o2), (a3, o3)], stream)
+    for t, o in ((a1, o1), (a2, o2), (a3, o3)):
+        assert_close('colsum_multi', o, t.double().sum(0))
     return errs
 
 

@@ -139,7 +139,8 @@ def _worker_inplace(rank, world, port, ret, batch_norm):
                 r_stack = FlatBufferAllReduce(enc.stack_flat_grad, world)
                 o, _, _ = enc(src, pe, edge_index, fi, batch, **kw)
                 enc.backward_head(o, dout)
-                assert enc.gcn.weight.grad.stride(0) == 0     # the broadcast row: only it travels
+                gw = enc.gcn.weight.grad      # dense, every row equal: row 0 travels, finish() rewrites the rest
+                assert gw.is_contiguous() and torch.equal(gw, gw[0:1].expand_as(gw))
                 w1 = r_head.start()
                 enc.backward_stack()
                 flat = enc.stack_flat_grad()
@@ -149,6 +150,8 @@ def _worker_inplace(rank, world, port, ret, batch_norm):
                 w2 = r_stack.start()
                 r_head.finish(w1)
                 r_stack.finish(w2)
+                gw = enc.gcn.weight.grad
+                assert torch.equal(gw, gw[0:1].expand_as(gw))
         out[mode] = _full_grads(enc)
     ret[rank] = (out['packed'], out['inplace'])
     dist.barrier()
