@@ -70,49 +70,6 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
   }
   if (a.b_in != nullptr) bin1 = a.b_in[2 * D + DH * h + lq];
   if (a.b_out != nullptr) bo = *reinterpret_cast<const float4*>(a.b_out + DH * h + 4 * g);
-  // ---- requests of a graph: node count, node rows, pe, degree.  The first graph's are issued HERE, in front of the
-  // weight requests, so that one memory round trip covers everything the workgroup needs before it can start (they
-  // used to follow the weight staging and the statistics: two more dependent round trips of ~2.5 k cycles each);
-  // indices are clamped, so nothing depends on the node count, which is only used for masks later
-  int n = 0;
-  float4 xv[NT];
-  const bool has_pe = a.pe != nullptr;
-  float pv[NT][NT][4];
-  float rsv[NT];
-  auto load_graph = [&](int b) {
-    n = a.n_real[b];
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const int idx = tid + kRowThreads * i, node = idx >> 4, q = idx & 15;
-      const int64_t row = (int64_t)b * a.row_sb + (int64_t)min(node, a.N - 1) * a.row_sn;
-      xv[i] = *reinterpret_cast<const float4*>(a.x + row * D + 4 * q);
-    }
-    // pe values of this lane's (query, key) pairs and the degree scale: used after the projections
-#pragma unroll
-    for (int qb = 0; qb < NT; ++qb) {
-      const int qc = min(16 * qb + lq, a.N - 1);
-      rsv[qb] = a.rowscale != nullptr ? a.rowscale[(int64_t)b * a.row_sb + (int64_t)qc * a.row_sn] : 1.0f;
-    }
-    if (has_pe) {   // one uniform branch around all the requests (a select per element compiles to a branch per load)
-#pragma unroll
-      for (int qb = 0; qb < NT; ++qb) {
-        const int qc = min(16 * qb + lq, a.N - 1);
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            pv[qb][kt][r] = a.pe[((int64_t)b * a.N + qc) * a.N + min(16 * kt + 4 * g + r, a.N - 1)];
-      }
-    } else {
-#pragma unroll
-      for (int qb = 0; qb < NT; ++qb)
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) pv[qb][kt][r] = 1.0f;
-    }
-  };
-  load_graph(blockIdx.x);
   {  // 256 rows of 16 float4 (W_in then W_out), 16 per thread: all loads, then all LDS writes
     float4 wv[16];
 #pragma unroll
@@ -157,11 +114,32 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
   }
   bool first = true;
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-  if (!first) {
-    __syncthreads();   // the tiles of the previous graph have been consumed
-    load_graph(b);
-  }
+  const int n = a.n_real[b];
+  if (!first) __syncthreads();   // the tiles of the previous graph have been consumed
   first = false;
+  // ---- requests of this graph: node rows, pe, degree -------------------------------------------------------
+  float4 xv[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int idx = tid + kRowThreads * i, node = idx >> 4, q = idx & 15;
+    const int64_t row = (int64_t)b * a.row_sb + (int64_t)min(node, a.N - 1) * a.row_sn;
+    xv[i] = *reinterpret_cast<const float4*>(a.x + row * D + 4 * q);
+  }
+  // pe values of this lane's (query, key) pairs, degree scale and biases: requested now, used after the
+  // projections (stores to qkv / attn_stats in between would otherwise pin these loads behind them)
+  const bool has_pe = a.pe != nullptr;
+  float pv[NT][NT][4];
+  float rsv[NT];
+#pragma unroll
+  for (int qb = 0; qb < NT; ++qb) {
+    const int qc = min(16 * qb + lq, a.N - 1);
+    rsv[qb] = a.rowscale != nullptr ? a.rowscale[(int64_t)b * a.row_sb + (int64_t)qc * a.row_sn] : 1.0f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        pv[qb][kt][r] = has_pe ? a.pe[((int64_t)b * a.N + qc) * a.N + min(16 * kt + 4 * g + r, a.N - 1)] : 1.0f;
+  }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
