@@ -83,6 +83,10 @@ def parse(argv=None):
     ap.add_argument('--no-share-graph', action='store_true',
                     help='heads_share_graph=False: the reference-literal un-replicated edge_index '
                          '(transformer/models.py:186), heads >= 1 filtered with L_hat = 0')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                    help="storage dtype of the timed leg: 'f32' = the reference's arithmetic (the headline), 'bf16' = "
+                         'BASELINE configs 3 / 5: bf16 activations / pe / U / attn / per-block filter weights, bf16 MFMA, '
+                         'fp32 statistics and master weights, bf16 gradient bucket')
     ap.add_argument('--no-literal', action='store_true', help='skip the reference_literal leg')
     ap.add_argument('--layer-norm', action='store_true', help='LayerNorm instead of the ZINC default BatchNorm')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of one hipGraph per step')
@@ -149,10 +153,14 @@ def build_encoder(args, filter_mode=None, share=None):
     torch.manual_seed(0)
     layer = DiffTransformerEncoderLayer(args.dim, args.heads, 2 * args.dim, 0.0,
                                         batch_norm=not args.layer_norm)
-    return DiffTransformerEncoderGenGCN(args.dim, args.heads, layer, args.layers,
-                                        num_coefficients=args.order,
-                                        heads_share_graph=(not args.no_share_graph) if share is None else share,
-                                        filter_mode=args.filter_mode if filter_mode is None else filter_mode)
+    enc = DiffTransformerEncoderGenGCN(args.dim, args.heads, layer, args.layers,
+                                       num_coefficients=args.order,
+                                       heads_share_graph=(not args.no_share_graph) if share is None else share,
+                                       filter_mode=args.filter_mode if filter_mode is None else filter_mode)
+    if args.dtype == 'bf16' and enc.filter_mode == 'spectral':
+        from feta_tmlr_amd.transformer.layers import set_storage_dtype
+        set_storage_dtype(enc, torch.bfloat16)
+    return enc
 
 
 def _sync(dev):
@@ -164,7 +172,8 @@ def make_step(args, enc, gpu, world, dev):
     """-> step(): one forward + backward (+ gradient all-reduce for world > 1) of `enc` on the resident batch,
     as one hipGraph replay (two for the split backward) unless --no-graph / --dry-cpu."""
     params = [p for p in enc.parameters()]
-    two_phase = args.two_phase or world > 1
+    lowp = getattr(enc, 'storage_dtype', torch.float32) != torch.float32
+    two_phase = (args.two_phase or world > 1) and not lowp   # the split backward needs the fused (fp32) stack
     fwd_args = (gpu['src'], gpu['pe'], gpu['edge_index'], gpu['fi'], gpu['batch'])
     fwd_kw = dict(degree=gpu['degree'], src_key_padding_mask=gpu['mask'], graph_cache=gpu['cache'])
     use_graph = not args.no_graph and dev.type == 'cuda'
@@ -186,7 +195,8 @@ def make_step(args, enc, gpu, world, dev):
         return g.replay
 
     if not two_phase:
-        reducer = FlatGradAllReduce(params, world)   # fresh .grad per step, one flat bucket for RCCL
+        # fresh .grad per step, one flat bucket for RCCL (a bf16 wire bucket on the bf16 storage path)
+        reducer = FlatGradAllReduce(params, world, bucket_dtype=torch.bfloat16 if lowp else None)
 
         held = {}
 
@@ -531,7 +541,8 @@ def main(argv=None):
     log('timed region done: %.3f ms/step' % (dt / args.steps * 1e3))
 
     literal = None
-    if not args.no_literal and not args.dry_cpu and not (args.filter_mode == 'cheb' and args.no_share_graph):
+    if (not args.no_literal and not args.dry_cpu and args.dtype == 'f32'
+            and not (args.filter_mode == 'cheb' and args.no_share_graph)):
         # the reference-literal operator on the same batch, same parameters, timed the same way
         enc_lit = build_encoder(args, filter_mode='cheb', share=False).to(dev)
         enc_lit.train()
@@ -550,7 +561,7 @@ def main(argv=None):
             'metric': 'graphs/sec fwd+bwd, ZINC batch (N<=37,d=64,K=16)',
             'value': round(total_graphs / dt, 2), 'unit': 'graphs/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
             'data': 'synthetic',
             'config': {'workload': args.shape.upper() + '-shaped synthetic padded-graph batch, ChebConvDynamic block '
                                    '(attention + coefficient generator + spectral filter), fwd+bwd',
@@ -566,12 +577,15 @@ def main(argv=None):
         if args.dry_cpu:
             res['invalid'] = 'dry-cpu launcher rehearsal on the host emulation of the kernels: not a measurement'
             res['data'] = 'synthetic (dry-cpu)'
+        elif args.dtype != 'f32':
+            res['note'] = ('bf16 storage leg (BASELINE configs 3 / 5): general bf16 kernels + library bf16 GEMMs, not the '
+                           'fused fp32 stack; the headline line is --dtype f32')
         else:
             res['roofline'] = roofline(args, gpu, dev)
             if args.stream_batch > 0:
                 res['roofline_streaming'] = roofline_streaming(args, dev)
             log('roofline kernels timed')
-            if world == 1 and not args.no_cpu_baseline:
+            if world == 1 and not args.no_cpu_baseline and args.dtype == 'f32':
                 res['cpu_baseline'] = cpu_baseline(args, cpu, enc, args.filter_mode == 'spectral', share)
             if literal is not None:
                 if world == 1 and not args.no_cpu_baseline:

@@ -58,6 +58,15 @@ SIGNATURES = {
                               C.c_int, C.c_int, C.c_int, _S], C.c_int),
 }
 
+SIGNATURES.update({
+    'feta_attn_fwd_bf16': SIGNATURES['feta_attn_fwd'],
+    'feta_attn_bwd_bf16': ([_F, _F, _F, C.c_int64, C.c_int64, _F, _I, _F, _F, C.c_int64, C.c_int64,
+                            _F, _F, _F, _F, _F, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, _S], C.c_int),
+    'feta_spec_filter_fwd_bf16': SIGNATURES['feta_spec_filter_fwd'],
+    'feta_spec_filter_bwd_bf16': SIGNATURES['feta_spec_filter_bwd'],
+})
+
+
 class ColsumSeg(C.Structure):
     """struct feta_colsum_seg (include/feta_hip.h)."""
     _fields_ = [('in_', _F), ('out', _F), ('R', C.c_int), ('C', C.c_int), ('ld', C.c_int),
@@ -143,6 +152,12 @@ def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def _same_dtype(dtype, *tensors):
+    for t in tensors:
+        if t is not None and t.dtype != dtype:
+            raise TypeError('expected %s operands, got %s' % (dtype, t.dtype))
+
+
 def tok_strides(t):
     """(sb, sn) element strides of a token tensor given as a [B, N, H, dh] view whose
     last two dims are dense (stride dh, 1)."""
@@ -176,13 +191,19 @@ class Abi:
         sb, sn = tok_strides(q)
         assert tok_strides(k) == (sb, sn) and tok_strides(v) == (sb, sn)
         osb, osn = tok_strides(out)
+        if q.dtype == torch.bfloat16:
+            _same_dtype(torch.bfloat16, k, v, pe, out, attn)
+            self._check(self.lib.feta_attn_fwd_bf16(_p(q), _p(k), _p(v), sb, sn, _p(pe), _p(n_real),
+                                                    _p(out), osb, osn, _p(attn), _p(stats), scale,
+                                                    b, n, h, dh, stream), 'feta_attn_fwd_bf16')
+            return
         self._check(self.lib.feta_attn_fwd(_p(q), _p(k), _p(v), sb, sn, _p(pe), _p(n_real),
                                            _p(out), osb, osn, _p(attn), _p(stats), scale,
                                            b, n, h, dh, stream), 'feta_attn_fwd')
 
     @staticmethod
-    def attn_bwd_takes_dout2(n, dh):
-        return n <= 64 and dh <= 16
+    def attn_bwd_takes_dout2(n, dh, dtype=torch.float32):
+        return n <= 64 and dh <= 16 and dtype == torch.float32
 
     def attn_bwd(self, q, k, v, pe, n_real, out, dout, stats, delta, dq, dk, dv, scale, stream, dout2=None):
         b, n, h, dh = q.shape
@@ -191,6 +212,14 @@ class Abi:
             assert tok_strides(t) == (sb, sn)
         osb, osn = tok_strides(out)
         assert tok_strides(dout) == (osb, osn)
+        if q.dtype == torch.bfloat16:
+            _same_dtype(torch.bfloat16, k, v, pe, out, dout, dq, dk, dv)
+            assert dout2 is None
+            self._check(self.lib.feta_attn_bwd_bf16(_p(q), _p(k), _p(v), sb, sn, _p(pe), _p(n_real),
+                                                    _p(out), _p(dout), osb, osn, _p(stats), _p(delta),
+                                                    _p(dq), _p(dk), _p(dv), scale, b, n, h, dh, stream),
+                        'feta_attn_bwd_bf16')
+            return
         self._check(self.lib.feta_attn_bwd(_p(q), _p(k), _p(v), sb, sn, _p(pe), _p(n_real),
                                            _p(out), _p(dout), _p(dout2), osb, osn, _p(stats), _p(delta),
                                            _p(dq), _p(dk), _p(dv), scale, b, n, h, dh, stream),
@@ -247,10 +276,12 @@ class Abi:
         k = u.shape[2]
         xsb, xsn = tok_strides(x)
         ysb, ysn = tok_strides(y)
-        self._check(self.lib.feta_spec_filter_fwd(_p(x), xsb, xsn, _p(u), _p(lam), _p(coeff),
-                                                  _p(bias), _p(n_real), _p(y), ysb, ysn, b, n, h, dh,
-                                                  order, k, int(share), stream),
-                    'feta_spec_filter_fwd')
+        fn, nm = self.lib.feta_spec_filter_fwd, 'feta_spec_filter_fwd'
+        if x.dtype == torch.bfloat16:
+            _same_dtype(torch.bfloat16, u, coeff, y)
+            fn, nm = self.lib.feta_spec_filter_fwd_bf16, 'feta_spec_filter_fwd_bf16'
+        self._check(fn(_p(x), xsb, xsn, _p(u), _p(lam), _p(coeff), _p(bias), _p(n_real), _p(y), ysb, ysn,
+                       b, n, h, dh, order, k, int(share), stream), nm)
 
     def spec_filter_bwd(self, x, u, lam, coeff, n_real, dy, dx, dcoeff, dbias_part, order, share,
                         stream):
@@ -259,10 +290,12 @@ class Abi:
         xsb, xsn = tok_strides(x)
         assert tok_strides(dx) == (xsb, xsn)
         ysb, ysn = tok_strides(dy)
-        self._check(self.lib.feta_spec_filter_bwd(_p(x), xsb, xsn, _p(u), _p(lam), _p(coeff),
-                                                  _p(n_real), _p(dy), ysb, ysn, _p(dx), _p(dcoeff),
-                                                  _p(dbias_part), b, n, h, dh, order, k, int(share),
-                                                  stream), 'feta_spec_filter_bwd')
+        fn, nm = self.lib.feta_spec_filter_bwd, 'feta_spec_filter_bwd'
+        if x.dtype == torch.bfloat16:
+            _same_dtype(torch.bfloat16, u, coeff, dy, dx, dcoeff)
+            fn, nm = self.lib.feta_spec_filter_bwd_bf16, 'feta_spec_filter_bwd_bf16'
+        self._check(fn(_p(x), xsb, xsn, _p(u), _p(lam), _p(coeff), _p(n_real), _p(dy), ysb, ysn, _p(dx),
+                       _p(dcoeff), _p(dbias_part), b, n, h, dh, order, k, int(share), stream), nm)
 
     ROWLIN_DIMS = (16, 32, 64, 128, 192, 256)
 

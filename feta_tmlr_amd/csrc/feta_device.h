@@ -22,6 +22,34 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// ---- bf16 storage (feta_bf16.h) ---------------------------------------------------------------------------
+struct bf16_t {
+  unsigned short bits;
+};
+struct __attribute__((aligned(8))) bf16x4_raw {
+  bf16_t v[4];
+};
+typedef short bf16x4_mfma __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf2f(bf16_t x) { return __builtin_bit_cast(float, (unsigned)x.bits << 16); }
+// round to nearest even; a plain cast (v_cvt_pk_bf16_f32 on gfx950) keeps a NaN a NaN, the integer trick does not
+__device__ __forceinline__ bf16_t f2bf(float x) {
+  bf16_t r;
+  r.bits = __builtin_bit_cast(unsigned short, static_cast<__bf16>(x));
+  return r;
+}
+// v_mfma_f32_16x16x16_bf16: D = A(16x16) B(16x16) + C, fp32 accumulate; lane l supplies A[l&15][4(l>>4) .. +3]
+// and B[4(l>>4) .. +3][l&15]; register r of the result is D[4(l>>4)+r][l&15] (the layout of mfma16)
+__device__ __forceinline__ f32x4 mfma16_bf16(const float (&a)[4], const float (&b)[4], f32x4 c) {
+  bf16x4_mfma av, bv;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    av[i] = (short)f2bf(a[i]).bits;
+    bv[i] = (short)f2bf(b[i]).bits;
+  }
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bv, c, 0, 0, 0);
+}
+
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }
 

@@ -25,9 +25,10 @@ def _dense_like(t, batch_first):
 
 
 def _new_token(b, n, h, dh, batch_first, ref):
+    """same storage dtype as ref (fp32, or bf16 on the bf16 storage path)"""
     if batch_first:
-        return torch.empty((b, n, h, dh), dtype=torch.float32, device=ref.device)
-    return torch.empty((n, b, h, dh), dtype=torch.float32, device=ref.device).permute(1, 0, 2, 3)
+        return torch.empty((b, n, h, dh), dtype=ref.dtype, device=ref.device)
+    return torch.empty((n, b, h, dh), dtype=ref.dtype, device=ref.device).permute(1, 0, 2, 3)
 
 
 class AttentionCoreFn(torch.autograd.Function):
@@ -47,9 +48,9 @@ class AttentionCoreFn(torch.autograd.Function):
         sel = (lambda i: v5[:, :, i]) if batch_first else (lambda i: v5[:, :, i].permute(1, 0, 2, 3))
         q, k, v = sel(0), (sel(0) if tie_qk else sel(1)), sel(2)
         out = _new_token(b, n, num_heads, dh, batch_first, qkv)
-        attn = torch.empty((b, num_heads, n, n), dtype=torch.float32, device=qkv.device) if need_attn else None
+        attn = torch.empty((b, num_heads, n, n), dtype=qkv.dtype, device=qkv.device) if need_attn else None
         stats = torch.empty((b, num_heads, n, 2), dtype=torch.float32, device=qkv.device)
-        pe_c = None if pe is None else pe.contiguous()
+        pe_c = None if pe is None else pe.to(qkv.dtype).contiguous()   # (bf16 storage: pe travels as bf16 too)
         scale = float(dh) ** -0.5
         abi.attn_fwd(q, k, v, pe_c, n_real, out, attn, stats, scale, stream)
         ctx.save_for_backward(qkv, pe_c, n_real, out, stats)
@@ -79,7 +80,7 @@ class AttentionCoreFn(torch.autograd.Function):
             sel = lambda i: v5[:, :, i].permute(1, 0, 2, 3)
             gsel = lambda i: g5[:, :, i].permute(1, 0, 2, 3)
         q, k, v = sel(0), (sel(0) if tie_qk else sel(1)), sel(2)
-        dout = _token_view(dconcat.contiguous(), batch_first, num_heads)
+        dout = _token_view(dconcat.to(qkv.dtype).contiguous(), batch_first, num_heads)
         delta = torch.empty((b, num_heads, n), dtype=torch.float32, device=qkv.device)
         abi.attn_bwd(q, k, v, pe_c, n_real, out, dout, stats, delta, gsel(0), gsel(1), gsel(2),
                      scale, stream)
@@ -176,7 +177,7 @@ class _FilterFn(torch.autograd.Function):
         mode, order, share, batch_first, has_bias = ctx.cfg
         abi, stream = _lib.backend(xs)
         b, n, h, dh = xs.shape
-        dys = _dense_like(dy, batch_first)
+        dys = _dense_like(dy.to(xs.dtype), batch_first)
         dx = _new_token(b, n, h, dh, batch_first, xs)
         dcoeff = torch.empty_like(coeff)
         dbp = torch.empty((b * h, dh), dtype=torch.float32, device=xs.device)
@@ -204,13 +205,15 @@ class FilterFromPooledFn(torch.autograd.Function):
         abi, stream = _lib.backend(x, pooled)
         b, n, h, dh = x.shape
         xs = _dense_like(x, batch_first)
-        coeff = torch.addmm(lin_b, pooled, lin_w.t())
+        coeff = torch.addmm(lin_b, pooled, lin_w.t())      # fp32 master precision (also what a regulariser sees)
+        # bf16 storage path: the per-block weights the filter kernel reads are bf16 copies of them
+        cw = coeff if x.dtype == torch.float32 else coeff.to(x.dtype)
         y = _new_token(b, n, h, dh, batch_first, x)
         if mode == 'cheb':
-            abi.cheb_filter_fwd(xs, g0, coeff, bias, n_real, y, order, share, stream)
+            abi.cheb_filter_fwd(xs, g0, cw, bias, n_real, y, order, share, stream)
         else:
-            abi.spec_filter_fwd(xs, g0, g1, coeff, bias, n_real, y, order, share, stream)
-        ctx.save_for_backward(xs, coeff, pooled, lin_w, n_real, g0, g1)
+            abi.spec_filter_fwd(xs, g0, g1, cw, bias, n_real, y, order, share, stream)
+        ctx.save_for_backward(xs, cw, pooled, lin_w, n_real, g0, g1)
         ctx.cfg = (mode, order, share, batch_first, bias is not None)
         ctx.set_materialize_grads(False)
         return y, coeff
@@ -227,7 +230,7 @@ class FilterFromPooledFn(torch.autograd.Function):
             db_lin = torch.empty(dcoeff.shape[1], dtype=torch.float32, device=xs.device)
             abi.colsum(dcoeff, db_lin, stream)
         else:
-            dys = _dense_like(dy, batch_first)
+            dys = _dense_like(dy.to(xs.dtype), batch_first)
             dx = _new_token(b, n, h, dh, batch_first, xs)
             dcoeff = torch.empty_like(coeff)
             dbp = torch.empty((b * h, dh), dtype=torch.float32, device=xs.device)
@@ -235,6 +238,8 @@ class FilterFromPooledFn(torch.autograd.Function):
                 abi.cheb_filter_bwd(xs, g0, coeff, n_real, dys, dx, dcoeff, dbp, order, share, stream)
             else:
                 abi.spec_filter_bwd(xs, g0, g1, coeff, n_real, dys, dx, dcoeff, dbp, order, share, stream)
+            if dcoeff.dtype != torch.float32:
+                dcoeff = dcoeff.float()      # the C x C linear's gradients accumulate in fp32
             if dcoeff_ext is not None:   # a regulariser on the coefficients (transformer/models.py:554-584)
                 dcoeff += dcoeff_ext
             both = torch.empty(dh + dcoeff.shape[1], dtype=torch.float32, device=xs.device)
@@ -250,6 +255,10 @@ def filter_from_pooled(x, pooled, lin_w, lin_b, bias, n_real, graph, mode, order
     """x [B,N,H,dh] view, pooled [H*B, C] -> (y, coeff [H*B, C]); graph = (lhat,) | (u, lam)."""
     g0 = graph[0].contiguous()
     g1 = graph[1].contiguous() if len(graph) > 1 else None
+    if x.dtype != torch.float32:
+        if mode != 'spec':
+            raise NotImplementedError("the bf16 storage path runs the eigenbasis filter (filter_mode='spectral')")
+        g0 = g0.to(x.dtype)      # U travels as bf16; lambda and t_k(lambda) stay fp32
     return FilterFromPooledFn.apply(x, pooled, lin_w, lin_b, bias, n_real, g0, g1, mode, order,
                                     bool(heads_share_graph), batch_first)
 

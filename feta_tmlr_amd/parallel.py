@@ -38,7 +38,10 @@ class FlatGradAllReduce:
         memsets the bucket.  No pack/unpack, one add kernel per parameter in backward.
     """
 
-    def __init__(self, params, world_size=None, process_group=None, views=False):
+    def __init__(self, params, world_size=None, process_group=None, views=False, bucket_dtype=None):
+        """bucket_dtype=torch.bfloat16 (BASELINE config 3): the collective moves a bf16 copy of the packed fp32
+        gradients - half the bytes over xGMI - and the averaged result is widened back into the fp32 bucket before
+        it is scattered to the (fp32) .grad tensors; master weights and optimizer never see bf16."""
         self.params = [p for p in params if p.requires_grad]
         assert self.params, 'no trainable parameters'
         dev, dt = self.params[0].device, self.params[0].dtype
@@ -56,6 +59,10 @@ class FlatGradAllReduce:
         sizes = [p.shape[1] if rc else p.numel() for p, rc in zip(self.params, self.rowconst)]
         self.numel = sum(sizes)
         self.flat = torch.zeros(self.numel, device=dev, dtype=dt)
+        self.wire = None
+        if bucket_dtype is not None and bucket_dtype != dt:
+            assert not views, 'a reduced-precision wire bucket needs the packed (non-view) mode'
+            self.wire = torch.zeros(self.numel, device=dev, dtype=bucket_dtype)
         self.slices = []
         off = 0
         for p, sz in zip(self.params, sizes):
@@ -102,7 +109,10 @@ class FlatGradAllReduce:
             return None
         if not self.views:
             self.pack()
-        return dist.all_reduce(self.flat, op=self._op(), group=self.group, async_op=True)
+        if self.wire is not None:
+            self.wire.copy_(self.flat)
+        return dist.all_reduce(self.flat if self.wire is None else self.wire, op=self._op(), group=self.group,
+                               async_op=True)
 
     def _op(self):
         return dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM
@@ -111,6 +121,8 @@ class FlatGradAllReduce:
         if work is None:
             return
         work.wait()
+        if self.wire is not None:
+            self.flat.copy_(self.wire)     # widened to fp32 before the scale and the scatter
         if not self.avg_in_collective:
             self.flat.mul_(1.0 / self.world_size)
         if not self.views:
@@ -118,15 +130,7 @@ class FlatGradAllReduce:
 
     def all_reduce(self):
         """Averaged gradients in every p.grad (and in .flat), identical on all ranks."""
-        if self.world_size == 1:
-            return
-        if not self.views:
-            self.pack()
-        dist.all_reduce(self.flat, op=self._op(), group=self.group)
-        if not self.avg_in_collective:
-            self.flat.mul_(1.0 / self.world_size)
-        if not self.views:
-            self.unpack()
+        self.finish(self.start())
 
 
 class HybridGradAllReduce:

@@ -129,6 +129,33 @@ class DiffTransformerEncoderLayer(nn.Module):
             self.norm2 = nn.LayerNorm(d_model)
         self.dropout1 = nn.Dropout(dropout)
         self.dropout2 = nn.Dropout(dropout)
+        self.storage_dtype = torch.float32   # torch.bfloat16: the bf16 storage path (set_storage_dtype)
+
+    def _forward_lowp(self, src, pe, degree_rows, n_real, need_heads, need_weights):
+        """bf16 STORAGE path (BASELINE configs 3 / 5; the reference has no reduced-precision mode): activations,
+        pe and attn live in HBM as bf16; the attention core runs in the bf16 kernels (feta_attn_fwd/bwd_bf16, bf16
+        MFMA, fp32 softmax statistics), the linears are plain library bf16 GEMMs on bf16 copies of the fp32 master
+        weights (gradients arrive on the masters in fp32), BatchNorm / LayerNorm statistics are computed in fp32."""
+        dt = self.storage_dtype
+        n, b, d = src.shape
+        m = n * b
+        a = self.self_attn
+        cast = lambda p: None if p is None else p.to(dt)
+        x0 = src.to(dt)
+        qkv = F.linear(x0, cast(a.in_proj_weight), cast(a.in_proj_bias))
+        concat, attn = FF.attention_core(qkv, pe, n_real, a.num_heads, need_attn=need_weights, tie_qk=a.tie_qk,
+                                         batch_first=False)
+        src2 = F.linear(concat, cast(a.out_proj.weight), cast(a.out_proj.bias))
+        if degree_rows is not None:
+            src2 = src2 * degree_rows.view(n, b, 1).to(dt)
+        y1 = x0 + self.dropout1(src2)
+        x1 = self.norm1(y1.reshape(m, d).float()).to(dt).view(n, b, d)
+        h = self.dropout(F.relu(F.linear(x1, cast(self.linear1.weight), cast(self.linear1.bias))))
+        y2 = x1 + self.dropout2(F.linear(h, cast(self.linear2.weight), cast(self.linear2.bias)))
+        out = self.norm2(y2.reshape(m, d).float()).to(dt).view(n, b, d)
+        if need_heads:
+            return out, attn, concat.view(n, b, a.num_heads, a.head_dim).permute(1, 0, 2, 3)
+        return out, attn
 
     def _norm(self, mod, y, stats):
         """y [M, d] -> normalised [M, d].  BatchNorm statistics run over all N*B rows, padded ones
@@ -151,6 +178,13 @@ class DiffTransformerEncoderLayer(nn.Module):
             raise NotImplementedError('attn_mask is not used on the FeTA path')
         n, b, d = src.shape
         m = n * b
+        if self.storage_dtype != torch.float32:
+            if degree is not None and degree_rows is None:
+                degree_rows = degree.transpose(0, 1).reshape(m).contiguous()
+            if n_real is None:
+                n_real = (n_real_from_mask(src_key_padding_mask) if src_key_padding_mask is not None else
+                          torch.full((b,), n, dtype=torch.int32, device=src.device))
+            return self._forward_lowp(src, pe, degree_rows, n_real, need_heads, need_weights)
         fuse_drop = not (self.training and self.dropout1.p > 0.0)
         x0 = src.reshape(m, d)
         concat, attn = self.self_attn.core(src, pe, src_key_padding_mask, need_weights, n_real)
@@ -178,6 +212,17 @@ class DiffTransformerEncoderLayer(nn.Module):
             heads = concat.view(n, b, self.self_attn.num_heads, self.self_attn.head_dim).permute(1, 0, 2, 3)
             return out, attn, heads
         return out, attn
+
+
+def set_storage_dtype(module, dtype):
+    """Switch every FeTA encoder / encoder layer below `module` to a storage dtype: torch.float32 (the reference's
+    arithmetic, fused kernels) or torch.bfloat16 (bf16 activations / pe / U / attn / per-block filter weights, bf16
+    MFMA, fp32 statistics and accumulators, fp32 master weights and gradients)."""
+    assert dtype in (torch.float32, torch.bfloat16)
+    for mod in module.modules():
+        if hasattr(mod, 'storage_dtype'):
+            mod.storage_dtype = dtype
+    return module
 
 
 def clone_layers(layer, n):

@@ -96,6 +96,7 @@ class DiffTransformerEncoderGenGCN(nn.Module):
         self.use_skip_conn = use_skip_conn
         self.heads_share_graph = heads_share_graph
         self.filter_mode = filter_mode
+        self.storage_dtype = torch.float32   # torch.bfloat16: bf16 storage path (layers.set_storage_dtype)
         self.spectral_k = None    # eigenpairs kept when the eigenbasis is computed here (None: all N_pad)
         self.fused_stack = True   # layer stacks (BatchNorm or LayerNorm) run as one autograd node when the dims allow
         self.keep_stack_boundary = False   # set by trainers that use backward_head / backward_stack
@@ -120,7 +121,7 @@ class DiffTransformerEncoderGenGCN(nn.Module):
         """get_filter_coefficients + filter of one layer (:173, :186-202) with ``self.linear`` folded into the
         filter's autograd node (functional.FilterFromPooledFn).  -> (coeff [H,B,C], out_filtered [N,B,d])"""
         bsz, n, h, dh = out_each_head.shape
-        pooled = FF.filter_coefficients(attn_weights.detach(), cache.n_real, self.gcn.weight, self.gcn.bias)
+        pooled = FF.filter_coefficients(attn_weights.detach().float(), cache.n_real, self.gcn.weight, self.gcn.bias)
         if self.filter_mode == 'cheb':
             graph, mode = (cache.lhat,), 'cheb'
         else:
@@ -221,7 +222,13 @@ class DiffTransformerEncoderGenGCN(nn.Module):
             degree_rows = cache.extra.get('degree_rows')   # collate(..., seq_first_degree=True) emits it
             if degree_rows is None or degree_rows.shape[0] != degree.numel():
                 degree_rows = degree.transpose(0, 1).reshape(-1).contiguous()
-        fused = (self.fused_stack and self.last_layer_filter and mask is None
+        lowp = self.storage_dtype != torch.float32
+        if lowp:
+            if self.filter_mode != 'spectral' or self.learn_only_filter_order_coeff:
+                raise NotImplementedError("the bf16 storage path runs filter_mode='spectral' with matrix coefficients")
+            output = output.to(self.storage_dtype)
+            pe = None if pe is None else pe.to(self.storage_dtype)    # once for all layers
+        fused = (not lowp and self.fused_stack and self.last_layer_filter and mask is None
                  and stack_supported(self.layers, src.shape[-1]))
         for layer_num, mod in enumerate(self.layers):
             last = layer_num + 1 == self.num_layers
@@ -260,7 +267,11 @@ class DiffTransformerEncoderGenGCN(nn.Module):
         if self.use_skip_conn and allout_filtered is not None:
             nn_, bb_, dd_ = output.shape
             wc = self.linear_cat.weight
-            if (dd_ % 16 == 0 and FF.row_linear_supported(2 * dd_, wc.shape[0])):
+            if lowp:    # plain library bf16 GEMM on bf16 copies of the master weights; the encoder hands back fp32
+                dt = self.storage_dtype
+                output = F.linear(torch.cat((output, allout_filtered.to(dt)), dim=-1), wc.to(dt),
+                                  self.linear_cat.bias.to(dt)).float()
+            elif (dd_ % 16 == 0 and FF.row_linear_supported(2 * dd_, wc.shape[0])):
                 # [output | allout_filtered] W^T + b without materialising the concatenation (:223-224)
                 output = FF.row_linear_cat(output.reshape(nn_ * bb_, dd_), allout_filtered.reshape(nn_ * bb_, dd_),
                                            wc, self.linear_cat.bias).view(nn_, bb_, -1)
@@ -268,6 +279,8 @@ class DiffTransformerEncoderGenGCN(nn.Module):
                 cat = torch.cat((output, allout_filtered), dim=-1)               # :223
                 output, _ = linear_rows(cat.reshape(nn_ * bb_, 2 * dd_), wc, self.linear_cat.bias)   # :224
                 output = output.view(nn_, bb_, -1)
+        if output.dtype != torch.float32:
+            output = output.float()
         if self.norm is not None:
             output = self.norm(output)
         if len(coefficients) == 1:      # last_layer_filter: a view, no copy of the [H, B, C] block

@@ -170,6 +170,35 @@ int feta_spec_filter_bwd(const float* x, int64_t x_sb, int64_t x_sn,
                          int B, int N, int H, int dh, int P, int K, int heads_share_graph,
                          feta_stream_t stream);
 
+/* ---- bf16 STORAGE variants of A1 and A3 (BASELINE configs 3 and 5) ----------------------------------
+ * Same operators, same argument meaning as feta_attn_fwd/bwd and feta_spec_filter_fwd/bwd; `void*`
+ * operands are bf16 (q, k, v, pe, out, attn, dout, dq, dk, dv; x, u, coeff, y, dy, dx, dcoeff), base
+ * pointers 8-byte aligned, strides in elements (multiples of 4).  stats, delta, lam, bias and dbias_part
+ * stay fp32; the contractions run on v_mfma_f32_16x16x16_bf16 with fp32 accumulation, softmax statistics
+ * and t_k(lambda) in fp32.  The reference has no reduced-precision mode: parity of these entry points is
+ * a stated tolerance against the fp64 oracle (tests/), the fp32 entry points are the reference arithmetic.
+ * dh in {16, 32, 64} (attention), {16, 32} (filter); N <= FETA_MAX_NODES; K <= 64. */
+int feta_attn_fwd_bf16(const void* q, const void* k, const void* v, int64_t qkv_sb, int64_t qkv_sn,
+                       const void* pe, const int32_t* n_real, void* out, int64_t o_sb, int64_t o_sn,
+                       void* attn, float* stats, float scale, int B, int N, int H, int dh,
+                       feta_stream_t stream);
+int feta_attn_bwd_bf16(const void* q, const void* k, const void* v, int64_t qkv_sb, int64_t qkv_sn,
+                       const void* pe, const int32_t* n_real, const void* out, const void* dout,
+                       int64_t o_sb, int64_t o_sn, const float* stats, float* delta,
+                       void* dq, void* dk, void* dv, float scale, int B, int N, int H, int dh,
+                       feta_stream_t stream);
+int feta_spec_filter_fwd_bf16(const void* x, int64_t x_sb, int64_t x_sn, const void* u, const float* lam,
+                              const void* coeff, const float* bias, const int32_t* n_real,
+                              void* y, int64_t y_sb, int64_t y_sn,
+                              int B, int N, int H, int dh, int P, int K, int heads_share_graph,
+                              feta_stream_t stream);
+int feta_spec_filter_bwd_bf16(const void* x, int64_t x_sb, int64_t x_sn, const void* u, const float* lam,
+                              const void* coeff, const int32_t* n_real,
+                              const void* dy, int64_t y_sb, int64_t y_sn,
+                              void* dx, void* dcoeff, float* dbias_part,
+                              int B, int N, int H, int dh, int P, int K, int heads_share_graph,
+                              feta_stream_t stream);
+
 /* ---- A1/A4: row-wise linears of the encoder layer and BatchNorm1d --------------------------
  * Replaces the F.linear / relu / degree scaling / residual / BatchNorm1d sequence of
  * DiffTransformerEncoderLayer.forward (contract transformer/models.py:166-167; body per upstream

@@ -9,9 +9,27 @@ import kernel_checks as KC
 from oracle import feta_oracle as O
 
 
+# bf16 storage leg (bench.py --dtype bf16): the whole encoder against the fp64 oracle on the SAME fp32 inputs and
+# master weights - so, unlike the kernel-level checks, the rounding of inputs and weights to bf16 is part of the
+# error: every tensor of the stack is stored with 8 significant bits.  Output: max-abs relative to max(1, max|ref|).
+# Parameter gradients: relative FROBENIUS error per parameter - with 8-bit activations a relu pre-activation near
+# zero takes the other branch for a few (row, unit) pairs, which moves single elements of dW1 / db1 by a whole
+# row contribution (any bf16 implementation does this); the norm-wise error is what stays bounded.
+BF16_MODEL_TOL = 3e-2
+BF16_GRAD_FRO_TOL = 1.2e-1
+
+
+def rel_fro(got, ref):
+    d = (got.detach().double().cpu() - ref.detach().double().cpu()).norm()
+    return float(d / ref.detach().double().norm().clamp(min=1e-30))
+
+
 def check_bench_step(dev, run_ctx, argv, filter_mode=None, share=None, replays=2, two_phase=False,
                      out_tol=KC.TOL, grad_tol=3e-5):
     args = bench.parse(list(argv) + (['--two-phase'] if two_phase else []))
+    lowp = args.dtype == 'bf16'
+    if lowp:
+        out_tol = BF16_MODEL_TOL
     cpu, gpu = bench.make_batch(args, 0, dev)
     enc = bench.build_encoder(args, filter_mode=filter_mode, share=share).to(dev)
     enc.train()
@@ -40,6 +58,12 @@ def check_bench_step(dev, run_ctx, argv, filter_mode=None, share=None, replays=2
         g_ref = p64[name].grad
         if p.grad is None:
             assert g_ref is None or float(g_ref.abs().max()) == 0.0, name
+            continue
+        if lowp:
+            if float(g_ref.norm()) < 1e-9:       # exactly-zero gradient (linear2.bias in front of BatchNorm)
+                continue
+            errs[name] = rel_fro(p.grad, g_ref)
+            assert errs[name] <= BF16_GRAD_FRO_TOL, 'grad %s: relative Frobenius error %.3e' % (name, errs[name])
             continue
         if not args.layer_norm and name.endswith('linear2.bias'):
             # linear2.bias sits directly in front of BatchNorm 2 (out_proj.bias does not: it is scaled by the degree

@@ -24,6 +24,14 @@ def test_bench_step_matches_oracle(emu, mode, share, two_phase):
                         replays=1, two_phase=two_phase)
 
 
+@pytest.mark.parametrize('share', [True, False])
+def test_bench_step_bf16_matches_oracle(emu, share):
+    """--dtype bf16 (BASELINE configs 3 / 5): bf16 storage, bf16 MFMA, fp32 statistics and master weights"""
+    errs, _ = BC.check_bench_step(CPU, lambda: _lib.override_for_tests(emu), SMALL + ['--dtype', 'bf16'],
+                                  share=share, replays=1)
+    print({k: '%.2e' % v for k, v in errs.items()})
+
+
 def test_bench_starts_its_own_ranks(emu):
     """python bench.py --gpus 2 (no WORLD_SIZE in the environment) spawns two ranks, prints ONE JSON line
     for the whole job and exits 0."""

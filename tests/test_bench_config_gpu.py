@@ -22,3 +22,12 @@ def test_timed_configuration_matches_oracle(hip, mode, share, two_phase):
                                            replays=3, two_phase=two_phase)
     assert used_graph
     print('max abs errors:', {k: '%.2e' % v for k, v in errs.items()})
+
+
+@pytest.mark.parametrize('argv', [[], ['--shape', 'molhiv', '--batch', '96', '--n-pad', '64', '--k-eig', '32', '--layer-norm']])
+def test_bf16_storage_leg_matches_oracle(hip, argv):
+    """bench.py --dtype bf16 (BASELINE config 3 shape, and a molhiv-shaped LayerNorm bucket of config 5) through the
+    captured hipGraph against the fp64 oracle, bf16 tolerance (bench_checks.BF16_MODEL_TOL)"""
+    errs, used_graph = BC.check_bench_step(hip[1], contextlib.nullcontext, argv + ['--dtype', 'bf16'], replays=2)
+    assert used_graph
+    print('max abs errors:', {k: '%.2e' % v for k, v in errs.items()})

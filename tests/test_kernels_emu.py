@@ -24,6 +24,20 @@ def test_attn(emu, bsz, n, h, dh, use_pe, seq_first):
     KC.check_attn(emu, CPU, None, bsz, n, h, dh, use_pe, seq_first)
 
 
+@pytest.mark.parametrize('bsz,n,h,dh,use_pe,seq_first', [(3, 21, 4, 16, True, True), (2, 37, 2, 32, False, False),
+                                                          (2, 70, 1, 64, True, True)])
+def test_attn_bf16(emu, bsz, n, h, dh, use_pe, seq_first):
+    """bf16 storage entry points (feta_attn_fwd_bf16 / feta_attn_bwd_bf16) against the fp64 oracle"""
+    KC.check_attn(emu, CPU, None, bsz, n, h, dh, use_pe, seq_first, dtype=KC.BF16)
+    KC.check_attn(emu, CPU, None, 2, 19, 2, 16, True, clamp_case=True, dtype=KC.BF16)
+
+
+@pytest.mark.parametrize('k_eig,share,dh', [(8, 1, 16), (16, 0, 16), (20, 1, 32)])
+def test_spec_filter_bf16(emu, k_eig, share, dh):
+    KC.check_filter(emu, CPU, None, 'spec', 3, 2, dh, 4, share, shape='zinc', n_min=5, n_max=30, k_eig=k_eig,
+                    dtype=KC.BF16)
+
+
 def test_attn_no_attn_write(emu):
     KC.check_attn(emu, CPU, None, 2, 21, 2, 16, True, write_attn=False)
 

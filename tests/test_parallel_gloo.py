@@ -32,7 +32,7 @@ def _full_grads(model):
                       for p in model.parameters()])
 
 
-def _worker(rank, world, port, ret, views):
+def _worker(rank, world, port, ret, views, wire=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import ctypes
@@ -45,7 +45,7 @@ def _worker(rank, world, port, ret, views):
     emu = _abi.bind(ctypes.CDLL(os.path.join(ROOT, 'tools', 'simt', 'libfeta_emu.so')))
     ds = D.SyntheticGraphDataset('mutag', 6, in_dim=8, seed=5, n_min=4, n_max=12)
     model = _build()
-    bucket = FlatGradAllReduce(model.parameters(), world, views=views)
+    bucket = FlatGradAllReduce(model.parameters(), world, views=views, bucket_dtype=wire)
     mine = [ds[i] for i in shard_indices(len(ds), rank, world)]
     with _lib.override_for_tests(emu):
         bucket.zero()
@@ -88,6 +88,20 @@ def test_flat_bucket_allreduce_world2(emu, views):
     n_unused = model.gcn.weight.numel() + model.gcn.bias.numel()
     names = [n for n, _ in model.named_parameters()]
     assert names[-6:-4] == ['gcn.weight', 'gcn.bias'] or 'gcn.weight' in names
+
+
+def test_bf16_wire_bucket_world2(emu):
+    """FlatGradAllReduce(bucket_dtype=bfloat16) (BASELINE config 3): the collective moves bf16, the gradients that
+    come back are fp32, identical on both ranks and within bf16 rounding (2^-8 relative per addend) of the fp32 bucket"""
+    world = 2
+    mgr = mp.Manager()
+    ret16, ret32 = mgr.dict(), mgr.dict()
+    port = 29500 + (os.getpid() % 1000) + 3
+    mp.spawn(_worker, args=(world, port, ret16, False, torch.bfloat16), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port + 1, ret32, False, None), nprocs=world, join=True)
+    assert ret16[0].dtype == torch.float32 and torch.equal(ret16[0], ret16[1])
+    err = (ret16[0] - ret32[0]).abs().max().item()
+    assert 0.0 < err <= 2.0 ** -7 * max(1.0, ret32[0].abs().max().item()), err
 
 
 def test_shard_indices_partition():

@@ -37,6 +37,52 @@ inline f32x4 mfma16(float a, float b, f32x4 c) {
   return d;
 }
 
+// ---- bf16 storage: same API as the device header ------------------------------------------------------
+struct bf16_t {
+  unsigned short bits;
+};
+struct alignas(8) bf16x4_raw {
+  bf16_t v[4];
+};
+inline float bf2f(bf16_t x) {
+  const uint32_t u = (uint32_t)x.bits << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+inline bf16_t f2bf(float x) {   // round to nearest even, NaN kept
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  bf16_t r;
+  if ((u & 0x7fffffffu) > 0x7f800000u) {
+    r.bits = (unsigned short)((u >> 16) | 0x40);
+    return r;
+  }
+  u += 0x7fffu + ((u >> 16) & 1u);
+  r.bits = (unsigned short)(u >> 16);
+  return r;
+}
+// v_mfma_f32_16x16x16_bf16: operands rounded to bf16, exact products, fp32 accumulation in k order
+inline f32x4 mfma16_bf16(const float (&a)[4], const float (&b)[4], f32x4 c) {
+  simt::WaveScratch& s = simt::wave_scratch();
+  const int l = lane_id();
+  for (int i = 0; i < 4; ++i) {
+    s.c[l][i] = bf2f(f2bf(a[i]));       // A[l&15][4(l>>4)+i]
+    s.d[l][i] = bf2f(f2bf(b[i]));       // B[4(l>>4)+i][l&15]
+  }
+  simt::wave_barrier();
+  f32x4 d;
+  const int col = l & 15;
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * (l >> 4) + r;
+    float acc = c[r];
+    for (int k = 0; k < 16; ++k) acc = fmaf(s.c[16 * (k >> 2) + row][k & 3], s.d[16 * (k >> 2) + col][k & 3], acc);
+    d[r] = acc;
+  }
+  simt::wave_barrier();
+  return d;
+}
+
 inline float shfl_xor(float v, int mask) {
   simt::WaveScratch& s = simt::wave_scratch();
   const int l = lane_id();

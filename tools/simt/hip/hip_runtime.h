@@ -45,6 +45,7 @@ struct WaveScratch {
   float a[64];
   float b[64];
   float c[64][4];
+  float d[64][4];
 };
 WaveScratch& wave_scratch();   // scratch of the CURRENT lane's wave
 void wave_barrier();           // all lanes of the current wave
