@@ -181,3 +181,24 @@ def test_spectral_kernel(hip, kind, zero_diag, from_device, shape, n_min, n_max)
 def test_layernorm(hip, m, d):
     abi, dev, stream = hip
     KC.check_layernorm(abi, dev, stream, m, d)
+
+
+@pytest.mark.parametrize('bsz,n,h,dh,use_pe,seq_first', [(128, 37, 4, 16, True, True), (5, 64, 2, 32, False, False),
+                                                          (3, 222, 4, 16, True, True), (2, 256, 1, 64, True, True)])
+def test_attn_bf16(hip, bsz, n, h, dh, use_pe, seq_first):
+    """feta_attn_fwd_bf16 / feta_attn_bwd_bf16 (bf16 storage, bf16 MFMA) against the fp64 oracle, KC.BF16_TOL"""
+    abi, dev, stream = hip
+    KC.check_attn(abi, dev, stream, bsz, n, h, dh, use_pe, seq_first, dtype=KC.BF16)
+
+
+def test_attn_bf16_clamped_rows(hip):
+    abi, dev, stream = hip
+    KC.check_attn(abi, dev, stream, 2, 19, 2, 16, True, clamp_case=True, dtype=KC.BF16)
+
+
+@pytest.mark.parametrize('bsz,k_eig,share,dh,shape,n_max', [(128, 16, 1, 16, 'zinc', 37), (16, 8, 0, 16, 'mutag', 28),
+                                                            (4, 32, 1, 16, 'pattern', 120), (6, 20, 1, 32, 'zinc', 30)])
+def test_spec_filter_bf16(hip, bsz, k_eig, share, dh, shape, n_max):
+    abi, dev, stream = hip
+    KC.check_filter(abi, dev, stream, 'spec', bsz, 4 if dh == 16 else 2, dh, 4, share, shape=shape, n_max=n_max,
+                    k_eig=k_eig, dtype=KC.BF16)
