@@ -52,7 +52,8 @@ SIGNATURES = {
     'feta_layernorm_fwd': ([_F, _F, _F, C.c_float, _F, _F, C.c_int, C.c_int, _S], C.c_int),
     'feta_layernorm_bwd': ([_F, _F, _F, _F, _F, _F, C.c_int, _F, C.c_int, C.c_int, _S], C.c_int),
     'feta_eigh_sym_supported': ([C.c_int], C.c_int),
-    'feta_eigh_sym': ([_F, _I, C.c_float, _F, _F, _I, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _S],
+    'feta_eigh_sym_workspace_bytes': ([C.c_int, C.c_int], C.c_int64),
+    'feta_eigh_sym': ([_F, _I, C.c_float, _F, _F, _I, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _S],
                       C.c_int),
     'feta_spectral_kernel': ([_F, _F, _I, C.c_int, C.c_float, C.c_int, C.c_float, C.c_int, _F,
                               C.c_int, C.c_int, C.c_int, _S], C.c_int),
@@ -435,10 +436,15 @@ class Abi:
     def eigh_sym_supported(self, n):
         return bool(self.lib.feta_eigh_sym_supported(n))
 
-    def eigh_sym(self, a, n_real, shift, u, lam, sweeps, max_sweeps, tol, stream):
+    def eigh_sym_workspace_bytes(self, b, n):
+        return int(self.lib.feta_eigh_sym_workspace_bytes(b, n))
+
+    def eigh_sym(self, a, n_real, shift, u, lam, sweeps, max_sweeps, tol, stream, workspace=None):
         b, n, k = u.shape
-        self._check(self.lib.feta_eigh_sym(_p(a), _p(n_real), shift, _p(u), _p(lam), _p(sweeps), b, n, k,
-                                           max_sweeps, tol, stream), 'feta_eigh_sym')
+        if workspace is None and self.eigh_sym_workspace_bytes(b, n) > 0:   # convenience for callers / tests
+            workspace = torch.empty(self.eigh_sym_workspace_bytes(b, n) // 4, dtype=torch.float32, device=a.device)
+        self._check(self.lib.feta_eigh_sym(_p(a), _p(n_real), shift, _p(u), _p(lam), _p(sweeps), _p(workspace),
+                                           b, n, k, max_sweeps, tol, stream), 'feta_eigh_sym')
 
     def spectral_kernel(self, u, lam, n_real, mode, beta, p, lam_offset, zero_diag, out, stream):
         b, n, k = u.shape

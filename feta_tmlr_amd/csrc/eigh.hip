@@ -4,7 +4,9 @@
 // (np.linalg.eig per graph, transformer/position_encoding.py:127-161; scipy expm / sparse matrix
 // powers per graph, :65-72 and :83-93) and caches the result in a pickle (:11-52).
 //
-// feta_eigh_sym: one workgroup per graph, the whole matrix in LDS, one-sided (Hestenes) Jacobi.
+// feta_eigh_sym: one workgroup per graph, the whole matrix in LDS (N <= 192; for 192 < N <= 256 - 266 KB, more than
+// a CU's 160 KB - in a caller-provided workspace that stays L2-resident: same code, the matrix pointer is global
+// memory and the round barrier orders the workgroup's own stores and loads), one-sided (Hestenes) Jacobi.
 // G = A + shift*I is symmetric positive definite (the caller's contract), so the rotations that
 // orthogonalise the columns of G from the right, G <- G J, end at G = (A + shift) V with
 // V^T (A+shift)^2 V diagonal: the columns are  g_j = sigma_j v_j,  sigma_j = lam_j + shift > 0, and
@@ -25,6 +27,7 @@ struct EighArgs {
   float* u;          // [B, N, K]
   float* lam;        // [B, K]
   int32_t* sweeps;   // [B] or null
+  float* work;       // [B, N, pitch] matrix storage when it does not fit in LDS, else null
   int B, N, max_sweeps;
 };
 
@@ -48,15 +51,16 @@ __device__ __forceinline__ void tournament_pair(int step, int k, int m, int& p, 
   }
 }
 
-template <int NC>
+template <int NC, bool GLOBAL>
 __global__ __launch_bounds__(512) void eigh_jacobi_kernel(EighArgs a) {
   constexpr int P = 64 * NC + 4;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int l = tid & 15, grp = tid >> 4, ngrp = nthr >> 4;
   const int b = blockIdx.x;
   const int n = min(a.n_real[b], a.N);
-  float* G = feta_lds;                      // column j at G + j * P, rows [0, 64 NC)
-  float* lamv = G + (size_t)P * a.N;        // [N] eigenvalue of column j
+  // column j at G + j * P, rows [0, 64 NC): in LDS, or (GLOBAL) in this graph's slice of the workspace
+  float* G = GLOBAL ? a.work + (size_t)b * P * a.N : feta_lds;
+  float* lamv = GLOBAL ? feta_lds : G + (size_t)P * a.N;        // [N] eigenvalue of column j
   float* scl = lamv + a.N;                  // [N] sign / norm of column j
   int* perm = reinterpret_cast<int*>(scl + a.N);   // [N] column holding the k-th smallest eigenvalue
   int* flags = perm + a.N;                  // [kEighMaxSweeps + 1] "a rotation happened in sweep s"
@@ -275,14 +279,22 @@ __global__ __launch_bounds__(256) void spectral_fn_kernel(SpecFnArgs a) {
 
 using namespace feta;
 
-extern "C" int feta_eigh_sym_supported(int N) { return N >= 1 && N <= 192 ? 1 : 0; }
+extern "C" int feta_eigh_sym_supported(int N) { return N >= 1 && N <= 256 ? 1 : 0; }
+
+extern "C" int64_t feta_eigh_sym_workspace_bytes(int B, int N) {
+  if (N <= 192) return 0;
+  return (int64_t)sizeof(float) * B * N * eigh_pitch((N + 63) / 64);
+}
 
 extern "C" int feta_eigh_sym(const float* a, const int32_t* n_real, float shift, float* u, float* lam,
-                             int32_t* sweeps, int B, int N, int K, int max_sweeps, float tol,
+                             int32_t* sweeps, float* workspace, int B, int N, int K, int max_sweeps, float tol,
                              feta_stream_t stream) {
   FETA_REQUIRE(a && n_real && u && lam && B > 0 && K >= 1 && K <= N, "eigh_sym: bad arguments");
-  FETA_REQUIRE(feta_eigh_sym_supported(N), "eigh_sym: N = %d not supported (1..192: the matrix lives in LDS)", N);
+  FETA_REQUIRE(feta_eigh_sym_supported(N), "eigh_sym: N = %d not supported (1..256)", N);
+  FETA_REQUIRE(N <= 192 || (workspace != nullptr && aligned16(workspace)),
+               "eigh_sym: N = %d needs a 16-byte aligned workspace of feta_eigh_sym_workspace_bytes(B, N)", N);
   EighArgs args;
+  args.work = N > 192 ? workspace : nullptr;
   args.a = a;
   args.n_real = n_real;
   args.shift = shift;
@@ -295,11 +307,17 @@ extern "C" int feta_eigh_sym(const float* a, const int32_t* n_real, float shift,
   args.N = N;
   args.max_sweeps = max_sweeps > 0 ? (max_sweeps < kEighMaxSweeps ? max_sweeps : kEighMaxSweeps) : 16;
   const int NC = (N + 63) / 64;
-  const size_t lds = sizeof(float) * eigh_lds_floats(NC, N);
+  const size_t lds = N > 192 ? sizeof(float) * (3 * (size_t)N + kEighMaxSweeps + 2)
+                             : sizeof(float) * eigh_lds_floats(NC, N);
   const dim3 grid(B), block(N > 32 ? 512 : 256);
+  if (N > 192) {
+    auto kern = eigh_jacobi_kernel<4, true>;
+    hipLaunchKernelGGL(kern, grid, block, lds, (hipStream_t)stream, args);
+    return check_launch("feta_eigh_sym");
+  }
 #define FETA_EIGH_CASE(nc)                                                           \
   case nc: {                                                                         \
-    auto kern = eigh_jacobi_kernel<nc>;                                              \
+    auto kern = eigh_jacobi_kernel<nc, false>;                                       \
     static LdsSeen seen;                                                          \
     allow_dynamic_lds(kern, lds, seen);                                              \
     hipLaunchKernelGGL(kern, grid, block, lds, (hipStream_t)stream, args);           \

@@ -465,7 +465,7 @@ def eigh_sym(a, n_real, shift, k=None, max_sweeps=0, tol=0.0, return_sweeps=Fals
     b, n, _ = a.shape
     k = n if k is None else int(k)
     if not abi.eigh_sym_supported(n):
-        raise ValueError('eigh_sym: N = %d does not fit one workgroup (N <= 192); decompose on the host' % n)
+        raise ValueError('eigh_sym: N = %d is beyond the kernels (N <= 256); decompose on the host' % n)
     u = torch.empty((b, n, k), dtype=torch.float32, device=a.device)
     lam = torch.empty((b, k), dtype=torch.float32, device=a.device)
     sweeps = torch.empty((b,), dtype=torch.int32, device=a.device) if return_sweeps else None

@@ -212,7 +212,7 @@ POSENCODINGS = {
 
 # ---- the same encodings for a whole padded batch, on the device ---------------------------------
 
-DEVICE_EIGH_MAX_N = 192   # feta_eigh_sym_supported: the matrix lives in one workgroup's LDS
+DEVICE_EIGH_MAX_N = 256   # feta_eigh_sym_supported (N <= 192: matrix in LDS; up to 256: in an L2-resident workspace)
 
 
 def device_spectrum(edge_index, batch, node_off, n_real, n_pad, k_eig=None):
@@ -226,8 +226,8 @@ def device_spectrum(edge_index, batch, node_off, n_real, n_pad, k_eig=None):
     if n_pad <= DEVICE_EIGH_MAX_N:
         u, lam = FF.eigh_sym(lhat, n_real, shift=2.0, k=k_eig)
         return lhat, u, lam
-    # the largest molhiv bucket (N_pad = 256): the matrix does not fit one workgroup's LDS - these batches are
-    # decomposed graph by graph on the host, as the reference does for every graph (:137)
+    # beyond the kernels' FETA_MAX_NODES = 256 (no BASELINE shape: the largest ogbg-molhiv graph has 222 nodes):
+    # graph by graph on the host, as the reference does for every graph (:137)
     import torch
     k = n_pad if k_eig is None else int(k_eig)
     lh, ns = lhat.cpu().double().numpy(), n_real.cpu().tolist()

@@ -416,7 +416,9 @@ int feta_layernorm_bwd(const float* dout, const float* y, const float* stats, co
                        feta_stream_t stream);
 
 /* ---- spectrum producer ------------------------------------------------
- * Batched symmetric eigendecomposition, one workgroup per graph, the matrix in LDS (N <= 192):
+ * Batched symmetric eigendecomposition, one workgroup per graph, the matrix in LDS (N <= 192) or, for
+ * 192 < N <= 256, in a caller-provided workspace of feta_eigh_sym_workspace_bytes(B, N) bytes (0 for N <= 192;
+ * the largest ogbg-molhiv bucket, BASELINE config 5, has 222 nodes):
  *   a [B,N,N]: the real n_b x n_b block of graph b is decomposed; as numpy.linalg.eigh does, only
  *   the LOWER triangle is read.  a + shift*I must be positive definite (Lhat = -D^-1/2 A D^-1/2 has
  *   its spectrum in [-1,1]: shift 2; L_sym: shift 1) - the one-sided Jacobi iteration runs on that
@@ -429,8 +431,9 @@ int feta_layernorm_bwd(const float* dout, const float* y, const float* stats, co
  * feeds feta_spec_filter_fwd/bwd (u, lam) directly.
  */
 int feta_eigh_sym_supported(int N);
+int64_t feta_eigh_sym_workspace_bytes(int B, int N);
 int feta_eigh_sym(const float* a, const int32_t* n_real, float shift, float* u, float* lam,
-                  int32_t* sweeps, int B, int N, int K, int max_sweeps, float tol,
+                  int32_t* sweeps, float* workspace, int B, int N, int K, int max_sweeps, float tol,
                   feta_stream_t stream);
 
 /* Kernel function of the spectrum on the real block, zero elsewhere:

@@ -150,11 +150,17 @@ def test_eigh_sym_truncated_equals_full(emu):
 
 
 def test_eigh_sym_rejects_large_n(emu):
-    assert emu.eigh_sym_supported(192) and not emu.eigh_sym_supported(193)
-    a = torch.zeros(1, 200, 200)
-    with pytest.raises(ValueError, match='192'):
-        emu.eigh_sym(a, torch.tensor([200], dtype=torch.int32), 2.0, torch.zeros(1, 200, 200), torch.zeros(1, 200),
+    assert emu.eigh_sym_supported(256) and not emu.eigh_sym_supported(257)
+    assert emu.eigh_sym_workspace_bytes(3, 192) == 0 and emu.eigh_sym_workspace_bytes(3, 222) == 4 * 3 * 222 * 260
+    a = torch.zeros(1, 300, 300)
+    with pytest.raises(ValueError, match='256'):
+        emu.eigh_sym(a, torch.tensor([300], dtype=torch.int32), 2.0, torch.zeros(1, 300, 300), torch.zeros(1, 300),
                      None, 0, 0.0, None)
+
+
+def test_eigh_sym_workspace_variant(emu):
+    """192 < N <= 256: the matrix lives in the caller's workspace instead of LDS (molhiv's 222-node bucket)"""
+    KC.check_eigh(emu, CPU, None, 'molhiv', 2, 0, 150, 222, 222)
 
 
 @pytest.mark.parametrize('kind,zero_diag,from_device', [('diffusion', False, True), ('pstep', True, True),

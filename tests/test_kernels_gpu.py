@@ -202,3 +202,10 @@ def test_spec_filter_bf16(hip, bsz, k_eig, share, dh, shape, n_max):
     abi, dev, stream = hip
     KC.check_filter(abi, dev, stream, 'spec', bsz, 4 if dh == 16 else 2, dh, 4, share, shape=shape, n_max=n_max,
                     k_eig=k_eig, dtype=KC.BF16)
+
+
+def test_eigh_sym_workspace_variant(hip):
+    """192 < N <= 256 (BASELINE config 5's largest bucket: 222 nodes) stays on the device"""
+    abi, dev, stream = hip
+    KC.check_eigh(abi, dev, stream, 'molhiv', 5, 0, 150, 222, 222)
+    KC.check_eigh(abi, dev, stream, 'pattern', 3, 1, 200, 256, 256)

@@ -419,7 +419,20 @@ def test_spectral_mode_without_eigenbasis(emu):
     check_spectral_mode_without_eigenbasis(CPU, lambda: _lib.override_for_tests(emu), spectral_k=6)
 
 
-def test_device_spectrum_falls_back_to_the_host_beyond_192_nodes(emu):
+def test_device_spectrum_beyond_192_nodes_stays_on_the_device(emu, monkeypatch):
+    """N_pad in (192, 256] (the largest ogbg-molhiv bucket): feta_eigh_sym with the matrix in a workspace; the host
+    fallback (numpy) is not taken"""
+    monkeypatch.setattr(np.linalg, 'eigh', lambda *a, **k: (_ for _ in ()).throw(AssertionError('host eigh used')))
+    _device_spectrum_200(emu)
+
+
+def test_device_spectrum_host_fallback_beyond_the_kernels(emu, monkeypatch):
+    from feta_tmlr_amd.transformer import position_encoding as PE
+    monkeypatch.setattr(PE, 'DEVICE_EIGH_MAX_N', 192)
+    _device_spectrum_200(emu)
+
+
+def _device_spectrum_200(emu):
     from feta_tmlr_amd.transformer import position_encoding as PE
     ds = D.SyntheticGraphDataset('molhiv', 2, in_dim=2, seed=0, pos_enc=False, with_eig=False, n_min=30, n_max=40)
     b9, cache = D.collate(ds.samples, n_pad=200)
