@@ -63,6 +63,11 @@ SIGNATURES.update({
     'feta_attn_fwd_bf16': SIGNATURES['feta_attn_fwd'],
     'feta_attn_bwd_bf16': ([_F, _F, _F, C.c_int64, C.c_int64, _F, _I, _F, _F, C.c_int64, C.c_int64,
                             _F, _F, _F, _F, _F, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, _S], C.c_int),
+    'feta_attn_fwd_drop': ([_F, _F, _F, C.c_int64, C.c_int64, _F, _I, _F, C.c_int64, C.c_int64, _F, _F, C.c_float,
+                            C.c_float, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _S], C.c_int),
+    'feta_attn_bwd_drop': ([_F, _F, _F, C.c_int64, C.c_int64, _F, _I, _F, _F, C.c_int64, C.c_int64, _F, _F, _F, _F, _F,
+                            C.c_float, C.c_float, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                            _S], C.c_int),
     'feta_spec_filter_fwd_bf16': SIGNATURES['feta_spec_filter_fwd'],
     'feta_spec_filter_bwd_bf16': SIGNATURES['feta_spec_filter_bwd'],
 })
@@ -187,11 +192,19 @@ class Abi:
             raise FetaError('%s failed (%d): %s' % (what, rc, msg))
 
     # q,k,v,out,...: [B,N,H,dh] views (any B/N strides)
-    def attn_fwd(self, q, k, v, pe, n_real, out, attn, stats, scale, stream):
+    def attn_fwd(self, q, k, v, pe, n_real, out, attn, stats, scale, stream, drop=None):
+        """drop = (p, seed, offset): attention-probability dropout (feta_attn_fwd_drop)"""
         b, n, h, dh = q.shape
         sb, sn = tok_strides(q)
         assert tok_strides(k) == (sb, sn) and tok_strides(v) == (sb, sn)
         osb, osn = tok_strides(out)
+        if drop is not None and drop[0] > 0.0:
+            _same_dtype(q.dtype, k, v, pe, out, attn)
+            self._check(self.lib.feta_attn_fwd_drop(_p(q), _p(k), _p(v), sb, sn, _p(pe), _p(n_real), _p(out), osb, osn,
+                                                    _p(attn), _p(stats), scale, float(drop[0]), int(drop[1]), int(drop[2]),
+                                                    1 if q.dtype == torch.bfloat16 else 0, b, n, h, dh, stream),
+                        'feta_attn_fwd_drop')
+            return
         if q.dtype == torch.bfloat16:
             _same_dtype(torch.bfloat16, k, v, pe, out, attn)
             self._check(self.lib.feta_attn_fwd_bf16(_p(q), _p(k), _p(v), sb, sn, _p(pe), _p(n_real),
@@ -206,13 +219,23 @@ class Abi:
     def attn_bwd_takes_dout2(n, dh, dtype=torch.float32):
         return n <= 64 and dh <= 16 and dtype == torch.float32
 
-    def attn_bwd(self, q, k, v, pe, n_real, out, dout, stats, delta, dq, dk, dv, scale, stream, dout2=None):
+    def attn_bwd(self, q, k, v, pe, n_real, out, dout, stats, delta, dq, dk, dv, scale, stream, dout2=None,
+                 drop=None):
         b, n, h, dh = q.shape
         sb, sn = tok_strides(q)
         for t in (k, v, dq, dk, dv):
             assert tok_strides(t) == (sb, sn)
         osb, osn = tok_strides(out)
         assert tok_strides(dout) == (osb, osn)
+        if drop is not None and drop[0] > 0.0:
+            _same_dtype(q.dtype, k, v, pe, out, dout, dq, dk, dv)
+            assert dout2 is None
+            self._check(self.lib.feta_attn_bwd_drop(_p(q), _p(k), _p(v), sb, sn, _p(pe), _p(n_real), _p(out), _p(dout),
+                                                    osb, osn, _p(stats), _p(delta), _p(dq), _p(dk), _p(dv), scale,
+                                                    float(drop[0]), int(drop[1]), int(drop[2]),
+                                                    1 if q.dtype == torch.bfloat16 else 0, b, n, h, dh, stream),
+                        'feta_attn_bwd_drop')
+            return
         if q.dtype == torch.bfloat16:
             _same_dtype(torch.bfloat16, k, v, pe, out, dout, dq, dk, dv)
             assert dout2 is None

@@ -37,7 +37,42 @@ struct AttnArgsT {
   int64_t qsb, qsn, osb, osn;
   float scale;
   int B, N, H, NB, total;
+  // attention-probability dropout (A1 step (6)): keep-threshold on 32 random bits per probability,
+  // Philox4x32-10 keyed by `seed`, counter = (index of the 4-key group of the probability, `offset`): the mask is
+  // a pure function of (seed, offset, b, h, query, key), regenerated in backward - no mask tensor
+  unsigned drop_thresh;   // keep iff bits >= drop_thresh; 0 = no dropout
+  float drop_scale;       // 1 / (1 - p)
+  unsigned seed_lo, seed_hi, off_lo, off_hi;
 };
+
+__device__ __forceinline__ unsigned mulhi32(unsigned a, unsigned b) {
+  return (unsigned)(((unsigned long long)a * (unsigned long long)b) >> 32);
+}
+// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3"): 4 x 32 random bits per counter
+__device__ __forceinline__ void philox4(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                        unsigned (&o)[4]) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const unsigned hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const unsigned hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0;
+    c1 = lo1;
+    c2 = hi0 ^ c3 ^ k1;
+    c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+// keep-scales (0 or 1/(1-p)) of the probabilities (query q, keys 4 kg .. 4 kg + 3) of block bh
+template <class A>
+__device__ __forceinline__ void drop_scales(const A& a, int bh, int q, int kg, float (&ms)[4]) {
+  const unsigned long long idx = ((unsigned long long)bh * a.N + q) * (unsigned long long)((a.N + 3) >> 2) + kg;
+  unsigned bits[4];
+  philox4((unsigned)idx, (unsigned)(idx >> 32), a.off_lo, a.off_hi, a.seed_lo, a.seed_hi, bits);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ms[r] = bits[r] >= a.drop_thresh ? a.drop_scale : 0.0f;
+}
 
 // ---- forward: one wave per (b, h, 16-query block), S^T in registers ------------------------------------------
 template <class T, int DH, int KT_MAX>
@@ -116,9 +151,11 @@ __global__ __launch_bounds__(64 * kLWaves) void attn_fwd_lp_kernel(AttnArgsT<T> 
     if (kt < KT) {
       float pa[4];
       float vb[CT][4];
+      float ms[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+      if (a.drop_thresh != 0u) drop_scales(a, bh, qc, 4 * kt + g, ms);   // (written to attn dropped, as nn.MultiheadAttention)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        acc[kt][r] *= rinv;
+        acc[kt][r] *= rinv * ms[r];
         pa[r] = acc[kt][r];
         const int key = 16 * kt + 4 * g + r;
         const T* vrow = tok_row_t(a.v, a.qsb, a.qsn, b, min(key, nm1), h, DH);
@@ -229,11 +266,13 @@ __global__ __launch_bounds__(64 * kLWaves) void attn_bwd_dq_lp_kernel(AttnArgsT<
     const f32x4 s = dot_rows_t<T, DH>(kf, qf, zero4());    // scores^T
     const f32x4 da = dot_rows_t<T, DH>(vf, dof, zero4());  // (dout . v^T)^T
     float ds[4];
+    float ms[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+    if (a.drop_thresh != 0u) drop_scales(a, bh, qc, 4 * kt + g, ms);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int key = 16 * kt + 4 * g + r;
       const float p = (key < n && qok) ? fast_exp(s[r] - m) * pv[r] * rinv : 0.0f;
-      ds[r] = p * (da[r] - delta);
+      ds[r] = p * (da[r] * ms[r] - delta);   // d(dropped probability) -> d(probability): the same keep-scale
     }
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) dq[ct] = Num<T>::mma4(ds, kb[ct], dq[ct]);
@@ -307,8 +346,15 @@ __global__ __launch_bounds__(64 * kLWaves) void attn_bwd_dkdv_lp_kernel(AttnArgs
       for (int r = 0; r < 4; ++r) {
         const int qq = 16 * qb + 4 * g + r;
         const float zz = sz[r];
-        p[r] = (qq < a.N && kok) ? fast_exp(s[r] - sm[r]) * pv[r] * (1.0f / fmaxf(zz, 1e-6f)) : 0.0f;
-        ds[r] = p[r] * (da[r] - (zz < 1e-6f ? 0.0f : sd[r]));
+        float mk = 1.0f;
+        if (a.drop_thresh != 0u) {   // this lane's key of query qq: element key & 3 of its 4-key group
+          float ms[4];
+          drop_scales(a, bh, min(qq, a.N - 1), keyc >> 2, ms);
+          mk = (keyc & 3) == 0 ? ms[0] : ((keyc & 3) == 1 ? ms[1] : ((keyc & 3) == 2 ? ms[2] : ms[3]));
+        }
+        const float pr = (qq < a.N && kok) ? fast_exp(s[r] - sm[r]) * pv[r] * (1.0f / fmaxf(zz, 1e-6f)) : 0.0f;
+        ds[r] = pr * (da[r] * mk - (zz < 1e-6f ? 0.0f : sd[r]));
+        p[r] = pr * mk;              // dV takes the dropped probabilities
       }
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
@@ -841,6 +887,7 @@ extern "C" int feta_attn_fwd_bf16(const void* q, const void* k, const void* v, i
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.pe = (const bf16_t*)pe; a.n_real = n_real;
   a.out_w = (bf16_t*)out; a.attn = (bf16_t*)attn; a.stats = stats; a.qsb = qkv_sb; a.qsn = qkv_sn; a.osb = o_sb;
   a.osn = o_sn; a.scale = scale; a.B = B; a.N = N; a.H = H; a.NB = (N + 15) / 16; a.total = B * H * a.NB;
+  a.drop_thresh = 0u; a.drop_scale = 1.0f;
 #define CALL(D) launch_attn_fwd_lp<bf16_t, D>(a, (hipStream_t)stream)
   FETA_LP_DH_SWITCH(dh, CALL)
 #undef CALL
@@ -862,10 +909,103 @@ extern "C" int feta_attn_bwd_bf16(const void* q, const void* k, const void* v, i
   a.out = (const bf16_t*)out; a.dout = (const bf16_t*)dout; a.stats_in = stats; a.delta = delta;
   a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.qsb = qkv_sb; a.qsn = qkv_sn; a.osb = o_sb; a.osn = o_sn;
   a.scale = scale; a.B = B; a.N = N; a.H = H; a.NB = (N + 15) / 16; a.total = B * H * a.NB;
+  a.drop_thresh = 0u; a.drop_scale = 1.0f;
 #define CALL(D) launch_attn_bwd_lp<bf16_t, D>(a, (hipStream_t)stream)
   FETA_LP_DH_SWITCH(dh, CALL)
 #undef CALL
   return FETA_E_ARG;
+}
+
+namespace {
+template <class T>
+void set_drop(AttnArgsT<T>& a, float p_drop, uint64_t seed, uint64_t offset) {
+  if (p_drop > 0.0f) {
+    const double t = (double)p_drop * 4294967296.0;
+    a.drop_thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)t;
+    if (a.drop_thresh == 0u) a.drop_thresh = 1u;
+    a.drop_scale = 1.0f / (1.0f - p_drop);
+  } else {
+    a.drop_thresh = 0u;
+    a.drop_scale = 1.0f;
+  }
+  a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32);
+  a.off_lo = (unsigned)offset; a.off_hi = (unsigned)(offset >> 32);
+}
+
+template <class T>
+int attn_fwd_drop_t(const void* q, const void* k, const void* v, int64_t qkv_sb, int64_t qkv_sn, const void* pe,
+                    const int32_t* n_real, void* out, int64_t o_sb, int64_t o_sn, void* attn, float* stats, float scale,
+                    float p_drop, uint64_t seed, uint64_t offset, int B, int N, int H, int dh, hipStream_t stream) {
+  AttnArgsT<T> a{};
+  a.q = (const T*)q; a.k = (const T*)k; a.v = (const T*)v; a.pe = (const T*)pe; a.n_real = n_real;
+  a.out_w = (T*)out; a.attn = (T*)attn; a.stats = stats; a.qsb = qkv_sb; a.qsn = qkv_sn; a.osb = o_sb;
+  a.osn = o_sn; a.scale = scale; a.B = B; a.N = N; a.H = H; a.NB = (N + 15) / 16; a.total = B * H * a.NB;
+  set_drop(a, p_drop, seed, offset);
+  switch (dh) {
+    case 16: return launch_attn_fwd_lp<T, 16>(a, stream);
+    case 32: return launch_attn_fwd_lp<T, 32>(a, stream);
+    case 64: return launch_attn_fwd_lp<T, 64>(a, stream);
+    default: return FETA_E_ARG;
+  }
+}
+
+template <class T>
+int attn_bwd_drop_t(const void* q, const void* k, const void* v, int64_t qkv_sb, int64_t qkv_sn, const void* pe,
+                    const int32_t* n_real, const void* out, const void* dout, int64_t o_sb, int64_t o_sn,
+                    const float* stats, float* delta, void* dq, void* dk, void* dv, float scale, float p_drop,
+                    uint64_t seed, uint64_t offset, int B, int N, int H, int dh, hipStream_t stream) {
+  AttnArgsT<T> a{};
+  a.q = (const T*)q; a.k = (const T*)k; a.v = (const T*)v; a.pe = (const T*)pe; a.n_real = n_real;
+  a.out = (const T*)out; a.dout = (const T*)dout; a.stats_in = stats; a.delta = delta;
+  a.dq = (T*)dq; a.dk = (T*)dk; a.dv = (T*)dv; a.qsb = qkv_sb; a.qsn = qkv_sn; a.osb = o_sb; a.osn = o_sn;
+  a.scale = scale; a.B = B; a.N = N; a.H = H; a.NB = (N + 15) / 16; a.total = B * H * a.NB;
+  set_drop(a, p_drop, seed, offset);
+  switch (dh) {
+    case 16: return launch_attn_bwd_lp<T, 16>(a, stream);
+    case 32: return launch_attn_bwd_lp<T, 32>(a, stream);
+    case 64: return launch_attn_bwd_lp<T, 64>(a, stream);
+    default: return FETA_E_ARG;
+  }
+}
+}  // namespace
+
+extern "C" int feta_attn_fwd_drop(const void* q, const void* k, const void* v, int64_t qkv_sb, int64_t qkv_sn,
+                                  const void* pe, const int32_t* n_real, void* out, int64_t o_sb, int64_t o_sn,
+                                  void* attn, float* stats, float scale, float p_drop, uint64_t seed, uint64_t offset,
+                                  int dtype, int B, int N, int H, int dh, feta_stream_t stream) {
+  FETA_REQUIRE(q && k && v && n_real && out && stats, "attn_fwd_drop: null pointer");
+  FETA_REQUIRE(B > 0 && H > 0 && N >= 1 && N <= FETA_MAX_NODES, "attn_fwd_drop: N=%d outside [1,%d]", N, FETA_MAX_NODES);
+  FETA_REQUIRE(dh == 16 || dh == 32 || dh == 64, "attn_fwd_drop: head dim %d not in {16,32,64}", dh);
+  FETA_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, "attn_fwd_drop: p = %g outside [0, 1)", (double)p_drop);
+  FETA_REQUIRE(dtype == FETA_DTYPE_F32 || dtype == FETA_DTYPE_BF16, "attn_fwd_drop: unknown dtype %d", dtype);
+  FETA_REQUIRE((qkv_sb & 3) == 0 && (qkv_sn & 3) == 0 && (o_sb & 3) == 0 && (o_sn & 3) == 0 &&
+               (dtype == FETA_DTYPE_F32 ? (aligned16(q) && aligned16(k) && aligned16(v) && aligned16(out))
+                                        : (aligned8(q) && aligned8(k) && aligned8(v) && aligned8(out))),
+               "attn_fwd_drop: misaligned token tensors / strides");
+  if (dtype == FETA_DTYPE_F32)
+    return attn_fwd_drop_t<float>(q, k, v, qkv_sb, qkv_sn, pe, n_real, out, o_sb, o_sn, attn, stats, scale, p_drop, seed,
+                                  offset, B, N, H, dh, (hipStream_t)stream);
+  return attn_fwd_drop_t<bf16_t>(q, k, v, qkv_sb, qkv_sn, pe, n_real, out, o_sb, o_sn, attn, stats, scale, p_drop, seed,
+                                 offset, B, N, H, dh, (hipStream_t)stream);
+}
+
+extern "C" int feta_attn_bwd_drop(const void* q, const void* k, const void* v, int64_t qkv_sb, int64_t qkv_sn,
+                                  const void* pe, const int32_t* n_real, const void* out, const void* dout,
+                                  int64_t o_sb, int64_t o_sn, const float* stats, float* delta, void* dq, void* dk,
+                                  void* dv, float scale, float p_drop, uint64_t seed, uint64_t offset, int dtype,
+                                  int B, int N, int H, int dh, feta_stream_t stream) {
+  FETA_REQUIRE(q && k && v && n_real && out && dout && stats && delta && dq && dk && dv, "attn_bwd_drop: null pointer");
+  FETA_REQUIRE(B > 0 && H > 0 && N >= 1 && N <= FETA_MAX_NODES, "attn_bwd_drop: N=%d outside [1,%d]", N, FETA_MAX_NODES);
+  FETA_REQUIRE(dh == 16 || dh == 32 || dh == 64, "attn_bwd_drop: head dim %d not in {16,32,64}", dh);
+  FETA_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, "attn_bwd_drop: p = %g outside [0, 1)", (double)p_drop);
+  FETA_REQUIRE(dtype == FETA_DTYPE_F32 || dtype == FETA_DTYPE_BF16, "attn_bwd_drop: unknown dtype %d", dtype);
+  FETA_REQUIRE((qkv_sb & 3) == 0 && (qkv_sn & 3) == 0 && (o_sb & 3) == 0 && (o_sn & 3) == 0,
+               "attn_bwd_drop: strides %% 4 == 0");
+  if (dtype == FETA_DTYPE_F32)
+    return attn_bwd_drop_t<float>(q, k, v, qkv_sb, qkv_sn, pe, n_real, out, dout, o_sb, o_sn, stats, delta, dq, dk, dv,
+                                  scale, p_drop, seed, offset, B, N, H, dh, (hipStream_t)stream);
+  return attn_bwd_drop_t<bf16_t>(q, k, v, qkv_sb, qkv_sn, pe, n_real, out, dout, o_sb, o_sn, stats, delta, dq, dk, dv,
+                                 scale, p_drop, seed, offset, B, N, H, dh, (hipStream_t)stream);
 }
 
 static int spec_args_bf16(FilterArgsT<bf16_t>& a, const void* x, int64_t x_sb, int64_t x_sn, const void* u,

@@ -36,7 +36,7 @@ class AttentionCoreFn(torch.autograd.Function):
     attn [B,H,N,N] or None).  C ABI: feta_attn_fwd / feta_attn_bwd."""
 
     @staticmethod
-    def forward(ctx, qkv, pe, n_real, num_heads, need_attn, tie_qk, batch_first):
+    def forward(ctx, qkv, pe, n_real, num_heads, need_attn, tie_qk, batch_first, drop=None):
         abi, stream = _lib.backend(qkv, pe, n_real)
         ctx.set_materialize_grads(False)   # no zero tensor for the non-differentiable attn output
         qkv = qkv.contiguous()
@@ -52,9 +52,10 @@ class AttentionCoreFn(torch.autograd.Function):
         stats = torch.empty((b, num_heads, n, 2), dtype=torch.float32, device=qkv.device)
         pe_c = None if pe is None else pe.to(qkv.dtype).contiguous()   # (bf16 storage: pe travels as bf16 too)
         scale = float(dh) ** -0.5
-        abi.attn_fwd(q, k, v, pe_c, n_real, out, attn, stats, scale, stream)
+        abi.attn_fwd(q, k, v, pe_c, n_real, out, attn, stats, scale, stream, drop=drop)
         ctx.save_for_backward(qkv, pe_c, n_real, out, stats)
         ctx.cfg = (num_heads, tie_qk, batch_first, scale)
+        ctx.drop = drop
         concat = (out if batch_first else out.permute(1, 0, 2, 3)).reshape(l0, l1, d)
         if attn is not None:
             ctx.mark_non_differentiable(attn)   # enters A2 detached (transformer/models.py:282)
@@ -64,7 +65,7 @@ class AttentionCoreFn(torch.autograd.Function):
     def backward(ctx, dconcat, _dattn):
         qkv, pe_c, n_real, out, stats = ctx.saved_tensors
         if dconcat is None:
-            return (None,) * 7
+            return (None,) * 8
         num_heads, tie_qk, batch_first, scale = ctx.cfg
         abi, stream = _lib.backend(qkv)
         l0, l1, d3 = qkv.shape
@@ -83,11 +84,11 @@ class AttentionCoreFn(torch.autograd.Function):
         dout = _token_view(dconcat.to(qkv.dtype).contiguous(), batch_first, num_heads)
         delta = torch.empty((b, num_heads, n), dtype=torch.float32, device=qkv.device)
         abi.attn_bwd(q, k, v, pe_c, n_real, out, dout, stats, delta, gsel(0), gsel(1), gsel(2),
-                     scale, stream)
+                     scale, stream, drop=ctx.drop)
         if tie_qk:
             dqkv[..., :d] += dqkv[..., d:2 * d]
             dqkv[..., d:2 * d] = 0
-        return dqkv, None, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None, None
 
 
 class FilterCoefficientsFn(torch.autograd.Function):
@@ -428,8 +429,34 @@ def layer_norm_rows(y, gamma, beta, eps):
     return LayerNormRowsFn.apply(y, gamma, beta, eps)
 
 
-def attention_core(qkv, pe, n_real, num_heads, need_attn=True, tie_qk=False, batch_first=False):
-    return AttentionCoreFn.apply(qkv, pe, n_real, num_heads, need_attn, tie_qk, batch_first)
+class DropoutState:
+    """(seed, offset) of the attention-probability dropout masks: every masked forward takes the next offset, so
+    masks differ between layers and steps and are reproducible from the seed (the kernels derive the mask from
+    (seed, offset, b, h, query, key): include/feta_hip.h, feta_attn_fwd_drop)."""
+    seed = None
+    offset = 0
+
+    @classmethod
+    def manual_seed(cls, seed):
+        cls.seed, cls.offset = int(seed) & (2 ** 63 - 1), 0
+
+    @classmethod
+    def next(cls):
+        if cls.seed is None:
+            cls.manual_seed(torch.initial_seed())
+        cls.offset += 1
+        return cls.seed, cls.offset
+
+
+def attention_core(qkv, pe, n_real, num_heads, need_attn=True, tie_qk=False, batch_first=False, dropout_p=0.0):
+    """dropout_p > 0: attention-probability dropout with a mask regenerated in backward (no mask tensor).  The
+    (seed, offset) are host values: a captured hipGraph would replay ONE mask, so dropout runs eagerly."""
+    drop = None
+    if dropout_p > 0.0:
+        if qkv.is_cuda and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('attention dropout inside a captured hipGraph would replay one fixed mask')
+        drop = (float(dropout_p),) + DropoutState.next()
+    return AttentionCoreFn.apply(qkv, pe, n_real, num_heads, need_attn, tie_qk, batch_first, drop)
 
 
 def filter_coefficients(attn, n_real, gcn_weight, gcn_bias):

@@ -79,10 +79,6 @@ class DiffMultiheadAttention(nn.Module):
 
     def core(self, query, pe, key_padding_mask, need_weights, n_real):
         """in_proj + attention core -> (concat [N,B,d] before out_proj, attn or None)."""
-        if self.training and self.dropout > 0.0:
-            raise NotImplementedError('attention-probability dropout is not built; the FeTA '
-                                      'scripts default to --dropout 0.0 '
-                                      '(experiments/run_transformer_gengcn.py:47)')
         n, b, d = query.shape
         if n_real is None:
             if key_padding_mask is None:
@@ -91,7 +87,8 @@ class DiffMultiheadAttention(nn.Module):
                 n_real = n_real_from_mask(key_padding_mask)
         qkv, _ = linear_rows(query.reshape(n * b, d), self.in_proj_weight, self.in_proj_bias)
         return FF.attention_core(qkv.view(n, b, 3 * d), pe, n_real, self.num_heads,
-                                 need_attn=need_weights, tie_qk=self.tie_qk, batch_first=False)
+                                 need_attn=need_weights, tie_qk=self.tie_qk, batch_first=False,
+                                 dropout_p=self.dropout if self.training else 0.0)
 
     def forward(self, query, key, value, pe=None, key_padding_mask=None, need_weights=True,
                 attn_mask=None, need_heads=False, n_real=None):
@@ -144,7 +141,7 @@ class DiffTransformerEncoderLayer(nn.Module):
         x0 = src.to(dt)
         qkv = F.linear(x0, cast(a.in_proj_weight), cast(a.in_proj_bias))
         concat, attn = FF.attention_core(qkv, pe, n_real, a.num_heads, need_attn=need_weights, tie_qk=a.tie_qk,
-                                         batch_first=False)
+                                         batch_first=False, dropout_p=a.dropout if self.training else 0.0)
         src2 = F.linear(concat, cast(a.out_proj.weight), cast(a.out_proj.bias))
         if degree_rows is not None:
             src2 = src2 * degree_rows.view(n, b, 1).to(dt)

@@ -199,6 +199,26 @@ int feta_spec_filter_bwd_bf16(const void* x, int64_t x_sb, int64_t x_sn, const v
                               int B, int N, int H, int dh, int P, int K, int heads_share_graph,
                               feta_stream_t stream);
 
+/* ---- A1 with attention-probability dropout (step (6) of the reconstructed layer; the reference
+ * scripts expose --dropout, default 0.0: experiments/run_transformer_gengcn.py:47) --------------------------
+ * attn = dropout(softmax-like probabilities, p) (kept entries scaled by 1/(1-p)); out = attn . v; the written
+ * attn is the dropped one (as nn.MultiheadAttention returns it).  The keep mask is a pure function of
+ * (seed, offset, b, h, query, key): Philox4x32-10, key = seed, counter = (g, offset) with
+ * g = ((b*H + h)*N + query) * ceil(N/4) + key/4, word key%4 of the output, keep iff word >= floor(p * 2^32);
+ * backward regenerates it from the same (seed, offset) - no mask tensor.  dtype: FETA_DTYPE_F32 (float
+ * operands, 16-byte aligned) or FETA_DTYPE_BF16 (as the *_bf16 entry points). */
+#define FETA_DTYPE_F32 0
+#define FETA_DTYPE_BF16 1
+int feta_attn_fwd_drop(const void* q, const void* k, const void* v, int64_t qkv_sb, int64_t qkv_sn,
+                       const void* pe, const int32_t* n_real, void* out, int64_t o_sb, int64_t o_sn,
+                       void* attn, float* stats, float scale, float p_drop, uint64_t seed, uint64_t offset,
+                       int dtype, int B, int N, int H, int dh, feta_stream_t stream);
+int feta_attn_bwd_drop(const void* q, const void* k, const void* v, int64_t qkv_sb, int64_t qkv_sn,
+                       const void* pe, const int32_t* n_real, const void* out, const void* dout,
+                       int64_t o_sb, int64_t o_sn, const float* stats, float* delta,
+                       void* dq, void* dk, void* dv, float scale, float p_drop, uint64_t seed, uint64_t offset,
+                       int dtype, int B, int N, int H, int dh, feta_stream_t stream);
+
 /* ---- A1/A4: row-wise linears of the encoder layer and BatchNorm1d --------------------------
  * Replaces the F.linear / relu / degree scaling / residual / BatchNorm1d sequence of
  * DiffTransformerEncoderLayer.forward (contract transformer/models.py:166-167; body per upstream

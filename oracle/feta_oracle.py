@@ -304,10 +304,12 @@ def get_filter_coefficients_collapsed(attn, masks, gcn_w, gcn_b, lin_w, lin_b):
 # ---------------------------------------------------------------------------
 
 
-def attention_core(qkv, pe, key_padding_mask, num_heads, tie_qk=False, detach_max=False):
-    """Scores -> masked exp -> (* pe) -> clamped normalisation -> weighted sum, from the
+def attention_core(qkv, pe, key_padding_mask, num_heads, tie_qk=False, detach_max=False, drop_scale=None):
+    """Scores -> masked exp -> (* pe) -> clamped normalisation -> (dropout) -> weighted sum, from the
     projected qkv [N,B,3d].  detach_max=True drops the (mathematically zero unless the
     1e-6 clamp is active) gradient through the row maximum, which is what the kernels do.
+    drop_scale [B,H,N,N] (0 or 1/(1-p)): the attention-probability dropout of step (6), SURVEY 8a A1, with the
+    mask handed in; the returned attn is the dropped one (nn.MultiheadAttention semantics).
     Returns (concat [N,B,d], attn [B,H,N,N], out_each_head [B,N,H,dh])."""
     n, b, d3 = qkv.shape
     d = d3 // 3
@@ -328,14 +330,16 @@ def attention_core(qkv, pe, key_padding_mask, num_heads, tie_qk=False, detach_ma
     if pe is not None:
         s = s * pe.unsqueeze(1)
     a = s / s.sum(dim=-1, keepdim=True).clamp(min=1e-6)
+    if drop_scale is not None:
+        a = a * drop_scale
     o = torch.bmm(a.view(b * num_heads, n, n), v).view(b, num_heads, n, dh)
     concat = o.permute(2, 0, 1, 3).reshape(n, b, d)
     return concat, a, o.permute(0, 2, 1, 3)
 
 
-def diff_attention(src, pe, key_padding_mask, in_w, in_b, num_heads, tie_qk=False):
+def diff_attention(src, pe, key_padding_mask, in_w, in_b, num_heads, tie_qk=False, drop_scale=None):
     """in_proj + attention_core."""
-    return attention_core(F.linear(src, in_w, in_b), pe, key_padding_mask, num_heads, tie_qk)
+    return attention_core(F.linear(src, in_w, in_b), pe, key_padding_mask, num_heads, tie_qk, drop_scale=drop_scale)
 
 
 def _norm(x, w, b, batch_norm):
@@ -347,13 +351,13 @@ def _norm(x, w, b, batch_norm):
 
 
 def encoder_layer(src, pe, degree, key_padding_mask, p, prefix, num_heads,
-                  batch_norm=False, tie_qk=False):
+                  batch_norm=False, tie_qk=False, drop_scale=None):
     """DiffTransformerEncoderLayer.forward(need_heads=True) -> (src', attn, out_each_head).
     p: dict of tensors keyed like the product's state_dict, prefix e.g. 'layers.0.'."""
     concat, attn, oh = diff_attention(src, pe, key_padding_mask,
                                       p[prefix + 'self_attn.in_proj_weight'],
                                       p.get(prefix + 'self_attn.in_proj_bias'),
-                                      num_heads, tie_qk)
+                                      num_heads, tie_qk, drop_scale)
     src2 = F.linear(concat, p[prefix + 'self_attn.out_proj.weight'],
                     p.get(prefix + 'self_attn.out_proj.bias'))
     if degree is not None:

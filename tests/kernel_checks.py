@@ -34,6 +34,35 @@ def assert_close(name, got, ref, tol=TOL):
     return err
 
 
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """numpy Philox4x32-10 on uint64 arrays holding 32-bit words (the generator of feta_attn_fwd_drop)."""
+    M = np.uint64(0xFFFFFFFF)
+    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint64) & M for c in (c0, c1, c2, c3))
+    k0, k1 = np.uint64(k0) & M, np.uint64(k1) & M
+    for _ in range(10):
+        p0, p1 = np.uint64(0xD2511F53) * c0, np.uint64(0xCD9E8D57) * c2
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & M, p1 >> np.uint64(32), p1 & M
+        c0, c1, c2, c3 = (hi1 ^ c1 ^ k0) & M, lo1, (hi0 ^ c3 ^ k1) & M, lo0
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & M, (k1 + np.uint64(0xBB67AE85)) & M
+    return c0, c1, c2, c3
+
+
+def dropout_scales(bsz, h, n, p, seed, offset):
+    """[B,H,N,N] keep-scales (0 or 1/(1-p)) exactly as the kernels derive them (include/feta_hip.h)."""
+    ng = (n + 3) // 4
+    bh = np.arange(bsz * h, dtype=np.uint64)[:, None, None]
+    q = np.arange(n, dtype=np.uint64)[None, :, None]
+    kg = np.arange(ng, dtype=np.uint64)[None, None, :]
+    idx = (bh * np.uint64(n) + q) * np.uint64(ng) + kg
+    words = philox4x32_10(idx & np.uint64(0xFFFFFFFF), idx >> np.uint64(32), offset & 0xFFFFFFFF, offset >> 32,
+                          seed & 0xFFFFFFFF, seed >> 32)
+    bits = np.stack(words, axis=-1).reshape(bsz * h, n, 4 * ng)[:, :, :n]
+    thresh = max(1, min(int(float(np.float32(p)) * 4294967296.0), 0xFFFFFFFF))
+    keep = bits >= np.uint64(thresh)
+    scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+    return torch.from_numpy(np.where(keep, np.float64(scale), 0.0)).reshape(bsz, h, n, n)
+
+
 def make_batch(shape, bsz, seed, in_dim, n_min=None, n_max=None, k_eig=None, full_first=True):
     ds = D.SyntheticGraphDataset(shape, bsz, in_dim=in_dim, seed=seed, n_min=n_min, n_max=n_max)
     return D.collate(ds.samples, k_eig=k_eig)
@@ -58,7 +87,8 @@ def to_view(t64, seq_first, dev, dtype=torch.float32):
 
 
 def check_attn(abi, dev, stream, bsz, n, h, dh, use_pe, seq_first=True, seed=0, write_attn=True,
-               clamp_case=False, dtype=torch.float32):
+               clamp_case=False, dtype=torch.float32, drop=None):
+    """drop = (p, seed, offset): attention-probability dropout - the oracle gets the mask the kernels derive."""
     g = torch.Generator().manual_seed(seed)
     d = h * dh
     tol = TOL if dtype == torch.float32 else BF16_TOL
@@ -77,7 +107,11 @@ def check_attn(abi, dev, stream, bsz, n, h, dh, use_pe, seq_first=True, seed=0, 
     dout = round_to(torch.randn(bsz, n, h, dh, generator=g, dtype=torch.float64), dtype)
 
     qkv_r = qkv.clone().requires_grad_(True)
-    _, a_ref, o_ref = O.attention_core(qkv_r, pe, mask, h, detach_max=clamp_case)
+    ds_ = None if drop is None else dropout_scales(bsz, h, n, *drop)
+    if drop is not None:
+        frac = float((ds_ == 0).double().mean())
+        assert abs(frac - drop[0]) < 0.05, 'dropped fraction %.3f for p = %.2f' % (frac, drop[0])
+    _, a_ref, o_ref = O.attention_core(qkv_r, pe, mask, h, detach_max=clamp_case, drop_scale=ds_)
     z_ref = None
     (o_ref * dout).sum().backward()
 
@@ -97,7 +131,7 @@ def check_attn(abi, dev, stream, bsz, n, h, dh, use_pe, seq_first=True, seed=0, 
     stats = torch.zeros(bsz, h, n, 2, device=dev)
     pe32 = None if pe is None else pe.to(dtype).contiguous().to(dev)
     nbd = nb.to(dev)
-    abi.attn_fwd(qv, kv, vv, pe32, nbd, out, attn, stats, dh ** -0.5, stream)
+    abi.attn_fwd(qv, kv, vv, pe32, nbd, out, attn, stats, dh ** -0.5, stream, drop=drop)
     errs = {}
     if write_attn:
         errs['attn'] = assert_close('attn', attn, a_ref, tol=tol)
@@ -112,7 +146,7 @@ def check_attn(abi, dev, stream, bsz, n, h, dh, use_pe, seq_first=True, seed=0, 
         dq, dk, dv = (g5[:, :, i] for i in range(3))
     delta = torch.zeros(bsz, h, n, device=dev)
     do = to_view(dout, seq_first, dev, dtype)
-    abi.attn_bwd(qv, kv, vv, pe32, nbd, out, do, stats, delta, dq, dk, dv, dh ** -0.5, stream)
+    abi.attn_bwd(qv, kv, vv, pe32, nbd, out, do, stats, delta, dq, dk, dv, dh ** -0.5, stream, drop=drop)
     errs['dqkv'] = assert_close('dqkv', dqkv, qkv_r.grad, tol=tol)
     return errs
 

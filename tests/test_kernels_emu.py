@@ -38,6 +38,15 @@ def test_spec_filter_bf16(emu, k_eig, share, dh):
                     dtype=KC.BF16)
 
 
+@pytest.mark.parametrize('bsz,n,h,dh,p,dtype', [(3, 21, 4, 16, 0.1, torch.float32), (2, 37, 2, 32, 0.5, torch.float32),
+                                                 (2, 70, 1, 64, 0.25, torch.float32), (3, 21, 4, 16, 0.2, KC.BF16)])
+def test_attn_dropout(emu, bsz, n, h, dh, p, dtype):
+    """attention-probability dropout (feta_attn_fwd_drop / _bwd_drop): forward, the written (dropped) attn and the
+    backward against the oracle holding the SAME mask, rebuilt on the host from (seed, offset)"""
+    KC.check_attn(emu, CPU, None, bsz, n, h, dh, True, drop=(p, 1234567891011, 7), dtype=dtype)
+    KC.check_attn(emu, CPU, None, bsz, n, h, dh, False, seq_first=False, drop=(p, 5, 2 ** 33 + 1), dtype=dtype)
+
+
 def test_attn_no_attn_write(emu):
     KC.check_attn(emu, CPU, None, 2, 21, 2, 16, True, write_attn=False)
 

@@ -209,3 +209,11 @@ def test_eigh_sym_workspace_variant(hip):
     abi, dev, stream = hip
     KC.check_eigh(abi, dev, stream, 'molhiv', 5, 0, 150, 222, 222)
     KC.check_eigh(abi, dev, stream, 'pattern', 3, 1, 200, 256, 256)
+
+
+@pytest.mark.parametrize('bsz,n,h,dh,p,dtype', [(128, 37, 4, 16, 0.1, torch.float32), (3, 222, 4, 16, 0.5, torch.float32),
+                                                 (4, 64, 2, 32, 0.25, KC.BF16)])
+def test_attn_dropout(hip, bsz, n, h, dh, p, dtype):
+    """feta_attn_fwd_drop / feta_attn_bwd_drop: the oracle holds the mask the kernels derive from (seed, offset)"""
+    abi, dev, stream = hip
+    KC.check_attn(abi, dev, stream, bsz, n, h, dh, True, drop=(p, 1234567891011, 7), dtype=dtype)

@@ -70,6 +70,58 @@ def test_model_forward_backward_matches_oracle(emu, batch_norm, share, mode, pe_
         KC.assert_close('grad ' + name, p.grad, ref, tol=2e-5)
 
 
+def check_layer_attention_dropout(dev, hook, bf16=False):
+    """DiffTransformerEncoderLayer in training mode with attention-probability dropout (--dropout of the reference
+    scripts, experiments/run_transformer_gengcn.py:47) against the oracle holding the same mask; eval mode is
+    dropout-free; two forwards draw different masks."""
+    from feta_tmlr_amd import functional as FF
+    from feta_tmlr_amd.transformer.layers import DiffTransformerEncoderLayer, set_storage_dtype
+    torch.manual_seed(0)
+    d, heads, p_drop = 32, 2, 0.25
+    layer = DiffTransformerEncoderLayer(d, heads, 2 * d, 0.0, batch_norm=False).to(dev)
+    layer.self_attn.dropout = p_drop          # only the attention probabilities: the activations' nn.Dropout
+    layer.train()                             # modules draw from torch's generator and stay at p = 0 here
+    if bf16:
+        set_storage_dtype(layer, torch.bfloat16)
+    ds = D.SyntheticGraphDataset('mutag', 4, in_dim=d, seed=2, n_min=5, n_max=19)
+    batch9, cache = D.collate(ds.samples, device=dev)
+    x, mask, pe, _, degree, _, _, _, _ = batch9
+    src = x.permute(1, 0, 2).contiguous().requires_grad_(True)
+    n, b = src.shape[0], src.shape[1]
+    FF.DropoutState.manual_seed(4242)
+    with hook():
+        out, attn, heads_out = layer(src, pe=pe, degree=degree, src_key_padding_mask=mask, need_heads=True)
+        w = torch.linspace(0.5, 1.5, out.numel(), device=dev).view_as(out)
+        (out.float() * w).sum().backward()
+        out2, attn2, _ = layer(src, pe=pe, degree=degree, src_key_padding_mask=mask, need_heads=True)
+        layer.eval()
+        out_eval, attn_eval = layer(src, pe=pe, degree=degree, src_key_padding_mask=mask)
+    p64 = {'l.' + k: v.detach().cpu().double() for k, v in layer.state_dict().items()}
+    src64 = src.detach().cpu().double().requires_grad_(True)
+    scales = KC.dropout_scales(b, heads, n, p_drop, 4242, 1)
+    ref, a_ref, _ = O.encoder_layer(src64, pe.cpu().double(), degree.cpu().double(), mask.cpu(), p64, 'l.', heads,
+                                    drop_scale=scales)
+    (ref * w.cpu().double()).sum().backward()
+    tol = KC.BF16_TOL * 2 if bf16 else KC.TOL
+    KC.assert_close('layer output', out, ref, tol=tol)
+    KC.assert_close('dropped attn', attn, a_ref, tol=tol)
+    # gradient w.r.t. the REAL input rows: a padded row is all zeros, its LayerNorm has rstd = eps^-1/2 = 316, which
+    # amplifies any rounding of the incoming gradient (bf16: 2^-9) by that factor - and nothing consumes it (padded
+    # inputs are zeros of a bias-free embedding, transformer/models.py:521-522)
+    real = (~mask).t().unsqueeze(-1).cpu()
+    KC.assert_close('dsrc', src.grad.cpu() * real, src64.grad * real, tol=5 * tol)
+    assert float((attn == 0).float().mean()) > float((attn_eval == 0).float().mean()) + 0.1   # entries were dropped
+    assert not torch.equal(attn2, attn)                 # the next forward takes the next offset
+    ref_eval, a_eval, _ = O.encoder_layer(src64.detach(), pe.cpu().double(), degree.cpu().double(), mask.cpu(), p64,
+                                          'l.', heads)
+    KC.assert_close('eval output', out_eval, ref_eval, tol=tol)
+
+
+@pytest.mark.parametrize('bf16', [False, True])
+def test_layer_attention_dropout(emu, bf16):
+    check_layer_attention_dropout(CPU, lambda: _lib.override_for_tests(emu), bf16)
+
+
 def test_unused_outer_gcn_has_no_grad(emu):
     """transformer/models.py:508 registers a GCNConv the forward never uses (matters for the
     data-parallel gradient bucket)."""

@@ -107,3 +107,10 @@ def test_spectral_mode_without_eigenbasis(spectral_k):
     import contextlib
     from test_modules_emu import check_spectral_mode_without_eigenbasis
     check_spectral_mode_without_eigenbasis(torch.device('cuda:0'), contextlib.nullcontext, spectral_k)
+
+
+@pytest.mark.parametrize('bf16', [False, True])
+def test_layer_attention_dropout(bf16):
+    import contextlib
+    from test_modules_emu import check_layer_attention_dropout
+    check_layer_attention_dropout(torch.device('cuda:0'), contextlib.nullcontext, bf16)
