@@ -278,3 +278,151 @@ def bucket_batches(samples, batch_size, buckets=BUCKETS, shuffle_rng=None):
         for k in range(0, len(idx), batch_size):
             out.append((npad, idx[k:k + batch_size]))
     return out
+
+
+# ---- N3: collate without a per-graph Python loop, staged through pinned host buffers -----------------------------
+
+class PackedGraphs:
+    """A whole split as flat arrays (one-time conversion of the GraphSample list): node features / degree of all
+    graphs back to back with per-graph offsets, edge lists likewise.  A batch is then a handful of vectorised gathers
+    instead of the reference's per-graph loop over Python lists (transformer/data.py:197-219)."""
+
+    def __init__(self, samples):
+        ns = np.array([g.num_nodes for g in samples], np.int64)
+        es = np.array([g.edge_index.shape[1] for g in samples], np.int64)
+        self.num_graphs = len(samples)
+        self.n = ns
+        self.node_off = np.concatenate([[0], np.cumsum(ns)])
+        self.edge_off = np.concatenate([[0], np.cumsum(es)])
+        self.x = np.concatenate([g.x for g in samples], axis=0).astype(np.float32)
+        self.edges = np.concatenate([g.edge_index for g in samples], axis=1).astype(np.int64)   # graph-local node ids
+        self.degree = (np.concatenate([g.degree for g in samples]).astype(np.float32)
+                       if samples[0].degree is not None else None)
+        y0 = samples[0].y
+        self.node_labels = isinstance(y0, np.ndarray) and y0.ndim >= 1 and y0.shape[0] == ns[0]
+        if self.node_labels:
+            self.y = np.concatenate([np.asarray(g.y) for g in samples]).astype(np.int64)
+        elif isinstance(y0, (int, np.integer)):
+            self.y = np.array([int(g.y) for g in samples], np.int64)
+        else:
+            self.y = np.array([g.y for g in samples], np.float32)
+
+
+class BatchStager:
+    """Builds the reference's 9-tuple (+ GraphBatchCache) for a list of graph ids of a PackedGraphs:
+      * vectorised fill of PREALLOCATED PINNED host buffers (x, mask, degree and its seq-first row layout, labels,
+        edge_index, batch, feature_indices, n_real, node_off): no per-graph Python loop, no allocation per batch;
+      * one asynchronous host-to-device copy per field on a copy stream, into preallocated device buffers (two
+        sets, used alternately, so that staging batch i + 1 overlaps the step on batch i);
+      * the dense per-graph matrices are NOT built on the host: pe ('diffusion' | 'pstep'), U / lambda (k_eig) and
+        the Laplacian eigenvector features (lap_dim) come from the device (attach_device_spectrum: edge list ->
+        Lhat -> feta_eigh_sym -> feta_spectral_kernel), which replaces the reference's offline pickle cache
+        (transformer/position_encoding.py:35-49) and its [B,N,N] host tensors.
+    Reference: GraphDataset_v2.collate_fn, transformer/data.py:161-225 (same tuple layout, dtypes, zero padding)."""
+
+    def __init__(self, packed, max_batch, n_pad, device, pos_enc=None, k_eig=None, lap_dim=None, beta=1.0, p=1,
+                 zero_diag=False):
+        self.pk, self.bmax, self.n_pad, self.device = packed, int(max_batch), int(n_pad), torch.device(device)
+        self.pos_enc, self.k_eig, self.lap_dim, self.beta, self.p, self.zero_diag = pos_enc, k_eig, lap_dim, beta, p, zero_diag
+        self.cuda = self.device.type == 'cuda'
+        f = packed.x.shape[1]
+        nmax_nodes = self.bmax * self.n_pad
+        emax = int(np.max(packed.edge_off[1:] - packed.edge_off[:-1])) * self.bmax if packed.num_graphs else 0
+        pin = self.cuda
+
+        def host(shape, dtype):
+            return torch.zeros(shape, dtype=dtype, pin_memory=pin)
+
+        self.sets = []
+        for _ in range(2):
+            h = dict(x=host((self.bmax, self.n_pad, f), torch.float32), mask=host((self.bmax, self.n_pad), torch.bool),
+                     degree=host((self.bmax, self.n_pad), torch.float32),
+                     degree_rows=host((self.n_pad * self.bmax,), torch.float32),
+                     labels=host((nmax_nodes if packed.node_labels else self.bmax,),
+                                 torch.int64 if packed.y.dtype == np.int64 else torch.float32),
+                     edge_index=host((2, emax), torch.int64), batch=host((nmax_nodes,), torch.int64),
+                     fi=host((nmax_nodes, 2), torch.int64), n_real=host((self.bmax,), torch.int32),
+                     node_off=host((self.bmax,), torch.int32))
+            d = {k: (torch.empty_like(v, device=self.device) if self.cuda else v) for k, v in h.items()}
+            self.sets.append((h, d))
+        self.turn = 0
+        self.copy_stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+
+    def stage(self, graph_ids):
+        """-> (batch9, cache) on the device; the copies are enqueued on the copy stream and the current stream is
+        made to wait for them (no host synchronisation)."""
+        pk, n_pad = self.pk, self.n_pad
+        ids = np.asarray(graph_ids, np.int64)
+        bsz = len(ids)
+        assert 0 < bsz <= self.bmax
+        h, d = self.sets[self.turn]
+        self.turn ^= 1
+        ns = pk.n[ids]
+        assert int(ns.max()) <= n_pad, 'graph with %d nodes in a batch padded to %d' % (int(ns.max()), n_pad)
+        n_tot = int(ns.sum())
+        offs = np.concatenate([[0], np.cumsum(ns)])[:-1]
+        # node (b, i) of the batch <- global node id of the split: one gather for every per-node field
+        b_of = np.repeat(np.arange(bsz), ns)
+        i_of = np.arange(n_tot) - np.repeat(offs, ns)
+        src = np.repeat(pk.node_off[ids], ns) + i_of
+        x = h['x'].numpy()
+        x[:bsz].fill(0.0)
+        x[b_of, i_of] = pk.x[src]
+        mask = h['mask'].numpy()
+        mask[:bsz] = np.arange(n_pad)[None, :] >= ns[:, None]
+        deg = None
+        if pk.degree is not None:
+            deg = h['degree'].numpy()
+            deg[:bsz].fill(0.0)
+            deg[b_of, i_of] = pk.degree[src]
+            rows = h['degree_rows'].numpy()[:n_pad * bsz].reshape(n_pad, bsz)
+            rows[:] = deg[:bsz].T                                  # row = node * B + graph (seq-first activations)
+        # edges: graph-local ids + the graph's offset in the batch
+        es = pk.edge_off[ids + 1] - pk.edge_off[ids]
+        e_tot = int(es.sum())
+        e_src = np.repeat(pk.edge_off[ids], es) + (np.arange(e_tot) - np.repeat(np.concatenate([[0], np.cumsum(es)])[:-1], es))
+        ei = h['edge_index'].numpy()
+        ei[:, :e_tot] = pk.edges[:, e_src] + np.repeat(offs, es)[None, :]
+        h['batch'].numpy()[:n_tot] = b_of
+        fi = h['fi'].numpy()
+        fi[:n_tot, 0] = b_of
+        fi[:n_tot, 1] = i_of
+        h['n_real'].numpy()[:bsz] = ns
+        h['node_off'].numpy()[:bsz] = offs
+        lab = h['labels'].numpy()
+        if pk.node_labels:
+            lab[:n_tot] = pk.y[src]
+            n_lab = n_tot
+        else:
+            lab[:bsz] = pk.y[ids]
+            n_lab = bsz
+        views = dict(x=(slice(0, bsz),), mask=(slice(0, bsz),), degree=(slice(0, bsz),),
+                     degree_rows=(slice(0, n_pad * bsz),), labels=(slice(0, n_lab),),
+                     edge_index=(slice(None), slice(0, e_tot)), batch=(slice(0, n_tot),), fi=(slice(0, n_tot),),
+                     n_real=(slice(0, bsz),), node_off=(slice(0, bsz),))
+        out = {}
+        if self.cuda:
+            cur = torch.cuda.current_stream(self.device)
+            self.copy_stream.wait_stream(cur)       # the device buffers of this set are free again
+            with torch.cuda.stream(self.copy_stream):
+                for k, sl in views.items():
+                    if k in ('degree', 'degree_rows') and deg is None:
+                        continue
+                    out[k] = d[k][sl]
+                    out[k].copy_(h[k][sl], non_blocking=True)
+            cur.wait_stream(self.copy_stream)
+        else:
+            for k, sl in views.items():
+                if k in ('degree', 'degree_rows') and deg is None:
+                    continue
+                out[k] = h[k][sl].clone()
+        batch9 = (out['x'], out['mask'], None, None, out.get('degree'), out['labels'], out['edge_index'], out['batch'],
+                  out['fi'])
+        cache = GraphBatchCache(n_real=out['n_real'], node_off=out['node_off'], n_pad=n_pad)
+        if 'degree_rows' in out:
+            cache.extra['degree_rows'] = out['degree_rows']
+        if self.pos_enc is not None or self.k_eig is not None or self.lap_dim is not None:
+            batch9, cache = attach_device_spectrum(batch9, cache, k_eig=self.k_eig, pos_enc=self.pos_enc,
+                                                   beta=self.beta, p=self.p, zero_diag=self.zero_diag,
+                                                   lap_dim=self.lap_dim)
+        return batch9, cache

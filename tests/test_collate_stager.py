@@ -1,0 +1,63 @@
+"""N3: the vectorised, pinned-buffer batch stager emits the same 9-tuple as the per-graph collate (reference
+layout: transformer/data.py:161-225), for graph-level and node-level labels, ragged batches and reused buffers."""
+import numpy as np
+import pytest
+import torch
+
+from feta_tmlr_amd.transformer import data as D
+
+
+def _same(a, b):
+    if a is None or b is None:
+        assert a is None and b is None
+        return
+    assert a.dtype == b.dtype and a.shape == b.shape, (a.dtype, b.dtype, a.shape, b.shape)
+    assert torch.equal(a.cpu(), b.cpu())
+
+
+@pytest.mark.parametrize('shape,labels', [('zinc', 'regression'), ('mutag', 'class'), ('pattern', 'node')])
+def test_stager_equals_collate(shape, labels):
+    ds = D.SyntheticGraphDataset(shape, 23, in_dim=6, seed=4, n_min=3, n_max=21, labels=labels, nb_class=3,
+                                 pos_enc=False, with_eig=False)
+    pk = D.PackedGraphs(ds.samples)
+    st = D.BatchStager(pk, max_batch=8, n_pad=21, device='cpu')
+    rng = np.random.default_rng(0)
+    for it in range(5):     # ragged sizes, buffers of both sets reused several times
+        ids = rng.choice(len(ds), size=int(rng.integers(1, 9)), replace=False)
+        b9, cache = st.stage(ids)
+        ref9, refc = D.collate([ds[i] for i in ids], n_pad=21)
+        for i in (0, 1, 4, 5, 6, 7, 8):
+            _same(b9[i], ref9[i])
+        assert b9[2] is None and b9[3] is None
+        _same(cache.n_real, refc.n_real)
+        _same(cache.node_off, refc.node_off)
+        _same(cache.extra['degree_rows'], refc.extra['degree_rows'])
+        assert cache.n_pad == 21
+
+
+def test_stager_rejects_oversized_graph():
+    ds = D.SyntheticGraphDataset('zinc', 4, in_dim=3, seed=1, n_min=10, n_max=12, pos_enc=False, with_eig=False)
+    st = D.BatchStager(D.PackedGraphs(ds.samples), 4, 8, 'cpu')
+    with pytest.raises(AssertionError):
+        st.stage([0, 1])
+
+
+@pytest.mark.gpu
+def test_stager_on_device_with_spectrum():
+    """pinned staging + async copies + device spectrum: tuple fields equal the host collate, pe equals the host
+    diffusion kernel (2e-5), the eigenbasis reproduces Lhat"""
+    dev = torch.device('cuda:0')
+    ds = D.SyntheticGraphDataset('zinc', 300, in_dim=28, seed=2)
+    pk = D.PackedGraphs(ds.samples)
+    st = D.BatchStager(pk, max_batch=128, n_pad=37, device=dev, pos_enc='diffusion', k_eig=16)
+    rng = np.random.default_rng(1)
+    for it in range(4):
+        ids = rng.choice(len(ds), size=128 if it < 3 else 57, replace=False)
+        b9, cache = st.stage(ids)
+        ref9, refc = D.collate([ds[i] for i in ids], n_pad=37, k_eig=16)
+        torch.cuda.synchronize()
+        for i in (0, 1, 4, 5, 6, 7, 8):
+            _same(b9[i], ref9[i])
+        assert float((b9[2].cpu() - ref9[2]).abs().max()) < 2e-5
+        assert float((cache.lam.cpu() - refc.lam).abs().max()) < 5e-6
+        assert cache.u.shape == refc.u.shape

@@ -50,6 +50,40 @@ opt_g = T.make_optimizer('zinc', model.parameters(), lr=1e-3, capturable=True)
 graphed = T.GraphedTrainStep('zinc', model, crit, opt_g, batch9, cache)
 graphed.set_lr(1e-3)
 cap = timed(lambda: graphed(batch9, cache))
+# ---- N3: what it costs to put the NEXT batch on the device ------------------------------------------
+big = D.SyntheticGraphDataset('zinc', 8 * args.batch, in_dim=28, seed=1, pos_enc=True, with_eig=True)
+rng = __import__('numpy').random.default_rng(0)
+id_sets = [rng.choice(len(big), size=args.batch, replace=False) for _ in range(20)]
+
+
+def host_collate():
+    for ids in id_sets:      # the reference's shape: per-graph loop, dense pe / U built on the host, pageable copies
+        D.collate([big[i] for i in ids], k_eig=16, n_pad=37, device=dev)
+    torch.cuda.synchronize()
+
+
+packed = D.PackedGraphs(big.samples)
+stager = D.BatchStager(packed, args.batch, 37, dev, pos_enc='diffusion', k_eig=16)
+
+
+def staged():
+    for ids in id_sets:      # vectorised fill of pinned buffers, async copies, pe / U / lambda produced on the device
+        stager.stage(ids)
+    torch.cuda.synchronize()
+
+
+def timed_host(fn, reps=3):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    return (time.perf_counter() - t0) / reps / len(id_sets)
+
+
+t_coll, t_stage = timed_host(host_collate), timed_host(staged)
+print('collate of one ZINC batch (B=%d, pe + U/lambda included): per-graph host collate %.1f us/graph | pinned stager + '
+      'device spectrum %.2f us/graph (%.0fx); step time per graph %.2f us'
+      % (args.batch, t_coll / args.batch * 1e6, t_stage / args.batch * 1e6, t_coll / t_stage, cap / args.batch * 1e6))
 print('ZINC task, B=%d, %s: eager %.3f ms/step (%.0f graphs/s) | one hipGraph per step %.3f ms/step (%.0f graphs/s)'
       % (args.batch, 'LayerNorm' if args.layer_norm else 'BatchNorm', eager * 1e3, args.batch / eager,
          cap * 1e3, args.batch / cap))
