@@ -122,13 +122,20 @@ __global__ __launch_bounds__(kRowThreads) void rowlin_fwd_kernel(RowLinArgs a, R
       });
   if (want_stats)
     for (int i = threadIdx.x; i < kRowWaves * 2 * tgw; i += kRowThreads) red[i] = 0.0f;
+  // a concatenated operand [x | x2] (linear_cat) is seen through its BatchNorm on the x part only: DS columns
+  const int DS = a.x2 != nullptr ? a.x_split : KI;
+  if (a.x2 != nullptr && x_norm)
+    for (int c = DS + threadIdx.x; c < KI; c += kRowThreads) {
+      xss[c] = 1.0f;
+      xss[KI + c] = 0.0f;
+    }
   if (a.x_stats != nullptr) {
     // first consumer of fresh statistics: finalize them (every block, redundantly and
     // deterministically); block 0 publishes the parameter block and the running statistics
-    reduce_partials(a.x_stats, a.Gx, KI, scr + 2 * KI, scr);
-    for (int c = threadIdx.x; c < KI; c += kRowThreads) {
+    reduce_partials(a.x_stats, a.Gx, DS, scr + 2 * DS, scr);
+    for (int c = threadIdx.x; c < DS; c += kRowThreads) {
       const float mean = scr[c] / (float)a.M;
-      const float var = fmaxf(scr[KI + c] / (float)a.M - mean * mean, 0.0f);
+      const float var = fmaxf(scr[DS + c] / (float)a.M - mean * mean, 0.0f);
       const float rstd = rsqrtf(var + a.eps);
       const float scale = a.x_gamma[c] * rstd;
       const float shift = a.x_beta[c] - mean * scale;
@@ -136,9 +143,9 @@ __global__ __launch_bounds__(kRowThreads) void rowlin_fwd_kernel(RowLinArgs a, R
       xss[KI + c] = shift;
       if (blockIdx.x == 0) {
         a.x_bn_out[c] = scale;
-        a.x_bn_out[KI + c] = shift;
-        a.x_bn_out[2 * KI + c] = mean;
-        a.x_bn_out[3 * KI + c] = rstd;
+        a.x_bn_out[DS + c] = shift;
+        a.x_bn_out[2 * DS + c] = mean;
+        a.x_bn_out[3 * DS + c] = rstd;
         if (a.x_rmean != nullptr) {
           const float unbiased = a.M > 1 ? var * (float)a.M / (float)(a.M - 1) : var;
           a.x_rmean[c] = (1.0f - a.momentum) * a.x_rmean[c] + a.momentum * mean;
@@ -148,7 +155,10 @@ __global__ __launch_bounds__(kRowThreads) void rowlin_fwd_kernel(RowLinArgs a, R
       }
     }
   } else if (a.x_bn != nullptr) {
-    for (int c = threadIdx.x; c < 2 * KI; c += kRowThreads) xss[c] = a.x_bn[c];
+    for (int c = threadIdx.x; c < DS; c += kRowThreads) {
+      xss[c] = a.x_bn[c];
+      xss[KI + c] = a.x_bn[DS + c];
+    }
   }
   __syncthreads();
 
@@ -252,6 +262,8 @@ __device__ void rowlin_dx_role(const RowLinArgs& a, const RowLinGeom& ge, const 
   float* red = ev + 7 * ks;      // [kRowWaves][2][16] column sums of the waves
   const bool want_sums = a.sum_out != nullptr;
   const bool gbn = a.g_y != nullptr;
+  // concatenated operand [x | x2]: sum_y / sum_bn / sum_out describe the BatchNorm of the x part (DS columns)
+  const int DS = a.x2 != nullptr ? a.x_split : a.KI;
   for (int i = threadIdx.x; i < ks; i += kRowThreads) {
     const int k = k_base + i;
     const bool kok = k < a.KI;
@@ -261,8 +273,8 @@ __device__ void rowlin_dx_role(const RowLinArgs& a, const RowLinGeom& ge, const 
     ev[2 * ks + i] = ad ? a.add_bn[3 * a.KI + k] : 0.0f;
     ev[3 * ks + i] = ad ? a.add_fin[k] : 0.0f;
     ev[4 * ks + i] = ad ? a.add_fin[a.KI + k] : 0.0f;
-    ev[5 * ks + i] = (want_sums && kok) ? a.sum_bn[2 * a.KI + k] : 0.0f;
-    ev[6 * ks + i] = (want_sums && kok) ? a.sum_bn[3 * a.KI + k] : 0.0f;
+    ev[5 * ks + i] = (want_sums && k < DS) ? a.sum_bn[2 * DS + k] : 0.0f;
+    ev[6 * ks + i] = (want_sums && k < DS) ? a.sum_bn[3 * DS + k] : 0.0f;
   }
   // wave -> (k tile, row tiles): 4 tiles: one tile, all 4 row tiles; 2 tiles: 2 row tiles; 1 tile: 1
   const int w = wave_id();
@@ -343,7 +355,9 @@ __device__ void rowlin_dx_role(const RowLinArgs& a, const RowLinGeom& ge, const 
           dv4 = *reinterpret_cast<const float4*>(a.add_dout + off);
           ay4 = *reinterpret_cast<const float4*>(a.add_y + off);
         }
-        if (want_sums) sy4 = *reinterpret_cast<const float4*>(a.sum_y + off);
+        const int ksum = k_base + 16 * t + 4 * g;
+        if (want_sums && ksum < DS)
+          sy4 = *reinterpret_cast<const float4*>(a.sum_y + (int64_t)min(row, row_last) * DS + ksum);
         // dX^T tile (k = k_base + 16t + 4g' + r, row): A[k = lq][o = 16j + 4g + s] = W[o][k]
         Feat<NO> gf;
         load_row<NO>(gf, gt + (16 * rt + lq) * GP, g);
@@ -395,7 +409,7 @@ __device__ void rowlin_dx_role(const RowLinArgs& a, const RowLinGeom& ge, const 
         const int tile = kl >> 4, c = kl & 15;
         float s = 0.0f;
         for (int gi = 0; gi < groups; ++gi) s += red[((gi * ntile + tile) * 2 + which) * 16 + c];
-        a.sum_out[((int64_t)rg * 2 + which) * a.KI + k_base + kl] = s;
+        if (k_base + kl < DS) a.sum_out[((int64_t)rg * 2 + which) * DS + k_base + kl] = s;
       }
     }
   }
@@ -426,6 +440,7 @@ __device__ void rowlin_dw_role_lds(const RowLinArgs& a, const RowLinGeom& ge, co
   const int ow = min(64, a.NO - o_base);  // outputs of this group
   float* gt = lds_free;                   // [64][GP]
   float* xt = gt + 64 * GP;               // [64][XP]
+  const int DSW = a.x2 != nullptr ? a.x_split : KI;
   const int nrb16 = (a.M + 15) / 16;
   const int per = (nrb16 + ge.RC - 1) / ge.RC;  // 16-row blocks per chunk
   const int row_lo = rc * per * 16, row_hi = min((rc + 1) * per * 16, a.M);
@@ -489,9 +504,14 @@ __device__ void rowlin_dw_role_lds(const RowLinArgs& a, const RowLinGeom& ge, co
         const int idx = min(base + u * kRowThreads, 64 * (KS / 4) - 1);
         const int rr = idx / (KS / 4), k = 4 * (idx - rr * (KS / 4));
         xv[u] = *reinterpret_cast<const float4*>(x_at(a, min(r0 + rr, row_last), k0 + k));
-        if (a.x_bn != nullptr) {
-          sc[u] = *reinterpret_cast<const float4*>(a.x_bn + k0 + k);
-          sh[u] = *reinterpret_cast<const float4*>(a.x_bn + KI + k0 + k);
+        if (a.x_bn != nullptr) {   // (concatenated operand: the parameter block covers the x part, DSW columns)
+          const int kb = k0 + k < DSW ? k0 + k : 0;
+          sc[u] = *reinterpret_cast<const float4*>(a.x_bn + kb);
+          sh[u] = *reinterpret_cast<const float4*>(a.x_bn + DSW + kb);
+          if (k0 + k >= DSW) {
+            sc[u] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+            sh[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          }
         }
       }
 #pragma unroll
@@ -837,15 +857,14 @@ extern "C" int feta_rowlin_fwd_ex(const feta_rowlin_ex* d, feta_stream_t stream)
   FETA_REQUIRE(!a.x_stats || (a.x_gamma && a.x_beta && a.x_bn_out && a.Gx > 0),
                "rowlin_fwd: x_stats needs gamma, beta, bn_out, Gx");
   FETA_REQUIRE(!a.res_bn || a.residual, "rowlin_fwd: res_bn without residual");
-  FETA_REQUIRE(!a.x2 || (a.x_split > 0 && a.x_split < a.KI && (a.x_split % 16) == 0 && aligned16(a.x2) &&
-                         !a.x_bn && !a.x_stats),
-               "rowlin_fwd: x2 needs 0 < x_split < KI, x_split %% 16 == 0, no input BatchNorm");
+  FETA_REQUIRE(!a.x2 || (a.x_split > 0 && a.x_split < a.KI && (a.x_split % 16) == 0 && aligned16(a.x2)),
+               "rowlin_fwd: x2 needs 0 < x_split < KI, x_split %% 16 == 0 (an input BatchNorm covers the x part)");
   RowLinGeom ge{};
   ge.G = row_blocks(a.M);
   ge.TG = tiles_fwd(a.KI);
   const int n_og = (a.NO / 16 + ge.TG - 1) / ge.TG;
   const size_t lds = sizeof(float) * (16 * ge.TG * (a.KI + 4) + kRowWaves * 2 * 16 * ge.TG + 2 * a.KI +
-                                      (a.x_stats ? reduce_scratch_floats(a.KI) : 0));
+                                      (a.x_stats ? reduce_scratch_floats(a.x2 ? a.x_split : a.KI) : 0));
 #define CALL(KV)                                                                                     \
   {                                                                                                  \
     auto kern = rowlin_fwd_kernel<KV>;                                                               \
@@ -879,8 +898,8 @@ extern "C" int feta_rowlin_bwd_ex(const feta_rowlin_ex* d, float* dwdb, feta_str
   FETA_REQUIRE(!a.sum_out || (a.sum_y && a.sum_bn), "rowlin_bwd: incomplete sum_* set");
   FETA_REQUIRE(!a.x2 == !a.dx2, "rowlin_bwd: x2 and dx2 go together");
   FETA_REQUIRE(!a.x2 || (a.x_split > 0 && a.x_split < a.KI && (a.x_split % 16) == 0 && aligned16(a.x2) &&
-                         aligned16(a.dx2) && !a.x_bn && !a.add_plain && !a.add_dout && !a.sum_out),
-               "rowlin_bwd: x2 needs 0 < x_split < KI, x_split %% 16 == 0 and no add_* / sum_* / x_bn");
+                         aligned16(a.dx2) && !a.add_plain && !a.add_dout),
+               "rowlin_bwd: x2 needs 0 < x_split < KI, x_split %% 16 == 0 and no add_* (x_bn / sum_* cover the x part)");
   RowLinGeom ge{};
   ge.RC = row_chunks(a.M);
   ge.G = row_blocks(a.M);

@@ -339,6 +339,52 @@ class RowLinearCatFn(torch.autograd.Function):
         return dx1, dx2, dwdb[:no * ki].view(no, ki), (dwdb[no * ki:] if ctx.has_bias else None)
 
 
+class RowLinearCatBNFn(torch.autograd.Function):
+    """linear_cat (transformer/models.py:223-224) over [BN(y2) | x2] where BN is the last BatchNorm of the fused
+    layer stack, never materialised: forward finalizes the statistics the stack left in `tail` and normalises inside
+    the operand loads; backward returns, for y2, the gradient w.r.t. the NORMALISED tensor and leaves the BatchNorm
+    backward partial sums in tail.gs (fused_stack.StackTail contract)."""
+
+    @staticmethod
+    def forward(ctx, y2, x2, w, bias, tail):
+        abi, stream = _lib.backend(y2, x2, w)
+        y2, x2, w = y2.contiguous(), x2.contiguous(), w.contiguous()
+        m, k1 = y2.shape
+        ki, no = k1 + x2.shape[1], w.shape[0]
+        out = torch.empty((m, no), dtype=torch.float32, device=y2.device)
+        nm = tail.norm
+        d = abi.rowlin_ex(m, ki, no, x=y2, x2=x2, x_split=k1, w=w, bias=bias, y=out, x_stats=tail.st2, Gx=tail.G2,
+                          x_gamma=tail.gamma, x_beta=tail.beta, x_bn_out=tail.prm2, x_rmean=nm.running_mean,
+                          x_rvar=nm.running_var, x_nbt=nm.num_batches_tracked, momentum=float(nm.momentum),
+                          eps=float(nm.eps))
+        abi.rowlin_fwd_ex(d, stream)
+        ctx.save_for_backward(y2, x2, w, tail.prm2)
+        ctx.tail = tail
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        y2, x2, w, prm2 = ctx.saved_tensors
+        abi, stream = _lib.backend(y2)
+        m, k1 = y2.shape
+        ki, no = k1 + x2.shape[1], w.shape[0]
+        dy = dy.contiguous()
+        dx1, dx2 = torch.empty_like(y2), torch.empty_like(x2)
+        partial = torch.empty((abi.rowlin_chunks(m), no * ki + no), dtype=torch.float32, device=y2.device)
+        dwdb = torch.empty(no * ki + no, dtype=torch.float32, device=y2.device)
+        gs = torch.empty((abi.rowlin_blocks(m), 2, k1), dtype=torch.float32, device=y2.device)
+        d = abi.rowlin_ex(m, ki, no, x=y2, x_bn=prm2, x2=x2, x_split=k1, w=w, dy=dy, dx=dx1, dx2=dx2, partial=partial,
+                          sum_y=y2, sum_bn=prm2, sum_out=gs)
+        abi.rowlin_bwd_ex(d, dwdb, stream)
+        ctx.tail.gs = gs
+        return dx1, dx2, dwdb[:no * ki].view(no, ki), (dwdb[no * ki:] if ctx.has_bias else None), None
+
+
+def row_linear_cat_bn(y2, x2, w, bias, tail):
+    return RowLinearCatBNFn.apply(y2, x2, w, bias, tail)
+
+
 class BatchNormTrainFn(torch.autograd.Function):
     """Training-mode BatchNorm1d over the rows of y [M, D] from per-block partial statistics.
     C ABI: feta_bn_stats (when the producer did not emit them), feta_bn_apply_fwd, feta_bn_bwd."""

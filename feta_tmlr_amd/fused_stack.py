@@ -90,10 +90,24 @@ def _cap_partials(abi, stream, st, new):
     return tot, 1
 
 
+class StackTail:
+    """Hand-over between the BatchNorm stack and the ONE consumer of its output when that consumer is linear_cat
+    (transformer/models.py:223-224): the last BatchNorm is then never materialised either.  The stack returns the
+    pre-norm y2 of the last layer and leaves its statistics here; linear_cat's forward kernel finalizes them and
+    applies the normalisation inside its operand loads (functional.RowLinearCatBNFn), its backward kernel emits the
+    partial sums (sum dout, sum dout * xhat) the BatchNorm backward needs from its dX epilogue.  Contract: the
+    gradient that reaches the stack's first output is the gradient w.r.t. the NORMALISED tensor, with `gs` set.
+    Saves the bn_apply_fwd and bn_bwd_reduce launches of a step."""
+
+    def __init__(self):
+        self.y2 = self.st2 = self.gamma = self.beta = self.norm = self.prm2 = self.gs = None
+        self.G2 = 0
+
+
 class FusedEncoderStackFn(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, src, pe, degree_rows, n_real, layers, need_attn, *params):
+    def forward(ctx, src, pe, degree_rows, n_real, layers, need_attn, tail, *params):
         abi, stream = _lib.backend(src, pe, n_real)
         ctx.set_materialize_grads(False)   # no zero tensor for the (non-differentiable) attn output
         if len(layers):
@@ -177,13 +191,21 @@ class FusedEncoderStackFn(torch.autograd.Function):
                 abi.rowlin_fwd_ex(dsc, stream)
             saved.append(dict(x0=y_prev, prm0=prm_prev, qkv=qkv, out=out, ast=ast, y1=y1, prm1=prm1, h=h, y2=y2))
             y_prev, st_prev, G2_prev = y2, st2, G2
-        # end of the stack: materialise BN2(y2) of the last layer
         last = layers[-1].norm2
-        final = new(m, d)
         prm2 = new(4, d)
-        abi.bn_apply_fwd_prm(y_prev, st_prev, params[(nl - 1) * PER_LAYER + 10], params[(nl - 1) * PER_LAYER + 11],
-                             final, prm2, last.running_mean, last.running_var, float(last.momentum),
-                             float(last.eps), stream, nbt=last.num_batches_tracked)
+        if tail is not None:
+            # the consumer (linear_cat) finalizes and applies BN2 of the last layer: nothing is materialised
+            tail.y2, tail.st2, tail.G2, tail.norm, tail.prm2 = y_prev, st_prev, G2_prev, last, prm2
+            tail.gamma, tail.beta = params[(nl - 1) * PER_LAYER + 10], params[(nl - 1) * PER_LAYER + 11]
+            tail.gs = None
+            final = y_prev.view(m, d)
+        else:
+            # end of the stack: materialise BN2(y2) of the last layer
+            final = new(m, d)
+            abi.bn_apply_fwd_prm(y_prev, st_prev, params[(nl - 1) * PER_LAYER + 10], params[(nl - 1) * PER_LAYER + 11],
+                                 final, prm2, last.running_mean, last.running_var, float(last.momentum),
+                                 float(last.eps), stream, nbt=last.num_batches_tracked)
+        ctx.tail = tail
         saved[-1]['prm2'] = prm2
         ctx.saved_state = saved
         ctx.meta = (n, b, d, heads, dh, tie, scale, G, nl)
@@ -229,8 +251,16 @@ class FusedEncoderStackFn(torch.autograd.Function):
         if d_final is None:   # only the per-head output of the last layer was used
             d_final = torch.zeros(n, b, d, dtype=torch.float32, device=dev)
         dcur = d_final.contiguous().view(m, d)
-        gs, Gs_cur = new(G, 2, d), G
-        abi.bn_bwd_reduce(saved[-1]['y2'], dcur, saved[-1]['prm2'], gs, stream)
+        if ctx.tail is not None:
+            # (StackTail contract) d_final is the gradient w.r.t. BN2(y2); its partial sums came with it
+            gs, Gs_cur = ctx.tail.gs, G
+            ctx.tail.gs = None
+            if gs is None:
+                raise RuntimeError('fused stack: the consumer of the un-normalised output did not leave the '
+                                   'BatchNorm backward sums (StackTail contract)')
+        else:
+            gs, Gs_cur = new(G, 2, d), G
+            abi.bn_bwd_reduce(saved[-1]['y2'], dcur, saved[-1]['prm2'], gs, stream)
         for li in range(nl - 1, -1, -1):
             s = saved[li]
             (w_in, b_in, w_o, b_o, g1, be1, w1, bb1, w2, bb2, g2, be2) = params[li * PER_LAYER:(li + 1) * PER_LAYER]
@@ -303,7 +333,7 @@ class FusedEncoderStackFn(torch.autograd.Function):
             grads[idx] = dwdb_all[off:off + no * ki].view(no, ki)
             if params[idx + 1] is not None:
                 grads[idx + 1] = dwdb_all[off + no * ki:off + no * ki + no]
-        return (dcur.view(n, b, d), None, None, None, None, None) + tuple(grads)
+        return (dcur.view(n, b, d), None, None, None, None, None, None) + tuple(grads)
 
 
 class FusedLayerNormStackFn(torch.autograd.Function):
@@ -321,9 +351,10 @@ class FusedLayerNormStackFn(torch.autograd.Function):
     flat gradient buffer layout as the BatchNorm stack (parallel.FlatBufferAllReduce)."""
 
     @staticmethod
-    def forward(ctx, src, pe, degree_rows, n_real, layers, need_attn, *params):
+    def forward(ctx, src, pe, degree_rows, n_real, layers, need_attn, tail, *params):
         abi, stream = _lib.backend(src, pe, n_real)
         ctx.set_materialize_grads(False)
+        assert tail is None   # (LayerNorm is row-local: its output is materialised by feta_layernorm_fwd)
         if len(layers):
             STACK_FLAT_GRAD.pop(layers[0], None)
         n, b, d = src.shape
@@ -486,13 +517,16 @@ class FusedLayerNormStackFn(torch.autograd.Function):
             grads[idx] = dwdb_all[off:off + no * ki].view(no, ki)
             if params[idx + 1] is not None:
                 grads[idx + 1] = dwdb_all[off + no * ki:off + no * ki + no]
-        return (dcur.view(n, b, d), None, None, None, None, None) + tuple(grads)
+        return (dcur.view(n, b, d), None, None, None, None, None, None) + tuple(grads)
 
 
-def fused_encoder_stack(src, pe, degree_rows, n_real, layers, need_attn=True):
-    """-> (output [N,B,d] of the last layer, concat heads of the last layer [N,B,d], attn or None)"""
+def fused_encoder_stack(src, pe, degree_rows, n_real, layers, need_attn=True, tail=None):
+    """-> (output [N,B,d] of the last layer, concat heads of the last layer [N,B,d], attn or None).
+    tail (a StackTail, BatchNorm stacks only): the output is the PRE-norm y2 of the last layer and the tail's
+    consumer applies the last BatchNorm (functional.row_linear_cat_bn)."""
     params = []
     for l in layers:
         params += layer_params(l)
-    fn = FusedEncoderStackFn if layers[0].batch_norm else FusedLayerNormStackFn
-    return fn.apply(src, pe, degree_rows, n_real, list(layers), need_attn, *params)
+    bn = layers[0].batch_norm
+    fn = FusedEncoderStackFn if bn else FusedLayerNormStackFn
+    return fn.apply(src, pe, degree_rows, n_real, list(layers), need_attn, tail if bn else None, *params)

@@ -21,7 +21,7 @@ from torch import nn
 import torch.nn.functional as F
 
 from .. import functional as FF
-from ..fused_stack import fused_encoder_stack, stack_supported
+from ..fused_stack import StackTail, fused_encoder_stack, stack_supported
 from ..parallel import mark_row_constant
 from .ChebNetDynamic import ChebConvDynamic
 from .data import GraphBatchCache
@@ -230,6 +230,11 @@ class DiffTransformerEncoderGenGCN(nn.Module):
             pe = None if pe is None else pe.to(self.storage_dtype)    # once for all layers
         fused = (not lowp and self.fused_stack and self.last_layer_filter and mask is None
                  and stack_supported(self.layers, src.shape[-1]))
+        # BatchNorm stack whose only consumer is linear_cat: the last BatchNorm is applied inside linear_cat's kernels
+        tail = None
+        if (fused and self.layers[0].batch_norm and self.use_skip_conn and self.norm is None
+                and src.shape[-1] % 16 == 0 and FF.row_linear_supported(2 * src.shape[-1], self.linear_cat.weight.shape[0])):
+            tail = StackTail()
         for layer_num, mod in enumerate(self.layers):
             last = layer_num + 1 == self.num_layers
             filt = last or not self.last_layer_filter                            # :169-171
@@ -239,7 +244,7 @@ class DiffTransformerEncoderGenGCN(nn.Module):
                 if not last:
                     continue
                 output, concat, attn = fused_encoder_stack(output, pe, degree_rows, cache.n_real,
-                                                           self.layers, need_attn=True)
+                                                           self.layers, need_attn=True, tail=tail)
                 if self.keep_stack_boundary:   # for backward_head / backward_stack
                     self._stack_boundary = (output, concat)
                 nn_, bb_, dd_ = concat.shape
@@ -271,6 +276,9 @@ class DiffTransformerEncoderGenGCN(nn.Module):
                 dt = self.storage_dtype
                 output = F.linear(torch.cat((output, allout_filtered.to(dt)), dim=-1), wc.to(dt),
                                   self.linear_cat.bias.to(dt)).float()
+            elif tail is not None:
+                output = FF.row_linear_cat_bn(output.reshape(nn_ * bb_, dd_), allout_filtered.reshape(nn_ * bb_, dd_),
+                                              wc, self.linear_cat.bias, tail).view(nn_, bb_, -1)
             elif (dd_ % 16 == 0 and FF.row_linear_supported(2 * dd_, wc.shape[0])):
                 # [output | allout_filtered] W^T + b without materialising the concatenation (:223-224)
                 output = FF.row_linear_cat(output.reshape(nn_ * bb_, dd_), allout_filtered.reshape(nn_ * bb_, dd_),

@@ -288,7 +288,9 @@ typedef struct feta_rowlin_ex {
   const float* add_bn;
   const float* add_fin;
   const float* x2;        /* x is the virtual concatenation [x (x_split cols) | x2 (KI - x_split cols)]: */
-  int x_split;            /*   linear_cat without materialising torch.cat; backward writes dx | dx2 */
+  int x_split;            /*   linear_cat without materialising torch.cat; backward writes dx | dx2.  With x2,
+                             x_bn / x_stats (and x_gamma ..) and sum_y / sum_bn / sum_out describe the BatchNorm
+                             of the x part only: x_split columns instead of KI */
   float* dx2;
   const float* sum_y;     /* [M,KI] pre-norm values of the BatchNorm that produced x: emit */
   const float* sum_bn;    /*   sum_out [feta_rowlin_blocks(M),2,KI] = partial (sum dx, sum dx*xhat) */
