@@ -147,6 +147,21 @@ SIGNATURES.update({
     'feta_ffn_fwd': ([C.POINTER(Ffn), _S], C.c_int),
 })
 
+class FfnGrad(C.Structure):
+    """struct feta_ffn_grad (include/feta_hip.h) - field order must match the header."""
+    _fields_ = [
+        ('dy', _F), ('g_y', _F), ('g_bn', _F), ('g_sum', _F), ('Gs', C.c_int), ('g_fin', _F), ('g_fin_out', _F),
+        ('dgamma', _F), ('dbeta', _F), ('h', _F), ('w2', _F), ('w1', _F), ('x', _F), ('x_bn', _F), ('dx', _F),
+        ('sum_out', _F), ('partial', _F), ('partial_ld', C.c_int), ('M', C.c_int), ('FF', C.c_int),
+    ]
+
+
+SIGNATURES.update({
+    'feta_ffn_bwd_supported': ([C.c_int, C.c_int], C.c_int),
+    'feta_ffn_bwd_blocks': ([C.c_int], C.c_int),
+    'feta_ffn_bwd': ([C.POINTER(FfnGrad), _S], C.c_int),
+})
+
 ABI_VERSION = 5
 
 
@@ -419,6 +434,29 @@ class Abi:
 
     def ffn_launch(self, desc, stream):
         self._check(self.lib.feta_ffn_fwd(C.byref(desc), stream), 'feta_ffn_fwd')
+
+    def ffn_bwd_supported(self, d_model, ff):
+        return bool(self.lib.feta_ffn_bwd_supported(d_model, ff))
+
+    def ffn_bwd_blocks(self, m):
+        return int(self.lib.feta_ffn_bwd_blocks(m))
+
+    def ffn_bwd_desc(self, m, ff, Gs=0, partial_ld=0, partial_ptr=None, **ptrs):
+        d = FfnGrad()
+        d.M, d.FF, d.Gs, d.partial_ld = m, ff, Gs, partial_ld
+        if partial_ptr is not None:
+            d.partial = partial_ptr
+        for k, t in ptrs.items():
+            if t is not None:
+                setattr(d, k, t.data_ptr())
+        return d
+
+    def ffn_bwd_launch(self, desc, stream):
+        self._check(self.lib.feta_ffn_bwd(C.byref(desc), stream), 'feta_ffn_bwd')
+
+    def ffn_bwd(self, m, ff, stream, **kw):
+        """feta_ffn_bwd; tensor-valued keyword arguments become the descriptor's pointers."""
+        self.ffn_bwd_launch(self.ffn_bwd_desc(m, ff, **kw), stream)
 
     def bn_apply_fwd_prm(self, y, stats, gamma, beta, out, bn_prm, running_mean, running_var, momentum,
                          eps, stream, nbt=None):

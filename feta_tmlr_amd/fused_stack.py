@@ -37,6 +37,8 @@ PER_LAYER = 12  # tensors per layer in the flat parameter list
 # FETA_ATTN_BLOCK=0 keeps the three-launch sequence (A/B timing, fallback for other shapes)
 USE_ATTN_BLOCK = os.environ.get('FETA_ATTN_BLOCK', '1') != '0'
 USE_FFN_FUSED = os.environ.get('FETA_FFN_FUSED', '1') != '0'
+# backward of the FFN half (linear2 + linear1) in one launch (csrc/ffn_bwd.hip); 0: two feta_rowlin_bwd_ex launches
+USE_FFN_BWD = os.environ.get('FETA_FFN_BWD', '1') != '0'
 
 def layer_params(layer):
     a = layer.self_attn
@@ -266,31 +268,41 @@ class FusedEncoderStackFn(torch.autograd.Function):
             (w_in, b_in, w_o, b_o, g1, be1, w1, bb1, w2, bb2, g2, be2) = params[li * PER_LAYER:(li + 1) * PER_LAYER]
             ff = w1.shape[0]
             base = li * PER_LAYER
-            # B1: linear2 backward, gradient = BN2 backward of dcur
-            dh_ = new(m, ff)
             fin2, dg2, db2 = new(2, d), bn_tail[li, 2], bn_tail[li, 3]
             pp, off = wslot(d, ff)
             slots[base + 8] = (off, d, ff)
-            dsc = abi.rowlin_ex(m, ff, d, x=s['h'], w=w2, dy=dcur, dx=dh_, partial_ptr=pp, partial_ld=total,
-                                g_y=s['y2'], g_bn=s['prm2'], g_sum=gs, Gs=Gs_cur, g_fin_out=fin2, dgamma=dg2,
-                                dbeta=db2)
-            abi.rowlin_bwd_ex(dsc, None, stream)
+            pp1, off1 = wslot(ff, d)
+            slots[base + 6] = (off1, ff, d)
+            dx1 = new(m, d)
+            if USE_FFN_BWD and abi.ffn_bwd_supported(d, ff):
+                # B1 + B2 in one launch (csrc/ffn_bwd.hip): the hidden gradient never leaves the chip
+                G1s = abi.ffn_bwd_blocks(m)
+                gs1 = new(G1s, 2, d)
+                abi.ffn_bwd(m, ff, stream, Gs=Gs_cur, partial_ptr=pp, partial_ld=total, dy=dcur, g_y=s['y2'],
+                            g_bn=s['prm2'], g_sum=gs, g_fin_out=fin2, dgamma=dg2, dbeta=db2, h=s['h'], w2=w2, w1=w1,
+                            x=s['y1'], x_bn=s['prm1'], dx=dx1, sum_out=gs1)
+                gs1, G1s = _cap_partials(abi, stream, gs1, new)
+            else:
+                # B1: linear2 backward, gradient = BN2 backward of dcur
+                dh_ = new(m, ff)
+                dsc = abi.rowlin_ex(m, ff, d, x=s['h'], w=w2, dy=dcur, dx=dh_, partial_ptr=pp, partial_ld=total,
+                                    g_y=s['y2'], g_bn=s['prm2'], g_sum=gs, Gs=Gs_cur, g_fin_out=fin2, dgamma=dg2,
+                                    dbeta=db2)
+                abi.rowlin_bwd_ex(dsc, None, stream)
+                # B2: linear1 backward (+ residual BN2 backward, + sums for BN1 backward)
+                gs1, G1s = new(G, 2, d), G
+                dsc = abi.rowlin_ex(m, d, ff, x=s['y1'], x_bn=s['prm1'], w=w1, dy=dh_, relu_y=s['h'], dx=dx1,
+                                    partial_ptr=pp1, partial_ld=total, add_dout=dcur, add_y=s['y2'],
+                                    add_bn=s['prm2'], add_fin=fin2, sum_y=s['y1'], sum_bn=s['prm1'], sum_out=gs1)
+                abi.rowlin_bwd_ex(dsc, None, stream)
             grads[base + 10], grads[base + 11] = dg2, db2
-            # B2: linear1 backward (+ residual BN2 backward, + sums for BN1 backward)
-            dx1, gs1 = new(m, d), new(G, 2, d)
-            pp, off = wslot(ff, d)
-            slots[base + 6] = (off, ff, d)
-            dsc = abi.rowlin_ex(m, d, ff, x=s['y1'], x_bn=s['prm1'], w=w1, dy=dh_, relu_y=s['h'], dx=dx1,
-                                partial_ptr=pp, partial_ld=total, add_dout=dcur, add_y=s['y2'],
-                                add_bn=s['prm2'], add_fin=fin2, sum_y=s['y1'], sum_bn=s['prm1'], sum_out=gs1)
-            abi.rowlin_bwd_ex(dsc, None, stream)
             # B3: out_proj backward, gradient = degree * BN1 backward of dx1
             dconcat = new(m, d)
             fin1, dg1, db1 = new(2, d), bn_tail[li, 0], bn_tail[li, 1]
             pp, off = wslot(d, d)
             slots[base + 2] = (off, d, d)
             dsc = abi.rowlin_ex(m, d, d, x=s['out'].view(m, d), w=w_o, dy=dx1, rowscale=degree_rows, dx=dconcat,
-                                partial_ptr=pp, partial_ld=total, g_y=s['y1'], g_bn=s['prm1'], g_sum=gs1, Gs=G,
+                                partial_ptr=pp, partial_ld=total, g_y=s['y1'], g_bn=s['prm1'], g_sum=gs1, Gs=G1s,
                                 g_fin_out=fin1, dgamma=dg1, dbeta=db1)
             abi.rowlin_bwd_ex(dsc, None, stream)
             grads[base + 4], grads[base + 5] = dg1, db1
@@ -462,18 +474,23 @@ class FusedLayerNormStackFn(torch.autograd.Function):
             base = li * PER_LAYER
             dy2 = ln_bwd(dcur, s['y2'], s['lst2'], g2, li, 1)
             grads[base + 10], grads[base + 11] = ln_tail[li, 2], ln_tail[li, 3]
-            # linear2, then linear1 with the residual gradient dy2 added in its dX epilogue
-            dh_ = new(m, ff)
             pp, off = wslot(d, ff)
             slots[base + 8] = (off, d, ff)
-            dsc = abi.rowlin_ex(m, ff, d, x=s['h'], w=w2, dy=dy2, dx=dh_, partial_ptr=pp, partial_ld=total)
-            abi.rowlin_bwd_ex(dsc, None, stream)
+            pp1, off1 = wslot(ff, d)
+            slots[base + 6] = (off1, ff, d)
             dx1 = new(m, d)
-            pp, off = wslot(ff, d)
-            slots[base + 6] = (off, ff, d)
-            dsc = abi.rowlin_ex(m, d, ff, x=s['x1'], w=w1, dy=dh_, relu_y=s['h'], dx=dx1, partial_ptr=pp,
-                                partial_ld=total, add_plain=dy2)
-            abi.rowlin_bwd_ex(dsc, None, stream)
+            if USE_FFN_BWD and abi.ffn_bwd_supported(d, ff):
+                # linear2 + linear1 backward in one launch (csrc/ffn_bwd.hip), dx1 = dy2 + dh W1
+                abi.ffn_bwd(m, ff, stream, partial_ptr=pp, partial_ld=total, dy=dy2, h=s['h'], w2=w2, w1=w1, x=s['x1'],
+                            dx=dx1)
+            else:
+                # linear2, then linear1 with the residual gradient dy2 added in its dX epilogue
+                dh_ = new(m, ff)
+                dsc = abi.rowlin_ex(m, ff, d, x=s['h'], w=w2, dy=dy2, dx=dh_, partial_ptr=pp, partial_ld=total)
+                abi.rowlin_bwd_ex(dsc, None, stream)
+                dsc = abi.rowlin_ex(m, d, ff, x=s['x1'], w=w1, dy=dh_, relu_y=s['h'], dx=dx1, partial_ptr=pp1,
+                                    partial_ld=total, add_plain=dy2)
+                abi.rowlin_bwd_ex(dsc, None, stream)
             dy1 = ln_bwd(dx1, s['y1'], s['lst1'], g1, li, 0)
             grads[base + 4], grads[base + 5] = ln_tail[li, 0], ln_tail[li, 1]
             # out_proj (gradient scaled by degree), attention, in_proj with the residual gradient dy1

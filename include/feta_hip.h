@@ -406,6 +406,45 @@ int feta_ffn_supported(int d_model, int ff);
 int feta_ffn_blocks(int M);
 int feta_ffn_fwd(const feta_ffn* d, feta_stream_t stream);
 
+/* ---- backward of the feed-forward half in ONE launch ------------------------------------------------
+ * (feta_ffn_bwd_supported: d_model = 64, dim_feedforward in {64,128}.)  Replaces the two feta_rowlin_bwd_ex
+ * launches of linear2 and linear1 of DiffTransformerEncoderLayer (contract transformer/models.py:166-167;
+ * y2 = x1 + linear2(relu(linear1(x1)))):
+ *   g2 = BatchNorm-2 backward of dy (g_y = y2 [M,64], g_bn [4][64], partial sums g_sum [Gs][2][64] finalized
+ *        here -> g_fin_out [2][64], dgamma, dbeta; or g_fin already finalized) - or dy itself when g_y is NULL
+ *        (LayerNorm stack: dy is the gradient w.r.t. y2);
+ *   dh = (g2 W2) * [h > 0] (never written to memory);  dx = g2 + dh W1;
+ *   sum_out (nullable) [feta_ffn_bwd_blocks(M)][2][64]: partial (sum dx, sum dx * xhat) with xhat from x = y1
+ *        (pre-norm) and x_bn [4][64], for the BatchNorm-1 backward;
+ *   partial: one row per feta_rowlin_chunks(M) chunk, pitch partial_ld (0: 2*64*FF + 64 + FF), columns
+ *        [dW2 (64 x FF) | db2 (64) | dW1 (FF x 64) | db1 (FF)], reduced by the caller (feta_colsum).
+ * x is seen through x_bn (scale, shift rows) when given, else used as it is. */
+typedef struct feta_ffn_grad {
+  const float* dy;
+  const float* g_y;
+  const float* g_bn;
+  const float* g_sum;
+  int Gs;
+  const float* g_fin;
+  float* g_fin_out;
+  float* dgamma;
+  float* dbeta;
+  const float* h;    /* [M,FF] saved relu output */
+  const float* w2;   /* [64,FF] */
+  const float* w1;   /* [FF,64] */
+  const float* x;    /* [M,64] */
+  const float* x_bn; /* [4][64] or NULL */
+  float* dx;         /* [M,64] */
+  float* sum_out;
+  float* partial;
+  int partial_ld;
+  int M, FF;
+} feta_ffn_grad;
+
+int feta_ffn_bwd_supported(int d_model, int ff);
+int feta_ffn_bwd_blocks(int M);
+int feta_ffn_bwd(const feta_ffn_grad* d, feta_stream_t stream);
+
 /* ---- graph preprocessing -------------------------------------------------------------
  * Dense Lhat = -D^-1/2 A D^-1/2 per graph from the batched edge list, with the exact
  * edge-list semantics of ChebConvDynamic.__norm__ (transformer/ChebNetDynamic.py:108-130):
