@@ -147,6 +147,24 @@ SIGNATURES.update({
     'feta_ffn_fwd': ([C.POINTER(Ffn), _S], C.c_int),
 })
 
+class AttnBlockGrad(C.Structure):
+    """struct feta_attn_block_grad (include/feta_hip.h) - field order must match the header."""
+    _fields_ = [
+        ('dy', _F), ('y1', _F), ('bn1', _F), ('g_sum', _F), ('Gs', C.c_int), ('fin_out', _F), ('dgamma', _F),
+        ('dbeta', _F), ('rowscale', _F), ('w_out', _F), ('w_in', _F), ('qkv', _F), ('out', _F), ('dout2', _F),
+        ('pe', _F), ('n_real', _I), ('attn_stats', _F), ('x0', _F), ('bn0', _F), ('dx', _F), ('sum_out', _F),
+        ('partial', _F), ('partial_ld', C.c_int), ('scale', C.c_float), ('B', C.c_int), ('N', C.c_int), ('M', C.c_int),
+        ('row_sb', C.c_int64), ('row_sn', C.c_int64),
+    ]
+
+
+SIGNATURES.update({
+    'feta_attn_block_bwd_supported': ([C.c_int, C.c_int, C.c_int], C.c_int),
+    'feta_attn_block_bwd_blocks': ([C.c_int], C.c_int),
+    'feta_attn_block_bwd': ([C.POINTER(AttnBlockGrad), _S], C.c_int),
+})
+
+
 class FfnGrad(C.Structure):
     """struct feta_ffn_grad (include/feta_hip.h) - field order must match the header."""
     _fields_ = [
@@ -413,6 +431,24 @@ class Abi:
 
     def attn_block_launch(self, desc, stream):
         self._check(self.lib.feta_attn_block_fwd(C.byref(desc), stream), 'feta_attn_block_fwd')
+
+    def attn_block_bwd_supported(self, n, d_model, heads):
+        return bool(self.lib.feta_attn_block_bwd_supported(n, d_model, heads))
+
+    def attn_block_bwd_blocks(self, b):
+        return int(self.lib.feta_attn_block_bwd_blocks(b))
+
+    def attn_block_bwd(self, b, n, scale, stream, seq_first=True, Gs=0, partial_ld=0, partial_ptr=None, **ptrs):
+        """feta_attn_block_bwd; tensor-valued keyword arguments become the descriptor's pointers."""
+        d = AttnBlockGrad()
+        d.B, d.N, d.M, d.scale, d.Gs, d.partial_ld = b, n, b * n, scale, Gs, partial_ld
+        d.row_sb, d.row_sn = (1, b) if seq_first else (n, 1)
+        if partial_ptr is not None:
+            d.partial = partial_ptr
+        for k, t in ptrs.items():
+            if t is not None:
+                setattr(d, k, t.data_ptr())
+        self._check(self.lib.feta_attn_block_bwd(C.byref(d), stream), 'feta_attn_block_bwd')
 
     def ffn_supported(self, d_model, ff):
         return bool(self.lib.feta_ffn_supported(d_model, ff))

@@ -281,9 +281,54 @@ __global__ __launch_bounds__(kCsCols * kCsSlices) void colsum_multi_kernel(Colsu
   }
 }
 
+// the same for segments of few rows x very many columns (the split-K weight-gradient partials of the layer stack: one
+// buffer per partial-row count): colsum_wide_kernel's arithmetic, workgroup -> (segment, 64 float4 columns)
+__global__ __launch_bounds__(64) void colsum_wide_multi_kernel(ColsumSegs a) {
+  int si = 0;
+  while (si + 1 < a.nseg && (int)blockIdx.x >= a.tile_end[si]) ++si;
+  const feta_colsum_seg sg = a.seg[si];
+  const int c4 = ((int)blockIdx.x - (si > 0 ? a.tile_end[si - 1] : 0)) * 64 + threadIdx.x;
+  if (c4 >= sg.C / 4) return;
+  const int ld = sg.ld > 0 ? sg.ld : sg.C;
+  const float* p = sg.in + 4 * (int64_t)c4;
+  float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  int r = 0;
+  for (; r + 8 <= sg.R; r += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(p + (int64_t)(r + i) * ld);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w;
+    }
+  }
+  for (; r < sg.R; ++r) {
+    const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)r * ld);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  *reinterpret_cast<float4*>(sg.out + 4 * (int64_t)c4) = acc;
+}
+
 int launch_colsum_multi(const feta_colsum_seg* segs, int nseg, hipStream_t stream) {
   ColsumSegs a{};
   a.nseg = nseg;
+  bool wide = true;
+  for (int i = 0; i < nseg; ++i) {
+    const int ld = segs[i].ld > 0 ? segs[i].ld : segs[i].C;
+    wide = wide && segs[i].R <= 512 && segs[i].C >= 4096 && (segs[i].C & 3) == 0 && (ld & 3) == 0 &&
+           aligned16(segs[i].in) && aligned16(segs[i].out) && segs[i].bcast_out == nullptr;
+  }
+  if (wide) {
+    int tiles = 0;
+    for (int i = 0; i < nseg; ++i) {
+      a.seg[i] = segs[i];
+      tiles += (segs[i].C / 4 + 63) / 64;
+      a.tile_end[i] = tiles;
+    }
+    auto kern = colsum_wide_multi_kernel;
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(64), 0, stream, a);
+    return check_launch("feta_colsum_multi");
+  }
   int tiles = 0;
   for (int i = 0; i < nseg; ++i) {
     a.seg[i] = segs[i];

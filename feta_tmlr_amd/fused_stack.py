@@ -39,6 +39,9 @@ USE_ATTN_BLOCK = os.environ.get('FETA_ATTN_BLOCK', '1') != '0'
 USE_FFN_FUSED = os.environ.get('FETA_FFN_FUSED', '1') != '0'
 # backward of the FFN half (linear2 + linear1) in one launch (csrc/ffn_bwd.hip); 0: two feta_rowlin_bwd_ex launches
 USE_FFN_BWD = os.environ.get('FETA_FFN_BWD', '1') != '0'
+# backward of the attention sub-block (out_proj + attention + in_proj) in one launch per layer (csrc/block_bwd.hip,
+# one workgroup per graph, up to 256 graphs); 0: three launches
+USE_ATTN_BLOCK_BWD = os.environ.get('FETA_ATTN_BLOCK_BWD', '1') != '0'
 
 def layer_params(layer):
     a = layer.self_attn
@@ -90,6 +93,30 @@ def _cap_partials(abi, stream, st, new):
     tot = new(1, 2, st.shape[2])
     abi.colsum(st.view(st.shape[0], -1), tot.view(-1), stream)
     return tot, 1
+
+
+def _partial_buffers(abi, new, m, b, n, d, heads, ff0, nl, fused_attn):
+    """Split-K partial buffers of a stack backward and the slot allocator.  Two buffers, because their row counts
+    differ: 'f' (linear2 / linear1 of every layer) has one row per feta_rowlin_chunks(M) row chunk, 'a' (out_proj /
+    in_proj) the same or - with the fused attention-block backward - one row per graph.  dwdb_all = [f columns |
+    a columns | norm tail] is the flat gradient buffer every parameter gradient is a view of; ONE multi-segment
+    reduction fills it at the end of backward.  -> (part_f, part_a, tf, ta, wslot)"""
+    rc = abi.rowlin_chunks(m)
+    ra = abi.attn_block_bwd_blocks(b) if fused_attn else rc
+    tf = nl * ((ff0 * d + ff0) + (d * ff0 + d))
+    ta = nl * ((d * d + d) + (3 * d * d + 3 * d))
+    part_f, part_a = new(rc, tf), new(ra, ta)
+    cur = {'f': 0, 'a': 0}
+
+    def wslot(kind, no, ki):
+        """-> (pointer to this linear's partial columns, its offset in dwdb_all)"""
+        off = cur[kind]
+        cur[kind] += no * ki + no
+        buf, base = (part_f, 0) if kind == 'f' else (part_a, tf)
+        return buf.data_ptr() + 4 * off, base + off
+
+    wslot.cur = cur
+    return part_f, part_a, tf, ta, wslot
 
 
 class StackTail:
@@ -228,26 +255,19 @@ class FusedEncoderStackFn(torch.autograd.Function):
         m = n * b
         dev = saved[0]['qkv'].device
         new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
-        RC = abi.rowlin_chunks(m)
         grads = [None] * len(params)
-        # every weight/bias gradient of the stack goes through ONE [RC, total] partial buffer and
-        # ONE deterministic reduction at the end (instead of one reduction launch per linear)
         ff0 = params[6].shape[0]
-        per_layer = (3 * d * d + 3 * d) + (d * d + d) + (ff0 * d + ff0) + (d * ff0 + d)
-        total = per_layer * nl
-        part_all = new(RC, total)
+        fused_attn = (USE_ATTN_BLOCK_BWD and not tie and abi.attn_block_bwd_supported(n, d, heads)
+                      and abi.attn_block_bwd_blocks(b) > 0)
+        # every weight/bias gradient of the stack goes through the split-K partial buffers and ONE deterministic
+        # reduction at the end (instead of one reduction launch per linear)
+        part_f, part_a, tf, ta, wslot = _partial_buffers(abi, new, m, b, n, d, heads, ff0, nl, fused_attn)
+        total = tf + ta
         # ONE flat gradient buffer for the whole stack: [weights and biases (reduced partials) | dgamma,
         # dbeta of norm1 / norm2 of every layer]; every parameter gradient returned below is a view of it,
         # so a data-parallel trainer all-reduces it in place (parallel.FlatBufferAllReduce)
         dwdb_all = new(total + nl * 4 * d)
         bn_tail = dwdb_all[total:].view(nl, 4, d)
-        cursor = [0]
-
-        def wslot(no, ki):
-            """-> (pointer to this linear's partial columns, its offset in dwdb_all)"""
-            off = cursor[0]
-            cursor[0] += no * ki + no
-            return part_all.data_ptr() + 4 * off, off
 
         slots = {}
         if d_final is None:   # only the per-head output of the last layer was used
@@ -269,49 +289,68 @@ class FusedEncoderStackFn(torch.autograd.Function):
             ff = w1.shape[0]
             base = li * PER_LAYER
             fin2, dg2, db2 = new(2, d), bn_tail[li, 2], bn_tail[li, 3]
-            pp, off = wslot(d, ff)
+            pp, off = wslot('f', d, ff)
             slots[base + 8] = (off, d, ff)
-            pp1, off1 = wslot(ff, d)
+            pp1, off1 = wslot('f', ff, d)
             slots[base + 6] = (off1, ff, d)
             dx1 = new(m, d)
             if USE_FFN_BWD and abi.ffn_bwd_supported(d, ff):
                 # B1 + B2 in one launch (csrc/ffn_bwd.hip): the hidden gradient never leaves the chip
                 G1s = abi.ffn_bwd_blocks(m)
                 gs1 = new(G1s, 2, d)
-                abi.ffn_bwd(m, ff, stream, Gs=Gs_cur, partial_ptr=pp, partial_ld=total, dy=dcur, g_y=s['y2'],
+                abi.ffn_bwd(m, ff, stream, Gs=Gs_cur, partial_ptr=pp, partial_ld=tf, dy=dcur, g_y=s['y2'],
                             g_bn=s['prm2'], g_sum=gs, g_fin_out=fin2, dgamma=dg2, dbeta=db2, h=s['h'], w2=w2, w1=w1,
                             x=s['y1'], x_bn=s['prm1'], dx=dx1, sum_out=gs1)
                 gs1, G1s = _cap_partials(abi, stream, gs1, new)
             else:
                 # B1: linear2 backward, gradient = BN2 backward of dcur
                 dh_ = new(m, ff)
-                dsc = abi.rowlin_ex(m, ff, d, x=s['h'], w=w2, dy=dcur, dx=dh_, partial_ptr=pp, partial_ld=total,
+                dsc = abi.rowlin_ex(m, ff, d, x=s['h'], w=w2, dy=dcur, dx=dh_, partial_ptr=pp, partial_ld=tf,
                                     g_y=s['y2'], g_bn=s['prm2'], g_sum=gs, Gs=Gs_cur, g_fin_out=fin2, dgamma=dg2,
                                     dbeta=db2)
                 abi.rowlin_bwd_ex(dsc, None, stream)
                 # B2: linear1 backward (+ residual BN2 backward, + sums for BN1 backward)
                 gs1, G1s = new(G, 2, d), G
                 dsc = abi.rowlin_ex(m, d, ff, x=s['y1'], x_bn=s['prm1'], w=w1, dy=dh_, relu_y=s['h'], dx=dx1,
-                                    partial_ptr=pp1, partial_ld=total, add_dout=dcur, add_y=s['y2'],
+                                    partial_ptr=pp1, partial_ld=tf, add_dout=dcur, add_y=s['y2'],
                                     add_bn=s['prm2'], add_fin=fin2, sum_y=s['y1'], sum_bn=s['prm1'], sum_out=gs1)
                 abi.rowlin_bwd_ex(dsc, None, stream)
             grads[base + 10], grads[base + 11] = dg2, db2
+            fin1, dg1, db1 = new(2, d), bn_tail[li, 0], bn_tail[li, 1]
+            grads[base + 4], grads[base + 5] = dg1, db1
+            ppo, offo = wslot('a', d, d)
+            slots[base + 2] = (offo, d, d)
+            ppi, offi = wslot('a', 3 * d, d)
+            slots[base + 0] = (offi, 3 * d, d)
+            d2 = d_concat_last if (li == nl - 1 and d_concat_last is not None) else None
+            if fused_attn:
+                # B3 + B4 + B5 in one launch, one workgroup per graph (csrc/block_bwd.hip): dconcat and dqkv stay on chip
+                dx0 = new(m, d)
+                GB = abi.attn_block_bwd_blocks(b)
+                gs_prev = new(2 * GB, 2, d) if li > 0 else None
+                abi.attn_block_bwd(b, n, scale, stream, Gs=G1s, partial_ptr=ppo, partial_ld=ta, dy=dx1, y1=s['y1'],
+                                   bn1=s['prm1'], g_sum=gs1, fin_out=fin1, dgamma=dg1, dbeta=db1, rowscale=degree_rows,
+                                   w_out=w_o, w_in=w_in, qkv=s['qkv'], out=s['out'],
+                                   dout2=None if d2 is None else d2.contiguous().view(m, d), pe=pe_c, n_real=n_real,
+                                   attn_stats=s['ast'], x0=s['x0'], bn0=s['prm0'] if li > 0 else None, dx=dx0,
+                                   sum_out=gs_prev)
+                Gs_next = 2 * GB
+                if gs_prev is not None:
+                    gs_prev, Gs_next = _cap_partials(abi, stream, gs_prev, new)
+                dcur, gs, Gs_cur = dx0, gs_prev, Gs_next
+                continue
             # B3: out_proj backward, gradient = degree * BN1 backward of dx1
             dconcat = new(m, d)
-            fin1, dg1, db1 = new(2, d), bn_tail[li, 0], bn_tail[li, 1]
-            pp, off = wslot(d, d)
-            slots[base + 2] = (off, d, d)
             dsc = abi.rowlin_ex(m, d, d, x=s['out'].view(m, d), w=w_o, dy=dx1, rowscale=degree_rows, dx=dconcat,
-                                partial_ptr=pp, partial_ld=total, g_y=s['y1'], g_bn=s['prm1'], g_sum=gs1, Gs=G1s,
+                                partial_ptr=ppo, partial_ld=ta, g_y=s['y1'], g_bn=s['prm1'], g_sum=gs1, Gs=G1s,
                                 g_fin_out=fin1, dgamma=dg1, dbeta=db1)
             abi.rowlin_bwd_ex(dsc, None, stream)
-            grads[base + 4], grads[base + 5] = dg1, db1
             dout2 = None
-            if li == nl - 1 and d_concat_last is not None:
+            if d2 is not None:
                 if abi.attn_bwd_takes_dout2(n, dh):   # added inside the kernel's loads
-                    dout2 = d_concat_last.contiguous().view(n, b, heads, dh).permute(1, 0, 2, 3)
+                    dout2 = d2.contiguous().view(n, b, heads, dh).permute(1, 0, 2, 3)
                 else:
-                    dconcat = dconcat + d_concat_last.contiguous().view(m, d)
+                    dconcat = dconcat + d2.contiguous().view(m, d)
             # B4: attention backward
             q, k, v = _views(s['qkv'], n, b, heads, dh)
             if tie:
@@ -327,18 +366,16 @@ class FusedEncoderStackFn(torch.autograd.Function):
                 dqkv[:, d:2 * d] = 0
             # B5: in_proj backward (+ residual BN1 backward, + sums for the previous layer's BN2)
             dx0 = new(m, d)
-            pp, off = wslot(3 * d, d)
-            slots[base + 0] = (off, 3 * d, d)
             gs_prev = new(G, 2, d) if li > 0 else None
             dsc = abi.rowlin_ex(m, d, 3 * d, x=s['x0'], x_bn=s['prm0'], w=w_in, dy=dqkv, dx=dx0,
-                                partial_ptr=pp, partial_ld=total, add_dout=dx1, add_y=s['y1'],
+                                partial_ptr=ppi, partial_ld=ta, add_dout=dx1, add_y=s['y1'],
                                 add_bn=s['prm1'], add_fin=fin1, sum_y=(s['x0'] if li > 0 else None),
                                 sum_bn=s['prm0'], sum_out=gs_prev)
             abi.rowlin_bwd_ex(dsc, None, stream)
             Gs_next = G
             dcur, gs, Gs_cur = dx0, gs_prev, Gs_next
-        assert cursor[0] == total
-        abi.colsum(part_all, dwdb_all[:total], stream)
+        assert wslot.cur == {'f': tf, 'a': ta}
+        abi.colsum_multi([(part_f, dwdb_all[:tf]), (part_a, dwdb_all[tf:total])], stream)
         if ctx.owner is not None:
             STACK_FLAT_GRAD[ctx.owner] = dwdb_all
         for idx, (off, no, ki) in slots.items():
@@ -440,22 +477,16 @@ class FusedLayerNormStackFn(torch.autograd.Function):
         m = n * b
         dev = saved[0]['qkv'].device
         new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
-        RC = abi.rowlin_chunks(m)
         GL = abi.layernorm_blocks(m)
         grads = [None] * len(params)
         ff0 = params[6].shape[0]
-        per_layer = (3 * d * d + 3 * d) + (d * d + d) + (ff0 * d + ff0) + (d * ff0 + d)
-        total = per_layer * nl
-        part_all = new(RC, total)
+        fused_attn = (USE_ATTN_BLOCK_BWD and not tie and abi.attn_block_bwd_supported(n, d, heads)
+                      and abi.attn_block_bwd_blocks(b) > 0)
+        part_f, part_a, tf, ta, wslot = _partial_buffers(abi, new, m, b, n, d, heads, ff0, nl, fused_attn)
+        total = tf + ta
         ln_part = new(GL, nl * 4 * d)
         dwdb_all = new(total + nl * 4 * d)          # same layout as the BatchNorm stack's flat buffer
         ln_tail = dwdb_all[total:].view(nl, 4, d)   # dgamma1, dbeta1, dgamma2, dbeta2 per layer
-        cursor = [0]
-
-        def wslot(no, ki):
-            off = cursor[0]
-            cursor[0] += no * ki + no
-            return part_all.data_ptr() + 4 * off, off
 
         def ln_bwd(dout, y, stats, gamma, li, which):
             dy = new(m, d)
@@ -474,38 +505,50 @@ class FusedLayerNormStackFn(torch.autograd.Function):
             base = li * PER_LAYER
             dy2 = ln_bwd(dcur, s['y2'], s['lst2'], g2, li, 1)
             grads[base + 10], grads[base + 11] = ln_tail[li, 2], ln_tail[li, 3]
-            pp, off = wslot(d, ff)
+            pp, off = wslot('f', d, ff)
             slots[base + 8] = (off, d, ff)
-            pp1, off1 = wslot(ff, d)
+            pp1, off1 = wslot('f', ff, d)
             slots[base + 6] = (off1, ff, d)
             dx1 = new(m, d)
             if USE_FFN_BWD and abi.ffn_bwd_supported(d, ff):
                 # linear2 + linear1 backward in one launch (csrc/ffn_bwd.hip), dx1 = dy2 + dh W1
-                abi.ffn_bwd(m, ff, stream, partial_ptr=pp, partial_ld=total, dy=dy2, h=s['h'], w2=w2, w1=w1, x=s['x1'],
+                abi.ffn_bwd(m, ff, stream, partial_ptr=pp, partial_ld=tf, dy=dy2, h=s['h'], w2=w2, w1=w1, x=s['x1'],
                             dx=dx1)
             else:
                 # linear2, then linear1 with the residual gradient dy2 added in its dX epilogue
                 dh_ = new(m, ff)
-                dsc = abi.rowlin_ex(m, ff, d, x=s['h'], w=w2, dy=dy2, dx=dh_, partial_ptr=pp, partial_ld=total)
+                dsc = abi.rowlin_ex(m, ff, d, x=s['h'], w=w2, dy=dy2, dx=dh_, partial_ptr=pp, partial_ld=tf)
                 abi.rowlin_bwd_ex(dsc, None, stream)
                 dsc = abi.rowlin_ex(m, d, ff, x=s['x1'], w=w1, dy=dh_, relu_y=s['h'], dx=dx1, partial_ptr=pp1,
-                                    partial_ld=total, add_plain=dy2)
+                                    partial_ld=tf, add_plain=dy2)
                 abi.rowlin_bwd_ex(dsc, None, stream)
             dy1 = ln_bwd(dx1, s['y1'], s['lst1'], g1, li, 0)
             grads[base + 4], grads[base + 5] = ln_tail[li, 0], ln_tail[li, 1]
+            ppo, offo = wslot('a', d, d)
+            slots[base + 2] = (offo, d, d)
+            ppi, offi = wslot('a', 3 * d, d)
+            slots[base + 0] = (offi, 3 * d, d)
+            d2 = d_concat_last if (li == nl - 1 and d_concat_last is not None) else None
+            if fused_attn:
+                # out_proj + attention + in_proj backward in one launch, one workgroup per graph (csrc/block_bwd.hip)
+                dx0 = new(m, d)
+                abi.attn_block_bwd(b, n, scale, stream, partial_ptr=ppo, partial_ld=ta, dy=dy1, rowscale=degree_rows,
+                                   w_out=w_o, w_in=w_in, qkv=s['qkv'], out=s['out'],
+                                   dout2=None if d2 is None else d2.contiguous().view(m, d), pe=pe_c, n_real=n_real,
+                                   attn_stats=s['ast'], x0=s['x0'], dx=dx0)
+                dcur = dx0
+                continue
             # out_proj (gradient scaled by degree), attention, in_proj with the residual gradient dy1
             dconcat = new(m, d)
-            pp, off = wslot(d, d)
-            slots[base + 2] = (off, d, d)
             dsc = abi.rowlin_ex(m, d, d, x=s['out'].view(m, d), w=w_o, dy=dy1, rowscale=degree_rows, dx=dconcat,
-                                partial_ptr=pp, partial_ld=total)
+                                partial_ptr=ppo, partial_ld=ta)
             abi.rowlin_bwd_ex(dsc, None, stream)
             dout2 = None
-            if li == nl - 1 and d_concat_last is not None:
+            if d2 is not None:
                 if abi.attn_bwd_takes_dout2(n, dh):
-                    dout2 = d_concat_last.contiguous().view(n, b, heads, dh).permute(1, 0, 2, 3)
+                    dout2 = d2.contiguous().view(n, b, heads, dh).permute(1, 0, 2, 3)
                 else:
-                    dconcat = dconcat + d_concat_last.contiguous().view(m, d)
+                    dconcat = dconcat + d2.contiguous().view(m, d)
             q, k, v = _views(s['qkv'], n, b, heads, dh)
             if tie:
                 k = q
@@ -519,14 +562,12 @@ class FusedLayerNormStackFn(torch.autograd.Function):
                 dqkv[:, :d] += dqkv[:, d:2 * d]
                 dqkv[:, d:2 * d] = 0
             dx0 = new(m, d)
-            pp, off = wslot(3 * d, d)
-            slots[base + 0] = (off, 3 * d, d)
-            dsc = abi.rowlin_ex(m, d, 3 * d, x=s['x0'], w=w_in, dy=dqkv, dx=dx0, partial_ptr=pp, partial_ld=total,
+            dsc = abi.rowlin_ex(m, d, 3 * d, x=s['x0'], w=w_in, dy=dqkv, dx=dx0, partial_ptr=ppi, partial_ld=ta,
                                 add_plain=dy1)
             abi.rowlin_bwd_ex(dsc, None, stream)
             dcur = dx0
-        assert cursor[0] == total
-        abi.colsum(part_all, dwdb_all[:total], stream)
+        assert wslot.cur == {'f': tf, 'a': ta}
+        abi.colsum_multi([(part_f, dwdb_all[:tf]), (part_a, dwdb_all[tf:total])], stream)
         abi.colsum(ln_part, dwdb_all[total:], stream)
         if ctx.owner is not None:
             STACK_FLAT_GRAD[ctx.owner] = dwdb_all

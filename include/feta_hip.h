@@ -375,6 +375,52 @@ typedef struct feta_attn_block {
 int feta_attn_block_supported(int N, int d_model, int heads);
 int feta_attn_block_fwd(const feta_attn_block* d, feta_stream_t stream);
 
+/* ---- backward of the attention sub-block in ONE launch ------------------------------------------------------
+ * (feta_attn_block_bwd_supported: d_model = 64, 4 heads, N <= 64; K not tied to Q.)  Replaces
+ * feta_rowlin_bwd_ex (out_proj) -> feta_attn_bwd -> feta_rowlin_bwd_ex (in_proj) of the layer's backward:
+ *   g1 = BatchNorm-1 backward of dy (y1 [M,64], bn1 [4][64], partial sums g_sum [Gs][2][64] finalized here ->
+ *        fin_out [2][64], dgamma, dbeta) - or dy itself when y1 is NULL (LayerNorm stack);
+ *   dconcat = (rowscale * g1) W_out (+ dout2 [M,64], the filter branch's gradient into out_each_head);
+ *   dq|dk|dv from q|k|v (qkv [M,192]), out [M,64], pe, attn_stats (feta_attn_bwd's arithmetic);
+ *   dx [M,64] = dqkv W_in + g1;  sum_out (nullable) [2 * feta_attn_block_bwd_blocks(B)][2][64]: partial
+ *        (sum dx, sum dx * xhat0), xhat0 from x0 (pre-norm) and bn0 [4][64];
+ *   partial: one row per workgroup (feta_attn_block_bwd_blocks(B) rows, pitch partial_ld, 0: 4*64*64 + 4*64),
+ *        columns [dW_out (64 x 64) | db_out (64) | dW_in (192 x 64) | db_in (192)], reduced by the caller;
+ *        dW_in contracts dqkv with x0 seen through bn0 (scale, shift rows) when given.
+ * Rows are addressed as in feta_attn_block: row(b, i) = b*row_sb + i*row_sn. */
+typedef struct feta_attn_block_grad {
+  const float* dy;
+  const float* y1;
+  const float* bn1;
+  const float* g_sum;
+  int Gs;
+  float* fin_out;
+  float* dgamma;
+  float* dbeta;
+  const float* rowscale;
+  const float* w_out;
+  const float* w_in;
+  const float* qkv;
+  const float* out;
+  const float* dout2;
+  const float* pe;
+  const int32_t* n_real;
+  const float* attn_stats;
+  const float* x0;
+  const float* bn0;
+  float* dx;
+  float* sum_out;
+  float* partial;
+  int partial_ld;
+  float scale;
+  int B, N, M;
+  int64_t row_sb, row_sn;
+} feta_attn_block_grad;
+
+int feta_attn_block_bwd_supported(int N, int d_model, int heads);
+int feta_attn_block_bwd_blocks(int B);
+int feta_attn_block_bwd(const feta_attn_block_grad* d, feta_stream_t stream);
+
 /* ---- feed-forward half of one encoder layer in ONE launch -----------------------------------
  * x = BN1(y1) (x_bn | x_stats as in feta_rowlin_ex / feta_attn_block);  h = relu(x W1^T + b1);
  * y = x + h W2^T + b2;  y_stats [feta_ffn_blocks(M)][2][64] per-workgroup (sum, sum of squares).

@@ -269,6 +269,7 @@ def _stack_run(model, batch9, cache, use_block, monkeypatch, hook):
     monkeypatch.setattr(fused_stack, 'USE_ATTN_BLOCK', use_block)   # csrc/block.hip vs three launches
     monkeypatch.setattr(fused_stack, 'USE_FFN_FUSED', use_block)    # csrc/ffn.hip vs two launches
     monkeypatch.setattr(fused_stack, 'USE_FFN_BWD', use_block)      # csrc/ffn_bwd.hip vs two launches
+    monkeypatch.setattr(fused_stack, 'USE_ATTN_BLOCK_BWD', use_block)   # csrc/block_bwd.hip vs three launches
     x, mask, pe, _, degree, _, edge_index, batch, fi = batch9
     x = x.clone().requires_grad_(True)
     model.zero_grad()
