@@ -75,8 +75,44 @@ def stack_layer_cases(abi, st, dev, b, n, d, heads, ff, pe, n_real, last_layer_a
         keep = (x, w, dy, dx, part, kw)
         cases.append((name, 1.0, lambda: (abi.rowlin_bwd_ex(dsc, None, st), keep)[0], f4 * nbytes, ['rowlin_bwd']))
 
-    bwd_case('rowlin_bwd linear2 (stack: BN-backward gradient)', ff, d, 'g')
-    bwd_case('rowlin_bwd linear1 (stack: relu, add, sums)', d, ff, 'ras')
-    bwd_case('rowlin_bwd out_proj (stack: BN-backward gradient)', d, d, 'g')
-    bwd_case('rowlin_bwd in_proj (stack: add, sums)', d, 3 * d, 'as')
+    fused_f = abi.ffn_bwd_supported(d, ff)
+    fused_a = abi.attn_block_bwd_supported(n, d, heads) and abi.attn_block_bwd_blocks(b) > 0
+    if fused_f:
+        # backward of the FFN half in one launch (csrc/ffn_bwd.hip), BatchNorm stack variant
+        dy, y2, hh, y1, dx = rnd(m, d), rnd(m, d), rnd(m, ff), rnd(m, d), new(m, d)
+        w2, w1 = rnd(d, ff) / ff ** 0.5, rnd(ff, d) / d ** 0.5
+        cols = 2 * d * ff + d + ff
+        part = new(RC, cols)
+        xb = abi.ffn_bwd_blocks(m)
+        kw = dict(dy=dy, g_y=y2, g_bn=prm_of(d), g_sum=rnd(G, 2, d), g_fin_out=new(2, d), dgamma=new(d), dbeta=new(d),
+                  h=hh, w2=w2, w1=w1, x=y1, x_bn=prm_of(d), dx=dx, sum_out=new(xb, 2, d))
+        fdsc = abi.ffn_bwd_desc(m, ff, Gs=G, partial_ld=cols, partial_ptr=part.data_ptr(), **kw)
+        keep_f = (kw, part)
+        cases.append(('ffn_bwd', 1.0, lambda: (abi.ffn_bwd_launch(fdsc, st), keep_f)[0],
+                      f4 * (4 * m * d + m * ff + 2 * d * ff + RC * cols), ['ffn_bwd']))
+    else:
+        bwd_case('rowlin_bwd linear2 (stack: BN-backward gradient)', ff, d, 'g')
+        bwd_case('rowlin_bwd linear1 (stack: relu, add, sums)', d, ff, 'ras')
+    if fused_a:
+        # backward of the attention sub-block in one launch (csrc/block_bwd.hip), BatchNorm stack variant
+        dy, y1, x0, qkv, out, dx = rnd(m, d), rnd(m, d), rnd(m, d), rnd(m, 3 * d), rnd(m, d), new(m, d)
+        w_o, w_in = rnd(d, d) / d ** 0.5, rnd(3 * d, d) / d ** 0.5
+        ast = torch.rand(b, heads, n, 2, generator=g).to(dev) + 1.0
+        deg = torch.rand(m, generator=g).to(dev)
+        cols = 4 * d * d + 4 * d
+        part = new(b, cols)
+        kw = dict(dy=dy, y1=y1, bn1=prm_of(d), g_sum=rnd(G, 2, d), fin_out=new(2, d), dgamma=new(d), dbeta=new(d),
+                  rowscale=deg, w_out=w_o, w_in=w_in, qkv=qkv, out=out, pe=pe, n_real=n_real, attn_stats=ast, x0=x0,
+                  bn0=prm_of(d), dx=dx, sum_out=new(2 * b, 2, d))
+        keep_a = (kw, part)
+        cases.append(('attn_block_bwd', 1.0,
+                      lambda: (abi.attn_block_bwd(b, n, dh ** -0.5, st, Gs=G, partial_ptr=part.data_ptr(), partial_ld=cols,
+                                                  **kw), keep_a)[0],
+                      f4 * (8 * m * d + (b * n * n if pe is not None else 0) + 2 * b * heads * n + 4 * d * d + b * cols),
+                      ['attn_block_bwd']))
+    else:
+        bwd_case('rowlin_bwd out_proj (stack: BN-backward gradient)', d, d, 'g')
+        bwd_case('rowlin_bwd in_proj (stack: add, sums)', d, 3 * d, 'as')
+    # linear_cat (2d -> d) of the filter stage: forward and backward, once per step
+    bwd_case('rowlin_bwd linear_cat', ff if ff == 2 * d else 2 * d, d, '')
     return cases

@@ -31,10 +31,9 @@ ROWS = [  # (bench row, kernel-symbol substrings enqueued by one call, in order)
     ('attn_block_fwd (no attn write)', ['attn_block_fwd']),
     ('attn_block_fwd (+attn write)', ['attn_block_fwd']),
     ('ffn_fwd', ['ffn_fwd']),
-    ('rowlin_bwd linear2 (stack: BN-backward gradient)', ['rowlin_bwd']),
-    ('rowlin_bwd linear1 (stack: relu, add, sums)', ['rowlin_bwd']),
-    ('rowlin_bwd out_proj (stack: BN-backward gradient)', ['rowlin_bwd']),
-    ('rowlin_bwd in_proj (stack: add, sums)', ['rowlin_bwd']),
+    ('ffn_bwd', ['ffn_bwd']),
+    ('attn_block_bwd', ['attn_block_bwd']),
+    ('rowlin_bwd linear_cat', ['rowlin_bwd']),
 ]
 
 
@@ -68,6 +67,10 @@ def main():
         for i, (row, _) in enumerate(ROWS):
             if row.startswith('attn_bwd'):
                 ROWS[i] = (row, ['attn_bwd_graph'])
+    if not any('attn_block_bwd' in name for name, _ in f):   # batches beyond the fused attention-block backward
+        i = [r for r, _ in ROWS].index('attn_block_bwd')
+        ROWS[i:i + 1] = [('rowlin_bwd out_proj (stack: BN-backward gradient)', ['rowlin_bwd']),
+                         ('rowlin_bwd in_proj (stack: add, sums)', ['rowlin_bwd'])]
     calls = int(sys.argv[3]) + 3
     fk, wk = walk(f, calls), walk(w, calls)
     res = {name: {'FETCH_SIZE_KB': round(fk[name], 1), 'WRITE_SIZE_KB': round(wk[name], 1),
