@@ -347,12 +347,20 @@ def roofline(args, gpu, dev):
     sum_n = int(nr.sum().item())
     rnd = lambda *s: torch.randn(*s, device=dev)
     cand = []   # (variant name, symbol, launches per step, fn, algorithmic bytes)
+    from feta_tmlr_amd import fused_stack
+    split_form = (fused_stack.USE_ATTN_BLOCK_SPLIT and fused_stack.USE_FFN_BWD and fused_stack.USE_ATTN_BLOCK_BWD
+                  and abi.ffn_bwd_supported(d, 2 * d) and abi.attn_block_bwd_supported(n, d, h)
+                  and abi.attn_block_bwd_blocks(b) > 0)
     for name, per_layer, fn, nbytes, syms in stack_layer_cases(abi, st, dev, b, n, d, h, 2 * d, gpu['pe'], nr):
         if name == 'attn_block_fwd (no attn write)':
             cnt = L - 1
         elif name == 'attn_block_fwd (+attn write)':
             cnt = 1
         elif 'linear_cat' in name:
+            cnt = 1
+        elif name in ('ffn_bwd (gradient in two parts)', 'attn_block_bwd (two workgroups per graph)'):
+            cnt = L - 1      # fused_stack.py: every layer but the first hands its input gradient to a fused FFN backward
+        elif name in ('ffn_bwd', 'attn_block_bwd') and split_form:
             cnt = 1
         else:
             cnt = L
@@ -406,8 +414,9 @@ def roofline(args, gpu, dev):
         if all(r['traffic'] is not None for r in rows):
             tr = int(sum(r['launches_per_step'] * r['traffic'] for r in rows) / launches)
         busy = None
-        for key, val in mfma.items():
-            if sym.split('<')[0] in key:
+        base, _, targ = sym.partition('<')
+        for key, val in mfma.items():   # keys: kernel names with template arguments
+            if base in key and (targ not in ('true>', 'false>') or key.rstrip().endswith(', ' + targ)):
                 busy = val.get('mfma_busy_pct')
                 break
         ach = bytes_step / t_step / 1e3       # bytes / us -> GB/s

@@ -152,7 +152,7 @@ class AttnBlockGrad(C.Structure):
     _fields_ = [
         ('dy', _F), ('y1', _F), ('bn1', _F), ('g_sum', _F), ('Gs', C.c_int), ('fin_out', _F), ('dgamma', _F),
         ('dbeta', _F), ('rowscale', _F), ('w_out', _F), ('w_in', _F), ('qkv', _F), ('out', _F), ('dout2', _F),
-        ('pe', _F), ('n_real', _I), ('attn_stats', _F), ('x0', _F), ('bn0', _F), ('dx', _F), ('sum_out', _F),
+        ('pe', _F), ('n_real', _I), ('attn_stats', _F), ('x0', _F), ('bn0', _F), ('dx', _F), ('dx_b', _F), ('sum_out', _F),
         ('partial', _F), ('partial_ld', C.c_int), ('scale', C.c_float), ('B', C.c_int), ('N', C.c_int), ('M', C.c_int),
         ('row_sb', C.c_int64), ('row_sn', C.c_int64),
     ]
@@ -168,7 +168,7 @@ SIGNATURES.update({
 class FfnGrad(C.Structure):
     """struct feta_ffn_grad (include/feta_hip.h) - field order must match the header."""
     _fields_ = [
-        ('dy', _F), ('g_y', _F), ('g_bn', _F), ('g_sum', _F), ('Gs', C.c_int), ('g_fin', _F), ('g_fin_out', _F),
+        ('dy', _F), ('dy_b', _F), ('g_y', _F), ('g_bn', _F), ('g_sum', _F), ('Gs', C.c_int), ('g_fin', _F), ('g_fin_out', _F),
         ('dgamma', _F), ('dbeta', _F), ('h', _F), ('w2', _F), ('w1', _F), ('x', _F), ('x_bn', _F), ('dx', _F),
         ('sum_out', _F), ('partial', _F), ('partial_ld', C.c_int), ('M', C.c_int), ('FF', C.c_int),
     ]
@@ -180,7 +180,7 @@ SIGNATURES.update({
     'feta_ffn_bwd': ([C.POINTER(FfnGrad), _S], C.c_int),
 })
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class FetaError(RuntimeError):

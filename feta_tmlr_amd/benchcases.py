@@ -90,6 +90,13 @@ def stack_layer_cases(abi, st, dev, b, n, d, heads, ff, pe, n_real, last_layer_a
         keep_f = (kw, part)
         cases.append(('ffn_bwd', 1.0, lambda: (abi.ffn_bwd_launch(fdsc, st), keep_f)[0],
                       f4 * (4 * m * d + m * ff + 2 * d * ff + RC * cols), ['ffn_bwd']))
+        if fused_a:
+            # ... below a layer whose attention backward ran as two workgroups per graph: the gradient in two parts
+            kw2 = dict(kw, dy_b=rnd(m, d))
+            fdsc2 = abi.ffn_bwd_desc(m, ff, Gs=G, partial_ld=cols, partial_ptr=part.data_ptr(), **kw2)
+            keep_f2 = (kw2, part)
+            cases.append(('ffn_bwd (gradient in two parts)', 1.0, lambda: (abi.ffn_bwd_launch(fdsc2, st), keep_f2)[0],
+                          f4 * (5 * m * d + m * ff + 2 * d * ff + RC * cols), ['ffn_bwd']))
     else:
         bwd_case('rowlin_bwd linear2 (stack: BN-backward gradient)', ff, d, 'g')
         bwd_case('rowlin_bwd linear1 (stack: relu, add, sums)', d, ff, 'ras')
@@ -109,7 +116,16 @@ def stack_layer_cases(abi, st, dev, b, n, d, heads, ff, pe, n_real, last_layer_a
                       lambda: (abi.attn_block_bwd(b, n, dh ** -0.5, st, Gs=G, partial_ptr=part.data_ptr(), partial_ld=cols,
                                                   **kw), keep_a)[0],
                       f4 * (8 * m * d + (b * n * n if pe is not None else 0) + 2 * b * heads * n + 4 * d * d + b * cols),
-                      ['attn_block_bwd']))
+                      ['attn_block_bwd<false>']))
+        if fused_f:
+            # two workgroups per graph (layers whose consumer is the fused FFN backward): dx in two parts
+            kws = dict(kw, dx_b=new(m, d))
+            keep_s = (kws, part)
+            cases.append(('attn_block_bwd (two workgroups per graph)', 1.0,
+                          lambda: (abi.attn_block_bwd(b, n, dh ** -0.5, st, Gs=G, partial_ptr=part.data_ptr(),
+                                                      partial_ld=cols, **kws), keep_s)[0],
+                          f4 * (9 * m * d + (b * n * n if pe is not None else 0) + 2 * b * heads * n + 4 * d * d + b * cols),
+                          ['attn_block_bwd<true>']))
     else:
         bwd_case('rowlin_bwd out_proj (stack: BN-backward gradient)', d, d, 'g')
         bwd_case('rowlin_bwd in_proj (stack: add, sums)', d, 3 * d, 'as')

@@ -15,6 +15,13 @@
 // own partial row of the weight gradients (accumulators that outlive a graph cost ~50 registers through the
 // attention phase: the kernel spilled), so the launch takes batches of up to kBbMaxGrid graphs; larger batches keep
 // the three-launch form, which is the better shape there anyway (feta_rowlin_bwd's row chunks fill the chip).
+//
+// SPLIT form (dx_b given): TWO workgroups per graph, one per pair of heads - at the BASELINE batch one workgroup per
+// graph leaves half of the 256 CUs idle and the kernel is MFMA-bound per CU.  Heads are independent up to dx, which
+// contracts over all of dqkv: each workgroup writes the part of dx its heads contribute (dx: pair 0, with the residual
+// g1; dx_b: pair 1) and the consumer adds the two on load (feta_ffn_bwd's dy_b); the partial sums of the previous
+// BatchNorm's backward are linear in dx, so they are emitted per workgroup as well; dW_out columns / dW_in rows of the
+// two pairs are disjoint parts of the graph's partial row.
 #include <cstdlib>
 
 #include "feta_abi_common.h"
@@ -37,11 +44,20 @@ __host__ __device__ inline int block_bwd_lds_floats(int nt, bool gbn) {
          + (gbn ? 5 * kBbD + reduce_scratch_floats(kBbD) : 0);
 }
 
-template <int NT>
+template <int NT, bool SPLIT>
 __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
   constexpr int D = kBbD, DH = kBbDH, H = kBbH, P = kBbP, NR = 16 * NT, PEP = NR + 1;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lq = lane & 15, g = lane >> 4;
-  const int h = wv & 3, role = wv >> 2;
+  const int hp = SPLIT ? (int)(blockIdx.x & 1) : 0;          // pair of heads of this workgroup
+  // attention part: wave = (head, role) - and, SPLIT, the parity of the tiles it walks
+  const int h = SPLIT ? 2 * hp + (wv & 1) : (wv & 3);
+  const int role = SPLIT ? ((wv >> 1) & 1) : (wv >> 2);
+  const int half = wv >> 2;
+  // row-wise parts: a wave owns the 16 columns `ct` (dconcat) / `kt` (dx) and the row tiles mine_*(rt)
+  const int ct = SPLIT ? 2 * hp + (wv & 1) : (wv & 3);
+  const int ktile = wv & 3;
+  auto mine_dc = [&](int rt) { return SPLIT ? rt == (wv >> 1) : (rt & 1) == (wv >> 2); };
+  auto mine_dx = [&](int rt) { return (rt & 1) == (wv >> 2); };
   float* Qs = feta_lds;        // [NR][P] q, later dq
   float* Ks = Qs + NR * P;     // k, later dk
   float* Vs = Ks + NR * P;     // v, later dv
@@ -87,17 +103,17 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
   }
   float sc0 = 1.0f, sh0 = 0.0f, mean0[4] = {0.f, 0.f, 0.f, 0.f}, rstd0[4] = {0.f, 0.f, 0.f, 0.f};
   if (xbn) {
-    sc0 = a.bn0[16 * h + lq];
-    sh0 = a.bn0[D + 16 * h + lq];
+    sc0 = a.bn0[16 * ktile + lq];
+    sh0 = a.bn0[D + 16 * ktile + lq];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      mean0[r] = a.bn0[2 * D + 16 * h + 4 * g + r];
-      rstd0[r] = a.bn0[3 * D + 16 * h + 4 * g + r];
+      mean0[r] = a.bn0[2 * D + 16 * ktile + 4 * g + r];
+      rstd0[r] = a.bn0[3 * D + 16 * ktile + 4 * g + r];
     }
   }
   const int nm1 = a.N - 1;
   {
-    const int b = blockIdx.x;        // one graph per workgroup
+    const int b = SPLIT ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;   // one graph per workgroup (SPLIT: per two)
     const int n = a.n_real[b];
     float sum1[4] = {0.f, 0.f, 0.f, 0.f}, sum2[4] = {0.f, 0.f, 0.f, 0.f};
     auto grow = [&](int node) { return (int64_t)b * a.row_sb + (int64_t)min(node, nm1) * a.row_sn; };
@@ -173,14 +189,14 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
     // ---- dconcat^T tiles (c = 16h + 4g + r, row = 16 rt + lq) = sum_o W_out[o][c] (degree g1)[row][o] (+ dout2) ----
     // (the wave's weight column slices are requested where they are used: held over the whole kernel they cost 64
     // registers that the attention phase needs - the kernel spilled)
-    float woA[4][4];    // W_out[o = 16j+4g+s][c = 16h + lq]: dconcat columns of head h
+    float woA[4][4];    // W_out[o = 16j+4g+s][c = 16 ct + lq]: dconcat columns of head ct
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) woA[j][s] = a.w_out[(int64_t)(16 * j + 4 * g + s) * D + 16 * h + lq];
+      for (int s = 0; s < 4; ++s) woA[j][s] = a.w_out[(int64_t)(16 * j + 4 * g + s) * D + 16 * ct + lq];
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) {
-      if ((rt & 1) != role) continue;
+      if (!mine_dc(rt)) continue;
       const int rowl = 16 * rt + lq;
       Feat<D> gf;
       load_row<D>(gf, Gt + rowl * P, g, RS[rowl]);
@@ -189,7 +205,7 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc = mfma16(woA[j][s], gf.f[j][s], acc);
-      float4* dst = reinterpret_cast<float4*>(Ds + rowl * P + 16 * h + 4 * g);
+      float4* dst = reinterpret_cast<float4*>(Ds + rowl * P + 16 * ct + 4 * g);
       const float4 d2 = *dst;
       *dst = make_float4(acc[0] + d2.x, acc[1] + d2.y, acc[2] + d2.z, acc[3] + d2.w);
     }
@@ -243,6 +259,7 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
           if (16 * kt >= n) continue;
+          if (SPLIT && ((qb * NT + kt) & 1) != half) continue;   // the partner wave takes the other tile pairs
           const f32x4 s = dot_rows<DH>(kf[kt], qf, zero4());
           const f32x4 da = dot_rows<DH>(vf[kt], dof, zero4());
 #pragma unroll
@@ -288,6 +305,7 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
         }
 #pragma unroll
         for (int qb = 0; qb < NT; ++qb) {
+          if (SPLIT && ((kt * NT + qb) & 1) != half) continue;
           const f32x4 s = dot_rows<DH>(qf[qb], kf, zero4());
           const f32x4 da = dot_rows<DH>(dof[qb], vf, zero4());
 #pragma unroll
@@ -304,53 +322,73 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
       }
     }
     __syncthreads();   // every wave has taken its operands: the q / k / v tiles become dq / dk / dv
+    // SPLIT: the two waves of a (head, role) hold partial sums over their tile pairs: one stores, then the other adds
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int pass = 0; pass < (SPLIT ? 2 : 1); ++pass) {
+      if (!SPLIT || half == pass) {
+        // (pass 0 overwrites: k / v rows of padded nodes were never written by the forward pass)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int rr = 16 * t + 4 * g + r;
-        if (role == 0) {
-          Qs[rr * P + co + lq] = r0[t][r] * a.scale;
-        } else {
-          Ks[rr * P + co + lq] = r0[t][r];
-          Vs[rr * P + co + lq] = r1[t][r];
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int rr = 16 * t + 4 * g + r;
+            if (role == 0) {
+              float* dq = Qs + rr * P + co + lq;
+              *dq = (pass == 0 ? 0.0f : *dq) + r0[t][r] * a.scale;
+            } else {
+              float* dk = Ks + rr * P + co + lq;
+              float* dv = Vs + rr * P + co + lq;
+              *dk = (pass == 0 ? 0.0f : *dk) + r0[t][r];
+              *dv = (pass == 0 ? 0.0f : *dv) + r1[t][r];
+            }
+          }
         }
       }
-    __syncthreads();
+      __syncthreads();
+    }
 
-    // ---- dx^T tiles (k = 16h + 4g + r, row) = sum_o W_in[o][k] dqkv[row][o] + g1[row][k]; sums for the previous BN ---
+    // ---- dx^T tiles (k = 16 ktile + 4g + r, row) = sum_o W_in[o][k] dqkv[row][o] (+ g1[row][k]); sums for the previous
+    // BatchNorm.  SPLIT: o runs over this pair's columns of dq | dk | dv only (the other columns of the tiles still hold
+    // q | k | v of the other pair), the residual belongs to pair 0
+    constexpr int NJX = SPLIT ? 2 : 4;
     f32x4 dxa[NT];
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) dxa[rt] = zero4();
 #pragma unroll
     for (int part = 0; part < 3; ++part) {
-      float wiA[4][4];   // W_in[o = 64 part + 16j+4g+s][k = 16h + lq]: dx columns 16h .. 16h+15
+      float wiA[NJX][4];   // W_in[o = 64 part + 16 jc + 4g+s][k = 16 ktile + lq], jc = this pair's (or every) head
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NJX; ++j)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) wiA[j][s] = a.w_in[(int64_t)(64 * part + 16 * j + 4 * g + s) * D + 16 * h + lq];
+        for (int s = 0; s < 4; ++s)
+          wiA[j][s] = a.w_in[(int64_t)(64 * part + 16 * (SPLIT ? 2 * hp + j : j) + 4 * g + s) * D + 16 * ktile + lq];
 #pragma unroll
       for (int rt = 0; rt < NT; ++rt) {
-        if ((rt & 1) != role) continue;
-        Feat<D> df;
-        load_row<D>(df, (part == 0 ? Qs : (part == 1 ? Ks : Vs)) + (16 * rt + lq) * P, g);
+        if (!mine_dx(rt)) continue;
+        const float* drow = (part == 0 ? Qs : (part == 1 ? Ks : Vs)) + (16 * rt + lq) * P + (SPLIT ? 32 * hp : 0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) dxa[rt] = mfma16(wiA[j][s], df.f[j][s], dxa[rt]);
+        for (int j = 0; j < NJX; ++j) {
+          const float4 dq4 = *reinterpret_cast<const float4*>(drow + 16 * j + 4 * g);
+          dxa[rt] = mfma16(wiA[j][0], dq4.x, dxa[rt]);
+          dxa[rt] = mfma16(wiA[j][1], dq4.y, dxa[rt]);
+          dxa[rt] = mfma16(wiA[j][2], dq4.z, dxa[rt]);
+          dxa[rt] = mfma16(wiA[j][3], dq4.w, dxa[rt]);
+        }
       }
     }
+    float* dxo = (SPLIT && hp == 1) ? a.dx_b : a.dx;
+    const float resw = (SPLIT && hp == 1) ? 0.0f : 1.0f;
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) {
-      if ((rt & 1) != role) continue;
+      if (!mine_dx(rt)) continue;
       const int rowl = 16 * rt + lq;
       const f32x4 acc = dxa[rt];
-      const float4 res = *reinterpret_cast<const float4*>(Gt + rowl * P + 16 * h + 4 * g);
-      const float v[4] = {acc[0] + res.x, acc[1] + res.y, acc[2] + res.z, acc[3] + res.w};
+      const float4 res = *reinterpret_cast<const float4*>(Gt + rowl * P + 16 * ktile + 4 * g);
+      const float v[4] = {acc[0] + resw * res.x, acc[1] + resw * res.y, acc[2] + resw * res.z, acc[3] + resw * res.w};
       const bool rok = rowl < a.N;
-      if (rok) *reinterpret_cast<float4*>(a.dx + grow(rowl) * D + 16 * h + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+      if (rok) *reinterpret_cast<float4*>(dxo + grow(rowl) * D + 16 * ktile + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
       if (want_sums) {
-        const float4 xr = *reinterpret_cast<const float4*>(X0 + rowl * P + 16 * h + 4 * g);
+        const float4 xr = *reinterpret_cast<const float4*>(X0 + rowl * P + 16 * ktile + 4 * g);
         const float xx[4] = {xr.x, xr.y, xr.z, xr.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -360,76 +398,118 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
         }
       }
     }
-
-    if (want_sums) {   // one partial row per (graph, role): the two roles cover alternate row tiles
+    if (want_sums) {
+      // partial (sum dx, sum dx * xhat0) rows: one per (graph, row-tile parity); SPLIT: the two parities are added
+      // through LDS first (pe is no longer needed), one row per workgroup = the same 2 B rows in both forms
+      float s1v[4], s2v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float s1 = row16_sum(sum1[r]), s2 = row16_sum(sum2[r]);
-        if (lq == 0) {
-          const int64_t prow = (int64_t)blockIdx.x * 2 + role;
-          a.sum_out[(prow * 2 + 0) * D + 16 * h + 4 * g + r] = s1;
-          a.sum_out[(prow * 2 + 1) * D + 16 * h + 4 * g + r] = s2;
+        s1v[r] = row16_sum(sum1[r]);
+        s2v[r] = row16_sum(sum2[r]);
+      }
+      if (SPLIT) {
+        float* red = PE;   // [4 k tiles][2][16]
+        if ((wv >> 2) == 1 && lq == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            red[(ktile * 2 + 0) * 16 + 4 * g + r] = s1v[r];
+            red[(ktile * 2 + 1) * 16 + 4 * g + r] = s2v[r];
+          }
+        }
+        __syncthreads();
+        if ((wv >> 2) == 0 && lq == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            a.sum_out[((int64_t)blockIdx.x * 2 + 0) * D + 16 * ktile + 4 * g + r] = s1v[r] + red[(ktile * 2 + 0) * 16 + 4 * g + r];
+            a.sum_out[((int64_t)blockIdx.x * 2 + 1) * D + 16 * ktile + 4 * g + r] = s2v[r] + red[(ktile * 2 + 1) * 16 + 4 * g + r];
+          }
+        }
+      } else if (lq == 0) {
+        const int64_t prow = (int64_t)blockIdx.x * 2 + (wv >> 2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          a.sum_out[(prow * 2 + 0) * D + 16 * ktile + 4 * g + r] = s1v[r];
+          a.sum_out[(prow * 2 + 1) * D + 16 * ktile + 4 * g + r] = s2v[r];
         }
       }
     }
 
     // ---- weight gradients of the graph, contraction over its rows (rows >= N are zero in every tile) -----------------
-    f32x4 aWo[2] = {zero4(), zero4()};   // dW_out[o = 16h + 4g' + r][c = 16 (2 role + i) + lq]
-    f32x4 aWi[6];                        // dW_in[o = 16 (6 role + i) + 4g' + r][k = 16h + lq]
+    // dW_out[o = 16 ktile + 4g' + r][c]: NWO column tiles per wave; dW_in[o][k = 16 ktile + lq]: NWI row tiles per wave
+    // (row tile = q | k | v part x head); SPLIT: only this pair's columns / rows
+    constexpr int NWO = SPLIT ? 1 : 2, NWI = SPLIT ? 3 : 6;
+    const int grp = wv >> 2;
+    f32x4 aWo[NWO], aWi[NWI];
+    float dbi[NWI];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) aWi[i] = zero4();
-    float dbo = 0.0f, dbi[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NWO; ++i) aWo[i] = zero4();
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) {
+      aWi[i] = zero4();
+      dbi[i] = 0.0f;
+    }
+    float dbo = 0.0f;
+    auto wo_ct = [&](int i) { return SPLIT ? 2 * hp + grp : 2 * grp + i; };          // column tile of dW_out
+    auto wi_part = [&](int i) { return SPLIT ? (3 * grp + i) >> 1 : (6 * grp + i) >> 2; };
+    auto wi_head = [&](int i) { return SPLIT ? 2 * hp + ((3 * grp + i) & 1) : ((6 * grp + i) & 3); };
     for (int st = 0; st < NR / 4; ++st) {
       const int rr = 4 * st + g;
-      const float ga = RS[rr] * Gt[rr * P + 16 * h + lq];       // (degree g1)[row][o = 16h + lq]
-      const float xb = X0[rr * P + 16 * h + lq] * sc0 + sh0;    // x0 seen through its BatchNorm, [row][k = 16h + lq]
-      if (role == 0) dbo += ga;
+      const float ga = RS[rr] * Gt[rr * P + 16 * ktile + lq];       // (degree g1)[row][o = 16 ktile + lq]
+      const float xb = X0[rr * P + 16 * ktile + lq] * sc0 + sh0;    // x0 through its BatchNorm, [row][k = 16 ktile + lq]
+      dbo += ga;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) aWo[i] = mfma16(ga, Os[rr * P + 16 * (2 * role + i) + lq], aWo[i]);
+      for (int i = 0; i < NWO; ++i) aWo[i] = mfma16(ga, Os[rr * P + 16 * wo_ct(i) + lq], aWo[i]);
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const int ot = 6 * role + i;      // 16-row tile of dW_in: q | k | v part ot / 4, columns 16 (ot % 4)
-        const float* src = ot < 4 ? Qs : (ot < 8 ? Ks : Vs);
-        const float da = src[rr * P + 16 * (ot & 3) + lq];
+      for (int i = 0; i < NWI; ++i) {
+        const int part = wi_part(i);
+        const float* src = part == 0 ? Qs : (part == 1 ? Ks : Vs);
+        const float da = src[rr * P + 16 * wi_head(i) + lq];
         dbi[i] += da;
         aWi[i] = mfma16(da, xb, aWi[i]);
       }
     }
     // ---- partial row of this graph: [dW_out (64 x 64) | db_out (64) | dW_in (192 x 64) | db_in (192)] --------------
-    float* p = a.partial + (int64_t)blockIdx.x * (a.partial_ld > 0 ? (int64_t)a.partial_ld : (int64_t)(4 * D * D + 4 * D));
+    float* p = a.partial + (int64_t)b * (a.partial_ld > 0 ? (int64_t)a.partial_ld : (int64_t)(4 * D * D + 4 * D));
     float* pWo = p;
     float* pbo = p + D * D;
     float* pWi = pbo + D;
     float* pbi = pWi + 3 * D * D;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NWO; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pWo[(int64_t)(16 * h + 4 * g + r) * D + 16 * (2 * role + i) + lq] = aWo[i][r];
+      for (int r = 0; r < 4; ++r) pWo[(int64_t)(16 * ktile + 4 * g + r) * D + 16 * wo_ct(i) + lq] = aWo[i][r];
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < NWI; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pWi[(int64_t)(16 * (6 * role + i) + 4 * g + r) * D + 16 * h + lq] = aWi[i][r];
+      for (int r = 0; r < 4; ++r)
+        pWi[(int64_t)(64 * wi_part(i) + 16 * wi_head(i) + 4 * g + r) * D + 16 * ktile + lq] = aWi[i][r];
     dbo += shfl_xor(dbo, 16);
     dbo += shfl_xor(dbo, 32);
-    if (role == 0 && g == 0) pbo[16 * h + lq] = dbo;
+    if (grp == 0 && hp == 0 && g == 0) pbo[16 * ktile + lq] = dbo;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < NWI; ++i) {
       float s = dbi[i];
       s += shfl_xor(s, 16);
       s += shfl_xor(s, 32);
-      if (h == 0 && g == 0) pbi[16 * (6 * role + i) + lq] = s;
+      if (ktile == 0 && g == 0) pbi[64 * wi_part(i) + 16 * wi_head(i) + lq] = s;
     }
   }
 }
 
-
 template <int NT>
 int launch_block_bwd(const BwdArgs& a, hipStream_t stream) {
   const size_t lds = sizeof(float) * block_bwd_lds_floats(NT, a.y1 != nullptr);
-  auto kern = attn_block_bwd_kernel<NT>;
-  static LdsSeen lds_seen;
-  allow_dynamic_lds(kern, lds, lds_seen);
-  hipLaunchKernelGGL(kern, dim3(a.B), dim3(kBbThreads), lds, stream, a);
+  if (a.dx_b != nullptr) {   // two workgroups per graph
+    auto kern = attn_block_bwd_kernel<NT, true>;
+    static LdsSeen lds_seen;
+    allow_dynamic_lds(kern, lds, lds_seen);
+    hipLaunchKernelGGL(kern, dim3(2 * a.B), dim3(kBbThreads), lds, stream, a);
+  } else {
+    auto kern = attn_block_bwd_kernel<NT, false>;
+    static LdsSeen lds_seen;
+    allow_dynamic_lds(kern, lds, lds_seen);
+    hipLaunchKernelGGL(kern, dim3(a.B), dim3(kBbThreads), lds, stream, a);
+  }
   return check_launch("feta_attn_block_bwd");
 }
 
@@ -454,7 +534,8 @@ extern "C" int feta_attn_block_bwd(const feta_attn_block_grad* d, feta_stream_t 
   FETA_REQUIRE(!a.y1 || (a.bn1 && a.g_sum && a.Gs > 0), "attn_block_bwd: y1 needs bn1, g_sum, Gs");
   FETA_REQUIRE(!a.sum_out || a.bn0, "attn_block_bwd: sum_out needs bn0");
   FETA_REQUIRE(aligned16(a.dy) && aligned16(a.qkv) && aligned16(a.out) && aligned16(a.x0) && aligned16(a.dx) &&
-               aligned16(a.y1) && aligned16(a.dout2) && aligned16(a.g_sum), "attn_block_bwd: tensors must be 16-byte aligned");
+               aligned16(a.y1) && aligned16(a.dout2) && aligned16(a.g_sum) && aligned16(a.dx_b),
+               "attn_block_bwd: tensors must be 16-byte aligned");
   const int nt = (a.N + 15) / 16;
   switch (nt) {
     case 1: return launch_block_bwd<1>(a, (hipStream_t)stream);

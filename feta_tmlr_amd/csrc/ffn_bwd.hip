@@ -135,7 +135,11 @@ __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, Ffn
         const int idx = tid + u * kRowThreads, rr = idx >> 4, c4 = idx & 15;
         const int64_t off = (int64_t)min(r0 + rr, row_last) * D + 4 * c4;
         dv[u] = *reinterpret_cast<const float4*>(a.dy + off);
-        yv[u] = gbn ? *reinterpret_cast<const float4*>(a.g_y + off) : dv[u];
+        if (a.dy_b != nullptr) {   // the gradient arrives in two parts (feta_attn_block_bwd, SPLIT form)
+          const float4 d2 = *reinterpret_cast<const float4*>(a.dy_b + off);
+          dv[u] = make_float4(dv[u].x + d2.x, dv[u].y + d2.y, dv[u].z + d2.z, dv[u].w + d2.w);
+        }
+        yv[u] = *reinterpret_cast<const float4*>((gbn ? a.g_y : a.dy) + off);
       }
       float4 hv[2][CT2], sy[2];
 #pragma unroll
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, Ffn
 #pragma unroll
         for (int t = 0; t < CT2; ++t)
           hv[rt][t] = *reinterpret_cast<const float4*>(a.h + rowc * FF + 16 * (w * CT2 + t) + 4 * g);
-        sy[rt] = want_sums ? *reinterpret_cast<const float4*>(a.x + rowc * D + 16 * w + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+        sy[rt] = *reinterpret_cast<const float4*>(a.x + rowc * D + 16 * w + 4 * g);
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -245,7 +249,11 @@ __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, Ffn
       const int idx = tid + u * kRowThreads, rr = idx >> 4, c4 = idx & 15;
       const int64_t off = (int64_t)min(r0 + rr, row_last) * D + 4 * c4;
       dv[u] = *reinterpret_cast<const float4*>(a.dy + off);
-      yv[u] = gbn ? *reinterpret_cast<const float4*>(a.g_y + off) : dv[u];
+      if (a.dy_b != nullptr) {
+        const float4 d2 = *reinterpret_cast<const float4*>(a.dy_b + off);
+        dv[u] = make_float4(dv[u].x + d2.x, dv[u].y + d2.y, dv[u].z + d2.z, dv[u].w + d2.w);
+      }
+      yv[u] = *reinterpret_cast<const float4*>((gbn ? a.g_y : a.dy) + off);
       xv[u] = *reinterpret_cast<const float4*>(a.x + off);
     }
 #pragma unroll
@@ -373,7 +381,7 @@ extern "C" int feta_ffn_bwd(const feta_ffn_grad* d, feta_stream_t stream) {
   FETA_REQUIRE(!a.g_y || (a.g_bn && (a.g_sum || a.g_fin)), "ffn_bwd: g_y needs g_bn and g_sum | g_fin");
   FETA_REQUIRE(!a.g_sum || a.Gs > 0, "ffn_bwd: g_sum needs Gs");
   FETA_REQUIRE(!a.sum_out || a.x_bn, "ffn_bwd: sum_out needs x_bn (the BatchNorm that produced x)");
-  FETA_REQUIRE(aligned16(a.dy) && aligned16(a.h) && aligned16(a.x) && aligned16(a.dx) && aligned16(a.g_y) &&
+  FETA_REQUIRE(aligned16(a.dy_b) && aligned16(a.dy) && aligned16(a.h) && aligned16(a.x) && aligned16(a.dx) && aligned16(a.g_y) &&
                aligned16(a.x_bn) && aligned16(a.g_sum), "ffn_bwd: pointers must be 16-byte aligned");
   if (a.FF == 64) return launch_ffn_bwd<64>(a, (hipStream_t)stream);
   return launch_ffn_bwd<128>(a, (hipStream_t)stream);

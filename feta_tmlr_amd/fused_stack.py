@@ -42,6 +42,9 @@ USE_FFN_BWD = os.environ.get('FETA_FFN_BWD', '1') != '0'
 # backward of the attention sub-block (out_proj + attention + in_proj) in one launch per layer (csrc/block_bwd.hip,
 # one workgroup per graph, up to 256 graphs); 0: three launches
 USE_ATTN_BLOCK_BWD = os.environ.get('FETA_ATTN_BLOCK_BWD', '1') != '0'
+# two workgroups per graph (one per pair of heads) where the consumer of dx is the fused FFN backward, which adds the
+# two parts on load (feta_attn_block_grad.dx_b); 0: one workgroup per graph everywhere (A/B timing)
+USE_ATTN_BLOCK_SPLIT = os.environ.get('FETA_ATTN_BLOCK_SPLIT', '1') != '0'
 
 def layer_params(layer):
     a = layer.self_attn
@@ -272,7 +275,7 @@ class FusedEncoderStackFn(torch.autograd.Function):
         slots = {}
         if d_final is None:   # only the per-head output of the last layer was used
             d_final = torch.zeros(n, b, d, dtype=torch.float32, device=dev)
-        dcur = d_final.contiguous().view(m, d)
+        dcur, dcur_b = d_final.contiguous().view(m, d), None
         if ctx.tail is not None:
             # (StackTail contract) d_final is the gradient w.r.t. BN2(y2); its partial sums came with it
             gs, Gs_cur = ctx.tail.gs, G
@@ -298,11 +301,12 @@ class FusedEncoderStackFn(torch.autograd.Function):
                 # B1 + B2 in one launch (csrc/ffn_bwd.hip): the hidden gradient never leaves the chip
                 G1s = abi.ffn_bwd_blocks(m)
                 gs1 = new(G1s, 2, d)
-                abi.ffn_bwd(m, ff, stream, Gs=Gs_cur, partial_ptr=pp, partial_ld=tf, dy=dcur, g_y=s['y2'],
+                abi.ffn_bwd(m, ff, stream, Gs=Gs_cur, partial_ptr=pp, partial_ld=tf, dy=dcur, dy_b=dcur_b, g_y=s['y2'],
                             g_bn=s['prm2'], g_sum=gs, g_fin_out=fin2, dgamma=dg2, dbeta=db2, h=s['h'], w2=w2, w1=w1,
                             x=s['y1'], x_bn=s['prm1'], dx=dx1, sum_out=gs1)
                 gs1, G1s = _cap_partials(abi, stream, gs1, new)
             else:
+                assert dcur_b is None
                 # B1: linear2 backward, gradient = BN2 backward of dcur
                 dh_ = new(m, ff)
                 dsc = abi.rowlin_ex(m, ff, d, x=s['h'], w=w2, dy=dcur, dx=dh_, partial_ptr=pp, partial_ld=tf,
@@ -326,9 +330,14 @@ class FusedEncoderStackFn(torch.autograd.Function):
             if fused_attn:
                 # B3 + B4 + B5 in one launch, one workgroup per graph (csrc/block_bwd.hip): dconcat and dqkv stay on chip
                 dx0 = new(m, d)
+                # the layer below takes the gradient in two parts iff its FFN backward is the fused kernel
+                split = (USE_ATTN_BLOCK_SPLIT and li > 0 and USE_FFN_BWD
+                         and abi.ffn_bwd_supported(d, params[(li - 1) * PER_LAYER + 6].shape[0]))
+                dx0b = new(m, d) if split else None
                 GB = abi.attn_block_bwd_blocks(b)
                 gs_prev = new(2 * GB, 2, d) if li > 0 else None
                 abi.attn_block_bwd(b, n, scale, stream, Gs=G1s, partial_ptr=ppo, partial_ld=ta, dy=dx1, y1=s['y1'],
+                                   dx_b=dx0b,
                                    bn1=s['prm1'], g_sum=gs1, fin_out=fin1, dgamma=dg1, dbeta=db1, rowscale=degree_rows,
                                    w_out=w_o, w_in=w_in, qkv=s['qkv'], out=s['out'],
                                    dout2=None if d2 is None else d2.contiguous().view(m, d), pe=pe_c, n_real=n_real,
@@ -337,7 +346,7 @@ class FusedEncoderStackFn(torch.autograd.Function):
                 Gs_next = 2 * GB
                 if gs_prev is not None:
                     gs_prev, Gs_next = _cap_partials(abi, stream, gs_prev, new)
-                dcur, gs, Gs_cur = dx0, gs_prev, Gs_next
+                dcur, dcur_b, gs, Gs_cur = dx0, dx0b, gs_prev, Gs_next
                 continue
             # B3: out_proj backward, gradient = degree * BN1 backward of dx1
             dconcat = new(m, d)
@@ -373,7 +382,8 @@ class FusedEncoderStackFn(torch.autograd.Function):
                                 sum_bn=s['prm0'], sum_out=gs_prev)
             abi.rowlin_bwd_ex(dsc, None, stream)
             Gs_next = G
-            dcur, gs, Gs_cur = dx0, gs_prev, Gs_next
+            dcur, dcur_b, gs, Gs_cur = dx0, None, gs_prev, Gs_next
+        assert dcur_b is None
         assert wslot.cur == {'f': tf, 'a': ta}
         abi.colsum_multi([(part_f, dwdb_all[:tf]), (part_a, dwdb_all[tf:total])], stream)
         if ctx.owner is not None:

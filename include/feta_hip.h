@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FETA_ABI_VERSION 5
+#define FETA_ABI_VERSION 6
 
 #define FETA_OK 0
 #define FETA_E_ARG (-1)     /* bad shape / stride / alignment / unsupported size */
@@ -409,6 +409,9 @@ typedef struct feta_attn_block_grad {
   const float* x0;
   const float* bn0;
   float* dx;
+  float* dx_b;       /* nullable: SPLIT form, two workgroups per graph (one per pair of heads): dx receives pair 0's part
+                        (with the residual g1), dx_b pair 1's; the consumer adds them (feta_ffn_grad.dy_b); sum_out
+                        rows then are partial sums of the two parts - same row count */
   float* sum_out;
   float* partial;
   int partial_ld;
@@ -467,6 +470,7 @@ int feta_ffn_fwd(const feta_ffn* d, feta_stream_t stream);
  * x is seen through x_bn (scale, shift rows) when given, else used as it is. */
 typedef struct feta_ffn_grad {
   const float* dy;
+  const float* dy_b;   /* nullable: second part of the gradient, added to dy on load (feta_attn_block_grad.dx_b) */
   const float* g_y;
   const float* g_bn;
   const float* g_sum;

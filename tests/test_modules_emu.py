@@ -264,8 +264,9 @@ def test_two_phase_backward_equals_single_backward(emu):
         {id(p) for p in enc.parameters()}
 
 
-def _stack_run(model, batch9, cache, use_block, monkeypatch, hook):
+def _stack_run(model, batch9, cache, use_block, monkeypatch, hook, split=True):
     from feta_tmlr_amd import fused_stack
+    monkeypatch.setattr(fused_stack, 'USE_ATTN_BLOCK_SPLIT', split)  # two workgroups per graph where it applies
     monkeypatch.setattr(fused_stack, 'USE_ATTN_BLOCK', use_block)   # csrc/block.hip vs three launches
     monkeypatch.setattr(fused_stack, 'USE_FFN_FUSED', use_block)    # csrc/ffn.hip vs two launches
     monkeypatch.setattr(fused_stack, 'USE_FFN_BWD', use_block)      # csrc/ffn_bwd.hip vs two launches
@@ -273,7 +274,7 @@ def _stack_run(model, batch9, cache, use_block, monkeypatch, hook):
     x, mask, pe, _, degree, _, edge_index, batch, fi = batch9
     x = x.clone().requires_grad_(True)
     model.zero_grad()
-    with hook():
+    with hook(), KC.poisoned_scratch():
         out, _, coeff = model(x, edge_index, batch, fi, mask, pe, degree=degree, return_filter_coeff=True,
                               graph_cache=cache)
         w = torch.linspace(0.5, 1.5, out.numel(), device=out.device).view_as(out)
@@ -282,7 +283,8 @@ def _stack_run(model, batch9, cache, use_block, monkeypatch, hook):
     return out.detach(), coeff.detach(), x.grad.detach(), grads
 
 
-def check_attn_block_equals_three_launches(dev, hook, monkeypatch, shape, n_min, n_max, tie_qk, pe_on, bsz=3):
+def check_attn_block_equals_three_launches(dev, hook, monkeypatch, shape, n_min, n_max, tie_qk, pe_on, bsz=3,
+                                           split=True):
     """in_proj + attention + out_proj as one launch (csrc/block.hip) == the three-launch sequence"""
     torch.manual_seed(5)
     model = DiffGraphTransformerGenGCN(9, 1, 64, 4, dim_feedforward=128, dropout=0.0, nb_layers=2,
@@ -297,7 +299,7 @@ def check_attn_block_equals_three_launches(dev, hook, monkeypatch, shape, n_min,
     n_pad = max(g.num_nodes for g in ds.samples)
     batch9, cache = D.collate(ds.samples, k_eig=n_pad, device=dev)
     model = model.to(dev)
-    a = _stack_run(model, batch9, cache, True, monkeypatch, hook)
+    a = _stack_run(model, batch9, cache, True, monkeypatch, hook, split)
     b = _stack_run(model, batch9, cache, False, monkeypatch, hook)
     KC.assert_close('output', a[0], b[0].double(), tol=2e-6)
     KC.assert_close('coefficients', a[1], b[1].double(), tol=2e-6)
@@ -307,14 +309,16 @@ def check_attn_block_equals_three_launches(dev, hook, monkeypatch, shape, n_min,
         KC.assert_close('grad ' + k, a[3][k], b[3][k].double(), tol=1e-5)
 
 
-@pytest.mark.parametrize('shape,n_min,n_max,tie_qk,pe_on', [
-    ('zinc', 20, 37, False, True),       # 3 row tiles
-    ('mutag', 3, 14, True, True),        # 1 row tile, K tied to Q
-    ('pattern', 44, 64, False, False),   # 4 row tiles, no positional kernel
+@pytest.mark.parametrize('shape,n_min,n_max,tie_qk,pe_on,split', [
+    ('zinc', 20, 37, False, True, True),        # 3 row tiles
+    ('zinc', 20, 37, False, True, False),       # ... one workgroup per graph in every layer
+    ('mutag', 3, 14, True, True, True),         # 1 row tile, K tied to Q
+    ('mutag', 17, 30, False, False, True),      # 2 row tiles
+    ('pattern', 44, 64, False, False, True),    # 4 row tiles, no positional kernel
 ])
-def test_attn_block_equals_three_launches(emu, monkeypatch, shape, n_min, n_max, tie_qk, pe_on):
+def test_attn_block_equals_three_launches(emu, monkeypatch, shape, n_min, n_max, tie_qk, pe_on, split):
     check_attn_block_equals_three_launches(CPU, lambda: _lib.override_for_tests(emu), monkeypatch, shape,
-                                           n_min, n_max, tie_qk, pe_on)
+                                           n_min, n_max, tie_qk, pe_on, split=split)
 
 
 def test_capped_statistics_partials_give_the_same_result(emu, monkeypatch):

@@ -56,17 +56,18 @@ def test_model_matches_oracle(shape, bsz, d, heads, layers, order, batch_norm, s
         KC.assert_close('grad ' + name, p.grad, p64[name].grad, tol=3e-5)
 
 
-@pytest.mark.parametrize('shape,n_min,n_max,tie_qk,pe_on,bsz', [
-    ('zinc', 9, 37, False, True, 128),
-    ('mutag', 3, 14, True, True, 5),
-    ('pattern', 44, 64, False, False, 9),
-    ('zinc', 17, 32, False, False, 33),
+@pytest.mark.parametrize('shape,n_min,n_max,tie_qk,pe_on,bsz,split', [
+    ('zinc', 9, 37, False, True, 128, True),
+    ('zinc', 9, 37, False, True, 128, False),
+    ('mutag', 3, 14, True, True, 5, True),
+    ('pattern', 44, 64, False, False, 9, True),
+    ('zinc', 17, 32, False, False, 33, True),
 ])
-def test_attn_block_equals_three_launches(monkeypatch, shape, n_min, n_max, tie_qk, pe_on, bsz):
+def test_attn_block_equals_three_launches(monkeypatch, shape, n_min, n_max, tie_qk, pe_on, bsz, split):
     import contextlib
     from test_modules_emu import check_attn_block_equals_three_launches
     check_attn_block_equals_three_launches(torch.device('cuda:0'), contextlib.nullcontext, monkeypatch, shape,
-                                           n_min, n_max, tie_qk, pe_on, bsz=bsz)
+                                           n_min, n_max, tie_qk, pe_on, bsz=bsz, split=split)
 
 
 @pytest.mark.parametrize('n_min,n_max,bsz', [(2, 3, 1), (1, 2, 2), (16, 16, 2), (17, 17, 1), (48, 48, 1), (9, 37, 300)])

@@ -32,7 +32,9 @@ ROWS = [  # (bench row, kernel-symbol substrings enqueued by one call, in order)
     ('attn_block_fwd (+attn write)', ['attn_block_fwd']),
     ('ffn_fwd', ['ffn_fwd']),
     ('ffn_bwd', ['ffn_bwd']),
+    ('ffn_bwd (gradient in two parts)', ['ffn_bwd']),
     ('attn_block_bwd', ['attn_block_bwd']),
+    ('attn_block_bwd (two workgroups per graph)', ['attn_block_bwd']),
     ('rowlin_bwd linear_cat', ['rowlin_bwd']),
 ]
 
@@ -69,6 +71,9 @@ def main():
                 ROWS[i] = (row, ['attn_bwd_graph'])
     if not any('attn_block_bwd' in name for name, _ in f):   # batches beyond the fused attention-block backward
         i = [r for r, _ in ROWS].index('attn_block_bwd')
+        del ROWS[i + 1]      # the two-workgroup form and the FFN backward that takes its two parts: not issued there
+        del ROWS[i - 1]
+        i -= 1
         ROWS[i:i + 1] = [('rowlin_bwd out_proj (stack: BN-backward gradient)', ['rowlin_bwd']),
                          ('rowlin_bwd in_proj (stack: add, sums)', ['rowlin_bwd'])]
     calls = int(sys.argv[3]) + 3
