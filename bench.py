@@ -396,6 +396,16 @@ def roofline(args, gpu, dev):
         cand.append(('spec_filter_bwd', 'spec_bwd', 1,
                      lambda: abi.spec_filter_bwd(xs, u, lam, coeff, nr, dys, dxs, dcoeff, dbp, p, 1, st),
                      spec_bytes(b, n, h, dh, k_eig, p, sum_n, True)))
+    r_ = h * b
+    if abi.lin_supported(r_, c, c):   # the C x C linear of the coefficient generator (csrc/lin.hip)
+        lw, lb, lx, ldy = rnd(c, c) / c ** 0.5, rnd(c), rnd(r_, c), rnd(r_, c)
+        ly, ldx, ldw, ldb = (torch.empty(r_, c, device=dev), torch.empty(r_, c, device=dev),
+                             torch.empty(c, c, device=dev), torch.empty(c, device=dev))
+        cat_part = rnd(abi.rowlin_chunks(b * n), d * 2 * d + d)
+        pairs = [(rnd(r_, dh), torch.empty(dh, device=dev)), (cat_part, torch.empty(cat_part.shape[1], device=dev))]
+        cand.append(('lin_fwd', 'lin_fwd', 1, lambda: abi.lin_fwd(lx, lw, lb, ly, st), 4 * (2 * r_ * c + c * c)))
+        cand.append(('lin_bwd', 'lin_bwd', 1, lambda: abi.lin_bwd(lx, lw, ldy, ldx, ldw, ldb, st, pairs=pairs),
+                     4 * (3 * r_ * c + 2 * c * c + cat_part.numel())))
     traffic = _load_json('r02_traffic_b128.json', 'traffic.json')
     mfma = _load_json('r02_pmc_mfma_b128.json', 'r01_pmc_mfma_b128.json')
     groups = {}

@@ -80,6 +80,10 @@ class ColsumSeg(C.Structure):
 
 
 SIGNATURES['feta_colsum_multi'] = ([C.POINTER(ColsumSeg), C.c_int, _S], C.c_int)
+SIGNATURES['feta_lin_supported'] = ([C.c_int, C.c_int, C.c_int], C.c_int)
+SIGNATURES['feta_lin_fwd'] = ([_F, _F, _F, _F, C.c_int, C.c_int, C.c_int, _S], C.c_int)
+SIGNATURES['feta_lin_bwd'] = ([_F, _F, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.POINTER(ColsumSeg), C.c_int, _S],
+                              C.c_int)
 
 
 class RowLinEx(C.Structure):
@@ -304,6 +308,23 @@ class Abi:
         for sg, (x, out) in zip(segs, pairs):
             sg.in_, sg.out, sg.R, sg.C, sg.ld = x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], x.stride(0)
         self._check(self.lib.feta_colsum_multi(segs, len(pairs), stream), 'feta_colsum_multi')
+
+    def lin_supported(self, r, k, n):
+        return bool(self.lib.feta_lin_supported(r, k, n))
+
+    def lin_fwd(self, x, w, bias, y, stream):
+        r, k = x.shape
+        self._check(self.lib.feta_lin_fwd(_p(x), _p(w), _p(bias), _p(y), r, k, w.shape[0], stream), 'feta_lin_fwd')
+
+    def lin_bwd(self, x, w, dy, dx, dw, db, stream, pairs=()):
+        """dx = dy w, dw = dy^T x, db = colsum(dy) in one launch; pairs: [(in [R, C], out [C])] pending column sums
+        that ride along in trailing workgroups."""
+        r, k = x.shape
+        segs = (ColsumSeg * max(len(pairs), 1))()
+        for sg, (xin, out) in zip(segs, pairs):
+            sg.in_, sg.out, sg.R, sg.C, sg.ld = xin.data_ptr(), out.data_ptr(), xin.shape[0], xin.shape[1], xin.stride(0)
+        self._check(self.lib.feta_lin_bwd(_p(x), _p(w), _p(dy), _p(dx), _p(dw), _p(db), r, k, w.shape[0], segs,
+                                          len(pairs), stream), 'feta_lin_bwd')
 
     def colsum(self, x, out, stream):
         r, c = x.shape

@@ -193,6 +193,25 @@ class _FilterFn(torch.autograd.Function):
         return dx, dcoeff, dbias, None, None, None, None, None, None, None
 
 
+class PendingSums:
+    """Column sums (split-K partial buffer -> gradient) that one backward node of the filter stage leaves for a LATER
+    node of the same backward pass which has a launch to carry them in trailing workgroups (feta_lin_bwd): every
+    launch of a captured step costs ~4.5 us whatever its size.  The encoder creates one per forward; the node that
+    will flush (FilterFromPooledFn) arms it in forward iff autograd is going to run its backward, and only then do
+    producers (linear_cat's backward, which always runs before it: the filter output is linear_cat's operand) defer."""
+
+    def __init__(self):
+        self.armed = False
+        self.items = []
+
+    def add(self, partial, out):
+        self.items.append((partial, out))
+
+    def take(self):
+        items, self.items = self.items, []
+        return items
+
+
 class FilterFromPooledFn(torch.autograd.Function):
     """``self.linear`` of the coefficient generator (transformer/models.py:284) and the dynamic filter
     (transformer/models.py:346-360, transformer/ChebNetDynamic.py:132-189) as ONE autograd node:
@@ -202,11 +221,21 @@ class FilterFromPooledFn(torch.autograd.Function):
     available together) instead of two, and no dcoeff hand-over through autograd."""
 
     @staticmethod
-    def forward(ctx, x, pooled, lin_w, lin_b, bias, n_real, g0, g1, mode, order, share, batch_first):
+    def forward(ctx, x, pooled, lin_w, lin_b, bias, n_real, g0, g1, mode, order, share, batch_first, pending):
         abi, stream = _lib.backend(x, pooled)
         b, n, h, dh = x.shape
         xs = _dense_like(x, batch_first)
-        coeff = torch.addmm(lin_b, pooled, lin_w.t())      # fp32 master precision (also what a regulariser sees)
+        # fp32 master precision (also what a regulariser sees)
+        pooled, lin_w = pooled.contiguous(), lin_w.contiguous()
+        ctx.own_gemm = abi.lin_supported(pooled.shape[0], pooled.shape[1], lin_w.shape[0])
+        if ctx.own_gemm:      # csrc/lin.hip: one 16 x 16 tile per wave, 1024 waves at the BASELINE batch
+            coeff = torch.empty((pooled.shape[0], lin_w.shape[0]), dtype=torch.float32, device=pooled.device)
+            abi.lin_fwd(pooled, lin_w, lin_b, coeff, stream)
+        else:
+            coeff = torch.addmm(lin_b, pooled, lin_w.t())
+        ctx.pending = pending
+        if pending is not None and any(ctx.needs_input_grad):
+            pending.armed = True
         # bf16 storage path: the per-block weights the filter kernel reads are bf16 copies of them
         cw = coeff if x.dtype == torch.float32 else coeff.to(x.dtype)
         y = _new_token(b, n, h, dh, batch_first, x)
@@ -225,11 +254,12 @@ class FilterFromPooledFn(torch.autograd.Function):
         mode, order, share, batch_first, has_bias = ctx.cfg
         abi, stream = _lib.backend(xs)
         b, n, h, dh = xs.shape
+        waiting = ctx.pending.take() if ctx.pending is not None else []
+        sums = []           # (in, out) column sums still to run
         if dy is None:      # only the coefficients were used downstream
             dx, dbias = None, None
             dcoeff = dcoeff_ext.contiguous()
             db_lin = torch.empty(dcoeff.shape[1], dtype=torch.float32, device=xs.device)
-            abi.colsum(dcoeff, db_lin, stream)
         else:
             dys = _dense_like(dy.to(xs.dtype), batch_first)
             dx = _new_token(b, n, h, dh, batch_first, xs)
@@ -245,14 +275,23 @@ class FilterFromPooledFn(torch.autograd.Function):
                 dcoeff += dcoeff_ext
             both = torch.empty(dh + dcoeff.shape[1], dtype=torch.float32, device=xs.device)
             dbias, db_lin = both[:dh], both[dh:]
-            abi.colsum_multi([(dbp, dbias), (dcoeff, db_lin)], stream)
-            if not has_bias:
-                dbias = None
-        return (dx, dcoeff.mm(lin_w), dcoeff.t().mm(pooled), db_lin, dbias) + (None,) * 7
+            sums.append((dbp, dbias))
+        sums += waiting
+        if ctx.own_gemm:
+            # dpooled, dW_lin, db_lin and every pending column sum in ONE launch (csrc/lin.hip)
+            dpooled = torch.empty_like(pooled) if ctx.needs_input_grad[1] else None
+            dw_lin = torch.empty_like(lin_w)
+            abi.lin_bwd(pooled, lin_w, dcoeff, dpooled, dw_lin, db_lin, stream, pairs=sums)
+        else:
+            abi.colsum_multi(sums + [(dcoeff, db_lin)], stream)
+            dpooled, dw_lin = dcoeff.mm(lin_w), dcoeff.t().mm(pooled)
+        if not has_bias:
+            dbias = None
+        return (dx, dpooled, dw_lin, db_lin, dbias) + (None,) * 8
 
 
 def filter_from_pooled(x, pooled, lin_w, lin_b, bias, n_real, graph, mode, order, heads_share_graph=False,
-                       batch_first=False):
+                       batch_first=False, pending=None):
     """x [B,N,H,dh] view, pooled [H*B, C] -> (y, coeff [H*B, C]); graph = (lhat,) | (u, lam)."""
     g0 = graph[0].contiguous()
     g1 = graph[1].contiguous() if len(graph) > 1 else None
@@ -261,7 +300,7 @@ def filter_from_pooled(x, pooled, lin_w, lin_b, bias, n_real, graph, mode, order
             raise NotImplementedError("the bf16 storage path runs the eigenbasis filter (filter_mode='spectral')")
         g0 = g0.to(x.dtype)      # U travels as bf16; lambda and t_k(lambda) stay fp32
     return FilterFromPooledFn.apply(x, pooled, lin_w, lin_b, bias, n_real, g0, g1, mode, order,
-                                    bool(heads_share_graph), batch_first)
+                                    bool(heads_share_graph), batch_first, pending)
 
 
 class RowLinearFn(torch.autograd.Function):
@@ -312,8 +351,9 @@ class RowLinearCatFn(torch.autograd.Function):
     transformer/models.py:223-224); backward writes dx1 and dx2 directly."""
 
     @staticmethod
-    def forward(ctx, x1, x2, w, bias):
+    def forward(ctx, x1, x2, w, bias, pending=None):
         abi, stream = _lib.backend(x1, x2, w)
+        ctx.defer = pending if (pending is not None and pending.armed and x2.requires_grad) else None
         x1, x2, w = x1.contiguous(), x2.contiguous(), w.contiguous()
         m, k1 = x1.shape
         ki, no = k1 + x2.shape[1], w.shape[0]
@@ -334,9 +374,14 @@ class RowLinearCatFn(torch.autograd.Function):
         dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
         partial = torch.empty((abi.rowlin_chunks(m), no * ki + no), dtype=torch.float32, device=x1.device)
         dwdb = torch.empty(no * ki + no, dtype=torch.float32, device=x1.device)
-        d = abi.rowlin_ex(m, ki, no, x=x1, x2=x2, x_split=k1, w=w, dy=dy, dx=dx1, dx2=dx2, partial=partial)
-        abi.rowlin_bwd_ex(d, dwdb, stream)
-        return dx1, dx2, dwdb[:no * ki].view(no, ki), (dwdb[no * ki:] if ctx.has_bias else None)
+        d = abi.rowlin_ex(m, ki, no, x=x1, x2=x2, x_split=k1, w=w, dy=dy, dx=dx1, dx2=dx2, partial=partial,
+                          partial_ld=(no * ki + no if ctx.defer is not None else 0))
+        if ctx.defer is not None:     # the filter's backward reduces the partials inside its own launch
+            abi.rowlin_bwd_ex(d, None, stream)
+            ctx.defer.add(partial, dwdb)
+        else:
+            abi.rowlin_bwd_ex(d, dwdb, stream)
+        return dx1, dx2, dwdb[:no * ki].view(no, ki), (dwdb[no * ki:] if ctx.has_bias else None), None
 
 
 class RowLinearCatBNFn(torch.autograd.Function):
@@ -346,8 +391,9 @@ class RowLinearCatBNFn(torch.autograd.Function):
     backward partial sums in tail.gs (fused_stack.StackTail contract)."""
 
     @staticmethod
-    def forward(ctx, y2, x2, w, bias, tail):
+    def forward(ctx, y2, x2, w, bias, tail, pending=None):
         abi, stream = _lib.backend(y2, x2, w)
+        ctx.defer = pending if (pending is not None and pending.armed and x2.requires_grad) else None
         y2, x2, w = y2.contiguous(), x2.contiguous(), w.contiguous()
         m, k1 = y2.shape
         ki, no = k1 + x2.shape[1], w.shape[0]
@@ -375,14 +421,18 @@ class RowLinearCatBNFn(torch.autograd.Function):
         dwdb = torch.empty(no * ki + no, dtype=torch.float32, device=y2.device)
         gs = torch.empty((abi.rowlin_blocks(m), 2, k1), dtype=torch.float32, device=y2.device)
         d = abi.rowlin_ex(m, ki, no, x=y2, x_bn=prm2, x2=x2, x_split=k1, w=w, dy=dy, dx=dx1, dx2=dx2, partial=partial,
-                          sum_y=y2, sum_bn=prm2, sum_out=gs)
-        abi.rowlin_bwd_ex(d, dwdb, stream)
+                          partial_ld=(no * ki + no if ctx.defer is not None else 0), sum_y=y2, sum_bn=prm2, sum_out=gs)
+        if ctx.defer is not None:     # the filter's backward reduces the partials inside its own launch
+            abi.rowlin_bwd_ex(d, None, stream)
+            ctx.defer.add(partial, dwdb)
+        else:
+            abi.rowlin_bwd_ex(d, dwdb, stream)
         ctx.tail.gs = gs
-        return dx1, dx2, dwdb[:no * ki].view(no, ki), (dwdb[no * ki:] if ctx.has_bias else None), None
+        return dx1, dx2, dwdb[:no * ki].view(no, ki), (dwdb[no * ki:] if ctx.has_bias else None), None, None
 
 
-def row_linear_cat_bn(y2, x2, w, bias, tail):
-    return RowLinearCatBNFn.apply(y2, x2, w, bias, tail)
+def row_linear_cat_bn(y2, x2, w, bias, tail, pending=None):
+    return RowLinearCatBNFn.apply(y2, x2, w, bias, tail, pending)
 
 
 class BatchNormTrainFn(torch.autograd.Function):
@@ -430,9 +480,9 @@ def row_linear(x, w, bias=None, rowscale=None, residual=None, relu=False, want_s
     return RowLinearFn.apply(x, w, bias, rowscale, residual, relu, want_stats)
 
 
-def row_linear_cat(x1, x2, w, bias=None):
+def row_linear_cat(x1, x2, w, bias=None, pending=None):
     """[x1 | x2] W^T + b on [M, .] rows; needs x1.shape[1] % 16 == 0 and supported total dims."""
-    return RowLinearCatFn.apply(x1, x2, w, bias)
+    return RowLinearCatFn.apply(x1, x2, w, bias, pending)
 
 
 def batch_norm_train(y, stats, gamma, beta, running_mean, running_var, momentum, eps, num_batches_tracked=None):

@@ -117,7 +117,7 @@ class DiffTransformerEncoderGenGCN(nn.Module):
         coeff = FF.dense_linear(pooled, self.linear.weight, self.linear.bias)    # :284
         return coeff.reshape(self.num_heads, attn_weights.shape[0], -1)          # :285
 
-    def _coefficients_and_filter(self, attn_weights, out_each_head, cache):
+    def _coefficients_and_filter(self, attn_weights, out_each_head, cache, pending=None):
         """get_filter_coefficients + filter of one layer (:173, :186-202) with ``self.linear`` folded into the
         filter's autograd node (functional.FilterFromPooledFn).  -> (coeff [H,B,C], out_filtered [N,B,d])"""
         bsz, n, h, dh = out_each_head.shape
@@ -131,7 +131,7 @@ class DiffTransformerEncoderGenGCN(nn.Module):
             graph, mode = (cache.u, cache.lam), 'spec'
         y, coeff = FF.filter_from_pooled(out_each_head, pooled, self.linear.weight, self.linear.bias,
                                          self.spectral_gnns.bias, cache.n_real, graph, mode, self.order,
-                                         self.heads_share_graph)
+                                         self.heads_share_graph, pending=pending)
         return coeff.reshape(h, bsz, -1), y.permute(1, 0, 2, 3).reshape(n, bsz, h * dh)
 
     # -- A3 ---------------------------------------------------------------------------------
@@ -235,6 +235,8 @@ class DiffTransformerEncoderGenGCN(nn.Module):
         if (fused and self.layers[0].batch_norm and self.use_skip_conn and self.norm is None
                 and src.shape[-1] % 16 == 0 and FF.row_linear_supported(2 * src.shape[-1], self.linear_cat.weight.shape[0])):
             tail = StackTail()
+        # linear_cat's weight-gradient partials are reduced inside the launch of the filter's backward (PendingSums)
+        pending = FF.PendingSums() if not lowp else None
         for layer_num, mod in enumerate(self.layers):
             last = layer_num + 1 == self.num_layers
             filt = last or not self.last_layer_filter                            # :169-171
@@ -261,7 +263,7 @@ class DiffTransformerEncoderGenGCN(nn.Module):
                                                                n_real=cache.n_real)   # :173
                 out_filtered = self.filter(coeff_all_heads, out_each_head, cache)     # :186-202
             else:
-                coeff_all_heads, out_filtered = self._coefficients_and_filter(attn, out_each_head, cache)
+                coeff_all_heads, out_filtered = self._coefficients_and_filter(attn, out_each_head, cache, pending)
             coefficients.append(coeff_all_heads)                                  # :198
             if self.use_skip_conn and allout_filtered is not None:
                 allout_filtered = allout_filtered + out_filtered                  # :209-213
@@ -278,11 +280,11 @@ class DiffTransformerEncoderGenGCN(nn.Module):
                                   self.linear_cat.bias.to(dt)).float()
             elif tail is not None:
                 output = FF.row_linear_cat_bn(output.reshape(nn_ * bb_, dd_), allout_filtered.reshape(nn_ * bb_, dd_),
-                                              wc, self.linear_cat.bias, tail).view(nn_, bb_, -1)
+                                              wc, self.linear_cat.bias, tail, pending).view(nn_, bb_, -1)
             elif (dd_ % 16 == 0 and FF.row_linear_supported(2 * dd_, wc.shape[0])):
                 # [output | allout_filtered] W^T + b without materialising the concatenation (:223-224)
                 output = FF.row_linear_cat(output.reshape(nn_ * bb_, dd_), allout_filtered.reshape(nn_ * bb_, dd_),
-                                           wc, self.linear_cat.bias).view(nn_, bb_, -1)
+                                           wc, self.linear_cat.bias, pending).view(nn_, bb_, -1)
             else:
                 cat = torch.cat((output, allout_filtered), dim=-1)               # :223
                 output, _ = linear_rows(cat.reshape(nn_ * bb_, 2 * dd_), wc, self.linear_cat.bias)   # :224

@@ -122,6 +122,19 @@ typedef struct feta_colsum_seg {
 } feta_colsum_seg;
 int feta_colsum_multi(const feta_colsum_seg* segs, int nseg, feta_stream_t stream);
 
+/* ---- the C x C linear of the coefficient generator (ABI 6) ----
+ * Replaces self.linear of DiffTransformerEncoderGenGCN (transformer/models.py:284; nn.Linear(C, C) applied to the
+ * pooled [H*B, C] rows) and its autograd backward: y = x w^T + bias as one launch, and dx = dy w, dw = dy^T x,
+ * db = colsum(dy) as ONE launch (workgroups take roles) that can also carry up to FETA_COLSUM_MAX_SEGS pending column
+ * sums of the caller in trailing workgroups.  x [R,K], w [N,K], y / dy [R,N]; exact-fp32 MFMA, deterministic.
+ * feta_lin_supported: R, K, N multiples of 4 and K, N >= 16 (else the caller uses a library GEMM).
+ * dx and db may be NULL. */
+int feta_lin_supported(int R, int K, int N);
+int feta_lin_fwd(const float* x, const float* w, const float* bias, float* y, int R, int K, int N,
+                 feta_stream_t stream);
+int feta_lin_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int R, int K,
+                 int N, const feta_colsum_seg* segs, int nseg, feta_stream_t stream);
+
 /* ---- A3: dynamic Chebyshev filter, direct recursion on a dense scaled Laplacian ----
  * Replaces ChebConvDynamic.forward + __norm__ (transformer/ChebNetDynamic.py:108-189)
  * and its head-stacking / gather / scatter glue (transformer/models.py:178-186,

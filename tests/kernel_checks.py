@@ -426,6 +426,31 @@ def check_colsum(abi, dev, stream, r, c, seed=0):
     assert_close('colsum %dx%d' % (r, c), out, x.double().sum(0))
 
 
+def check_lin(abi, dev, stream, r, k, n, seed=0, with_dx=True, segs=((40, 16), (9, 2048 + 64), (70, 100))):
+    """feta_lin_fwd / feta_lin_bwd (csrc/lin.hip) against float64: y = x w^T + b; dx, dw, db in one launch together
+    with pending column sums (tall, few-rows-many-columns and odd-width segments)."""
+    g = torch.Generator().manual_seed(seed)
+    x, w, b, dy = torch.randn(r, k, generator=g), torch.randn(n, k, generator=g) / k ** 0.5, torch.randn(n, generator=g), \
+        torch.randn(r, n, generator=g)
+    assert abi.lin_supported(r, k, n)
+    nan = lambda *s: torch.full(s, float('nan'), device=dev)
+    xd, wd, bd, dyd = x.to(dev), w.to(dev), b.to(dev), dy.to(dev)
+    y = nan(r, n)
+    abi.lin_fwd(xd, wd, bd, y, stream)
+    errs = {'y': assert_close('lin y', y, x.double() @ w.double().t() + b.double(), tol=2e-6)}
+    dx, dw, db = (nan(r, k) if with_dx else None), nan(n, k), nan(n)
+    ins = [torch.randn(sr, sc, generator=g) for sr, sc in segs]
+    outs = [nan(sc) for _, sc in segs]
+    abi.lin_bwd(xd, wd, dyd, dx, dw, db, stream, pairs=[(i.to(dev), o) for i, o in zip(ins, outs)])
+    if with_dx:
+        errs['dx'] = assert_close('lin dx', dx, dy.double() @ w.double(), tol=2e-6)
+    errs['dw'] = assert_close('lin dw', dw, dy.double().t() @ x.double(), tol=2e-6)
+    errs['db'] = assert_close('lin db', db, dy.double().sum(0), tol=2e-6)
+    for i, o in zip(ins, outs):
+        assert_close('lin segment %dx%d' % tuple(i.shape), o, i.double().sum(0), tol=2e-6)
+    return errs
+
+
 # ---- spectrum producer (SURVEY 8f N2 / N4) ------------------------------------------------------
 
 

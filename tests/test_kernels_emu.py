@@ -129,6 +129,12 @@ def test_colsum_shapes(emu, r, c):
     KC.check_colsum(emu, CPU, None, r, c)
 
 
+@pytest.mark.parametrize('r,k,n,with_dx', [(64, 64, 64, True), (36, 48, 80, True), (20, 16, 16, False), (8, 100, 36, True)])
+def test_lin_gemm(emu, r, k, n, with_dx):
+    """the C x C linear of the coefficient generator: forward and the one-launch backward, ragged tiles"""
+    KC.check_lin(emu, CPU, None, r, k, n, with_dx=with_dx)
+
+
 @pytest.mark.parametrize('bsz,n,use_pe,seq_first,clamp', [
     (3, 37, True, True, False), (2, 64, True, False, False), (4, 9, False, True, False), (2, 19, True, True, True),
 ])

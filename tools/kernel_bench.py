@@ -150,6 +150,18 @@ def main():
         from feta_tmlr_amd.benchcases import stack_layer_cases
         for name, _, fn, nbytes, _ in stack_layer_cases(abi, st, dev, b, n, d, h, 2 * d, pe, nr):
             add(name, fn, nbytes)
+        # the C x C linear of the coefficient generator (csrc/lin.hip) with the column sums it carries in the step:
+        # filter-bias partials and linear_cat's split-K weight-gradient partials
+        r_ = h * b
+        if abi.lin_supported(r_, c, c):
+            lw, lb, lx, ldy = rnd(c, c) / c ** 0.5, rnd(c), rnd(r_, c), rnd(r_, c)
+            ly, ldx, ldw, ldb = (torch.empty(r_, c, device=dev), torch.empty(r_, c, device=dev),
+                                 torch.empty(c, c, device=dev), torch.empty(c, device=dev))
+            add('lin_fwd %dx%dx%d' % (r_, c, c), lambda: abi.lin_fwd(lx, lw, lb, ly, st), f4 * (2 * r_ * c + c * c))
+            cat_part = rnd(abi.rowlin_chunks(m), d * 2 * d + d)
+            pairs = [(rnd(r_, dh), torch.empty(dh, device=dev)), (cat_part, torch.empty(cat_part.shape[1], device=dev))]
+            add('lin_bwd (dx, dw, db + 2 colsum)', lambda: abi.lin_bwd(lx, lw, ldy, ldx, ldw, ldb, st, pairs=pairs),
+                f4 * (3 * r_ * c + 2 * c * c + cat_part.numel()))
 
     if a.json:
         print(json.dumps({'batch': b, 'mean_nodes': mean_n,

@@ -36,6 +36,8 @@ ROWS = [  # (bench row, kernel-symbol substrings enqueued by one call, in order)
     ('attn_block_bwd', ['attn_block_bwd']),
     ('attn_block_bwd (two workgroups per graph)', ['attn_block_bwd']),
     ('rowlin_bwd linear_cat', ['rowlin_bwd']),
+    ('lin_fwd', ['lin_fwd']),
+    ('lin_bwd', ['lin_bwd']),
 ]
 
 
