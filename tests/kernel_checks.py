@@ -444,7 +444,8 @@ def check_lin(abi, dev, stream, r, k, n, seed=0, with_dx=True, segs=((40, 16), (
     abi.lin_bwd(xd, wd, dyd, dx, dw, db, stream, pairs=[(i.to(dev), o) for i, o in zip(ins, outs)])
     if with_dx:
         errs['dx'] = assert_close('lin dx', dx, dy.double() @ w.double(), tol=2e-6)
-    errs['dw'] = assert_close('lin dw', dw, dy.double().t() @ x.double(), tol=2e-6)
+    # (a fp32 accumulation chain over r terms: the rounding error grows ~ sqrt(r))
+    errs['dw'] = assert_close('lin dw', dw, dy.double().t() @ x.double(), tol=2e-6 * max(1.0, r / 512.0) ** 0.5)
     errs['db'] = assert_close('lin db', db, dy.double().sum(0), tol=2e-6)
     for i, o in zip(ins, outs):
         assert_close('lin segment %dx%d' % tuple(i.shape), o, i.double().sum(0), tol=2e-6)
