@@ -302,12 +302,21 @@ class Abi:
                                             0 if dw_dense is None else dw_dense.shape[0], b, n, h, c, stream),
                     'feta_coeff_bwd')
 
-    def colsum_multi(self, pairs, stream):
-        """pairs: [(in [R, C], out [C])] - all reduced by one launch."""
-        segs = (ColsumSeg * len(pairs))()
-        for sg, (x, out) in zip(segs, pairs):
+    @staticmethod
+    def _colsum_segs(pairs):
+        """pairs: [(in [R, C] (row stride >= C), out [C]) or (in, out, bcast [rows, C])] -> feta_colsum_seg array"""
+        segs = (ColsumSeg * max(len(pairs), 1))()
+        for sg, pr in zip(segs, pairs):
+            x, out = pr[0], pr[1]
+            assert x.stride(1) == 1
             sg.in_, sg.out, sg.R, sg.C, sg.ld = x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], x.stride(0)
-        self._check(self.lib.feta_colsum_multi(segs, len(pairs), stream), 'feta_colsum_multi')
+            if len(pr) > 2 and pr[2] is not None:
+                sg.bcast_out, sg.bcast_rows = pr[2].data_ptr(), pr[2].shape[0]
+        return segs
+
+    def colsum_multi(self, pairs, stream):
+        """pairs: [(in [R, C], out [C]) or (in, out, bcast [rows, C])] - all reduced by one launch."""
+        self._check(self.lib.feta_colsum_multi(self._colsum_segs(pairs), len(pairs), stream), 'feta_colsum_multi')
 
     def lin_supported(self, r, k, n):
         return bool(self.lib.feta_lin_supported(r, k, n))
@@ -320,11 +329,8 @@ class Abi:
         """dx = dy w, dw = dy^T x, db = colsum(dy) in one launch; pairs: [(in [R, C], out [C])] pending column sums
         that ride along in trailing workgroups."""
         r, k = x.shape
-        segs = (ColsumSeg * max(len(pairs), 1))()
-        for sg, (xin, out) in zip(segs, pairs):
-            sg.in_, sg.out, sg.R, sg.C, sg.ld = xin.data_ptr(), out.data_ptr(), xin.shape[0], xin.shape[1], xin.stride(0)
-        self._check(self.lib.feta_lin_bwd(_p(x), _p(w), _p(dy), _p(dx), _p(dw), _p(db), r, k, w.shape[0], segs,
-                                          len(pairs), stream), 'feta_lin_bwd')
+        self._check(self.lib.feta_lin_bwd(_p(x), _p(w), _p(dy), _p(dx), _p(dw), _p(db), r, k, w.shape[0],
+                                          self._colsum_segs(pairs), len(pairs), stream), 'feta_lin_bwd')
 
     def colsum(self, x, out, stream):
         r, c = x.shape

@@ -12,6 +12,7 @@
 
 #include "feta_abi_common.h"
 #include <feta_device.h>
+#include "feta_colsum.h"
 
 namespace feta {
 
@@ -309,14 +310,24 @@ __global__ __launch_bounds__(64) void colsum_wide_multi_kernel(ColsumSegs a) {
   *reinterpret_cast<float4*>(sg.out + 4 * (int64_t)c4) = acc;
 }
 
+// segments of both shapes in one launch (feta_colsum.h)
+__global__ __launch_bounds__(kColsumRoleThreads) void colsum_mixed_kernel(ColsumPlan p) { colsum_role(p, (int)blockIdx.x); }
+
 int launch_colsum_multi(const feta_colsum_seg* segs, int nseg, hipStream_t stream) {
   ColsumSegs a{};
   a.nseg = nseg;
-  bool wide = true;
+  bool wide = true, any_wide = false;
   for (int i = 0; i < nseg; ++i) {
-    const int ld = segs[i].ld > 0 ? segs[i].ld : segs[i].C;
-    wide = wide && segs[i].R <= 512 && segs[i].C >= 4096 && (segs[i].C & 3) == 0 && (ld & 3) == 0 &&
-           aligned16(segs[i].in) && aligned16(segs[i].out) && segs[i].bcast_out == nullptr;
+    const bool w = colsum_seg_wide(segs[i], 4096);
+    wide = wide && w;
+    any_wide = any_wide || w;
+  }
+  if (any_wide && !wide) {
+    ColsumPlan p{};
+    const int tiles = plan_colsum(segs, nseg, p);
+    auto kern = colsum_mixed_kernel;
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(kColsumRoleThreads), kColsumRoleThreads * sizeof(float), stream, p);
+    return check_launch("feta_colsum_multi");
   }
   if (wide) {
     int tiles = 0;
@@ -377,7 +388,7 @@ extern "C" int feta_coeff_bwd(const float* cj, const int32_t* n_real, const floa
                               const float* gcn_bias, const float* dpooled, float* partial, float* ds,
                               float* dbias, float* dw_dense, int dw_rows, int B, int N, int H, int C,
                               feta_stream_t stream) {
-  FETA_REQUIRE(cj && n_real && s && gcn_bias && dpooled && partial && ds && dbias,
+  FETA_REQUIRE(cj && n_real && s && gcn_bias && dpooled && partial && (ds == nullptr || dbias != nullptr),
                "coeff_bwd: null pointer");
   FETA_REQUIRE(B > 0 && H > 0 && C > 0 && N > 0, "coeff_bwd: empty shape");
   const int G = feta_coeff_bwd_groups(B, H);
@@ -386,7 +397,7 @@ extern "C" int feta_coeff_bwd(const float* cj, const int32_t* n_real, const floa
   hipLaunchKernelGGL(kern, grid, block, kCoeffPass * N * sizeof(float), (hipStream_t)stream, cj, n_real, s,
                      gcn_bias, dpooled, partial, B, N, H, C, G);
   int rc = check_launch("feta_coeff_bwd");
-  if (rc != FETA_OK) return rc;
+  if (rc != FETA_OK || ds == nullptr) return rc;   // ds == NULL: the caller reduces the [G, 2C] partials itself
   if (dw_dense != nullptr) {
     // one launch: ds (also written to every row of the dense [dw_rows][C] weight gradient) and dbias
     FETA_REQUIRE(dw_rows > 0, "coeff_bwd: dw_dense needs dw_rows");

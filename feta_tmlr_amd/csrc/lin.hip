@@ -13,11 +13,12 @@
 // Arithmetic: v_mfma_f32_16x16x4_f32, k-ordered exact fp32 - the same contraction order for every output element
 // (k ascending in steps of 16, inside a step the four k-quads of the MFMA), deterministic.
 #include "feta_abi_common.h"
+#include "feta_colsum.h"
 #include "feta_tiles.h"
 
 namespace feta {
 
-constexpr int kLinThreads = 256;   // 4 waves = a 32 x 32 output tile
+constexpr int kLinThreads = kColsumRoleThreads;   // 4 waves = a 32 x 32 output tile
 
 // One wave: acc[r] = sum_k A(m0 + 4g + r, k) B(k, n0 + lq).
 //   A_KC: A stored [row][k] (k contiguous: one float4 per step) else [k][row] (four scalar loads, lanes contiguous)
@@ -118,13 +119,6 @@ __global__ __launch_bounds__(kLinThreads) void lin_fwd_kernel(LinFwdArgs a) {
   store_tile(a.y, a.N, m0, n0, a.R, a.N, acc, a.bias, lq, g);
 }
 
-struct LinSegs {   // column sums riding along in trailing workgroups
-  feta_colsum_seg seg[FETA_COLSUM_MAX_SEGS];
-  int tile_end[FETA_COLSUM_MAX_SEGS];
-  int wide[FETA_COLSUM_MAX_SEGS];   // 1: one thread per 4 columns, no tree (few rows x many columns)
-  int nseg;
-};
-
 struct LinBwdArgs {
   const float* x;    // [R][K]  (pooled)
   const float* w;    // [N][K]
@@ -135,59 +129,8 @@ struct LinBwdArgs {
   int R, K, N;
   int tk;            // 32-column tiles over K (both products have K columns)
   int nx, nw;        // workgroups of the dX role / of the dW role
-  LinSegs segs;
+  ColsumPlan segs;
 };
-
-// out[c] = sum_r in[r][c] for one tile of one segment (256 threads): colsum_kernel's tree with 16 slices, or
-// colsum_wide_kernel's row walk
-__device__ __forceinline__ void colsum_role(const LinSegs& sg, int tile_id) {
-  int si = 0;
-  while (si + 1 < sg.nseg && tile_id >= sg.tile_end[si]) ++si;
-  const feta_colsum_seg s = sg.seg[si];
-  const int tile = tile_id - (si > 0 ? sg.tile_end[si - 1] : 0);
-  const int ld = s.ld > 0 ? s.ld : s.C;
-  if (sg.wide[si]) {
-    const int c4 = tile * kLinThreads + (int)threadIdx.x;
-    if (c4 >= s.C / 4) return;
-    const float* p = s.in + 4 * (int64_t)c4;
-    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    int r = 0;
-    for (; r + 8 <= s.R; r += 8) {
-      float4 v[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(p + (int64_t)(r + i) * ld);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w;
-      }
-    }
-    for (; r < s.R; ++r) {
-      const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)r * ld);
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-    *reinterpret_cast<float4*>(s.out + 4 * (int64_t)c4) = acc;
-    return;
-  }
-  constexpr int COLS = 16, SL = kLinThreads / COLS;
-  float* red = feta_lds;   // [SL][COLS]
-  const int lc = threadIdx.x & (COLS - 1), slice = threadIdx.x / COLS;
-  const int col = tile * COLS + lc;
-  float acc = 0.0f;
-  if (col < s.C)
-    for (int r = slice; r < s.R; r += SL) acc += s.in[(int64_t)r * ld + col];
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int half = SL / 2; half >= 1; half >>= 1) {
-    if (slice < half) red[threadIdx.x] += red[threadIdx.x + half * COLS];
-    __syncthreads();
-  }
-  if (col < s.C) {
-    const float v = red[lc];
-    if (slice == 0) s.out[col] = v;
-    if (s.bcast_out != nullptr)
-      for (int r = slice; r < s.bcast_rows; r += SL) s.bcast_out[(int64_t)r * s.C + col] = v;
-  }
-}
 
 __global__ __launch_bounds__(kLinThreads) void lin_bwd_kernel(LinBwdArgs a) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lq = lane & 15, g = lane >> 4;
@@ -255,20 +198,8 @@ extern "C" int feta_lin_bwd(const float* x, const float* w, const float* dy, flo
   a.tk = (K + 31) / 32;
   a.nx = dx != nullptr ? ((R + 31) / 32) * a.tk : 0;
   a.nw = ((N + 31) / 32) * a.tk;
-  int tiles = 0;
-  a.segs.nseg = nseg;
-  for (int i = 0; i < nseg; ++i) {
-    const feta_colsum_seg& s = segs[i];
-    FETA_REQUIRE(s.in && s.out && s.R > 0 && s.C > 0 && (s.ld == 0 || s.ld >= s.C) &&
-                 (s.bcast_out == nullptr || s.bcast_rows > 0), "lin_bwd: bad segment %d", i);
-    const int ld = s.ld > 0 ? s.ld : s.C;
-    const bool wide = s.R <= 512 && s.C >= 1024 && (s.C & 3) == 0 && (ld & 3) == 0 && aligned16(s.in) &&
-                      aligned16(s.out) && s.bcast_out == nullptr;
-    a.segs.seg[i] = s;
-    a.segs.wide[i] = wide ? 1 : 0;
-    tiles += wide ? (s.C / 4 + kLinThreads - 1) / kLinThreads : (s.C + 15) / 16;
-    a.segs.tile_end[i] = tiles;
-  }
+  for (int i = 0; i < nseg; ++i) FETA_REQUIRE(colsum_seg_ok(segs[i]), "lin_bwd: bad segment %d", i);
+  const int tiles = plan_colsum(segs, nseg, a.segs);
   auto kern = lin_bwd_kernel;
   hipLaunchKernelGGL(kern, dim3(a.nx + a.nw + tiles), dim3(kLinThreads), kLinThreads * sizeof(float),
                      (hipStream_t)stream, a);

@@ -96,8 +96,11 @@ class FilterCoefficientsFn(torch.autograd.Function):
     (transformer/models.py:240-283 collapsed; C ABI: feta_colsum, feta_coeff_fwd/bwd)."""
 
     @staticmethod
-    def forward(ctx, attn, n_real, gcn_weight, gcn_bias):
+    def forward(ctx, attn, n_real, gcn_weight, gcn_bias, pending=None):
         abi, stream = _lib.backend(attn, gcn_weight)
+        ctx.pending = pending
+        if pending is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]):
+            pending.coeff_armed = True      # this node's backward is the last of the filter stage: it flushes
         attn = attn.contiguous()
         b, h, n, _ = attn.shape
         c = gcn_weight.shape[1]
@@ -125,8 +128,15 @@ class FilterCoefficientsFn(torch.autograd.Function):
         # s = 1^T W  =>  every row of dW equals ds: the reduction launch writes the dense rows itself (an
         # expanded view would be copied into a dense .grad by autograd: one more 4 MB kernel per step)
         dw = torch.empty((rows, c), dtype=torch.float32, device=cj.device)
-        abi.coeff_bwd(cj, n_real, s, gb, dpooled.contiguous(), partial, ds, db, b, n, h, stream, dw_dense=dw)
-        return None, None, dw, db
+        waiting = ctx.pending.take() if ctx.pending is not None else []
+        if waiting:
+            # ONE reduction launch for this node's partials and every column sum the nodes before it left pending
+            abi.coeff_bwd(cj, n_real, s, gb, dpooled.contiguous(), partial, None, None, b, n, h, stream)
+            p2 = partial.view(groups, 2 * c)
+            abi.colsum_multi([(p2[:, :c], ds, dw), (p2[:, c:], db)] + waiting, stream)
+        else:
+            abi.coeff_bwd(cj, n_real, s, gb, dpooled.contiguous(), partial, ds, db, b, n, h, stream, dw_dense=dw)
+        return None, None, dw, db, None
 
 
 class DenseLinearFn(torch.autograd.Function):
@@ -193,19 +203,37 @@ class _FilterFn(torch.autograd.Function):
         return dx, dcoeff, dbias, None, None, None, None, None, None, None
 
 
+LIN_OWN_GEMM_MAX_MACS = 1 << 27
+
+
 class PendingSums:
     """Column sums (split-K partial buffer -> gradient) that one backward node of the filter stage leaves for a LATER
-    node of the same backward pass which has a launch to carry them in trailing workgroups (feta_lin_bwd): every
-    launch of a captured step costs ~4.5 us whatever its size.  The encoder creates one per forward; the node that
-    will flush (FilterFromPooledFn) arms it in forward iff autograd is going to run its backward, and only then do
-    producers (linear_cat's backward, which always runs before it: the filter output is linear_cat's operand) defer."""
+    node of the same backward pass which has a launch to carry them (trailing workgroups of feta_lin_bwd, or the
+    reduction launch of the coefficient generator's backward): every launch of a captured step costs ~4.5 us whatever
+    its size.  The encoder creates one per forward; a node that will flush arms it in forward iff autograd is going
+    to run its backward, and only then do the nodes that run BEFORE it in backward defer: linear_cat -> filter
+    (the filter output is linear_cat's operand) -> coefficient generator (pooled is the filter node's operand)."""
 
     def __init__(self):
-        self.armed = False
+        self.armed = False         # FilterFromPooledFn will run a backward (it takes what linear_cat leaves)
+        self.coeff_armed = False   # FilterCoefficientsFn will (it takes whatever is left: the stage's last node)
         self.items = []
 
+    @staticmethod
+    def untouched(*params):
+        """A gradient may be completed after its node returned only if nothing reads it before the flush: the
+        parameter has no .grad to accumulate into (autograd then keeps the returned tensor itself) and no hooks."""
+        for p in params:
+            if p is None:
+                continue
+            if p.grad is not None or p._backward_hooks or getattr(p, '_post_accumulate_grad_hooks', None):
+                return False
+        return True
+
     def add(self, partial, out):
-        self.items.append((partial, out))
+        # (a second tensor object on the same storage: autograd keeps a returned gradient without copying it only
+        # if nobody else holds a reference to that tensor object)
+        self.items.append((partial, out.detach()))
 
     def take(self):
         items, self.items = self.items, []
@@ -227,13 +255,20 @@ class FilterFromPooledFn(torch.autograd.Function):
         xs = _dense_like(x, batch_first)
         # fp32 master precision (also what a regulariser sees)
         pooled, lin_w = pooled.contiguous(), lin_w.contiguous()
-        ctx.own_gemm = abi.lin_supported(pooled.shape[0], pooled.shape[1], lin_w.shape[0])
-        if ctx.own_gemm:      # csrc/lin.hip: one 16 x 16 tile per wave, 1024 waves at the BASELINE batch
+        r_, k_, n_ = pooled.shape[0], pooled.shape[1], lin_w.shape[0]
+        # csrc/lin.hip (one 16 x 16 tile per wave straight from L2, gradient products and column sums in one launch)
+        # where the products are launch-bound; the library GEMM where they are compute-bound (C = 1024 at the
+        # BASELINE shape: 1 GFLOP each, ~12 us at half the fp32 matrix peak; lin.hip is L2-bound there, 31 us)
+        ctx.own_gemm = abi.lin_supported(r_, k_, n_) and r_ * k_ * n_ <= LIN_OWN_GEMM_MAX_MACS
+        if ctx.own_gemm:
             coeff = torch.empty((pooled.shape[0], lin_w.shape[0]), dtype=torch.float32, device=pooled.device)
             abi.lin_fwd(pooled, lin_w, lin_b, coeff, stream)
         else:
             coeff = torch.addmm(lin_b, pooled, lin_w.t())
         ctx.pending = pending
+        # pooled's gradient flows into FilterCoefficientsFn: if that node flushes, it runs after this one
+        ctx.defer = pending is not None and pending.coeff_armed and ctx.needs_input_grad[1] and not ctx.own_gemm
+        ctx.params = (lin_b, bias)
         if pending is not None and any(ctx.needs_input_grad):
             pending.armed = True
         # bf16 storage path: the per-block weights the filter kernel reads are bf16 copies of them
@@ -283,7 +318,12 @@ class FilterFromPooledFn(torch.autograd.Function):
             dw_lin = torch.empty_like(lin_w)
             abi.lin_bwd(pooled, lin_w, dcoeff, dpooled, dw_lin, db_lin, stream, pairs=sums)
         else:
-            abi.colsum_multi(sums + [(dcoeff, db_lin)], stream)
+            sums.append((dcoeff, db_lin))
+            if ctx.defer and PendingSums.untouched(*ctx.params):
+                for pr in sums:
+                    ctx.pending.add(*pr)
+            else:
+                abi.colsum_multi(sums, stream)
             dpooled, dw_lin = dcoeff.mm(lin_w), dcoeff.t().mm(pooled)
         if not has_bias:
             dbias = None
@@ -354,6 +394,7 @@ class RowLinearCatFn(torch.autograd.Function):
     def forward(ctx, x1, x2, w, bias, pending=None):
         abi, stream = _lib.backend(x1, x2, w)
         ctx.defer = pending if (pending is not None and pending.armed and x2.requires_grad) else None
+        ctx.params = (w, bias)
         x1, x2, w = x1.contiguous(), x2.contiguous(), w.contiguous()
         m, k1 = x1.shape
         ki, no = k1 + x2.shape[1], w.shape[0]
@@ -371,6 +412,8 @@ class RowLinearCatFn(torch.autograd.Function):
         m, k1 = x1.shape
         ki, no = k1 + x2.shape[1], w.shape[0]
         dy = dy.contiguous()
+        if ctx.defer is not None and not PendingSums.untouched(*ctx.params):
+            ctx.defer = None
         dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
         partial = torch.empty((abi.rowlin_chunks(m), no * ki + no), dtype=torch.float32, device=x1.device)
         dwdb = torch.empty(no * ki + no, dtype=torch.float32, device=x1.device)
@@ -394,6 +437,7 @@ class RowLinearCatBNFn(torch.autograd.Function):
     def forward(ctx, y2, x2, w, bias, tail, pending=None):
         abi, stream = _lib.backend(y2, x2, w)
         ctx.defer = pending if (pending is not None and pending.armed and x2.requires_grad) else None
+        ctx.params = (w, bias)
         y2, x2, w = y2.contiguous(), x2.contiguous(), w.contiguous()
         m, k1 = y2.shape
         ki, no = k1 + x2.shape[1], w.shape[0]
@@ -416,6 +460,8 @@ class RowLinearCatBNFn(torch.autograd.Function):
         m, k1 = y2.shape
         ki, no = k1 + x2.shape[1], w.shape[0]
         dy = dy.contiguous()
+        if ctx.defer is not None and not PendingSums.untouched(*ctx.params):
+            ctx.defer = None
         dx1, dx2 = torch.empty_like(y2), torch.empty_like(x2)
         partial = torch.empty((abi.rowlin_chunks(m), no * ki + no), dtype=torch.float32, device=y2.device)
         dwdb = torch.empty(no * ki + no, dtype=torch.float32, device=y2.device)
@@ -555,8 +601,8 @@ def attention_core(qkv, pe, n_real, num_heads, need_attn=True, tie_qk=False, bat
     return AttentionCoreFn.apply(qkv, pe, n_real, num_heads, need_attn, tie_qk, batch_first, drop)
 
 
-def filter_coefficients(attn, n_real, gcn_weight, gcn_bias):
-    return FilterCoefficientsFn.apply(attn, n_real, gcn_weight, gcn_bias)
+def filter_coefficients(attn, n_real, gcn_weight, gcn_bias, pending=None):
+    return FilterCoefficientsFn.apply(attn, n_real, gcn_weight, gcn_bias, pending)
 
 
 def cheb_filter(x, lhat, coeff, bias, n_real, order, heads_share_graph=False, batch_first=False):

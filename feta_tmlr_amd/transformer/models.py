@@ -121,7 +121,8 @@ class DiffTransformerEncoderGenGCN(nn.Module):
         """get_filter_coefficients + filter of one layer (:173, :186-202) with ``self.linear`` folded into the
         filter's autograd node (functional.FilterFromPooledFn).  -> (coeff [H,B,C], out_filtered [N,B,d])"""
         bsz, n, h, dh = out_each_head.shape
-        pooled = FF.filter_coefficients(attn_weights.detach().float(), cache.n_real, self.gcn.weight, self.gcn.bias)
+        pooled = FF.filter_coefficients(attn_weights.detach().float(), cache.n_real, self.gcn.weight, self.gcn.bias,
+                                        pending)
         if self.filter_mode == 'cheb':
             graph, mode = (cache.lhat,), 'cheb'
         else:
@@ -236,7 +237,9 @@ class DiffTransformerEncoderGenGCN(nn.Module):
                 and src.shape[-1] % 16 == 0 and FF.row_linear_supported(2 * src.shape[-1], self.linear_cat.weight.shape[0])):
             tail = StackTail()
         # linear_cat's weight-gradient partials are reduced inside the launch of the filter's backward (PendingSums)
-        pending = FF.PendingSums() if not lowp else None
+        # (one filter stage per forward only: a parameter that collects several contributions is summed by autograd
+        # as they arrive)
+        pending = FF.PendingSums() if (not lowp and self.last_layer_filter) else None
         for layer_num, mod in enumerate(self.layers):
             last = layer_num + 1 == self.num_layers
             filt = last or not self.last_layer_filter                            # :169-171

@@ -98,7 +98,8 @@ int feta_coeff_fwd(const float* attn, const int32_t* n_real,
 
 /* ds[c] = sum_{blk,j} dpooled*(1-z^2)*c_j/n ; dbias[c] likewise without c_j.
  * partial [G, 2, C] scratch with G = feta_coeff_bwd_groups(B,H); when dbias == ds + C both are
- * reduced by one launch.  dw_dense (nullable) [dw_rows, C]: the gradient of gcn.weight itself - s = 1^T W,
+ * reduced by one launch.  ds == NULL (ABI 6): no reduction launch - the caller reduces the partials ([G, 2C]: ds from
+ * columns 0..C-1, dbias from C..2C-1) with feta_colsum_multi, together with whatever else it has pending.  dw_dense (nullable) [dw_rows, C]: the gradient of gcn.weight itself - s = 1^T W,
  * so every row of dW equals ds; the reduction launch writes the rows (no broadcast copy afterwards). */
 int feta_coeff_bwd_groups(int B, int H);
 int feta_coeff_bwd(const float* cj, const int32_t* n_real,

@@ -426,6 +426,26 @@ def check_colsum(abi, dev, stream, r, c, seed=0):
     assert_close('colsum %dx%d' % (r, c), out, x.double().sum(0))
 
 
+def check_colsum_multi_mixed(abi, dev, stream, seed=0):
+    """feta_colsum_multi with tall, wide, strided and row-broadcast segments in ONE launch (the reduction the
+    coefficient generator's backward issues for the whole filter stage)."""
+    g = torch.Generator().manual_seed(seed)
+    nan = lambda *s: torch.full(s, float('nan'), device=dev)
+    part = torch.randn(23, 2 * 96, generator=g)          # [G, 2C]: two strided halves, the first broadcast to rows
+    tall, wide, small = torch.randn(300, 100, generator=g), torch.randn(19, 4096 + 64, generator=g), torch.randn(64, 16, generator=g)
+    pd = part.to(dev)
+    ds, db, dw = nan(96), nan(96), nan(7, 96)
+    o_tall, o_wide, o_small = nan(100), nan(4096 + 64), nan(16)
+    abi.colsum_multi([(pd[:, :96], ds, dw), (pd[:, 96:], db), (tall.to(dev), o_tall), (wide.to(dev), o_wide),
+                      (small.to(dev), o_small)], stream)
+    assert_close('ds', ds, part[:, :96].double().sum(0))
+    assert_close('db', db, part[:, 96:].double().sum(0))
+    assert_close('dw rows', dw, part[:, :96].double().sum(0).expand(7, 96))
+    assert_close('tall', o_tall, tall.double().sum(0))
+    assert_close('wide', o_wide, wide.double().sum(0))
+    assert_close('small', o_small, small.double().sum(0))
+
+
 def check_lin(abi, dev, stream, r, k, n, seed=0, with_dx=True, segs=((40, 16), (9, 2048 + 64), (70, 100))):
     """feta_lin_fwd / feta_lin_bwd (csrc/lin.hip) against float64: y = x w^T + b; dx, dw, db in one launch together
     with pending column sums (tall, few-rows-many-columns and odd-width segments)."""

@@ -129,6 +129,10 @@ def test_colsum_shapes(emu, r, c):
     KC.check_colsum(emu, CPU, None, r, c)
 
 
+def test_colsum_multi_mixed_segments(emu):
+    KC.check_colsum_multi_mixed(emu, CPU, None)
+
+
 @pytest.mark.parametrize('r,k,n,with_dx', [(64, 64, 64, True), (36, 48, 80, True), (20, 16, 16, False), (8, 100, 36, True)])
 def test_lin_gemm(emu, r, k, n, with_dx):
     """the C x C linear of the coefficient generator: forward and the one-launch backward, ragged tiles"""

@@ -134,6 +134,10 @@ def test_colsum_shapes(hip, r, c):
     KC.check_colsum(*hip, r, c)
 
 
+def test_colsum_multi_mixed_segments(hip):
+    KC.check_colsum_multi_mixed(*hip)
+
+
 @pytest.mark.parametrize('r,k,n,with_dx', [(512, 512, 512, True), (36, 48, 80, True), (20, 16, 16, False), (8, 100, 36, True),
                                            (4096, 512, 512, True), (520, 256, 256, True)])
 def test_lin_gemm(hip, r, k, n, with_dx):

@@ -264,6 +264,54 @@ def test_two_phase_backward_equals_single_backward(emu):
         {id(p) for p in enc.parameters()}
 
 
+@pytest.mark.parametrize('own_gemm', [True, False])
+def test_deferred_column_sums_and_gradient_accumulation(emu, monkeypatch, own_gemm):
+    """The filter stage leaves its bias / weight-gradient column sums to the reduction launch of its last backward
+    node (functional.PendingSums) only while nothing can read them early: a second backward that accumulates into
+    existing .grad tensors, and a parameter with a hook, must see finished values."""
+    from feta_tmlr_amd import functional as FF
+    if not own_gemm:    # library GEMMs for the C x C linear: its column sums wait for the coefficient node as well
+        monkeypatch.setattr(FF, 'LIN_OWN_GEMM_MAX_MACS', 0)
+    model, batch9, cache = _model_case(True, 1, 'spectral', True, bsz=3, d=64, heads=4, layers=2, order=2)
+    x, mask, pe, _, degree, _, edge_index, batch, fi = batch9
+    seen = []
+    taken = []
+    orig_take = FF.PendingSums.take
+
+    def take(self):
+        r = orig_take(self)
+        taken.append(len(r))
+        return r
+
+    def run():
+        out, _, coeff = model(x, edge_index, batch, fi, mask, pe, degree=degree, return_filter_coeff=True,
+                              graph_cache=cache)
+        ((out * out).sum() + 0.01 * coeff.pow(2).sum()).backward()
+
+    FF.PendingSums.take = take
+    try:
+        with _lib.override_for_tests(emu):
+            model.zero_grad(set_to_none=True)
+            run()
+            # linear_cat's partials ride in feta_lin_bwd / they, the filter bias and the linear bias in the last reduction
+            assert max(taken) >= (1 if own_gemm else 3), taken
+            once = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+            taken.clear()
+            run()                                # accumulates into the existing .grad: nothing may be deferred
+            assert max(taken) == 0, taken
+            for n, p in model.named_parameters():
+                if p.grad is not None:
+                    KC.assert_close('accumulated ' + n, p.grad, 2.0 * once[n].double(), tol=1e-5)
+            model.zero_grad(set_to_none=True)
+            h = model.encoder.linear.bias.register_hook(lambda g: seen.append(g.clone()))
+            run()
+            h.remove()
+    finally:
+        FF.PendingSums.take = orig_take
+    KC.assert_close('hooked gradient', seen[0], once['encoder.linear.bias'].double(), tol=1e-6)
+    KC.assert_close('after hook', model.encoder.linear.bias.grad, once['encoder.linear.bias'].double(), tol=1e-6)
+
+
 def _stack_run(model, batch9, cache, use_block, monkeypatch, hook, split=True):
     from feta_tmlr_amd import fused_stack
     monkeypatch.setattr(fused_stack, 'USE_ATTN_BLOCK_SPLIT', split)  # two workgroups per graph where it applies
