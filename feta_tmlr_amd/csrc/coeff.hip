@@ -311,7 +311,9 @@ __global__ __launch_bounds__(64) void colsum_wide_multi_kernel(ColsumSegs a) {
 }
 
 // segments of both shapes in one launch (feta_colsum.h)
-__global__ __launch_bounds__(kColsumRoleThreads) void colsum_mixed_kernel(ColsumPlan p) { colsum_role(p, (int)blockIdx.x); }
+__global__ __launch_bounds__(kColsumMixedThreads) void colsum_mixed_kernel(ColsumPlan p) {
+  colsum_role<kColsumMixedThreads>(p, (int)blockIdx.x);
+}
 
 int launch_colsum_multi(const feta_colsum_seg* segs, int nseg, hipStream_t stream) {
   ColsumSegs a{};
@@ -326,7 +328,8 @@ int launch_colsum_multi(const feta_colsum_seg* segs, int nseg, hipStream_t strea
     ColsumPlan p{};
     const int tiles = plan_colsum(segs, nseg, p);
     auto kern = colsum_mixed_kernel;
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(kColsumRoleThreads), kColsumRoleThreads * sizeof(float), stream, p);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(kColsumMixedThreads),
+                       colsum_role_lds_floats(kColsumMixedThreads) * sizeof(float), stream, p);
     return check_launch("feta_colsum_multi");
   }
   if (wide) {

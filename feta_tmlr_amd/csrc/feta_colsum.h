@@ -1,17 +1,18 @@
 // Column sums as a ROLE: trailing workgroups of a launch (feta_lin_bwd) - or a launch of their own
 // (feta_colsum_multi with segments of both shapes) - reduce a list of independent [R, C] buffers, one tile per
 // workgroup of kColsumRoleThreads threads.  Two shapes of segment:
-//   tall   16 columns x 16 row slices per workgroup, LDS tree over the slices (colsum_kernel's arithmetic)
-//   wide   few rows x very many columns (split-K weight-gradient partials): one thread per 4 columns, every row
-//          requested before the first add (colsum_wide_kernel's arithmetic)
-// Deterministic: the order of the adds depends on the segment's shape only.
+//   tall   16 columns x (threads / 16) row slices per workgroup, LDS tree over the slices
+//   wide   few rows x very many columns (split-K weight-gradient partials): one thread per 4 columns (256 float4
+//          columns per workgroup, larger workgroups split the rows), eight rows requested before the first add
+// Deterministic: the order of the adds depends on the segment's shape and the workgroup size only.
 #pragma once
 #include "feta_abi_common.h"
 #include <feta_device.h>
 
 namespace feta {
 
-constexpr int kColsumRoleThreads = 256;
+constexpr int kColsumRoleThreads = 256;    // as a role of feta_lin_bwd
+constexpr int kColsumMixedThreads = 1024;  // as a launch of its own
 
 struct ColsumPlan {
   feta_colsum_seg seg[FETA_COLSUM_MAX_SEGS];
@@ -30,61 +31,87 @@ inline bool colsum_seg_wide(const feta_colsum_seg& s, int min_cols) {
          s.bcast_out == nullptr;
 }
 
-// fills the plan, returns the number of tiles (= workgroups of the role)
+// fills the plan, returns the number of tiles (= workgroups of the role); wide tiles are 256 float4 columns whatever
+// the workgroup size (larger workgroups split the rows)
 inline int plan_colsum(const feta_colsum_seg* segs, int nseg, ColsumPlan& p) {
   int tiles = 0;
   p.nseg = nseg;
   for (int i = 0; i < nseg; ++i) {
-    const bool wide = colsum_seg_wide(segs[i], 1024);
+    const bool wide = colsum_seg_wide(segs[i], 4096);   // (a wide tile is one workgroup per 1024 columns)
     p.seg[i] = segs[i];
     p.wide[i] = wide ? 1 : 0;
-    tiles += wide ? (segs[i].C / 4 + kColsumRoleThreads - 1) / kColsumRoleThreads : (segs[i].C + 15) / 16;
+    tiles += wide ? (segs[i].C / 4 + 255) / 256 : (segs[i].C + 15) / 16;
     p.tile_end[i] = tiles;
   }
   return tiles;
 }
 
-// out[c] = sum_r in[r][c] for one tile of one segment (256 threads): colsum_kernel's tree with 16 slices, or
-// colsum_wide_kernel's row walk
+// dynamic LDS floats the role needs in a workgroup of THREADS threads
+constexpr int colsum_role_lds_floats(int threads) { return threads > 256 ? 4 * threads : threads; }
+
+__device__ __forceinline__ void add4(float4& a, const float4& v) {
+  a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+}
+
+// out[c] = sum_r in[r][c] for one tile of one segment, by a workgroup of THREADS (256 or 1024) threads; every thread
+// of the workgroup must call it (barriers).  The order of the adds depends on the shape and on THREADS only.
+template <int THREADS>
 __device__ __forceinline__ void colsum_role(const ColsumPlan& sg, int tile_id) {
   int si = 0;
   while (si + 1 < sg.nseg && tile_id >= sg.tile_end[si]) ++si;
   const feta_colsum_seg s = sg.seg[si];
   const int tile = tile_id - (si > 0 ? sg.tile_end[si - 1] : 0);
   const int ld = s.ld > 0 ? s.ld : s.C;
+  const int tid = threadIdx.x;
   if (sg.wide[si]) {
-    const int c4 = tile * kColsumRoleThreads + (int)threadIdx.x;
-    if (c4 >= s.C / 4) return;
-    const float* p = s.in + 4 * (int64_t)c4;
+    // 256 float4 columns per tile; THREADS / 256 row slices, tree over the slices through LDS
+    constexpr int SLW = THREADS / 256;
+    const int c4 = tile * 256 + (tid & 255), slice = tid >> 8;
+    const bool ok = c4 < s.C / 4;
+    const float* p = s.in + 4 * (int64_t)(ok ? c4 : 0);
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    int r = 0;
-    for (; r + 8 <= s.R; r += 8) {
+    int r = slice;
+    for (; r + 7 * SLW < s.R; r += 8 * SLW) {
       float4 v[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(p + (int64_t)(r + i) * ld);
+      for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(p + (int64_t)(r + i * SLW) * ld);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w;
+      for (int i = 0; i < 8; ++i) add4(acc, v[i]);
+    }
+    for (; r < s.R; r += SLW) add4(acc, *reinterpret_cast<const float4*>(p + (int64_t)r * ld));
+    if (SLW > 1) {
+      float4* red = reinterpret_cast<float4*>(feta_lds);   // [SLW][256]
+      red[tid] = acc;
+      __syncthreads();
+      for (int half = SLW / 2; half >= 1; half >>= 1) {
+        if (slice < half) add4(red[tid], red[tid + half * 256]);
+        __syncthreads();
       }
+      acc = red[tid & 255];
     }
-    for (; r < s.R; ++r) {
-      const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)r * ld);
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-    *reinterpret_cast<float4*>(s.out + 4 * (int64_t)c4) = acc;
+    if (ok && slice == 0) *reinterpret_cast<float4*>(s.out + 4 * (int64_t)c4) = acc;
     return;
   }
-  constexpr int COLS = 16, SL = kColsumRoleThreads / COLS;
+  // 16 columns x THREADS / 16 row slices, pairwise tree over the slices
+  constexpr int COLS = 16, SL = THREADS / COLS;
   float* red = feta_lds;   // [SL][COLS]
-  const int lc = threadIdx.x & (COLS - 1), slice = threadIdx.x / COLS;
+  const int lc = tid & (COLS - 1), slice = tid / COLS;
   const int col = tile * COLS + lc;
   float acc = 0.0f;
-  if (col < s.C)
-    for (int r = slice; r < s.R; r += SL) acc += s.in[(int64_t)r * ld + col];
-  red[threadIdx.x] = acc;
+  if (col < s.C) {
+    const float* p = s.in + col;
+    int r = slice;
+    for (; r + 3 * SL < s.R; r += 4 * SL) {   // four rows in flight
+      const float v0 = p[(int64_t)r * ld], v1 = p[(int64_t)(r + SL) * ld], v2 = p[(int64_t)(r + 2 * SL) * ld],
+                  v3 = p[(int64_t)(r + 3 * SL) * ld];
+      acc += v0; acc += v1; acc += v2; acc += v3;
+    }
+    for (; r < s.R; r += SL) acc += p[(int64_t)r * ld];
+  }
+  red[tid] = acc;
   __syncthreads();
   for (int half = SL / 2; half >= 1; half >>= 1) {
-    if (slice < half) red[threadIdx.x] += red[threadIdx.x + half * COLS];
+    if (slice < half) red[tid] += red[tid + half * COLS];
     __syncthreads();
   }
   if (col < s.C) {

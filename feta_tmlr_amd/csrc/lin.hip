@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kLinThreads) void lin_bwd_kernel(LinBwdArgs a) {
     }
     return;
   }
-  colsum_role(a.segs, blk - a.nw);
+  colsum_role<kLinThreads>(a.segs, blk - a.nw);
 }
 
 }  // namespace feta

@@ -99,6 +99,7 @@ class FilterCoefficientsFn(torch.autograd.Function):
     def forward(ctx, attn, n_real, gcn_weight, gcn_bias, pending=None):
         abi, stream = _lib.backend(attn, gcn_weight)
         ctx.pending = pending
+        ctx.params = (gcn_weight, gcn_bias)
         if pending is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]):
             pending.coeff_armed = True      # this node's backward is the last of the filter stage: it flushes
         attn = attn.contiguous()
@@ -128,7 +129,15 @@ class FilterCoefficientsFn(torch.autograd.Function):
         # s = 1^T W  =>  every row of dW equals ds: the reduction launch writes the dense rows itself (an
         # expanded view would be copied into a dense .grad by autograd: one more 4 MB kernel per step)
         dw = torch.empty((rows, c), dtype=torch.float32, device=cj.device)
-        waiting = ctx.pending.take() if ctx.pending is not None else []
+        pend = ctx.pending
+        if (pend is not None and pend.stack_armed and not pend.stack_done and PendingSums.untouched(*ctx.params)):
+            # the layer stack's backward comes after this node and ends in a reduction launch: it takes these too
+            abi.coeff_bwd(cj, n_real, s, gb, dpooled.contiguous(), partial, None, None, b, n, h, stream)
+            p2 = partial.view(groups, 2 * c)
+            pend.add(p2[:, :c], ds, dw)
+            pend.add(p2[:, c:], db)
+            return None, None, dw, db, None
+        waiting = pend.take() if pend is not None else []
         if waiting:
             # ONE reduction launch for this node's partials and every column sum the nodes before it left pending
             abi.coeff_bwd(cj, n_real, s, gb, dpooled.contiguous(), partial, None, None, b, n, h, stream)
@@ -217,7 +226,10 @@ class PendingSums:
     def __init__(self):
         self.armed = False         # FilterFromPooledFn will run a backward (it takes what linear_cat leaves)
         self.coeff_armed = False   # FilterCoefficientsFn will (it takes whatever is left: the stage's last node)
+        self.stack_armed = False   # the fused layer stack will, in the same backward pass (set by the encoder), and
+        self.stack_done = False    # ... has not yet: its one reduction launch takes what the stage's last node leaves
         self.items = []
+        self._callback_queued = False
 
     @staticmethod
     def untouched(*params):
@@ -230,14 +242,26 @@ class PendingSums:
                 return False
         return True
 
-    def add(self, partial, out):
+    def add(self, partial, out, bcast=None):
         # (a second tensor object on the same storage: autograd keeps a returned gradient without copying it only
         # if nobody else holds a reference to that tensor object)
-        self.items.append((partial, out.detach()))
+        self.items.append((partial, out.detach(), None if bcast is None else bcast.detach()))
+        if not self._callback_queued:
+            # safety net: whatever no later node took (autograd pruned it from this pass) is reduced when the
+            # backward pass ends
+            torch.autograd.Variable._execution_engine.queue_callback(self._finish_pass)
+            self._callback_queued = True
 
     def take(self):
         items, self.items = self.items, []
         return items
+
+    def _finish_pass(self):
+        self._callback_queued = False
+        items = self.take()
+        if items:
+            abi, stream = _lib.backend(items[0][0])
+            abi.colsum_multi(items, stream)
 
 
 class FilterFromPooledFn(torch.autograd.Function):

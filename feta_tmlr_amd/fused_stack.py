@@ -139,7 +139,7 @@ class StackTail:
 class FusedEncoderStackFn(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, src, pe, degree_rows, n_real, layers, need_attn, tail, *params):
+    def forward(ctx, src, pe, degree_rows, n_real, layers, need_attn, tail, pending, *params):
         abi, stream = _lib.backend(src, pe, n_real)
         ctx.set_materialize_grads(False)   # no zero tensor for the (non-differentiable) attn output
         if len(layers):
@@ -238,6 +238,7 @@ class FusedEncoderStackFn(torch.autograd.Function):
                                  final, prm2, last.running_mean, last.running_var, float(last.momentum),
                                  float(last.eps), stream, nbt=last.num_batches_tracked)
         ctx.tail = tail
+        ctx.pending = pending
         saved[-1]['prm2'] = prm2
         ctx.saved_state = saved
         ctx.meta = (n, b, d, heads, dh, tie, scale, G, nl)
@@ -385,14 +386,15 @@ class FusedEncoderStackFn(torch.autograd.Function):
             dcur, dcur_b, gs, Gs_cur = dx0, None, gs_prev, Gs_next
         assert dcur_b is None
         assert wslot.cur == {'f': tf, 'a': ta}
-        abi.colsum_multi([(part_f, dwdb_all[:tf]), (part_a, dwdb_all[tf:total])], stream)
+        # ... and whatever column sums the filter stage left for this launch (functional.PendingSums)
+        abi.colsum_multi([(part_f, dwdb_all[:tf]), (part_a, dwdb_all[tf:total])] + _take_pending(ctx), stream)
         if ctx.owner is not None:
             STACK_FLAT_GRAD[ctx.owner] = dwdb_all
         for idx, (off, no, ki) in slots.items():
             grads[idx] = dwdb_all[off:off + no * ki].view(no, ki)
             if params[idx + 1] is not None:
                 grads[idx + 1] = dwdb_all[off + no * ki:off + no * ki + no]
-        return (dcur.view(n, b, d), None, None, None, None, None, None) + tuple(grads)
+        return (dcur.view(n, b, d), None, None, None, None, None, None, None) + tuple(grads)
 
 
 class FusedLayerNormStackFn(torch.autograd.Function):
@@ -410,10 +412,11 @@ class FusedLayerNormStackFn(torch.autograd.Function):
     flat gradient buffer layout as the BatchNorm stack (parallel.FlatBufferAllReduce)."""
 
     @staticmethod
-    def forward(ctx, src, pe, degree_rows, n_real, layers, need_attn, tail, *params):
+    def forward(ctx, src, pe, degree_rows, n_real, layers, need_attn, tail, pending, *params):
         abi, stream = _lib.backend(src, pe, n_real)
         ctx.set_materialize_grads(False)
         assert tail is None   # (LayerNorm is row-local: its output is materialised by feta_layernorm_fwd)
+        ctx.pending = pending
         if len(layers):
             STACK_FLAT_GRAD.pop(layers[0], None)
         n, b, d = src.shape
@@ -577,24 +580,36 @@ class FusedLayerNormStackFn(torch.autograd.Function):
             abi.rowlin_bwd_ex(dsc, None, stream)
             dcur = dx0
         assert wslot.cur == {'f': tf, 'a': ta}
-        abi.colsum_multi([(part_f, dwdb_all[:tf]), (part_a, dwdb_all[tf:total])], stream)
-        abi.colsum(ln_part, dwdb_all[total:], stream)
+        abi.colsum_multi([(part_f, dwdb_all[:tf]), (part_a, dwdb_all[tf:total]), (ln_part, dwdb_all[total:])]
+                         + _take_pending(ctx), stream)
         if ctx.owner is not None:
             STACK_FLAT_GRAD[ctx.owner] = dwdb_all
         for idx, (off, no, ki) in slots.items():
             grads[idx] = dwdb_all[off:off + no * ki].view(no, ki)
             if params[idx + 1] is not None:
                 grads[idx + 1] = dwdb_all[off + no * ki:off + no * ki + no]
-        return (dcur.view(n, b, d), None, None, None, None, None, None) + tuple(grads)
+        return (dcur.view(n, b, d), None, None, None, None, None, None, None) + tuple(grads)
 
 
-def fused_encoder_stack(src, pe, degree_rows, n_real, layers, need_attn=True, tail=None):
+def _take_pending(ctx):
+    """Column sums the filter stage handed to the stack's reduction launch; from here on its nodes reduce on their
+    own (a node of the stage that autograd schedules after this one)."""
+    pend = ctx.pending
+    if pend is None:
+        return []
+    pend.stack_done = True
+    return pend.take()
+
+
+def fused_encoder_stack(src, pe, degree_rows, n_real, layers, need_attn=True, tail=None, pending=None):
     """-> (output [N,B,d] of the last layer, concat heads of the last layer [N,B,d], attn or None).
     tail (a StackTail, BatchNorm stacks only): the output is the PRE-norm y2 of the last layer and the tail's
-    consumer applies the last BatchNorm (functional.row_linear_cat_bn)."""
+    consumer applies the last BatchNorm (functional.row_linear_cat_bn).
+    pending (a functional.PendingSums whose stack_armed the caller set): the stack's one reduction launch also
+    carries the column sums the filter stage's backward left in it."""
     params = []
     for l in layers:
         params += layer_params(l)
     bn = layers[0].batch_norm
     fn = FusedEncoderStackFn if bn else FusedLayerNormStackFn
-    return fn.apply(src, pe, degree_rows, n_real, list(layers), need_attn, tail if bn else None, *params)
+    return fn.apply(src, pe, degree_rows, n_real, list(layers), need_attn, tail if bn else None, pending, *params)

@@ -249,9 +249,13 @@ class DiffTransformerEncoderGenGCN(nn.Module):
                 if not last:
                     continue
                 output, concat, attn = fused_encoder_stack(output, pe, degree_rows, cache.n_real,
-                                                           self.layers, need_attn=True, tail=tail)
+                                                           self.layers, need_attn=True, tail=tail, pending=pending)
                 if self.keep_stack_boundary:   # for backward_head / backward_stack
                     self._stack_boundary = (output, concat)
+                elif pending is not None and concat.requires_grad:
+                    # one backward pass runs the filter stage and then the stack: the stack's reduction launch takes
+                    # the stage's column sums (two passes: the head gradients must be final when the first returns)
+                    pending.stack_armed = True
                 nn_, bb_, dd_ = concat.shape
                 out_each_head = concat.view(nn_, bb_, self.num_heads, dd_ // self.num_heads).permute(1, 0, 2, 3)
             else:

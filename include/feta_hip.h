@@ -113,7 +113,7 @@ int feta_colsum(const float* in, float* out, int R, int C, feta_stream_t stream)
 /* Several independent column sums in one launch (bias gradients that become available together):
  * out[c] = sum_r in[r*ld + c], r < R, c < C (ld = 0: C); bcast_out (nullable) [bcast_rows, C] additionally
  * receives the result in every row. */
-#define FETA_COLSUM_MAX_SEGS 8
+#define FETA_COLSUM_MAX_SEGS 12
 typedef struct feta_colsum_seg {
   const float* in;
   float* out;

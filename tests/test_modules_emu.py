@@ -302,6 +302,16 @@ def test_deferred_column_sums_and_gradient_accumulation(emu, monkeypatch, own_ge
             for n, p in model.named_parameters():
                 if p.grad is not None:
                     KC.assert_close('accumulated ' + n, p.grad, 2.0 * once[n].double(), tol=1e-5)
+            # a pass that autograd prunes before the layer stack (nobody left to take the sums): end-of-pass flush
+            model.zero_grad(set_to_none=True)
+            out, _, coeff = model(x, edge_index, batch, fi, mask, pe, degree=degree, return_filter_coeff=True,
+                                  graph_cache=cache)
+            enc = model.encoder
+            heads = [enc.linear.bias, enc.gcn.bias, enc.linear_cat.weight, enc.spectral_gnns.bias]
+            names = ['encoder.linear.bias', 'encoder.gcn.bias', 'encoder.linear_cat.weight', 'encoder.spectral_gnns.bias']
+            got = torch.autograd.grad((out * out).sum() + 0.01 * coeff.pow(2).sum(), heads)
+            for nme, gg in zip(names, got):
+                KC.assert_close('pruned pass ' + nme, gg, once[nme].double(), tol=1e-6)
             model.zero_grad(set_to_none=True)
             h = model.encoder.linear.bias.register_hook(lambda g: seen.append(g.clone()))
             run()
