@@ -37,13 +37,27 @@ __host__ __device__ inline int block_lds_floats(int nt, bool attn) {
   const int fin = reduce_scratch_floats(kBlkD);
   const int stg = attn ? kBlkH * 16 * (nr + 1) : 0;  // per-wave probability staging
   f += fin > stg ? fin : stg;
+  f += nr * (nr + 4);                                // pe tile
   return f;
 }
 
 #ifdef FETA_TIMING
-__device__ unsigned long long feta_block_stamps[16];
+// [launch & 3][workgroup / 32][stamp]: s_memrealtime (100 MHz, one clock for the whole chip) of wave 0 of every 32nd
+// workgroup over four consecutive launches: start skew, phase times and the gap between launches (tools/block_timing.py)
+__device__ unsigned long long feta_block_stamps[4 * 8 * 8];
+__device__ unsigned int feta_block_launch;
+#define FETA_STAMP(i)                                                                                   \
+  do {                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    unsigned long long t_;                                                                              \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    if (threadIdx.x == 0 && (blockIdx.x & 31) == 0 && blockIdx.x < 256)                                 \
+      feta_block_stamps[((feta_block_launch & 3) * 8 + (blockIdx.x >> 5)) * 8 + (i)] = t_;              \
+  } while (0)
+#else
+#define FETA_STAMP(i)
 #endif
-#define FETA_STAMP(i) FETA_STAMP_TO(feta_block_stamps, i, blockIdx.x == 0 && threadIdx.x == 0)
 
 template <int NT>
 __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a) {
@@ -55,12 +69,48 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
   float* Os = Xs + NR * P;           // [NR][P]  per-head outputs (concat)
   float* xss = Os + NR * P;          // [2][64]
   float* scr = xss + 2 * D;          // finalize scratch, later the probability staging
+  constexpr int PEP = NR + 4;        // pitch of the pe tile (16-byte operand reads)
+  float* Pe = feta_lds + block_lds_floats(NT, a.attn != nullptr) - NR * PEP;   // [NR][PEP] rows < N
   const bool x_norm = a.x_stats != nullptr || a.x_bn != nullptr;
   FETA_STAMP(0);
 
   // ---- once per workgroup: biases, W_in / W_out into LDS, BatchNorm of the input finalized; the
   // workgroup then walks its graphs (b, b + gridDim.x, ...) with the weights in place - at large
   // batches the 64 KB of weights per graph would otherwise be the largest stream of the kernel
+  // The global loads of the prologue are requested before the first one is consumed (partial statistics, the first
+  // graph's rows, biases, weights: in-order returns): after a kernel boundary each first touch is a ~1-2 us round trip,
+  // and they used to run one after the other.
+  PartialBatch pb;   // (requested unconditionally - a conditionally filled array lives in scratch; G = 0 reads row 0 of
+                     // a tensor that is always there)
+  partials_request(a.x_stats != nullptr ? a.x_stats : a.w_in, a.x_stats != nullptr ? a.Gx : 0, D, pb);
+  const bool has_pe = a.pe != nullptr;
+  constexpr int PEI = (NR * NR + kRowThreads - 1) / kRowThreads;
+  float4 xv[NT];
+  float pel[PEI];
+  float rsv[NT];
+  int n = 0;
+  const int nn = a.N * a.N;
+  // node rows, the graph's pe block as ONE coalesced stream (it is contiguous: N x N floats; every head needs all of
+  // it - four waves gathering their (query, key) pairs 4 bytes at a time took ~2.5 us, and a __syncthreads waits for
+  // every load in flight: vmcnt counts loads and stores alike on gfx9), the degree scale of this lane's rows
+  auto request_graph = [&](int b) {
+    n = a.n_real[b];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int idx = tid + kRowThreads * i, node = idx >> 4, q = idx & 15;
+      const int64_t row = (int64_t)b * a.row_sb + (int64_t)min(node, a.N - 1) * a.row_sn;
+      xv[i] = *reinterpret_cast<const float4*>(a.x + row * D + 4 * q);
+    }
+#pragma unroll
+    for (int i = 0; i < PEI; ++i)
+      pel[i] = has_pe ? a.pe[(int64_t)b * nn + min(tid + kRowThreads * i, nn - 1)] : 1.0f;
+#pragma unroll
+    for (int qb = 0; qb < NT; ++qb) {
+      const int qc = min(16 * qb + lq, a.N - 1);
+      rsv[qb] = a.rowscale != nullptr ? a.rowscale[(int64_t)b * a.row_sb + (int64_t)qc * a.row_sn] : 1.0f;
+    }
+  };
+  request_graph(blockIdx.x);
   float4 bin4[3], bo = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   float bin1 = 0.0f;
 #pragma unroll
@@ -70,30 +120,36 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
   }
   if (a.b_in != nullptr) bin1 = a.b_in[2 * D + DH * h + lq];
   if (a.b_out != nullptr) bo = *reinterpret_cast<const float4*>(a.b_out + DH * h + 4 * g);
-  {  // 256 rows of 16 float4 (W_in then W_out), 16 per thread: all loads, then all LDS writes
-    float4 wv[16];
+  // 256 rows of 16 float4 (W_in then W_out), 16 per thread
+  float4 wv[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int idx = tid + kRowThreads * i, r = idx >> 4, q = idx & 15;
-      const float* src = r < 3 * D ? a.w_in + (int64_t)r * D : a.w_out + (int64_t)(r - 3 * D) * D;
-      wv[i] = *reinterpret_cast<const float4*>(src + 4 * q);
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int idx = tid + kRowThreads * i;
-      *reinterpret_cast<float4*>(Wi + (idx >> 4) * P + 4 * (idx & 15)) = wv[i];
-    }
+  for (int i = 0; i < 16; ++i) {
+    const int idx = tid + kRowThreads * i, r = idx >> 4, q = idx & 15;
+    const float* src = r < 3 * D ? a.w_in + (int64_t)r * D : a.w_out + (int64_t)(r - 3 * D) * D;
+    wv[i] = *reinterpret_cast<const float4*>(src + 4 * q);
   }
+  float xg = 1.0f, xb = 0.0f;
+  if (a.x_stats != nullptr && tid < D) {
+    xg = a.x_gamma[tid];
+    xb = a.x_beta[tid];
+  }
+  // (the weights were requested last: when they are here, so is everything requested before them)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int idx = tid + kRowThreads * i;
+    *reinterpret_cast<float4*>(Wi + (idx >> 4) * P + 4 * (idx & 15)) = wv[i];
+  }
+  FETA_STAMP(6);
   if (a.x_stats != nullptr) {
     // first consumer of fresh statistics: every workgroup finalizes them (redundantly and
     // deterministically); workgroup 0 publishes the parameter block and the running statistics
-    reduce_partials(a.x_stats, a.Gx, D, scr + 2 * D, scr);
+    reduce_partials_finish(a.x_stats, a.Gx, D, pb, scr + 2 * D, scr);
     for (int c = tid; c < D; c += kRowThreads) {
       const float mean = scr[c] / (float)a.M;
       const float var = fmaxf(scr[D + c] / (float)a.M - mean * mean, 0.0f);
       const float rstd = rsqrtf(var + a.eps);
-      const float scale = a.x_gamma[c] * rstd;
-      const float shift = a.x_beta[c] - mean * scale;
+      const float scale = xg * rstd;
+      const float shift = xb - mean * scale;
       xss[c] = scale;
       xss[D + c] = shift;
       if (blockIdx.x == 0) {
@@ -112,34 +168,14 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
   } else if (a.x_bn != nullptr) {
     for (int c = tid; c < 2 * D; c += kRowThreads) xss[c] = a.x_bn[c];
   }
+  FETA_STAMP(7);
   bool first = true;
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-  const int n = a.n_real[b];
-  if (!first) __syncthreads();   // the tiles of the previous graph have been consumed
+  if (!first) {
+    __syncthreads();   // the tiles of the previous graph have been consumed
+    request_graph(b);
+  }
   first = false;
-  // ---- requests of this graph: node rows, pe, degree -------------------------------------------------------
-  float4 xv[NT];
-#pragma unroll
-  for (int i = 0; i < NT; ++i) {
-    const int idx = tid + kRowThreads * i, node = idx >> 4, q = idx & 15;
-    const int64_t row = (int64_t)b * a.row_sb + (int64_t)min(node, a.N - 1) * a.row_sn;
-    xv[i] = *reinterpret_cast<const float4*>(a.x + row * D + 4 * q);
-  }
-  // pe values of this lane's (query, key) pairs, degree scale and biases: requested now, used after the
-  // projections (stores to qkv / attn_stats in between would otherwise pin these loads behind them)
-  const bool has_pe = a.pe != nullptr;
-  float pv[NT][NT][4];
-  float rsv[NT];
-#pragma unroll
-  for (int qb = 0; qb < NT; ++qb) {
-    const int qc = min(16 * qb + lq, a.N - 1);
-    rsv[qb] = a.rowscale != nullptr ? a.rowscale[(int64_t)b * a.row_sb + (int64_t)qc * a.row_sn] : 1.0f;
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        pv[qb][kt][r] = has_pe ? a.pe[((int64_t)b * a.N + qc) * a.N + min(16 * kt + 4 * g + r, a.N - 1)] : 1.0f;
-  }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
@@ -151,6 +187,16 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
       v = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
     }
     *reinterpret_cast<float4*>(Xs + node * P + 4 * q) = v;  // rows >= N: a copy of row N-1, never stored
+  }
+  {
+    const float rn = 1.0f / (float)a.N;
+#pragma unroll
+    for (int i = 0; i < PEI; ++i) {
+      const int idx = tid + kRowThreads * i;
+      // idx / N: (idx + 1/2) / N is at least 1 / (2 N) away from an integer, far beyond the rounding of the product
+      const int qq = (int)(((float)idx + 0.5f) * rn), kk = idx - qq * a.N;
+      if (idx < nn) Pe[qq * PEP + kk] = pel[i];
+    }
   }
   __syncthreads();
   FETA_STAMP(1);
@@ -251,6 +297,18 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
   for (int qb = 0; qb < NT; ++qb) mx[qb] = fmaxf(mx[qb], shfl_xor(mx[qb], 32));
 #pragma unroll
   for (int qb = 0; qb < NT; ++qb) zs[qb] = 0.0f;
+  // pe of this lane's (query lq, keys 4g .. 4g+3) pairs: one 16-byte LDS read per tile pair (columns >= N of the tile
+  // hold whatever was there: those keys are masked by selects)
+  float pv[NT][NT][4];
+#pragma unroll
+  for (int qb = 0; qb < NT; ++qb) {
+    const int qc = min(16 * qb + lq, a.N - 1);
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      const float4 t = *reinterpret_cast<const float4*>(Pe + qc * PEP + 16 * kt + 4 * g);
+      pv[qb][kt][0] = t.x; pv[qb][kt][1] = t.y; pv[qb][kt][2] = t.z; pv[qb][kt][3] = t.w;
+    }
+  }
 #pragma unroll
   for (int kt = 0; kt < NT; ++kt) {
     if (16 * kt >= n) continue;
@@ -259,7 +317,7 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const bool kok = 16 * kt + 4 * g + r < n;
-        const float e = kok ? fast_exp(acc[qb][kt][r] - mx[qb]) * pv[qb][kt][r] : 0.0f;
+        const float e = kok ? fast_exp(acc[qb][kt][r] - mx[qb]) * pv[qb][kt][r] : 0.0f;   // (pv: see below)
         acc[qb][kt][r] = e;
         zs[qb] += e;
       }
@@ -359,6 +417,9 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
   }
   }  // graphs of this workgroup
   FETA_STAMP(5);
+#ifdef FETA_TIMING
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) atomicAdd(&feta_block_launch, 1u);
+#endif
 }
 
 template <int NT>
@@ -379,8 +440,8 @@ int launch_block_fwd(const BlockArgs& a, hipStream_t stream) {
 using namespace feta;
 
 #ifdef FETA_TIMING
-extern "C" int feta_debug_block_stamps(unsigned long long* out16) {
-  return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(feta_block_stamps), sizeof(unsigned long long) * 16);
+extern "C" int feta_debug_block_stamps(unsigned long long* out256) {
+  return (int)hipMemcpyFromSymbol(out256, HIP_SYMBOL(feta_block_stamps), sizeof(unsigned long long) * 256);
 }
 #endif
 

@@ -42,18 +42,39 @@ __device__ __forceinline__ void stage_float4(int count, Src src, Dst dst) {
   }
 }
 
-// sums the G partial pairs [G][2][D] with all 256 threads; on return tot[c], tot[D + c] (LDS)
-// hold the totals.  red: [slices][2][D] scratch.
+// Sum of the G partial pairs [G][2][D] with the first 256 threads; on return tot[c], tot[D + c] (LDS) hold the
+// totals.  red: [slices][2][D] scratch.
+// One partial = 2D contiguous floats = nq float4; thread -> (float4 column q, row slice).  The FIRST batch of rows
+// (kPartialFirst per slice: 128 rows at D = 64 - every partial row of the BASELINE batch) can be requested ahead of
+// everything else a kernel loads (partials_request) and summed later (reduce_partials_finish): after a kernel boundary
+// every first touch is a ~1-2 us round trip to the memory side, and the consumers of fresh BatchNorm statistics used
+// to pay one for their weights, one or two for the partial rows and one for their row tile, one after the other.
+// Further rows are taken kPartialUnroll at a time (independent accumulators), the tail as one clamped batch.
 #ifndef FETA_PARTIAL_UNROLL
 #define FETA_PARTIAL_UNROLL 8
 #endif
-constexpr int kPartialUnroll = FETA_PARTIAL_UNROLL;   // 16-byte loads in flight per thread in reduce_partials
+constexpr int kPartialUnroll = FETA_PARTIAL_UNROLL;   // 16-byte loads in flight per thread beyond the first batch
+constexpr int kPartialFirst = 16;
 
-__device__ __forceinline__ void reduce_partials(const float* part, int G, int D, float* red,
-                                                float* tot) {
-  // one partial = 2D contiguous floats = nq float4; thread -> (float4 column q, slice); rows are
-  // requested kPartialUnroll at a time (independent accumulators), the tail as one clamped batch: every
-  // batch is one memory round trip per consumer workgroup (a scalar loop cost ~10 us per consumer)
+struct PartialBatch {
+  float4 v[kPartialFirst];
+};
+
+__device__ __forceinline__ void partials_request(const float* part, int G, int D, PartialBatch& pb) {
+  const int nq = 2 * D / 4;
+  const int slices = kRowThreads / nq > 0 ? kRowThreads / nq : 1;
+  const int q = threadIdx.x % nq, slice = threadIdx.x / nq;
+  const float4* p4 = reinterpret_cast<const float4*>(part);
+  const bool mine = (int)threadIdx.x < slices * nq;
+#pragma unroll
+  for (int u = 0; u < kPartialFirst; ++u) {
+    const int gr = slice + u * slices;
+    pb.v[u] = p4[(int64_t)((mine && gr < G) ? gr : 0) * nq + (mine ? q : 0)];
+  }
+}
+
+__device__ __forceinline__ void reduce_partials_finish(const float* part, int G, int D, const PartialBatch& pb,
+                                                       float* red, float* tot) {
   const int nq = 2 * D / 4;
   const int slices = kRowThreads / nq > 0 ? kRowThreads / nq : 1;
   const int q = threadIdx.x % nq, slice = threadIdx.x / nq;
@@ -63,7 +84,12 @@ __device__ __forceinline__ void reduce_partials(const float* part, int G, int D,
     float4 s[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) s[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    int gi = slice;
+#pragma unroll
+    for (int u = 0; u < kPartialFirst; ++u) {
+      const float m = slice + u * slices < G ? 1.0f : 0.0f;
+      s[u & 3].x += m * pb.v[u].x; s[u & 3].y += m * pb.v[u].y; s[u & 3].z += m * pb.v[u].z; s[u & 3].w += m * pb.v[u].w;
+    }
+    int gi = slice + kPartialFirst * slices;
     for (; gi + (U - 1) * slices < G; gi += U * slices) {
       float4 v[U];
 #pragma unroll
@@ -99,6 +125,12 @@ __device__ __forceinline__ void reduce_partials(const float* part, int G, int D,
     tot[c] = t;
   }
   __syncthreads();
+}
+
+__device__ __forceinline__ void reduce_partials(const float* part, int G, int D, float* red, float* tot) {
+  PartialBatch pb;
+  partials_request(part, G, D, pb);
+  reduce_partials_finish(part, G, D, pb, red, tot);
 }
 
 __host__ __device__ inline int reduce_red_floats(int D) {
