@@ -130,6 +130,7 @@ class AttnBlock(C.Structure):
 SIGNATURES.update({
     'feta_attn_block_supported': ([C.c_int, C.c_int, C.c_int], C.c_int),
     'feta_attn_block_fwd': ([C.POINTER(AttnBlock), _S], C.c_int),
+    'feta_attn_block_fwd_sums': ([C.POINTER(AttnBlock), C.POINTER(ColsumSeg), C.c_int, _S], C.c_int),
 })
 
 
@@ -441,10 +442,10 @@ class Abi:
         return bool(self.lib.feta_attn_block_supported(n, d_model, heads))
 
     def attn_block_fwd(self, b, n, scale, stream, seq_first=True, momentum=0.1, eps=1e-5, Gx=0, tie_qk=False,
-                       **ptrs):
+                       sums=(), **ptrs):
         """feta_attn_block_fwd; tensor-valued keyword arguments become the descriptor's pointers."""
         self.attn_block_launch(self.attn_block_desc(b, n, scale, seq_first, momentum, eps, Gx, tie_qk, **ptrs),
-                               stream)
+                               stream, sums)
 
     def attn_block_desc(self, b, n, scale, seq_first=True, momentum=0.1, eps=1e-5, Gx=0, tie_qk=False, **ptrs):
         d = AttnBlock()
@@ -456,8 +457,13 @@ class Abi:
                 setattr(d, k, t.data_ptr())
         return d
 
-    def attn_block_launch(self, desc, stream):
-        self._check(self.lib.feta_attn_block_fwd(C.byref(desc), stream), 'feta_attn_block_fwd')
+    def attn_block_launch(self, desc, stream, sums=()):
+        """sums: [(in [R, C], out [C])] column sums that ride in trailing workgroups of the launch"""
+        if sums:
+            self._check(self.lib.feta_attn_block_fwd_sums(C.byref(desc), self._colsum_segs(sums), len(sums), stream),
+                        'feta_attn_block_fwd_sums')
+        else:
+            self._check(self.lib.feta_attn_block_fwd(C.byref(desc), stream), 'feta_attn_block_fwd')
 
     def attn_block_bwd_supported(self, n, d_model, heads):
         return bool(self.lib.feta_attn_block_bwd_supported(n, d_model, heads))

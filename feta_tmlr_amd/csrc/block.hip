@@ -19,6 +19,7 @@
 #include <cstdlib>
 
 #include "feta_abi_common.h"
+#include "feta_colsum.h"
 #include "feta_rowops.h"
 
 namespace feta {
@@ -59,9 +60,16 @@ __device__ unsigned int feta_block_launch;
 #define FETA_STAMP(i)
 #endif
 
+// Workgroups beyond main_grid reduce the column sums of `sums` (feta_colsum.h): the first launch of a forward pass
+// leaves half of the chip idle at the BASELINE batch, and s = colsum(gcn.weight) of the coefficient generator - a
+// function of the parameters alone - would otherwise be a launch of its own (~7 us).
 template <int NT>
-__global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a) {
+__global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a, ColsumPlan sums, int main_grid) {
   constexpr int D = kBlkD, DH = kBlkDH, P = kBlkP, NR = 16 * NT, KP = NR + 1;
+  if ((int)blockIdx.x >= main_grid) {
+    colsum_role<kRowThreads>(sums, (int)blockIdx.x - main_grid);
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6, lq = lane & 15, g = lane >> 4;
   float* Wi = feta_lds;              // [192][P]
   float* Wo = Wi + 3 * D * P;        // [64][P]
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
   }
   FETA_STAMP(7);
   bool first = true;
-  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+  for (int b = blockIdx.x; b < a.B; b += main_grid) {
   if (!first) {
     __syncthreads();   // the tiles of the previous graph have been consumed
     request_graph(b);
@@ -423,7 +431,7 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
 }
 
 template <int NT>
-int launch_block_fwd(const BlockArgs& a, hipStream_t stream) {
+int launch_block_fwd(const BlockArgs& a, const feta_colsum_seg* segs, int nseg, hipStream_t stream) {
   const size_t lds = sizeof(float) * block_lds_floats(NT, a.attn != nullptr);
   auto kern = attn_block_fwd_kernel<NT>;
   static LdsSeen lds_seen;
@@ -431,7 +439,9 @@ int launch_block_fwd(const BlockArgs& a, hipStream_t stream) {
   int cap = kBlkMaxGrid;   // one resident workgroup per CU (LDS); FETA_BLOCK_MAX_GRID: tests force the loop
   if (const char* e = getenv("FETA_BLOCK_MAX_GRID")) cap = atoi(e) > 0 ? atoi(e) : cap;
   const int grid = a.B < cap ? a.B : cap;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kRowThreads), lds, stream, a);
+  ColsumPlan plan{};
+  const int tiles = plan_colsum(segs, nseg, plan);
+  hipLaunchKernelGGL(kern, dim3(grid + tiles), dim3(kRowThreads), lds, stream, a, plan, grid);
   return check_launch("feta_attn_block_fwd");
 }
 
@@ -450,7 +460,15 @@ extern "C" int feta_attn_block_supported(int N, int d_model, int heads) {
 }
 
 extern "C" int feta_attn_block_fwd(const feta_attn_block* d, feta_stream_t stream) {
+  return feta_attn_block_fwd_sums(d, nullptr, 0, stream);
+}
+
+extern "C" int feta_attn_block_fwd_sums(const feta_attn_block* d, const feta_colsum_seg* segs, int nseg,
+                                        feta_stream_t stream) {
   FETA_REQUIRE(d != nullptr, "attn_block_fwd: null descriptor");
+  FETA_REQUIRE(nseg >= 0 && nseg <= FETA_COLSUM_MAX_SEGS && (nseg == 0 || segs != nullptr),
+               "attn_block_fwd: 0..%d column-sum segments", FETA_COLSUM_MAX_SEGS);
+  for (int i = 0; i < nseg; ++i) FETA_REQUIRE(colsum_seg_ok(segs[i]), "attn_block_fwd: bad segment %d", i);
   const BlockArgs& a = *d;
   FETA_REQUIRE(a.x && a.w_in && a.w_out && a.n_real && a.qkv && a.out && a.attn_stats && a.y && a.y_stats,
                "attn_block_fwd: null pointer");
@@ -463,9 +481,9 @@ extern "C" int feta_attn_block_fwd(const feta_attn_block* d, feta_stream_t strea
                "attn_block_fwd: tensors must be 16-byte aligned");
   const int nt = (a.N + 15) / 16;
   switch (nt) {
-    case 1: return launch_block_fwd<1>(a, (hipStream_t)stream);
-    case 2: return launch_block_fwd<2>(a, (hipStream_t)stream);
-    case 3: return launch_block_fwd<3>(a, (hipStream_t)stream);
-    default: return launch_block_fwd<4>(a, (hipStream_t)stream);
+    case 1: return launch_block_fwd<1>(a, segs, nseg, (hipStream_t)stream);
+    case 2: return launch_block_fwd<2>(a, segs, nseg, (hipStream_t)stream);
+    case 3: return launch_block_fwd<3>(a, segs, nseg, (hipStream_t)stream);
+    default: return launch_block_fwd<4>(a, segs, nseg, (hipStream_t)stream);
   }
 }

@@ -106,8 +106,15 @@ class FilterCoefficientsFn(torch.autograd.Function):
         b, h, n, _ = attn.shape
         c = gcn_weight.shape[1]
         dev = attn.device
-        s = torch.empty(c, dtype=torch.float32, device=dev)
-        abi.colsum(gcn_weight.contiguous(), s, stream)
+        if pending is not None and pending.s is not None:
+            s = pending.s                 # requested by the encoder ...
+            left = pending.take_fwd()     # ... and computed inside the layer stack's first launch, or not yet
+            if left:
+                abi.colsum_multi(left, stream)
+            pending.s = None
+        else:
+            s = torch.empty(c, dtype=torch.float32, device=dev)
+            abi.colsum(gcn_weight.contiguous(), s, stream)
         gb = gcn_bias.contiguous()
         cj = torch.empty((h * b, n), dtype=torch.float32, device=dev)
         pooled = torch.empty((h * b, c), dtype=torch.float32, device=dev)
@@ -230,6 +237,10 @@ class PendingSums:
         self.stack_done = False    # ... has not yet: its one reduction launch takes what the stage's last node leaves
         self.items = []
         self._callback_queued = False
+        # forward direction: column sums of parameters that a launch of the layer stack carries in trailing workgroups
+        # (s = colsum(gcn.weight) of the coefficient generator); whoever needs them first runs them if nobody did
+        self.fwd_sums = []
+        self.s = None
 
     @staticmethod
     def untouched(*params):
@@ -255,6 +266,10 @@ class PendingSums:
     def take(self):
         items, self.items = self.items, []
         return items
+
+    def take_fwd(self):
+        sums, self.fwd_sums = self.fwd_sums, []
+        return sums
 
     def _finish_pass(self):
         self._callback_queued = False

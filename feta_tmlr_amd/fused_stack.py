@@ -184,7 +184,8 @@ class FusedEncoderStackFn(torch.autograd.Function):
                 st1 = new(G1, 2, d)
                 abi.attn_block_fwd(b, n, scale, stream, tie_qk=tie, x=y_prev, w_in=w_in, b_in=b_in, w_out=w_o,
                                    b_out=b_o, pe=pe_c, n_real=n_real, rowscale=degree_rows, qkv=qkv, out=out,
-                                   attn_stats=ast, attn=attn, y=y1, y_stats=st1, **bn_prev)
+                                   attn_stats=ast, attn=attn, y=y1, y_stats=st1,
+                                   sums=(pending.take_fwd() if (pending is not None and li == 0) else ()), **bn_prev)
                 st1, G1 = _cap_partials(abi, stream, st1, new)
             else:
                 # F1
@@ -445,7 +446,8 @@ class FusedLayerNormStackFn(torch.autograd.Function):
             if block:
                 abi.attn_block_fwd(b, n, scale, stream, tie_qk=tie, x=x_in, w_in=w_in, b_in=b_in, w_out=w_o,
                                    b_out=b_o, pe=pe_c, n_real=n_real, rowscale=degree_rows, qkv=qkv, out=out,
-                                   attn_stats=ast, attn=attn, y=y1, y_stats=new(b, 2, d))   # (statistics unused)
+                                   attn_stats=ast, attn=attn, y=y1, y_stats=new(b, 2, d),   # (statistics unused)
+                                   sums=(pending.take_fwd() if (pending is not None and li == 0) else ()))
             else:
                 dsc = abi.rowlin_ex(m, d, 3 * d, x=x_in, w=w_in, bias=b_in, y=qkv)
                 abi.rowlin_fwd_ex(dsc, stream)

@@ -240,6 +240,11 @@ class DiffTransformerEncoderGenGCN(nn.Module):
         # (one filter stage per forward only: a parameter that collects several contributions is summed by autograd
         # as they arrive)
         pending = FF.PendingSums() if (not lowp and self.last_layer_filter) else None
+        if (pending is not None and fused and not self.learn_only_filter_order_coeff and self.linear.bias is not None):
+            # s = colsum(gcn.weight) of the coefficient generator: computed by trailing workgroups of the stack's
+            # first launch instead of a launch of its own
+            pending.s = torch.empty(self.gcn.weight.shape[1], dtype=torch.float32, device=src.device)
+            pending.fwd_sums = [(self.gcn.weight.detach(), pending.s)]
         for layer_num, mod in enumerate(self.layers):
             last = layer_num + 1 == self.num_layers
             filt = last or not self.last_layer_filter                            # :169-171

@@ -388,6 +388,11 @@ typedef struct feta_attn_block {
 
 int feta_attn_block_supported(int N, int d_model, int heads);
 int feta_attn_block_fwd(const feta_attn_block* d, feta_stream_t stream);
+/* the same launch with up to FETA_COLSUM_MAX_SEGS independent column sums in trailing workgroups (ABI 6): at the
+ * BASELINE batch the first launch of a forward pass leaves half the chip idle, and s = colsum(gcn.weight) of the
+ * coefficient generator (transformer/models.py:280-282: the GCN only ever sees an all-ones input) depends on the
+ * parameters alone. */
+int feta_attn_block_fwd_sums(const feta_attn_block* d, const feta_colsum_seg* segs, int nseg, feta_stream_t stream);
 
 /* ---- backward of the attention sub-block in ONE launch ------------------------------------------------------
  * (feta_attn_block_bwd_supported: d_model = 64, 4 heads, N <= 64; K not tied to Q.)  Replaces

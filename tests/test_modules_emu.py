@@ -258,8 +258,10 @@ def test_two_phase_backward_equals_single_backward(emu):
         enc.backward_stack()
     got = {n: p.grad for n, p in enc.named_parameters() if p.grad is not None}
     assert set(got) == set(ref)
+    # (not bit-equal: in one pass the stack's reduction launch also carries the filter stage's column sums and runs
+    # as the mixed tall / wide kernel, whose split-K partial rows are added in another - equally fixed - order)
     for n in ref:
-        assert torch.equal(got[n], ref[n]), n
+        KC.assert_close(n, got[n], ref[n].double(), tol=2e-6)
     assert {id(p) for p in enc.head_parameters()} | {id(p) for p in enc.stack_parameters()} == \
         {id(p) for p in enc.parameters()}
 
