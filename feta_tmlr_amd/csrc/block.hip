@@ -43,22 +43,10 @@ __host__ __device__ inline int block_lds_floats(int nt, bool attn) {
 }
 
 #ifdef FETA_TIMING
-// [launch & 3][workgroup / 32][stamp]: s_memrealtime (100 MHz, one clock for the whole chip) of wave 0 of every 32nd
-// workgroup over four consecutive launches: start skew, phase times and the gap between launches (tools/block_timing.py)
-__device__ unsigned long long feta_block_stamps[4 * 8 * 8];
+__device__ unsigned long long feta_block_stamps[4 * 8 * 8];   // FETA_RT_STAMP (feta_rowops.h), tools/block_timing.py
 __device__ unsigned int feta_block_launch;
-#define FETA_STAMP(i)                                                                                   \
-  do {                                                                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                                  \
-    unsigned long long t_;                                                                              \
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                      \
-    __builtin_amdgcn_sched_barrier(0);                                                                  \
-    if (threadIdx.x == 0 && (blockIdx.x & 31) == 0 && blockIdx.x < 256)                                 \
-      feta_block_stamps[((feta_block_launch & 3) * 8 + (blockIdx.x >> 5)) * 8 + (i)] = t_;              \
-  } while (0)
-#else
-#define FETA_STAMP(i)
 #endif
+#define FETA_STAMP(i) FETA_RT_STAMP(feta_block_stamps, feta_block_launch, i)
 
 // Workgroups beyond main_grid reduce the column sums of `sums` (feta_colsum.h): the first launch of a forward pass
 // leaves half of the chip idle at the BASELINE batch, and s = colsum(gcn.weight) of the coefficient generator - a
@@ -425,9 +413,7 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
   }
   }  // graphs of this workgroup
   FETA_STAMP(5);
-#ifdef FETA_TIMING
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) atomicAdd(&feta_block_launch, 1u);
-#endif
+  FETA_RT_LAUNCH_DONE(feta_block_launch);
 }
 
 template <int NT>

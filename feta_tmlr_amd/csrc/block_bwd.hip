@@ -44,6 +44,12 @@ __host__ __device__ inline int block_bwd_lds_floats(int nt, bool gbn) {
          + (gbn ? 5 * kBbD + reduce_scratch_floats(kBbD) : 0);
 }
 
+#ifdef FETA_TIMING
+__device__ unsigned long long feta_bbwd_stamps[4 * 8 * 8];   // FETA_RT_STAMP (feta_rowops.h), tools/block_timing.py
+__device__ unsigned int feta_bbwd_launch;
+#endif
+#define BB_STAMP(i) FETA_RT_STAMP(feta_bbwd_stamps, feta_bbwd_launch, i)
+
 template <int NT, bool SPLIT>
 __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
   constexpr int D = kBbD, DH = kBbDH, H = kBbH, P = kBbP, NR = 16 * NT, PEP = NR + 1;
@@ -73,6 +79,7 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
   const bool has_pe = a.pe != nullptr;
   const bool want_sums = a.sum_out != nullptr;
   const bool xbn = a.bn0 != nullptr;
+  BB_STAMP(0);
 
   // ---- once per workgroup: BatchNorm-1 backward parameters, weight column slices ----------------------------------
   if (gbn) {
@@ -115,6 +122,7 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
   {
     const int b = SPLIT ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;   // one graph per workgroup (SPLIT: per two)
     const int n = a.n_real[b];
+    BB_STAMP(1);
     float sum1[4] = {0.f, 0.f, 0.f, 0.f}, sum2[4] = {0.f, 0.f, 0.f, 0.f};
     auto grow = [&](int node) { return (int64_t)b * a.row_sb + (int64_t)min(node, nm1) * a.row_sn; };
 
@@ -185,6 +193,7 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
       if (idx < NR * NR) PE[(idx / NR) * PEP + idx % NR] = pev[i];
     }
     __syncthreads();
+    BB_STAMP(2);
 
     // ---- dconcat^T tiles (c = 16h + 4g + r, row = 16 rt + lq) = sum_o W_out[o][c] (degree g1)[row][o] (+ dout2) ----
     // (the wave's weight column slices are requested where they are used: held over the whole kernel they cost 64
@@ -210,6 +219,7 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
       *dst = make_float4(acc[0] + d2.x, acc[1] + d2.y, acc[2] + d2.z, acc[3] + d2.w);
     }
     __syncthreads();
+    BB_STAMP(3);
 
     // ---- attention backward (attn_bwd_graph_kernel, attn.hip): role 0 dq over the head's query tiles, role 1 dk / dv
     const int co = DH * h;
@@ -321,6 +331,7 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
         }
       }
     }
+    BB_STAMP(4);
     __syncthreads();   // every wave has taken its operands: the q / k / v tiles become dq / dk / dv
     // SPLIT: the two waves of a (head, role) hold partial sums over their tile pairs: one stores, then the other adds
 #pragma unroll
@@ -347,6 +358,7 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
       __syncthreads();
     }
 
+    BB_STAMP(5);
     // ---- dx^T tiles (k = 16 ktile + 4g + r, row) = sum_o W_in[o][k] dqkv[row][o] (+ g1[row][k]); sums for the previous
     // BatchNorm.  SPLIT: o runs over this pair's columns of dq | dk | dv only (the other columns of the tiles still hold
     // q | k | v of the other pair), the residual belongs to pair 0
@@ -434,6 +446,7 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
       }
     }
 
+    BB_STAMP(6);
     // ---- weight gradients of the graph, contraction over its rows (rows >= N are zero in every tile) -----------------
     // dW_out[o = 16 ktile + 4g' + r][c]: NWO column tiles per wave; dW_in[o][k = 16 ktile + lq]: NWI row tiles per wave
     // (row tile = q | k | v part x head); SPLIT: only this pair's columns / rows
@@ -494,6 +507,8 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
       if (ktile == 0 && g == 0) pbi[64 * wi_part(i) + 16 * wi_head(i) + lq] = s;
     }
   }
+  BB_STAMP(7);
+  FETA_RT_LAUNCH_DONE(feta_bbwd_launch);
 }
 
 template <int NT>
@@ -516,6 +531,12 @@ int launch_block_bwd(const BwdArgs& a, hipStream_t stream) {
 }  // namespace feta
 
 using namespace feta;
+
+#ifdef FETA_TIMING
+extern "C" int feta_debug_bbwd_stamps(unsigned long long* out256) {
+  return (int)hipMemcpyFromSymbol(out256, HIP_SYMBOL(feta_bbwd_stamps), sizeof(unsigned long long) * 256);
+}
+#endif
 
 extern "C" int feta_attn_block_bwd_supported(int N, int d_model, int heads) {
   return (d_model == kBbD && heads == kBbH && N >= 1 && N <= 64) ? 1 : 0;

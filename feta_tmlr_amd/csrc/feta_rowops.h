@@ -14,8 +14,26 @@
     __builtin_amdgcn_sched_barrier(0);                                                  \
     if (cond) arr[i] = t_;                                                              \
   } while (0)
+// s_memrealtime (100 MHz, one clock for the whole chip) of wave 0 of every 32nd workgroup into
+// arr[launch & 3][workgroup / 32][stamp], over four consecutive launches (the last workgroup of a launch bumps the
+// counter): start skew, phase times and the gap between launches
+#define FETA_RT_STAMP(arr, launch, i)                                                                   \
+  do {                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    unsigned long long t_;                                                                              \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    if (threadIdx.x == 0 && (blockIdx.x & 31) == 0 && blockIdx.x < 256)                                 \
+      arr[(((launch) & 3) * 8 + (blockIdx.x >> 5)) * 8 + (i)] = t_;                                     \
+  } while (0)
+#define FETA_RT_LAUNCH_DONE(launch)                                                                     \
+  do {                                                                                                  \
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) atomicAdd(&(launch), 1u);                      \
+  } while (0)
 #else
 #define FETA_STAMP_TO(arr, i, cond)
+#define FETA_RT_STAMP(arr, launch, i)
+#define FETA_RT_LAUNCH_DONE(launch)
 #endif
 
 namespace feta {

@@ -1,6 +1,13 @@
-"""Phase timing inside attn_block_fwd_kernel (s_memtime stamps of workgroup 0, wave 0): builds a
-diagnostic copy of the library with -DFETA_TIMING into tools/_timing/ (git-ignored) and prints the
-cycles between stamps.  Run on the GPU box:  python tools/block_timing.py [--batch 128]"""
+"""Phase timing inside the fused kernels of the layer stack: builds a diagnostic copy of the library with
+-DFETA_TIMING into tools/_timing/ (git-ignored) whose kernels record s_memrealtime (100 MHz, one clock for the
+whole chip) of wave 0 of every 32nd workgroup at their phase boundaries, over four consecutive launches
+(FETA_RT_STAMP, csrc/feta_rowops.h).  Prints the launch-to-launch time of the kernel inside a hipGraph (what a
+captured step pays), the start skew of the workgroups, the gap between consecutive launches and the time of every
+phase.  Run on the GPU box:
+
+    python tools/block_timing.py --kernel fwd            # attn_block_fwd as the stack issues it
+    python tools/block_timing.py --kernel bwd [--split]   # attn_block_bwd, one / two workgroups per graph
+"""
 import argparse
 import ctypes
 import glob
@@ -12,12 +19,23 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from feta_tmlr_amd import _abi   # noqa: E402
+from feta_tmlr_amd import _abi                              # noqa: E402
+from feta_tmlr_amd.benchcases import stack_layer_cases      # noqa: E402
 
 OUT = os.path.join(ROOT, 'tools', '_timing', 'libfeta_timing.so')
 
+KERNELS = {
+    'fwd': ('attn_block_fwd (no attn write)', 'feta_debug_block_stamps',
+            ['prologue loads, weights in LDS', 'statistics final', 'rows + pe staged', 'in_proj', 'attention core',
+             'barrier', 'concat store + out_proj'], [0, 6, 7, 1, 2, 3, 4, 5]),
+    'bwd': ('attn_block_bwd', 'feta_debug_bbwd_stamps',
+            ['BatchNorm-1 sums final', 'graph tiles staged', 'dconcat', 'attention backward', 'barrier + dq/dk/dv tiles',
+             'dx + sums', 'weight gradients'], [0, 1, 2, 3, 4, 5, 6, 7]),
+}
+
 
 def build():
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(ROOT, 'feta_tmlr_amd', 'csrc', '*.hip')))
     cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-DFETA_TIMING',
            '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.join(ROOT, 'feta_tmlr_amd', 'csrc')] + srcs + ['-o', OUT]
@@ -28,9 +46,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=128)
     ap.add_argument('--n-pad', type=int, default=37)
+    ap.add_argument('--kernel', choices=sorted(KERNELS), default='fwd')
+    ap.add_argument('--split', action='store_true', help='bwd: the two-workgroups-per-graph form')
     ap.add_argument('--build-only', action='store_true')
     ap.add_argument('--lib', default=OUT, help='a diagnostic build to load instead (A/B timing of an older source)')
-    ap.add_argument('--no-stats', dest='stats', action='store_false')
     a = ap.parse_args()
     if not os.path.exists(OUT) or a.build_only:
         build()
@@ -40,41 +59,25 @@ def main():
     abi = _abi.bind(lib)
     dev = torch.device('cuda:0')
     b, n, d, h = a.batch, a.n_pad, 64, 4
-    m = b * n
     g = torch.Generator().manual_seed(0)
-    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
     nr = torch.randint(9, n + 1, (b,), generator=g, dtype=torch.int32).to(dev)
-    x, w_in, b_in, w_o, b_o = rnd(m, d), rnd(3 * d, d) / 8, rnd(3 * d), rnd(d, d) / 8, rnd(d)
     pe = torch.rand(b, n, n, generator=g).to(dev)
-    qkv, out = torch.empty(m, 3 * d, device=dev), torch.empty(m, d, device=dev)
-    y, yst = torch.empty(m, d, device=dev), torch.empty(b, 2, d, device=dev)
-    ast = torch.empty(b, h, n, 2, device=dev)
-    deg = torch.rand(m, generator=g).to(dev)
-    st = torch.cuda.current_stream().cuda_stream
-    # as inside the layer stack: the input is seen through the previous BatchNorm, whose statistics this launch
-    # finalizes from the per-block partial sums
-    G = abi.ffn_blocks(m) if a.stats else 0
-    xst = torch.rand(max(G, 1), 2, d, generator=g).to(dev) + 1.0
-    xst[:, 1] += 2.0 * m
-    gam, bet, prm = rnd(d), rnd(d), torch.empty(4, d, device=dev)
-    kw = dict(x_stats=xst, x_gamma=gam, x_beta=bet, x_bn_out=prm) if a.stats else {}
-    print('partial rows of the input statistics:', G)
-    call = lambda: abi.attn_block_fwd(b, n, 0.25, st, Gx=G, x=x, w_in=w_in, b_in=b_in, w_out=w_o, b_out=b_o, pe=pe,
-                                      n_real=nr, rowscale=deg, qkv=qkv, out=out, attn_stats=ast, attn=None, y=y,
-                                      y_stats=yst, **kw)
-    for _ in range(5):
-        call()
-    torch.cuda.synchronize()
-    # eight launches back to back inside one hipGraph (what a captured step issues)
+    case, getter, names, order = KERNELS[a.kernel]
+    split = a.kernel == 'bwd' and a.split
+    if split:
+        case = 'attn_block_bwd (two workgroups per graph)'
     s2 = torch.cuda.Stream()
     with torch.cuda.stream(s2):
         st = s2.cuda_stream
-        call()
+        fn = {nm: f for nm, _, f, _, _ in stack_layer_cases(abi, st, dev, b, n, d, h, 2 * d, pe, nr)}[case]
+        for _ in range(5):
+            fn()
         torch.cuda.synchronize()
+        # eight launches back to back inside one hipGraph (what a captured step issues)
         gr = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gr, stream=s2):
             for _ in range(8):
-                call()
+                fn()
     gr.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -83,32 +86,29 @@ def main():
         gr.replay()
     e1.record()
     torch.cuda.synchronize()
-    print('launch-to-launch inside the graph: %.2f us' % (e0.elapsed_time(e1) / 160 * 1e3))
+    print('%s: launch-to-launch inside the graph %.2f us' % (case, e0.elapsed_time(e1) / 160 * 1e3))
     buf = (ctypes.c_ulonglong * 256)()
-    lib.feta_debug_block_stamps(buf)
+    getattr(lib, getter)(buf)
     t = [[[buf[(l * 8 + w) * 8 + i] for i in range(8)] for w in range(8)] for l in range(4)]
-    nwg = (b + 31) // 32
-    names = ['loads + staging + finalize', 'in_proj', 'attention core', 'barrier wait', 'concat store + out_proj']
-    order = sorted(range(4), key=lambda l: t[l][0][0])      # the ring of the last four launches, oldest first
+    grid = 2 * b if split else b
+    nwg = min(8, (min(grid, 256) + 31) // 32)
+    first, last = order[0], order[-1]
+    ring = sorted(range(4), key=lambda l: t[l][0][first])      # the last four launches, oldest first
     tick = 0.01   # us per s_memrealtime tick (100 MHz)
-    print('n_real[0] =', int(nr[0]))
-    for li, l in enumerate(order):
-        t0 = min(t[l][w][0] for w in range(nwg))
-        t5 = max(t[l][w][5] for w in range(nwg))
-        line = 'launch %d: first stamp -> last stamp %.2f us; workgroup starts (us after the first): %s' % (
-            li, (t5 - t0) * tick, ' '.join('%.2f' % ((t[l][w][0] - t0) * tick) for w in range(nwg)))
-        print(line)
+    for li, l in enumerate(ring):
+        t0 = min(t[l][w][first] for w in range(nwg))
+        t5 = max(t[l][w][last] for w in range(nwg))
+        print('launch %d: first stamp -> last stamp %.2f us; workgroup starts (us after the first): %s' % (
+            li, (t5 - t0) * tick, ' '.join('%.2f' % ((t[l][w][first] - t0) * tick) for w in range(nwg))))
         if li > 0:
-            prev = order[li - 1]
+            prev = ring[li - 1]
             print('   gap to the previous launch (its last stamp -> this first stamp): %.2f us' %
-                  ((t0 - max(t[prev][w][5] for w in range(nwg))) * tick))
-    l = order[-1]
+                  ((t0 - max(t[prev][w][last] for w in range(nwg))) * tick))
+    l = ring[-1]
     for w in range(nwg):
-        print('workgroup %3d: weights in LDS %.2f, statistics final %.2f, rows staged %.2f |' % (
-            32 * w, (t[l][w][6] - t[l][w][0]) * tick, (t[l][w][7] - t[l][w][6]) * tick, (t[l][w][1] - t[l][w][7]) * tick), end=' ')
-        print('workgroup %3d: %s   total %.2f us' % (32 * w, '  '.join(
-            '%s %.2f' % (nm.split()[0], (t[l][w][i + 1] - t[l][w][i]) * tick) for i, nm in enumerate(names)),
-            (t[l][w][5] - t[l][w][0]) * tick))
+        print('workgroup %3d (n = %2d):' % (32 * w, int(nr[(32 * w) // (2 if split else 1)])),
+              ' | '.join('%s %.2f' % (nm, (t[l][w][order[i + 1]] - t[l][w][order[i]]) * tick) for i, nm in enumerate(names)),
+              ' | total %.2f us' % ((t[l][w][last] - t[l][w][first]) * tick))
 
 
 if __name__ == '__main__':
