@@ -282,7 +282,7 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
       }
     } else {
       Feat<DH> qf[NT], dof[NT];
-      float qb4[NT][4], dob[NT][4], sd[NT][4];
+      float qb4[NT][4], dob[NT][4], sd[NT][4], mq[NT][4], rz[NT][4];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int rowl = 16 * t + lq;
@@ -300,6 +300,12 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
           qb4[t][r] = ok ? Qs[rr * P + co + lq] * a.scale : 0.0f;
           dob[t][r] = ok ? dvv : 0.0f;
           sd[t][r] = row16_sum(ok ? dvv * Os[rr * P + co + lq] : 0.0f);   // delta[q = 4g + r]
+          // softmax statistics of the query: once per query, not once per (query, key tile) - the division alone is
+          // a dozen instructions and this role is the one the other waves wait for
+          const float z = ST[(h * NR + rr) * 2 + 1];
+          mq[t][r] = ST[(h * NR + rr) * 2];
+          rz[t][r] = ok ? 1.0f / fmaxf(z, 1e-6f) : 0.0f;
+          if (z < 1e-6f) sd[t][r] = 0.0f;
         }
       }
 #pragma unroll
@@ -321,10 +327,8 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int q = 16 * qb + 4 * g + r;
-            const float m = ST[(h * NR + q) * 2], z = ST[(h * NR + q) * 2 + 1];
-            const bool ok = q < a.N && key < n;
-            const float p = ok ? fast_exp(s[r] - m) * PE[q * PEP + key] * (1.0f / fmaxf(z, 1e-6f)) : 0.0f;
-            const float ds = p * (da[r] - (z < 1e-6f ? 0.0f : sd[qb][r]));
+            const float p = key < n ? fast_exp(s[r] - mq[qb][r]) * PE[q * PEP + key] * rz[qb][r] : 0.0f;   // rz = 0: q >= N
+            const float ds = p * (da[r] - sd[qb][r]);
             r1[kt] = mfma16(p, dob[qb][r], r1[kt]);    // dv (key 4g+r, c lq)
             r0[kt] = mfma16(ds, qb4[qb][r], r0[kt]);   // dk
           }
