@@ -397,7 +397,10 @@ def roofline(args, gpu, dev):
                      lambda: abi.spec_filter_bwd(xs, u, lam, coeff, nr, dys, dxs, dcoeff, dbp, p, 1, st),
                      spec_bytes(b, n, h, dh, k_eig, p, sum_n, True)))
     r_ = h * b
-    if abi.lin_supported(r_, c, c):   # the C x C linear of the coefficient generator (csrc/lin.hip)
+    from feta_tmlr_amd import functional as FF
+    if abi.lin_supported(r_, c, c) and r_ * c * c <= FF.LIN_OWN_GEMM_MAX_MACS:
+        # the C x C linear of the coefficient generator runs as csrc/lin.hip at this size (else: library GEMMs, which
+        # are not candidates - the roofline object prices the hand-written kernels)
         lw, lb, lx, ldy = rnd(c, c) / c ** 0.5, rnd(c), rnd(r_, c), rnd(r_, c)
         ly, ldx, ldw, ldb = (torch.empty(r_, c, device=dev), torch.empty(r_, c, device=dev),
                              torch.empty(c, c, device=dev), torch.empty(c, device=dev))
