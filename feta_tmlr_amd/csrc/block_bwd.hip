@@ -54,7 +54,10 @@ template <int NT, bool SPLIT>
 __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
   constexpr int D = kBbD, DH = kBbDH, H = kBbH, P = kBbP, NR = 16 * NT, PEP = NR + 1;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lq = lane & 15, g = lane >> 4;
-  const int hp = SPLIT ? (int)(blockIdx.x & 1) : 0;          // pair of heads of this workgroup
+  // pair of heads of this workgroup: workgroups b and b + B share a graph - and, workgroups being dealt round-robin to
+  // the 8 XCDs, an L2 when B is a multiple of 8 (adjacent workgroups never do: both would fetch the graph's tiles from
+  // HBM, 1.5x the algorithmic bytes by the counters)
+  const int hp = SPLIT ? ((int)blockIdx.x >= a.B ? 1 : 0) : 0;
   // attention part: wave = (head, role) - and, SPLIT, the parity of the tiles it walks
   const int h = SPLIT ? 2 * hp + (wv & 1) : (wv & 3);
   const int role = SPLIT ? ((wv >> 1) & 1) : (wv >> 2);
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
   }
   const int nm1 = a.N - 1;
   {
-    const int b = SPLIT ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;   // one graph per workgroup (SPLIT: per two)
+    const int b = (int)blockIdx.x - hp * a.B;   // one graph per workgroup (SPLIT: per two)
     const int n = a.n_real[b];
     BB_STAMP(1);
     float sum1[4] = {0.f, 0.f, 0.f, 0.f}, sum2[4] = {0.f, 0.f, 0.f, 0.f};
