@@ -35,6 +35,7 @@ struct FfnBwdGeom {
   int RC;   // row chunks of the weight gradient (feta_rowlin_chunks)
   int per;  // 16-row blocks per chunk
   int NS;   // hidden-unit slices per chunk
+  int xcd;  // 1: XCD-aware order of the workgroups (see ffn_bwd_kernel)
 };
 
 inline int ffn_bwd_xblocks(int M) {
@@ -62,6 +63,23 @@ template <int FF>
 __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, FfnBwdGeom ge) {
   constexpr int D = kFbD, NJ2 = FF / 16;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lq = lane & 15, g = lane >> 4;
+  // Which piece of work this workgroup is.  A 64-row chunk is touched by six workgroups (its two X-role blocks and the
+  // four hidden-unit slices of the W role), and workgroups are dealt round-robin to the 8 XCDs, each with its own L2:
+  // in launch order (X blocks, then W slices) the six sat on up to six XCDs and the chunk's rows of dy, y2, y1 left HBM
+  // up to six times (2.3x the algorithmic bytes by the counters).  With ge.xcd the grid is read as
+  // (chunk group, item, XCD): all six items of chunk 8 * group + XCD run on that XCD.
+  int xblk, wbi;
+  if (ge.xcd) {
+    const int xcd = (int)blockIdx.x & 7, v = (int)blockIdx.x >> 3, items = 2 + ge.NS;
+    const int item = v % items, rc = (v / items) * 8 + xcd;
+    if (rc >= ge.RC) return;
+    xblk = item < 2 ? 2 * rc + item : -1;
+    wbi = item < 2 ? -1 : rc * ge.NS + (item - 2);
+    if (item < 2 && xblk >= ge.XB) return;
+  } else {
+    xblk = (int)blockIdx.x < ge.XB ? (int)blockIdx.x : -1;
+    wbi = (int)blockIdx.x - ge.XB;
+  }
   float* gv = feta_lds;   // [5][64]
   float* after = gv;
   const bool gbn = a.g_y != nullptr;
@@ -95,7 +113,7 @@ __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, Ffn
     __syncthreads();
   }
 
-  if ((int)blockIdx.x < ge.XB) {
+  if (xblk >= 0) {
     // ================================ X role: dh tile -> dx1 ================================================
     constexpr int GP = D + 4, DP = FF + 4, CT2 = FF / 64;   // CT2 column tiles of dh per wave
     float* gt = after;              // [32][GP]  g2
@@ -125,9 +143,9 @@ __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, Ffn
     float sum1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, sum2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const int nblk = (a.M + kFbRows - 1) / kFbRows;
     const int row_last = a.M - 1;
-    for (int blk = blockIdx.x; blk < nblk; blk += ge.XB) {
+    for (int blk = xblk; blk < nblk; blk += ge.XB) {
       const int r0 = blk * kFbRows;
-      if (blk != (int)blockIdx.x) __syncthreads();   // the tiles of the previous block have been consumed
+      if (blk != xblk) __syncthreads();   // the tiles of the previous block have been consumed
       // requests of the block: gradient tile (2 items per thread), relu operands, residual rows of the sums
       float4 dv[2], yv[2];
 #pragma unroll
@@ -210,8 +228,8 @@ __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, Ffn
       for (int r = 0; r < 4; ++r) {
         const float s1 = row16_sum(sum1[r]), s2 = row16_sum(sum2[r]);
         if (lq == 0) {
-          a.sum_out[((int64_t)blockIdx.x * 2 + 0) * D + 16 * w + 4 * g + r] = s1;
-          a.sum_out[((int64_t)blockIdx.x * 2 + 1) * D + 16 * w + 4 * g + r] = s2;
+          a.sum_out[((int64_t)xblk * 2 + 0) * D + 16 * w + 4 * g + r] = s1;
+          a.sum_out[((int64_t)xblk * 2 + 1) * D + 16 * w + 4 * g + r] = s2;
         }
       }
     }
@@ -220,7 +238,7 @@ __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, Ffn
 
   // ================================== W role: dW2 | db2 | dW1 | db1 of one (chunk, hidden slice) ===================
   constexpr int GPW = D + 16, HP = kFbSlice + 16;
-  const int bi = blockIdx.x - ge.XB;
+  const int bi = wbi;
   const int si = bi % ge.NS, rc = bi / ge.NS;
   const int c0 = kFbSlice * si;
   float* gt = after;             // [64][GPW] g2
@@ -361,7 +379,12 @@ int launch_ffn_bwd(const FfnGradArgs& a, hipStream_t stream) {
   auto kern = ffn_bwd_kernel<FF>;
   static LdsSeen seen;
   allow_dynamic_lds(kern, lds, seen);
-  hipLaunchKernelGGL(kern, dim3(ge.XB + ge.RC * ge.NS), dim3(kRowThreads), lds, stream, a, ge);
+  // XCD-aware order: every 32-row block has its own X-role workgroup and a chunk is exactly two of them
+  const int nblk = (a.M + kFbRows - 1) / kFbRows;
+  ge.xcd = (ge.XB == nblk && ge.per == 4) ? 1 : 0;
+  if (const char* e = getenv("FETA_FFN_BWD_XCD")) ge.xcd = ge.xcd && atoi(e) != 0;
+  const int grid = ge.xcd ? 8 * ((ge.RC + 7) / 8) * (2 + ge.NS) : ge.XB + ge.RC * ge.NS;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kRowThreads), lds, stream, a, ge);
   return check_launch("feta_ffn_bwd");
 }
 
