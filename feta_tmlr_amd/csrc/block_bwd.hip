@@ -338,6 +338,34 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
         }
       }
     }
+    // ---- dW_out = (degree g1)^T out and db_out: independent of the attention results, so the dq waves - which finish
+    // well before the dk / dv waves (their set-up alone is twice as long) - take them while they would otherwise wait
+    // at the barrier: o tile `ot` per wave, every column tile of this workgroup's heads
+    constexpr int NWO = SPLIT ? 2 : 4;
+    float* prow = a.partial + (int64_t)b * (a.partial_ld > 0 ? (int64_t)a.partial_ld : (int64_t)(4 * D * D + 4 * D));
+    if (role == 0) {
+      const int ot = SPLIT ? (wv & 1) + 2 * (wv >> 2) : (wv & 3);
+      f32x4 aWo[NWO];
+#pragma unroll
+      for (int i = 0; i < NWO; ++i) aWo[i] = zero4();
+      float dbo = 0.0f;
+#pragma unroll 2
+      for (int st = 0; st < NR / 4; ++st) {
+        const int rr = 4 * st + g;
+        const float ga = RS[rr] * Gt[rr * P + 16 * ot + lq];   // (degree g1)[row][o = 16 ot + lq]
+        dbo += ga;
+#pragma unroll
+        for (int i = 0; i < NWO; ++i) aWo[i] = mfma16(ga, Os[rr * P + 16 * (SPLIT ? 2 * hp + i : i) + lq], aWo[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < NWO; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          prow[(int64_t)(16 * ot + 4 * g + r) * D + 16 * (SPLIT ? 2 * hp + i : i) + lq] = aWo[i][r];
+      dbo += shfl_xor(dbo, 16);
+      dbo += shfl_xor(dbo, 32);
+      if (hp == 0 && g == 0) prow[D * D + 16 * ot + lq] = dbo;
+    }
     BB_STAMP(4);
     __syncthreads();   // every wave has taken its operands: the q / k / v tiles become dq / dk / dv
     // SPLIT: the two waves of a (head, role) hold partial sums over their tile pairs: one stores, then the other adds
@@ -454,31 +482,22 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
     }
 
     BB_STAMP(6);
-    // ---- weight gradients of the graph, contraction over its rows (rows >= N are zero in every tile) -----------------
-    // dW_out[o = 16 ktile + 4g' + r][c]: NWO column tiles per wave; dW_in[o][k = 16 ktile + lq]: NWI row tiles per wave
-    // (row tile = q | k | v part x head); SPLIT: only this pair's columns / rows
-    constexpr int NWO = SPLIT ? 1 : 2, NWI = SPLIT ? 3 : 6;
+    // ---- dW_in of the graph, contraction over its rows (rows >= N are zero in every tile): dW_in[o][k = 16 ktile + lq],
+    // NWI row tiles per wave (row tile = q | k | v part x head); SPLIT: only this pair's rows
+    constexpr int NWI = SPLIT ? 3 : 6;
     const int grp = wv >> 2;
-    f32x4 aWo[NWO], aWi[NWI];
+    f32x4 aWi[NWI];
     float dbi[NWI];
-#pragma unroll
-    for (int i = 0; i < NWO; ++i) aWo[i] = zero4();
 #pragma unroll
     for (int i = 0; i < NWI; ++i) {
       aWi[i] = zero4();
       dbi[i] = 0.0f;
     }
-    float dbo = 0.0f;
-    auto wo_ct = [&](int i) { return SPLIT ? 2 * hp + grp : 2 * grp + i; };          // column tile of dW_out
     auto wi_part = [&](int i) { return SPLIT ? (3 * grp + i) >> 1 : (6 * grp + i) >> 2; };
     auto wi_head = [&](int i) { return SPLIT ? 2 * hp + ((3 * grp + i) & 1) : ((6 * grp + i) & 3); };
     for (int st = 0; st < NR / 4; ++st) {
       const int rr = 4 * st + g;
-      const float ga = RS[rr] * Gt[rr * P + 16 * ktile + lq];       // (degree g1)[row][o = 16 ktile + lq]
       const float xb = X0[rr * P + 16 * ktile + lq] * sc0 + sh0;    // x0 through its BatchNorm, [row][k = 16 ktile + lq]
-      dbo += ga;
-#pragma unroll
-      for (int i = 0; i < NWO; ++i) aWo[i] = mfma16(ga, Os[rr * P + 16 * wo_ct(i) + lq], aWo[i]);
 #pragma unroll
       for (int i = 0; i < NWI; ++i) {
         const int part = wi_part(i);
@@ -489,23 +508,13 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
       }
     }
     // ---- partial row of this graph: [dW_out (64 x 64) | db_out (64) | dW_in (192 x 64) | db_in (192)] --------------
-    float* p = a.partial + (int64_t)b * (a.partial_ld > 0 ? (int64_t)a.partial_ld : (int64_t)(4 * D * D + 4 * D));
-    float* pWo = p;
-    float* pbo = p + D * D;
-    float* pWi = pbo + D;
+    float* pWi = prow + D * D + D;
     float* pbi = pWi + 3 * D * D;
-#pragma unroll
-    for (int i = 0; i < NWO; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) pWo[(int64_t)(16 * ktile + 4 * g + r) * D + 16 * wo_ct(i) + lq] = aWo[i][r];
 #pragma unroll
     for (int i = 0; i < NWI; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         pWi[(int64_t)(64 * wi_part(i) + 16 * wi_head(i) + 4 * g + r) * D + 16 * ktile + lq] = aWi[i][r];
-    dbo += shfl_xor(dbo, 16);
-    dbo += shfl_xor(dbo, 32);
-    if (grp == 0 && hp == 0 && g == 0) pbo[16 * ktile + lq] = dbo;
 #pragma unroll
     for (int i = 0; i < NWI; ++i) {
       float s = dbi[i];
