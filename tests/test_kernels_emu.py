@@ -1,6 +1,8 @@
 """The kernel sources (feta_tmlr_amd/csrc/*.hip) compiled for the host by tools/simt and
 checked against the oracle through the C ABI - no GPU needed.  The same checks run on the
 MI355X in test_kernels_gpu.py."""
+import os
+
 import pytest
 import torch
 
@@ -177,9 +179,11 @@ def test_eigh_sym_rejects_large_n(emu):
                      None, 0, 0.0, None)
 
 
+@pytest.mark.skipif(not os.environ.get('FETA_SLOW_TESTS'), reason='~1 min in the host emulation (512 fibers x ~10^3 '
+                    'rotation rounds); the GPU suite runs this variant on the 222- and 256-node buckets')
 def test_eigh_sym_workspace_variant(emu):
     """192 < N <= 256: the matrix lives in the caller's workspace instead of LDS (molhiv's 222-node bucket)"""
-    KC.check_eigh(emu, CPU, None, 'molhiv', 2, 0, 150, 222, 222)
+    KC.check_eigh(emu, CPU, None, 'molhiv', 1, 0, 200, 200, 200)
 
 
 @pytest.mark.parametrize('kind,zero_diag,from_device', [('diffusion', False, True), ('pstep', True, True),
