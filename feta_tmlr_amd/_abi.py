@@ -135,6 +135,18 @@ SIGNATURES.update({
 
 
 
+class CoeffFwdRole(C.Structure):
+    """struct feta_coeff_fwd_role (include/feta_hip.h)."""
+    _fields_ = [('attn', _F), ('n_real', _I), ('s', _F), ('gcn_bias', _F), ('cj', _F), ('pooled', _F),
+                ('B', C.c_int), ('N', C.c_int), ('H', C.c_int), ('C', C.c_int)]
+
+
+class CoeffBwdRole(C.Structure):
+    """struct feta_coeff_bwd_role (include/feta_hip.h)."""
+    _fields_ = [('cj', _F), ('n_real', _I), ('s', _F), ('gcn_bias', _F), ('dpooled', _F), ('partial', _F),
+                ('B', C.c_int), ('N', C.c_int), ('H', C.c_int), ('C', C.c_int)]
+
+
 class Ffn(C.Structure):
     """struct feta_ffn (include/feta_hip.h) - field order must match the header."""
     _fields_ = [
@@ -150,6 +162,7 @@ SIGNATURES.update({
     'feta_ffn_supported': ([C.c_int, C.c_int], C.c_int),
     'feta_ffn_blocks': ([C.c_int], C.c_int),
     'feta_ffn_fwd': ([C.POINTER(Ffn), _S], C.c_int),
+    'feta_ffn_fwd_coeff': ([C.POINTER(Ffn), C.POINTER(CoeffFwdRole), _S], C.c_int),
 })
 
 class AttnBlockGrad(C.Structure):
@@ -183,6 +196,7 @@ SIGNATURES.update({
     'feta_ffn_bwd_supported': ([C.c_int, C.c_int], C.c_int),
     'feta_ffn_bwd_blocks': ([C.c_int], C.c_int),
     'feta_ffn_bwd': ([C.POINTER(FfnGrad), _S], C.c_int),
+    'feta_ffn_bwd_coeff': ([C.POINTER(FfnGrad), C.POINTER(CoeffBwdRole), _S], C.c_int),
 })
 
 ABI_VERSION = 6
@@ -489,9 +503,10 @@ class Abi:
     def ffn_blocks(self, m):
         return int(self.lib.feta_ffn_blocks(m))
 
-    def ffn_fwd(self, m, ff, stream, momentum=0.1, eps=1e-5, Gx=0, **ptrs):
-        """feta_ffn_fwd; tensor-valued keyword arguments become the descriptor's pointers."""
-        self.ffn_launch(self.ffn_desc(m, ff, momentum, eps, Gx, **ptrs), stream)
+    def ffn_fwd(self, m, ff, stream, momentum=0.1, eps=1e-5, Gx=0, coeff=None, **ptrs):
+        """feta_ffn_fwd; tensor-valued keyword arguments become the descriptor's pointers.  coeff (optional): the
+        arguments of coeff_fwd as a tuple - the coefficient generator's forward rides in trailing workgroups."""
+        self.ffn_launch(self.ffn_desc(m, ff, momentum, eps, Gx, **ptrs), stream, coeff)
 
     def ffn_desc(self, m, ff, momentum=0.1, eps=1e-5, Gx=0, **ptrs):
         d = Ffn()
@@ -501,8 +516,16 @@ class Abi:
                 setattr(d, k, t.data_ptr())
         return d
 
-    def ffn_launch(self, desc, stream):
-        self._check(self.lib.feta_ffn_fwd(C.byref(desc), stream), 'feta_ffn_fwd')
+    def ffn_launch(self, desc, stream, coeff=None):
+        if coeff is None:
+            self._check(self.lib.feta_ffn_fwd(C.byref(desc), stream), 'feta_ffn_fwd')
+            return
+        attn, n_real, s, gcn_bias, cj, pooled = coeff
+        b, h, n, _ = attn.shape
+        r = CoeffFwdRole()
+        r.attn, r.n_real, r.s, r.gcn_bias, r.cj, r.pooled = (t.data_ptr() for t in (attn, n_real, s, gcn_bias, cj, pooled))
+        r.B, r.N, r.H, r.C = b, n, h, s.shape[0]
+        self._check(self.lib.feta_ffn_fwd_coeff(C.byref(desc), C.byref(r), stream), 'feta_ffn_fwd_coeff')
 
     def ffn_bwd_supported(self, d_model, ff):
         return bool(self.lib.feta_ffn_bwd_supported(d_model, ff))
@@ -520,12 +543,21 @@ class Abi:
                 setattr(d, k, t.data_ptr())
         return d
 
-    def ffn_bwd_launch(self, desc, stream):
-        self._check(self.lib.feta_ffn_bwd(C.byref(desc), stream), 'feta_ffn_bwd')
+    def ffn_bwd_launch(self, desc, stream, coeff=None):
+        if coeff is None:
+            self._check(self.lib.feta_ffn_bwd(C.byref(desc), stream), 'feta_ffn_bwd')
+            return
+        cj, n_real, s, gcn_bias, dpooled, partial, b, n, h = coeff
+        r = CoeffBwdRole()
+        r.cj, r.n_real, r.s, r.gcn_bias, r.dpooled, r.partial = (t.data_ptr() for t in
+                                                                (cj, n_real, s, gcn_bias, dpooled, partial))
+        r.B, r.N, r.H, r.C = b, n, h, s.shape[0]
+        self._check(self.lib.feta_ffn_bwd_coeff(C.byref(desc), C.byref(r), stream), 'feta_ffn_bwd_coeff')
 
-    def ffn_bwd(self, m, ff, stream, **kw):
-        """feta_ffn_bwd; tensor-valued keyword arguments become the descriptor's pointers."""
-        self.ffn_bwd_launch(self.ffn_bwd_desc(m, ff, **kw), stream)
+    def ffn_bwd(self, m, ff, stream, coeff=None, **kw):
+        """feta_ffn_bwd; tensor-valued keyword arguments become the descriptor's pointers.  coeff (optional): the
+        arguments of coeff_bwd as a tuple - the coefficient generator's backward kernel rides in trailing workgroups."""
+        self.ffn_bwd_launch(self.ffn_bwd_desc(m, ff, **kw), stream, coeff)
 
     def bn_apply_fwd_prm(self, y, stats, gamma, beta, out, bn_prm, running_mean, running_var, momentum,
                          eps, stream, nbt=None):

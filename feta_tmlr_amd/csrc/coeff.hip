@@ -12,174 +12,23 @@
 
 #include "feta_abi_common.h"
 #include <feta_device.h>
+#include "feta_coeff.h"
 #include "feta_colsum.h"
 
 namespace feta {
-
-constexpr int kCoeffThreads = 256;
-constexpr int kCoeffGroupsMax = 128;
-constexpr int kCoeffLdsTileMax = 12 * 1024;  // floats of attention staged per block (48 KB)
 
 __global__ __launch_bounds__(kCoeffThreads) void coeff_fwd_kernel(
     const float* __restrict__ attn, const int32_t* __restrict__ n_real, const float* __restrict__ s,
     const float* __restrict__ gbias, float* __restrict__ cj_out, float* __restrict__ pooled, int B,
     int N, int H, int C, int stage) {
-  float* dis = feta_lds;            // [N]
-  float* cjs = feta_lds + N;        // [N]
-  float* ps = feta_lds + 2 * N;     // [4][64] column partial sums (staged path)
-  float* tile = ps + 4 * 64;        // [n][N] when staged
-  const int blk = blockIdx.x;       // h * B + b  (transformer/models.py:244,275,285)
-  const int h = blk / B, b = blk % B;
-  const int n = n_real[b];
-  const float* a = attn + ((int64_t)b * H + h) * N * N;
-  const int j = threadIdx.x;
-
-  if (stage && N <= 64) {
-    // the block's attention rows in ONE batch of requests (16 per thread cover 64 x 64), then
-    // both column sweeps with all 256 threads: thread (column j, slice sl) takes rows i = sl mod 4
-    const int cnt = n * N;
-    float v[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int idx = threadIdx.x + u * kCoeffThreads;
-      v[u] = a[idx < cnt ? idx : (cnt > 0 ? cnt - 1 : 0)];
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int idx = threadIdx.x + u * kCoeffThreads;
-      if (idx < cnt) tile[idx] = v[u];
-    }
-    __syncthreads();
-    const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    // edges with attn == 0 are dropped (models.py:276,281): they add nothing to the sums,
-    // but a dropped self loop is re-created with weight 1 by add_remaining_self_loops.
-    float wjj = 0.0f;
-    if (col < n) {
-      wjj = tile[col * N + col];
-      if (wjj == 0.0f) wjj = 1.0f;
-    }
-    float part = 0.0f;
-    if (col < n)
-      for (int i = sl; i < n; i += 4) part += (i == col) ? wjj : tile[i * N + col];
-    ps[sl * 64 + col] = part;
-    __syncthreads();
-    if (sl == 0 && col < n) {
-      const float deg = (ps[col] + ps[64 + col]) + (ps[128 + col] + ps[192 + col]);
-      dis[col] = deg > 0.0f ? rsqrtf(deg) : 0.0f;
-    }
-    __syncthreads();
-    part = 0.0f;
-    if (col < n)
-      for (int i = sl; i < n; i += 4) part += dis[i] * ((i == col) ? wjj : tile[i * N + col]);
-    __syncthreads();   // ps is reused
-    ps[sl * 64 + col] = part;
-    __syncthreads();
-    if (sl == 0 && col < N) {
-      float c = 0.0f;
-      if (col < n) c = ((ps[col] + ps[64 + col]) + (ps[128 + col] + ps[192 + col])) * dis[col];
-      cjs[col] = c;
-      cj_out[(int64_t)blk * N + col] = c;
-    }
-    __syncthreads();
-  } else {
-    const float* src = a;
-    if (stage) {
-      // eight requests in flight per thread (a plain copy loop pays one memory latency per 256 floats)
-      const int cnt = n * N;
-      for (int base = threadIdx.x; base < cnt; base += 8 * kCoeffThreads) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int idx = base + u * kCoeffThreads;
-          v[u] = a[idx < cnt ? idx : cnt - 1];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int idx = base + u * kCoeffThreads;
-          if (idx < cnt) tile[idx] = v[u];
-        }
-      }
-      __syncthreads();
-      src = tile;
-    }
-    float wjj = 0.0f, deg = 0.0f;
-    if (j < n) {
-      wjj = src[j * N + j];
-      if (wjj == 0.0f) wjj = 1.0f;
-      for (int i = 0; i < n; ++i) deg += (i == j) ? wjj : src[i * N + j];
-      dis[j] = deg > 0.0f ? rsqrtf(deg) : 0.0f;
-    }
-    __syncthreads();
-    if (j < N) {
-      float c = 0.0f;
-      if (j < n) {
-        for (int i = 0; i < n; ++i) c += dis[i] * ((i == j) ? wjj : src[i * N + j]);
-        c *= dis[j];
-      }
-      cjs[j] = c;
-      cj_out[(int64_t)blk * N + j] = c;
-    }
-    __syncthreads();
-  }
-  const float inv_n = 1.0f / (float)n;
-  for (int c = threadIdx.x; c < C; c += kCoeffThreads) {
-    const float sc = s[c], bc = gbias[c];
-    float acc = 0.0f;
-    for (int i = 0; i < n; ++i) acc += fast_tanh(cjs[i] * sc + bc);
-    pooled[(int64_t)blk * C + c] = acc * inv_n;
-  }
+  coeff_fwd_body(attn, n_real, s, gbias, cj_out, pooled, B, N, H, C, stage, (int)blockIdx.x);
 }
 
-// partial[0][grp][c] = sum over the group's blocks of dpooled*(1-z^2)*c_j/n ; partial[1] without c_j.
-// A workgroup walks its blocks in passes of kCoeffPass: the dpooled values and c_j rows of a pass are
-// requested together (one memory latency per pass, not per block).
-constexpr int kCoeffPass = 4;
 __global__ __launch_bounds__(kCoeffThreads) void coeff_bwd_kernel(
     const float* __restrict__ cj, const int32_t* __restrict__ n_real, const float* __restrict__ s,
     const float* __restrict__ gbias, const float* __restrict__ dpooled, float* __restrict__ partial,
     int B, int N, int H, int C, int G) {
-  float* cjs = feta_lds;  // [kCoeffPass][N] c_j rows of the current pass
-  const int c = blockIdx.x * kCoeffThreads + threadIdx.x;
-  const int cc = c < C ? c : C - 1;
-  const int grp = blockIdx.y;
-  const int total = B * H;
-  const float sc = s[cc], bc = gbias[cc];
-  float as = 0.0f, ab = 0.0f;
-  for (int blk0 = grp; blk0 < total; blk0 += G * kCoeffPass) {
-    float dp[kCoeffPass];
-    int nn[kCoeffPass];
-#pragma unroll
-    for (int u = 0; u < kCoeffPass; ++u) {
-      const int blk = blk0 + u * G;
-      const int bc_ = blk < total ? blk : total - 1;
-      nn[u] = blk < total ? n_real[bc_ % B] : 0;
-      dp[u] = dpooled[(int64_t)bc_ * C + cc];
-    }
-    __syncthreads();   // the previous pass has been consumed
-    for (int i = threadIdx.x; i < kCoeffPass * N; i += kCoeffThreads) {
-      const int u = i / N, k = i - u * N;
-      const int blk = blk0 + u * G;
-      cjs[i] = blk < total ? cj[(int64_t)blk * N + k] : 0.0f;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < kCoeffPass; ++u) {
-      const int n = nn[u];
-      if (n == 0) continue;
-      const float dpn = dp[u] / (float)n;
-      for (int i = 0; i < n; ++i) {
-        const float ci = cjs[u * N + i];
-        const float z = fast_tanh(ci * sc + bc);
-        const float t = dpn * (1.0f - z * z);
-        as += t * ci;
-        ab += t;
-      }
-    }
-  }
-  if (c < C) {
-    partial[(int64_t)grp * 2 * C + c] = as;      // [G][2][C]: one colsum reduces both
-    partial[(int64_t)grp * 2 * C + C + c] = ab;
-  }
+  coeff_bwd_body(cj, n_real, s, gbias, dpooled, partial, B, N, H, C, G, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // out[c] = sum_r in[r][c]: 16 columns x 64 row slices per workgroup (64-byte row segments),
@@ -364,8 +213,8 @@ extern "C" int feta_coeff_fwd(const float* attn, const int32_t* n_real, const fl
   FETA_REQUIRE(attn && n_real && s && gcn_bias && cj && pooled, "coeff_fwd: null pointer");
   FETA_REQUIRE(B > 0 && H > 0 && C > 0 && N > 0 && N <= kCoeffThreads,
                "coeff_fwd: need 0 < N <= %d (got %d)", kCoeffThreads, N);
-  const int stage = N * N <= kCoeffLdsTileMax ? 1 : 0;
-  const size_t lds = sizeof(float) * (2 * N + 4 * 64 + (stage ? N * N : 0));
+  const int stage = coeff_fwd_stage(N);
+  const size_t lds = sizeof(float) * coeff_fwd_lds_floats(N);
   const dim3 grid(B * H), block(kCoeffThreads);
   auto kern = coeff_fwd_kernel;
   hipLaunchKernelGGL(kern, grid, block, lds, (hipStream_t)stream, attn, n_real, s, gcn_bias, cj,

@@ -14,6 +14,7 @@
 #include <cstdlib>
 
 #include "feta_abi_common.h"
+#include "feta_coeff.h"
 #include "feta_rowops.h"
 
 namespace feta {
@@ -44,9 +45,16 @@ __device__ unsigned long long feta_ffn_stamps[16];
 #endif
 #define FFN_STAMP(i) FETA_STAMP_TO(feta_ffn_stamps, i, blockIdx.x == 0 && threadIdx.x == 0)
 
+// Workgroups beyond main_grid run the forward of the coefficient generator (feta_coeff.h), one (head, graph) block each:
+// it depends on the attention matrix of the last layer only, so it shares the launch of that layer's feed-forward half.
 template <int FF>
-__global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a) {
+__global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a, CoeffFwdRole cf, int main_grid) {
   constexpr int D = kFfnD, P1 = D + 4, P2 = FF + 4, HT = FF / 32;  // HT hidden tiles per half
+  if ((int)blockIdx.x >= main_grid) {
+    coeff_fwd_body(cf.attn, cf.n_real, cf.s, cf.gbias, cf.cj, cf.pooled, cf.B, cf.N, cf.H, cf.C, coeff_fwd_stage(cf.N),
+                   (int)blockIdx.x - main_grid);
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lq = lane & 15, g = lane >> 4;
   const int rt = wv >> 1, hh = wv & 1;
   float* W1 = feta_lds;            // [FF][P1]
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a) {
   FFN_STAMP(2);
   const bool want_stats = a.y_stats != nullptr;
   float tot1[1] = {0.0f};   // thread tid < 128: one entry of the workgroup's [2][64] (sum, sum of squares)
-  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+  for (int blk = blockIdx.x; blk < nblk; blk += main_grid) {
   if (blk != (int)blockIdx.x) {
     __syncthreads();   // exchange / reduction scratch of the previous row block consumed
     row = blk * kFfnRows + 16 * rt + lq;
@@ -228,12 +236,16 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a) {
 }
 
 template <int FF>
-int launch_ffn_fwd(const FfnArgs& a, hipStream_t stream) {
-  const size_t lds = sizeof(float) * ffn_lds_floats(FF);
+int launch_ffn_fwd(const FfnArgs& a, const CoeffFwdRole& cf, hipStream_t stream) {
+  size_t floats = ffn_lds_floats(FF);
+  const int role = cf.attn != nullptr ? cf.B * cf.H : 0;
+  if (role > 0 && (size_t)coeff_fwd_lds_floats(cf.N) > floats) floats = coeff_fwd_lds_floats(cf.N);
+  const size_t lds = sizeof(float) * floats;
   auto kern = ffn_fwd_kernel<FF>;
   static LdsSeen lds_seen;
   allow_dynamic_lds(kern, lds, lds_seen);
-  hipLaunchKernelGGL(kern, dim3(ffn_grid(a.M)), dim3(kRowThreads), lds, stream, a);
+  const int grid = ffn_grid(a.M);
+  hipLaunchKernelGGL(kern, dim3(grid + role), dim3(kRowThreads), lds, stream, a, cf, grid);
   return check_launch("feta_ffn_fwd");
 }
 
@@ -253,8 +265,17 @@ extern "C" int feta_ffn_supported(int d_model, int ff) {
 
 extern "C" int feta_ffn_blocks(int M) { return ffn_grid(M); }
 
-extern "C" int feta_ffn_fwd(const feta_ffn* d, feta_stream_t stream) {
+extern "C" int feta_ffn_fwd(const feta_ffn* d, feta_stream_t stream) { return feta_ffn_fwd_coeff(d, nullptr, stream); }
+
+extern "C" int feta_ffn_fwd_coeff(const feta_ffn* d, const feta_coeff_fwd_role* c, feta_stream_t stream) {
   FETA_REQUIRE(d != nullptr, "ffn_fwd: null descriptor");
+  CoeffFwdRole cf{};
+  if (c != nullptr) {
+    FETA_REQUIRE(c->attn && c->n_real && c->s && c->gcn_bias && c->cj && c->pooled, "ffn_fwd_coeff: null pointer");
+    FETA_REQUIRE(c->B > 0 && c->H > 0 && c->C > 0 && c->N > 0 && c->N <= kCoeffThreads,
+                 "ffn_fwd_coeff: need 0 < N <= %d (got %d)", kCoeffThreads, c->N);
+    cf = CoeffFwdRole{c->attn, c->n_real, c->s, c->gcn_bias, c->cj, c->pooled, c->B, c->N, c->H, c->C};
+  }
   const FfnArgs& a = *d;
   FETA_REQUIRE(a.x && a.w1 && a.w2 && a.h && a.y && a.M > 0, "ffn_fwd: null pointer / empty");
   FETA_REQUIRE(feta_ffn_supported(kFfnD, a.FF), "ffn_fwd: dim_feedforward %d not in {64,128,256}", a.FF);
@@ -264,8 +285,8 @@ extern "C" int feta_ffn_fwd(const feta_ffn* d, feta_stream_t stream) {
                    aligned16(a.b1) && aligned16(a.b2) && aligned16(a.x_stats) && aligned16(a.y_stats),
                "ffn_fwd: tensors must be 16-byte aligned");
   switch (a.FF) {
-    case 64: return launch_ffn_fwd<64>(a, (hipStream_t)stream);
-    case 128: return launch_ffn_fwd<128>(a, (hipStream_t)stream);
-    default: return launch_ffn_fwd<256>(a, (hipStream_t)stream);
+    case 64: return launch_ffn_fwd<64>(a, cf, (hipStream_t)stream);
+    case 128: return launch_ffn_fwd<128>(a, cf, (hipStream_t)stream);
+    default: return launch_ffn_fwd<256>(a, cf, (hipStream_t)stream);
   }
 }

@@ -20,6 +20,7 @@
 #include <cstdlib>
 
 #include "feta_abi_common.h"
+#include "feta_coeff.h"
 #include "feta_rowops.h"
 
 namespace feta {
@@ -36,6 +37,7 @@ struct FfnBwdGeom {
   int per;  // 16-row blocks per chunk
   int NS;   // hidden-unit slices per chunk
   int xcd;  // 1: XCD-aware order of the workgroups (see ffn_bwd_kernel)
+  int main_grid;   // workgroups of the two roles above; beyond: the coefficient generator's backward (feta_coeff.h)
 };
 
 inline int ffn_bwd_xblocks(int M) {
@@ -60,8 +62,15 @@ __device__ __forceinline__ float4 g2_of(const float4& dv, const float4& yv, cons
 }
 
 template <int FF>
-__global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, FfnBwdGeom ge) {
+__global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, FfnBwdGeom ge, CoeffBwdRole cb) {
   constexpr int D = kFbD, NJ2 = FF / 16;
+  if ((int)blockIdx.x >= ge.main_grid) {
+    // trailing workgroups: the backward of the coefficient generator (feta_coeff.h) - it depends on the filter stage
+    // only, and this is the first launch of the layer stack's backward
+    const int r = (int)blockIdx.x - ge.main_grid, nbx = (cb.C + kCoeffThreads - 1) / kCoeffThreads;
+    coeff_bwd_body(cb.cj, cb.n_real, cb.s, cb.gbias, cb.dpooled, cb.partial, cb.B, cb.N, cb.H, cb.C, cb.G, r % nbx, r / nbx);
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lq = lane & 15, g = lane >> 4;
   // Which piece of work this workgroup is.  A 64-row chunk is touched by six workgroups (its two X-role blocks and the
   // four hidden-unit slices of the W role), and workgroups are dealt round-robin to the 8 XCDs, each with its own L2:
@@ -365,7 +374,7 @@ __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, Ffn
 extern int row_chunks(int M);   // rowwise.hip
 
 template <int FF>
-int launch_ffn_bwd(const FfnGradArgs& a, hipStream_t stream) {
+int launch_ffn_bwd(const FfnGradArgs& a, const CoeffBwdRole& cb, hipStream_t stream) {
   FfnBwdGeom ge{};
   ge.XB = ffn_bwd_xblocks(a.M);
   ge.RC = row_chunks(a.M);
@@ -374,8 +383,10 @@ int launch_ffn_bwd(const FfnGradArgs& a, hipStream_t stream) {
   ge.NS = FF / kFbSlice;
   const size_t x_lds = kFbRows * (kFbD + 4) + kFbRows * (FF + 4);
   const size_t w_lds = 2 * 64 * (kFbD + 16) + 2 * 64 * (kFbSlice + 16);
-  const size_t lds = sizeof(float) * ((x_lds > w_lds ? x_lds : w_lds) +
-                                      (a.g_y ? 5 * kFbD + reduce_scratch_floats(kFbD) : 0));
+  size_t floats = (x_lds > w_lds ? x_lds : w_lds) + (a.g_y ? 5 * kFbD + reduce_scratch_floats(kFbD) : 0);
+  const int role = cb.cj != nullptr ? ((cb.C + kCoeffThreads - 1) / kCoeffThreads) * cb.G : 0;
+  if (role > 0 && (size_t)(kCoeffPass * cb.N) > floats) floats = kCoeffPass * cb.N;
+  const size_t lds = sizeof(float) * floats;
   auto kern = ffn_bwd_kernel<FF>;
   static LdsSeen seen;
   allow_dynamic_lds(kern, lds, seen);
@@ -384,7 +395,8 @@ int launch_ffn_bwd(const FfnGradArgs& a, hipStream_t stream) {
   ge.xcd = (ge.XB == nblk && ge.per == 4) ? 1 : 0;
   if (const char* e = getenv("FETA_FFN_BWD_XCD")) ge.xcd = ge.xcd && atoi(e) != 0;
   const int grid = ge.xcd ? 8 * ((ge.RC + 7) / 8) * (2 + ge.NS) : ge.XB + ge.RC * ge.NS;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kRowThreads), lds, stream, a, ge);
+  ge.main_grid = grid;
+  hipLaunchKernelGGL(kern, dim3(grid + role), dim3(kRowThreads), lds, stream, a, ge, cb);
   return check_launch("feta_ffn_bwd");
 }
 
@@ -396,8 +408,17 @@ extern "C" int feta_ffn_bwd_supported(int d_model, int ff) { return (d_model == 
 
 extern "C" int feta_ffn_bwd_blocks(int M) { return ffn_bwd_xblocks(M); }
 
-extern "C" int feta_ffn_bwd(const feta_ffn_grad* d, feta_stream_t stream) {
+extern "C" int feta_ffn_bwd(const feta_ffn_grad* d, feta_stream_t stream) { return feta_ffn_bwd_coeff(d, nullptr, stream); }
+
+extern "C" int feta_ffn_bwd_coeff(const feta_ffn_grad* d, const feta_coeff_bwd_role* c, feta_stream_t stream) {
   FETA_REQUIRE(d != nullptr, "ffn_bwd: null descriptor");
+  CoeffBwdRole cb{};
+  if (c != nullptr) {
+    FETA_REQUIRE(c->cj && c->n_real && c->s && c->gcn_bias && c->dpooled && c->partial, "ffn_bwd_coeff: null pointer");
+    FETA_REQUIRE(c->B > 0 && c->H > 0 && c->C > 0 && c->N > 0, "ffn_bwd_coeff: empty shape");
+    cb = CoeffBwdRole{c->cj, c->n_real, c->s, c->gcn_bias, c->dpooled, c->partial, c->B, c->N, c->H, c->C,
+                      feta_coeff_bwd_groups(c->B, c->H)};
+  }
   const FfnGradArgs& a = *d;
   FETA_REQUIRE(a.dy && a.h && a.w2 && a.w1 && a.x && a.dx && a.partial && a.M > 0, "ffn_bwd: null pointer / empty");
   FETA_REQUIRE(feta_ffn_bwd_supported(kFbD, a.FF), "ffn_bwd: dim_feedforward %d not in {64,128}", a.FF);
@@ -406,6 +427,6 @@ extern "C" int feta_ffn_bwd(const feta_ffn_grad* d, feta_stream_t stream) {
   FETA_REQUIRE(!a.sum_out || a.x_bn, "ffn_bwd: sum_out needs x_bn (the BatchNorm that produced x)");
   FETA_REQUIRE(aligned16(a.dy_b) && aligned16(a.dy) && aligned16(a.h) && aligned16(a.x) && aligned16(a.dx) && aligned16(a.g_y) &&
                aligned16(a.x_bn) && aligned16(a.g_sum), "ffn_bwd: pointers must be 16-byte aligned");
-  if (a.FF == 64) return launch_ffn_bwd<64>(a, (hipStream_t)stream);
-  return launch_ffn_bwd<128>(a, (hipStream_t)stream);
+  if (a.FF == 64) return launch_ffn_bwd<64>(a, cb, (hipStream_t)stream);
+  return launch_ffn_bwd<128>(a, cb, (hipStream_t)stream);
 }

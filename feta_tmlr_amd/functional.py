@@ -116,9 +116,15 @@ class FilterCoefficientsFn(torch.autograd.Function):
             s = torch.empty(c, dtype=torch.float32, device=dev)
             abi.colsum(gcn_weight.contiguous(), s, stream)
         gb = gcn_bias.contiguous()
-        cj = torch.empty((h * b, n), dtype=torch.float32, device=dev)
-        pooled = torch.empty((h * b, c), dtype=torch.float32, device=dev)
-        abi.coeff_fwd(attn, n_real, s, gb, cj, pooled, stream)
+        if pending is not None and pending.coeff_fwd_out is not None:
+            cj, pooled = pending.coeff_fwd_out      # ran in the launch of the last layer's feed-forward half
+            pending.coeff_fwd_out = None
+        else:
+            cj = torch.empty((h * b, n), dtype=torch.float32, device=dev)
+            pooled = torch.empty((h * b, c), dtype=torch.float32, device=dev)
+            abi.coeff_fwd(attn, n_real, s, gb, cj, pooled, stream)
+        if pending is not None:
+            pending.coeff_fwd_req = None
         ctx.save_for_backward(cj, n_real, s, gb)
         ctx.dims = (b, n, h, gcn_weight.shape[0])
         return pooled
@@ -138,8 +144,9 @@ class FilterCoefficientsFn(torch.autograd.Function):
         dw = torch.empty((rows, c), dtype=torch.float32, device=cj.device)
         pend = ctx.pending
         if (pend is not None and pend.stack_armed and not pend.stack_done and PendingSums.untouched(*ctx.params)):
-            # the layer stack's backward comes after this node and ends in a reduction launch: it takes these too
-            abi.coeff_bwd(cj, n_real, s, gb, dpooled.contiguous(), partial, None, None, b, n, h, stream)
+            # the layer stack's backward comes after this node: its first launch carries this node's kernel in trailing
+            # workgroups (feta_ffn_bwd_coeff), its reduction launch the sums
+            pend.coeff_bwd_req = (cj, n_real, s, gb, dpooled.contiguous(), partial, b, n, h)
             p2 = partial.view(groups, 2 * c)
             pend.add(p2[:, :c], ds, dw)
             pend.add(p2[:, c:], db)
@@ -241,6 +248,13 @@ class PendingSums:
         # (s = colsum(gcn.weight) of the coefficient generator); whoever needs them first runs them if nobody did
         self.fwd_sums = []
         self.s = None
+        # ... and the coefficient generator's kernels themselves: its forward shares the launch of the last layer's
+        # feed-forward half (it needs that layer's attention matrix only), its backward kernel the first launch of the
+        # stack's backward.  coeff_fwd_req = gcn bias (set by the encoder); coeff_fwd_out = (cj, pooled) once run;
+        # coeff_bwd_req = the argument tuple of abi.coeff_bwd left by FilterCoefficientsFn.backward
+        self.coeff_fwd_req = None
+        self.coeff_fwd_out = None
+        self.coeff_bwd_req = None
 
     @staticmethod
     def untouched(*params):
@@ -271,11 +285,31 @@ class PendingSums:
         sums, self.fwd_sums = self.fwd_sums, []
         return sums
 
+    def coeff_fwd_role(self, attn, n_real):
+        """Called by the layer stack for the launch that follows the last attention: -> the argument tuple of the
+        coefficient generator's forward (outputs allocated here), or None if nobody asked / s is not ready."""
+        if self.coeff_fwd_req is None or self.s is None or self.fwd_sums or attn is None:
+            return None
+        gcn_bias, self.coeff_fwd_req = self.coeff_fwd_req, None
+        b, h, n, _ = attn.shape
+        cj = torch.empty((h * b, n), dtype=torch.float32, device=attn.device)
+        pooled = torch.empty((h * b, self.s.shape[0]), dtype=torch.float32, device=attn.device)
+        self.coeff_fwd_out = (cj, pooled)
+        return (attn, n_real, self.s, gcn_bias.detach().contiguous(), cj, pooled)
+
+    def take_coeff_bwd(self):
+        req, self.coeff_bwd_req = self.coeff_bwd_req, None
+        return req
+
     def _finish_pass(self):
         self._callback_queued = False
+        req = self.take_coeff_bwd()
         items = self.take()
         if items:
             abi, stream = _lib.backend(items[0][0])
+            if req is not None:
+                cj, n_real, s, gb, dpooled, partial, b, n, h = req
+                abi.coeff_bwd(cj, n_real, s, gb, dpooled, partial, None, None, b, n, h, stream)
             abi.colsum_multi(items, stream)
 
 

@@ -211,7 +211,8 @@ class FusedEncoderStackFn(torch.autograd.Function):
                 # F4 + F5 in one launch: the hidden activations stay in registers (csrc/ffn.hip)
                 G2 = abi.ffn_blocks(m)
                 st2 = new(G2, 2, d)
-                abi.ffn_fwd(m, ff, stream, x=y1, w1=w1, b1=bb1, w2=w2, b2=bb2, h=h, y=y2, y_stats=st2, **bn1)
+                abi.ffn_fwd(m, ff, stream, x=y1, w1=w1, b1=bb1, w2=w2, b2=bb2, h=h, y=y2, y_stats=st2,
+                            coeff=_coeff_fwd_role(pending, li, nl, attn, n_real), **bn1)
                 st2, G2 = _cap_partials(abi, stream, st2, new)
             else:
                 # F4
@@ -267,6 +268,7 @@ class FusedEncoderStackFn(torch.autograd.Function):
         # every weight/bias gradient of the stack goes through the split-K partial buffers and ONE deterministic
         # reduction at the end (instead of one reduction launch per linear)
         part_f, part_a, tf, ta, wslot = _partial_buffers(abi, new, m, b, n, d, heads, ff0, nl, fused_attn)
+        coeff_req = _coeff_bwd_request(ctx, abi, stream, d, params[(nl - 1) * PER_LAYER + 6].shape[0])
         total = tf + ta
         # ONE flat gradient buffer for the whole stack: [weights and biases (reduced partials) | dgamma,
         # dbeta of norm1 / norm2 of every layer]; every parameter gradient returned below is a view of it,
@@ -303,7 +305,8 @@ class FusedEncoderStackFn(torch.autograd.Function):
                 # B1 + B2 in one launch (csrc/ffn_bwd.hip): the hidden gradient never leaves the chip
                 G1s = abi.ffn_bwd_blocks(m)
                 gs1 = new(G1s, 2, d)
-                abi.ffn_bwd(m, ff, stream, Gs=Gs_cur, partial_ptr=pp, partial_ld=tf, dy=dcur, dy_b=dcur_b, g_y=s['y2'],
+                abi.ffn_bwd(m, ff, stream, coeff=(coeff_req if li == nl - 1 else None), Gs=Gs_cur, partial_ptr=pp,
+                            partial_ld=tf, dy=dcur, dy_b=dcur_b, g_y=s['y2'],
                             g_bn=s['prm2'], g_sum=gs, g_fin_out=fin2, dgamma=dg2, dbeta=db2, h=s['h'], w2=w2, w1=w1,
                             x=s['y1'], x_bn=s['prm1'], dx=dx1, sum_out=gs1)
                 gs1, G1s = _cap_partials(abi, stream, gs1, new)
@@ -462,7 +465,8 @@ class FusedLayerNormStackFn(torch.autograd.Function):
             abi.layernorm_fwd(y1, g1, be1, float(layer.norm1.eps), x1, lst1, stream)
             h, y2 = new(m, ff), new(m, d)
             if USE_FFN_FUSED and abi.ffn_supported(d, ff):
-                abi.ffn_fwd(m, ff, stream, x=x1, w1=w1, b1=bb1, w2=w2, b2=bb2, h=h, y=y2)
+                abi.ffn_fwd(m, ff, stream, x=x1, w1=w1, b1=bb1, w2=w2, b2=bb2, h=h, y=y2,
+                            coeff=_coeff_fwd_role(pending, li, nl, attn, n_real))
             else:
                 dsc = abi.rowlin_ex(m, d, ff, relu=True, x=x1, w=w1, bias=bb1, y=h)
                 abi.rowlin_fwd_ex(dsc, stream)
@@ -498,6 +502,7 @@ class FusedLayerNormStackFn(torch.autograd.Function):
         fused_attn = (USE_ATTN_BLOCK_BWD and not tie and abi.attn_block_bwd_supported(n, d, heads)
                       and abi.attn_block_bwd_blocks(b) > 0)
         part_f, part_a, tf, ta, wslot = _partial_buffers(abi, new, m, b, n, d, heads, ff0, nl, fused_attn)
+        coeff_req = _coeff_bwd_request(ctx, abi, stream, d, params[(nl - 1) * PER_LAYER + 6].shape[0])
         total = tf + ta
         ln_part = new(GL, nl * 4 * d)
         dwdb_all = new(total + nl * 4 * d)          # same layout as the BatchNorm stack's flat buffer
@@ -527,7 +532,8 @@ class FusedLayerNormStackFn(torch.autograd.Function):
             dx1 = new(m, d)
             if USE_FFN_BWD and abi.ffn_bwd_supported(d, ff):
                 # linear2 + linear1 backward in one launch (csrc/ffn_bwd.hip), dx1 = dy2 + dh W1
-                abi.ffn_bwd(m, ff, stream, partial_ptr=pp, partial_ld=tf, dy=dy2, h=s['h'], w2=w2, w1=w1, x=s['x1'],
+                abi.ffn_bwd(m, ff, stream, coeff=(coeff_req if li == nl - 1 else None), partial_ptr=pp, partial_ld=tf,
+                            dy=dy2, h=s['h'], w2=w2, w1=w1, x=s['x1'],
                             dx=dx1)
             else:
                 # linear2, then linear1 with the residual gradient dy2 added in its dX epilogue
@@ -591,6 +597,24 @@ class FusedLayerNormStackFn(torch.autograd.Function):
             if params[idx + 1] is not None:
                 grads[idx + 1] = dwdb_all[off + no * ki:off + no * ki + no]
         return (dcur.view(n, b, d), None, None, None, None, None, None, None) + tuple(grads)
+
+
+def _coeff_fwd_role(pending, li, nl, attn, n_real):
+    """The coefficient generator's forward rides in the launch of the LAST layer's feed-forward half."""
+    if pending is None or li != nl - 1:
+        return None
+    return pending.coeff_fwd_role(attn, n_real)
+
+
+def _coeff_bwd_request(ctx, abi, stream, d, ff_last):
+    """The coefficient generator's backward kernel, left by its autograd node for the first launch of this backward
+    (the last layer's fused FFN backward); run here on its own when that launch is not the fused kernel."""
+    req = ctx.pending.take_coeff_bwd() if ctx.pending is not None else None
+    if req is not None and not (USE_FFN_BWD and abi.ffn_bwd_supported(d, ff_last)):
+        cj, n_real, s, gb, dpooled, partial, b, n, h = req
+        abi.coeff_bwd(cj, n_real, s, gb, dpooled, partial, None, None, b, n, h, stream)
+        req = None
+    return req
 
 
 def _take_pending(ctx):

@@ -245,6 +245,8 @@ class DiffTransformerEncoderGenGCN(nn.Module):
             # first launch instead of a launch of its own
             pending.s = torch.empty(self.gcn.weight.shape[1], dtype=torch.float32, device=src.device)
             pending.fwd_sums = [(self.gcn.weight.detach(), pending.s)]
+            # ... and the generator's forward kernel in the launch of the last layer's feed-forward half
+            pending.coeff_fwd_req = self.gcn.bias
         for layer_num, mod in enumerate(self.layers):
             last = layer_num + 1 == self.num_layers
             filt = last or not self.last_layer_filter                            # :169-171

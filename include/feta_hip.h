@@ -473,6 +473,14 @@ typedef struct feta_ffn {
 int feta_ffn_supported(int d_model, int ff);
 int feta_ffn_blocks(int M);
 int feta_ffn_fwd(const feta_ffn* d, feta_stream_t stream);
+/* the same launch with the FORWARD of the coefficient generator (feta_coeff_fwd's arguments) in trailing workgroups
+ * (ABI 6): get_filter_coefficients (transformer/models.py:240-283) needs only the attention matrix of the last layer,
+ * which the launch before this one wrote - two half-empty launches of a captured step become one. */
+typedef struct feta_coeff_fwd_role {
+  const float* attn; const int32_t* n_real; const float* s; const float* gcn_bias; float* cj; float* pooled;
+  int B, N, H, C;
+} feta_coeff_fwd_role;
+int feta_ffn_fwd_coeff(const feta_ffn* d, const feta_coeff_fwd_role* c, feta_stream_t stream);
 
 /* ---- backward of the feed-forward half in ONE launch ------------------------------------------------
  * (feta_ffn_bwd_supported: d_model = 64, dim_feedforward in {64,128}.)  Replaces the two feta_rowlin_bwd_ex
@@ -513,6 +521,13 @@ typedef struct feta_ffn_grad {
 int feta_ffn_bwd_supported(int d_model, int ff);
 int feta_ffn_bwd_blocks(int M);
 int feta_ffn_bwd(const feta_ffn_grad* d, feta_stream_t stream);
+/* ... and the BACKWARD kernel of the coefficient generator (feta_coeff_bwd with ds = NULL: partial [G, 2, C] is left
+ * for the caller's feta_colsum_multi) in trailing workgroups of the first launch of the layer stack's backward. */
+typedef struct feta_coeff_bwd_role {
+  const float* cj; const int32_t* n_real; const float* s; const float* gcn_bias; const float* dpooled; float* partial;
+  int B, N, H, C;
+} feta_coeff_bwd_role;
+int feta_ffn_bwd_coeff(const feta_ffn_grad* d, const feta_coeff_bwd_role* c, feta_stream_t stream);
 
 /* ---- graph preprocessing -------------------------------------------------------------
  * Dense Lhat = -D^-1/2 A D^-1/2 per graph from the batched edge list, with the exact

@@ -291,10 +291,16 @@ def test_deferred_column_sums_and_gradient_accumulation(emu, monkeypatch, own_ge
         ((out * out).sum() + 0.01 * coeff.pow(2).sum()).backward()
 
     FF.PendingSums.take = take
+    alone = []      # stand-alone launches of the coefficient generator's kernels
+    orig_cf, orig_cb = emu.coeff_fwd, emu.coeff_bwd
+    emu.coeff_fwd = lambda *a, **k: (alone.append('fwd'), orig_cf(*a, **k))[1]
+    emu.coeff_bwd = lambda *a, **k: (alone.append('bwd'), orig_cb(*a, **k))[1]
     try:
         with _lib.override_for_tests(emu):
             model.zero_grad(set_to_none=True)
             run()
+            # both ran as trailing workgroups of the stack's feed-forward launches (feta_ffn_fwd_coeff / _bwd_coeff)
+            assert alone == [], alone
             # linear_cat's partials ride in feta_lin_bwd / they, the filter bias and the linear bias in the last reduction
             assert max(taken) >= (1 if own_gemm else 3), taken
             once = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
@@ -320,6 +326,8 @@ def test_deferred_column_sums_and_gradient_accumulation(emu, monkeypatch, own_ge
             h.remove()
     finally:
         FF.PendingSums.take = orig_take
+        emu.coeff_fwd, emu.coeff_bwd = orig_cf, orig_cb
+    assert 'bwd' in alone      # the accumulating / pruned passes ran the backward kernel on its own
     KC.assert_close('hooked gradient', seen[0], once['encoder.linear.bias'].double(), tol=1e-6)
     KC.assert_close('after hook', model.encoder.linear.bias.grad, once['encoder.linear.bias'].double(), tol=1e-6)
 
