@@ -351,6 +351,7 @@ def roofline(args, gpu, dev):
     split_form = (fused_stack.USE_ATTN_BLOCK_SPLIT and fused_stack.USE_FFN_BWD and fused_stack.USE_ATTN_BLOCK_BWD
                   and abi.ffn_bwd_supported(d, 2 * d) and abi.attn_block_bwd_supported(n, d, h)
                   and abi.attn_block_bwd_blocks(b) > 0)
+    coeff_roles = args.filter_mode in ('spectral', 'cheb') and not args.two_phase and args.gpus == 1 and p == 4
     for name, per_layer, fn, nbytes, syms in stack_layer_cases(abi, st, dev, b, n, d, h, 2 * d, gpu['pe'], nr):
         if name == 'attn_block_fwd (no attn write)':
             cnt = L - 1
@@ -360,10 +361,18 @@ def roofline(args, gpu, dev):
             cnt = 1
         elif name in ('ffn_bwd (gradient in two parts)', 'attn_block_bwd (two workgroups per graph)'):
             cnt = L - 1      # fused_stack.py: every layer but the first hands its input gradient to a fused FFN backward
-        elif name in ('ffn_bwd', 'attn_block_bwd') and split_form:
+        elif name == 'attn_block_bwd' and split_form:
             cnt = 1
+        elif name in ('ffn_fwd (+ coefficient generator)', 'ffn_bwd (+ coefficient generator)'):
+            cnt = 1 if coeff_roles else 0      # the last layer's launches (functional.PendingSums)
+        elif name == 'ffn_fwd':
+            cnt = L - 1 if coeff_roles else L
+        elif name == 'ffn_bwd':
+            cnt = (0 if coeff_roles else 1) if split_form else (L - 1 if coeff_roles else L)
         else:
             cnt = L
+        if cnt == 0:
+            continue
         sym = syms[0]
         if sym == 'rowlin_bwd':   # one template instantiation (= one symbol) per (KI, NO)
             sym = 'rowlin_bwd<%s>' % name.split()[1]

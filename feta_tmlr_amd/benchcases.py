@@ -52,6 +52,14 @@ def stack_layer_cases(abi, st, dev, b, n, d, heads, ff, pe, n_real, last_layer_a
         fd = abi.ffn_desc(m, ff, Gx=g1, **fkw)
         cases.append(('ffn_fwd', 1.0, lambda: (abi.ffn_launch(fd, st), fkw)[0],
                       f4 * (m * d + 2 * d * ff + m * ff + m * d), ['ffn_fwd']))
+        # the last layer's launch carries the coefficient generator's forward in trailing workgroups
+        # (feta_ffn_fwd_coeff): C = P dh^2 channels at the reference's filter order 4
+        cgen = 4 * (d // heads) ** 2
+        attn_in = torch.rand(b, heads, n, n, generator=g).to(dev)
+        crole = (attn_in, n_real, rnd(cgen), rnd(cgen), new(heads * b, n), new(heads * b, cgen))
+        cases.append(('ffn_fwd (+ coefficient generator)', 1.0, lambda: (abi.ffn_launch(fd, st, crole), fkw)[0],
+                      f4 * (m * d + 2 * d * ff + m * ff + m * d + b * (heads * n * n + heads * cgen + heads * n)),
+                      ['ffn_fwd']))
 
     def bwd_case(name, ki, no, extras):
         x, w, dy, dx = rnd(m, ki), rnd(no, ki) / ki ** 0.5, rnd(m, no), new(m, ki)
@@ -90,6 +98,14 @@ def stack_layer_cases(abi, st, dev, b, n, d, heads, ff, pe, n_real, last_layer_a
         keep_f = (kw, part)
         cases.append(('ffn_bwd', 1.0, lambda: (abi.ffn_bwd_launch(fdsc, st), keep_f)[0],
                       f4 * (4 * m * d + m * ff + 2 * d * ff + RC * cols), ['ffn_bwd']))
+        # the last layer's launch (the first of the stack's backward) carries the coefficient generator's backward
+        # kernel in trailing workgroups (feta_ffn_bwd_coeff)
+        cgen = 4 * (d // heads) ** 2
+        cgrp = abi.coeff_bwd_groups(b, heads)
+        brole = (rnd(heads * b, n), n_real, rnd(cgen), rnd(cgen), rnd(heads * b, cgen), new(cgrp, 2, cgen), b, n, heads)
+        cases.append(('ffn_bwd (+ coefficient generator)', 1.0, lambda: (abi.ffn_bwd_launch(fdsc, st, brole), keep_f)[0],
+                      f4 * (4 * m * d + m * ff + 2 * d * ff + RC * cols + b * (heads * cgen + heads * n) + cgrp * 2 * cgen),
+                      ['ffn_bwd']))
         if fused_a:
             # ... below a layer whose attention backward ran as two workgroups per graph: the gradient in two parts
             kw2 = dict(kw, dy_b=rnd(m, d))

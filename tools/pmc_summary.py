@@ -31,7 +31,9 @@ ROWS = [  # (bench row, kernel-symbol substrings enqueued by one call, in order)
     ('attn_block_fwd (no attn write)', ['attn_block_fwd']),
     ('attn_block_fwd (+attn write)', ['attn_block_fwd']),
     ('ffn_fwd', ['ffn_fwd']),
+    ('ffn_fwd (+ coefficient generator)', ['ffn_fwd']),
     ('ffn_bwd', ['ffn_bwd']),
+    ('ffn_bwd (+ coefficient generator)', ['ffn_bwd']),
     ('ffn_bwd (gradient in two parts)', ['ffn_bwd']),
     ('attn_block_bwd', ['attn_block_bwd']),
     ('attn_block_bwd (two workgroups per graph)', ['attn_block_bwd']),
