@@ -210,6 +210,35 @@ def check_coeff(abi, dev, stream, bsz, n, h, c, seed=0, zero_diag=True, faithful
     abi.coeff_bwd(cj, nbd, s, gb32, dp.float().to(dev), partial, ds2, db2, bsz, n, h, stream, dw_dense=dw)
     assert torch.equal(ds2, ds) and torch.equal(db2, db)
     assert torch.equal(dw, ds.unsqueeze(0).expand_as(dw))
+    # the same two kernels as trailing workgroups of a feed-forward launch (feta_ffn_fwd_coeff / feta_ffn_bwd_coeff):
+    # bit-identical results, and the host launch's own outputs unaffected
+    if abi.ffn_supported(64, 128) and abi.ffn_bwd_supported(64, 128):
+        m, d, ff = 70, 64, 128
+        rnd = lambda *sh: torch.randn(*sh, generator=g).to(dev)
+        x, w1, b1, w2, b2 = rnd(m, d), rnd(ff, d) / 8, rnd(ff), rnd(d, ff) / 11, rnd(d)
+        outs = []
+        for role in (False, True):
+            hbuf, y2 = torch.full((m, ff), float('nan'), device=dev), torch.full((m, d), float('nan'), device=dev)
+            cj2 = torch.full((h * bsz, n), float('nan'), device=dev)
+            pooled2 = torch.full((h * bsz, c), float('nan'), device=dev)
+            abi.ffn_fwd(m, ff, stream, x=x, w1=w1, b1=b1, w2=w2, b2=b2, h=hbuf, y=y2,
+                        coeff=(attn32, nbd, s, gb32, cj2, pooled2) if role else None)
+            outs.append((hbuf, y2))
+        assert torch.equal(cj2, cj) and torch.equal(pooled2, pooled), 'coefficient generator forward as a role'
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        dy, dpd = rnd(m, d), dp.float().to(dev)
+        rc = abi.rowlin_chunks(m)
+        cols = 2 * d * ff + d + ff
+        res = []
+        for role in (False, True):
+            dx, part = torch.full((m, d), float('nan'), device=dev), torch.full((rc, cols), float('nan'), device=dev)
+            partial2 = torch.full((groups, 2, c), float('nan'), device=dev)
+            abi.ffn_bwd(m, ff, stream, coeff=(cj, nbd, s, gb32, dpd, partial2, bsz, n, h) if role else None,
+                        partial_ptr=part.data_ptr(), partial_ld=cols, dy=dy, h=outs[0][0], w2=w2, w1=w1, x=x, dx=dx)
+            res.append((dx, part))
+        abi.coeff_bwd(cj, nbd, s, gb32, dpd, partial, None, None, bsz, n, h, stream)    # partials only
+        assert torch.equal(partial2.view(-1), partial.view(-1)[:partial2.numel()]), 'coefficient generator backward as a role'
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     # several column sums in one launch
     a1 = torch.randn(37, 16, generator=g).to(dev)
     a2 = torch.randn(11, c, generator=g).to(dev)
