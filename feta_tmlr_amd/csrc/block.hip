@@ -20,6 +20,7 @@
 
 #include "feta_abi_common.h"
 #include "feta_colsum.h"
+#include "feta_lp.h"
 #include "feta_rowops.h"
 
 namespace feta {
@@ -30,16 +31,18 @@ constexpr int kBlkD = 64, kBlkH = 4, kBlkDH = 16;
 constexpr int kBlkP = kBlkD + 4;  // LDS pitch of every staged 64-float row
 constexpr int kBlkMaxGrid = 256;  // workgroups of a launch (MI355X: 256 CUs, one such workgroup each)
 
-__host__ __device__ inline int block_lds_floats(int nt, bool attn) {
-  const int nr = 16 * nt;
-  int f = 3 * kBlkD * kBlkP + kBlkD * kBlkP;  // W_in, W_out
-  f += 2 * nr * kBlkP;                         // X tile, OUT tile
-  f += 2 * kBlkD;                              // scale / shift of the input BatchNorm
+// LDS of a workgroup, in bytes: tiles of T (pitch kBlkD + Lp<T>::PAD elements), fp32 for everything else
+template <class T>
+__host__ __device__ inline int block_lds_bytes(int nt, bool attn) {
+  const int nr = 16 * nt, P = kBlkD + Lp<T>::PAD;
+  int b = (int)sizeof(T) * (3 * kBlkD * P + kBlkD * P);   // W_in, W_out
+  b += (int)sizeof(T) * 2 * nr * P;                          // X tile, OUT tile
+  int f = 2 * kBlkD;                                         // scale / shift of the input BatchNorm
   const int fin = reduce_scratch_floats(kBlkD);
-  const int stg = attn ? kBlkH * 16 * (nr + 1) : 0;  // per-wave probability staging
+  const int stg = attn ? kBlkH * 16 * (nr + 1) : 0;          // per-wave probability staging
   f += fin > stg ? fin : stg;
-  f += nr * (nr + 4);                                // pe tile
-  return f;
+  f += nr * (nr + 4);                                        // pe tile (fp32 whatever the storage type)
+  return b + 4 * f;
 }
 
 #ifdef FETA_TIMING
@@ -51,22 +54,33 @@ __device__ unsigned int feta_block_launch;
 // Workgroups beyond main_grid reduce the column sums of `sums` (feta_colsum.h): the first launch of a forward pass
 // leaves half of the chip idle at the BASELINE batch, and s = colsum(gcn.weight) of the coefficient generator - a
 // function of the parameters alone - would otherwise be a launch of its own (~7 us).
-template <int NT>
+// T: storage type of x, pe, qkv, out, y and of the LDS tiles (feta_lp.h); weights, biases, statistics, attn: fp32.
+template <class T, int NT>
 __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a, ColsumPlan sums, int main_grid) {
-  constexpr int D = kBlkD, DH = kBlkDH, P = kBlkP, NR = 16 * NT, KP = NR + 1;
+  typedef Lp<T> L;
+  typedef typename L::Op Op;
+  typedef typename L::Vec Vec;
+  constexpr int D = kBlkD, DH = kBlkDH, P = kBlkD + L::PAD, NR = 16 * NT, KP = NR + 1;
+  constexpr int RV = D / L::VEC;                                  // 16-byte vectors of a 64-element row
+  constexpr int XI = (NR * RV + kRowThreads - 1) / kRowThreads;   // ... of the graph's rows, per thread
   if ((int)blockIdx.x >= main_grid) {
     colsum_role<kRowThreads>(sums, (int)blockIdx.x - main_grid);
     return;
   }
   const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6, lq = lane & 15, g = lane >> 4;
-  float* Wi = feta_lds;              // [192][P]
-  float* Wo = Wi + 3 * D * P;        // [64][P]
-  float* Xs = Wo + D * P;            // [NR][P]  layer input, BatchNorm applied
-  float* Os = Xs + NR * P;           // [NR][P]  per-head outputs (concat)
-  float* xss = Os + NR * P;          // [2][64]
-  float* scr = xss + 2 * D;          // finalize scratch, later the probability staging
-  constexpr int PEP = NR + 4;        // pitch of the pe tile (16-byte operand reads)
-  float* Pe = feta_lds + block_lds_floats(NT, a.attn != nullptr) - NR * PEP;   // [NR][PEP] rows < N
+  T* Wi = reinterpret_cast<T*>(lds_bytes());   // [192][P]
+  T* Wo = Wi + 3 * D * P;                      // [64][P]
+  T* Xs = Wo + D * P;                          // [NR][P]  layer input, BatchNorm applied
+  T* Os = Xs + NR * P;                         // [NR][P]  per-head outputs (concat)
+  float* xss = reinterpret_cast<float*>(Os + NR * P);   // [2][64]
+  float* scr = xss + 2 * D;                    // finalize scratch, later the probability staging
+  constexpr int PEP = NR + 4;                  // pitch of the pe tile (16-byte operand reads)
+  float* Pe = reinterpret_cast<float*>(lds_bytes() + block_lds_bytes<T>(NT, a.attn != nullptr)) - NR * PEP;   // [NR][PEP]
+  const T* gx = reinterpret_cast<const T*>(a.x);
+  const T* gpe = reinterpret_cast<const T*>(a.pe);
+  T* gqkv = reinterpret_cast<T*>(a.qkv);
+  T* gout = reinterpret_cast<T*>(a.out);
+  T* gy = reinterpret_cast<T*>(a.y);
   const bool x_norm = a.x_stats != nullptr || a.x_bn != nullptr;
   FETA_STAMP(0);
 
@@ -81,25 +95,25 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
   partials_request(a.x_stats != nullptr ? a.x_stats : a.w_in, a.x_stats != nullptr ? a.Gx : 0, D, pb);
   const bool has_pe = a.pe != nullptr;
   constexpr int PEI = (NR * NR + kRowThreads - 1) / kRowThreads;
-  float4 xv[NT];
+  Vec xv[XI];
   float pel[PEI];
   float rsv[NT];
   int n = 0;
   const int nn = a.N * a.N;
-  // node rows, the graph's pe block as ONE coalesced stream (it is contiguous: N x N floats; every head needs all of
-  // it - four waves gathering their (query, key) pairs 4 bytes at a time took ~2.5 us, and a __syncthreads waits for
+  // node rows, the graph's pe block as ONE coalesced stream (it is contiguous: N x N elements; every head needs all of
+  // it - four waves gathering their (query, key) pairs one element at a time took ~2.5 us, and a __syncthreads waits for
   // every load in flight: vmcnt counts loads and stores alike on gfx9), the degree scale of this lane's rows
   auto request_graph = [&](int b) {
     n = a.n_real[b];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const int idx = tid + kRowThreads * i, node = idx >> 4, q = idx & 15;
+    for (int i = 0; i < XI; ++i) {
+      const int idx = min(tid + kRowThreads * i, NR * RV - 1), node = idx / RV, q = idx % RV;
       const int64_t row = (int64_t)b * a.row_sb + (int64_t)min(node, a.N - 1) * a.row_sn;
-      xv[i] = *reinterpret_cast<const float4*>(a.x + row * D + 4 * q);
+      xv[i] = L::ldv(gx + row * D + L::VEC * q);
     }
 #pragma unroll
     for (int i = 0; i < PEI; ++i)
-      pel[i] = has_pe ? a.pe[(int64_t)b * nn + min(tid + kRowThreads * i, nn - 1)] : 1.0f;
+      pel[i] = has_pe ? L::ld1(gpe + (int64_t)b * nn + min(tid + kRowThreads * i, nn - 1)) : 1.0f;
 #pragma unroll
     for (int qb = 0; qb < NT; ++qb) {
       const int qc = min(16 * qb + lq, a.N - 1);
@@ -116,7 +130,7 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
   }
   if (a.b_in != nullptr) bin1 = a.b_in[2 * D + DH * h + lq];
   if (a.b_out != nullptr) bo = *reinterpret_cast<const float4*>(a.b_out + DH * h + 4 * g);
-  // 256 rows of 16 float4 (W_in then W_out), 16 per thread
+  // 256 rows of 16 float4 (W_in then W_out: fp32 masters), 16 per thread
   float4 wv[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -133,7 +147,7 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int idx = tid + kRowThreads * i;
-    *reinterpret_cast<float4*>(Wi + (idx >> 4) * P + 4 * (idx & 15)) = wv[i];
+    L::st4(Wi + (idx >> 4) * P + 4 * (idx & 15), wv[i].x, wv[i].y, wv[i].z, wv[i].w);   // (rounded once, here, for bf16)
   }
   FETA_STAMP(6);
   if (a.x_stats != nullptr) {
@@ -174,15 +188,18 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
   first = false;
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < NT; ++i) {
-    const int idx = tid + kRowThreads * i, node = idx >> 4, q = idx & 15;
-    float4 v = xv[i];
+  for (int i = 0; i < XI; ++i) {
+    const int idx = tid + kRowThreads * i, node = idx / RV, q = idx % RV;
+    if (XI * kRowThreads != NR * RV && idx >= NR * RV) continue;
+    Vec v = xv[i];
     if (x_norm) {
-      const float4 sc = *reinterpret_cast<const float4*>(xss + 4 * q);
-      const float4 sh = *reinterpret_cast<const float4*>(xss + D + 4 * q);
-      v = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+      float f[L::VEC];
+      L::unpack(v, f);
+#pragma unroll
+      for (int e = 0; e < L::VEC; ++e) f[e] = f[e] * xss[L::VEC * q + e] + xss[D + L::VEC * q + e];
+      v = L::pack(f);
     }
-    *reinterpret_cast<float4*>(Xs + node * P + 4 * q) = v;  // rows >= N: a copy of row N-1, never stored
+    L::stv(Xs + node * P + L::VEC * q, v);  // rows >= N: a copy of row N-1, never stored
   }
   {
     const float rn = 1.0f / (float)a.N;
@@ -197,61 +214,58 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
   __syncthreads();
   FETA_STAMP(1);
 
-  // ---- in_proj for this head: Q^T, K^T ("row operand" layout), V (B-operand layout) ---------------
-  Feat<DH> qf[NT], kf[NT];
-  f32x4 vb[NT];
+  // ---- in_proj for this head: Q^T (scaled), K^T ("row operand" layout), V (B-operand layout) -----
+  Op qs[NT], kf[NT], vbo[NT];
   {
-    Feat<D> xf[NT];
+    RowOp<T, D> xf[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) load_row<D>(xf[nt], Xs + (16 * nt + lq) * P, g);
+    for (int nt = 0; nt < NT; ++nt) load_row_op<T, D>(xf[nt], Xs + (16 * nt + lq) * P, g);
 #pragma unroll
     for (int part = 0; part < 3; ++part) {
       if (part == 1 && a.tie_qk) continue;
-      Feat<D> wf;
-      load_row<D>(wf, Wi + (part * D + DH * h + lq) * P, g);
+      RowOp<T, D> wf;
+      load_row_op<T, D>(wf, Wi + (part * D + DH * h + lq) * P, g);
       const float4 bv4 = bin4[part];
       const float bv1 = bin1;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int node = 16 * nt + lq;
         if (part > 0 && 16 * nt >= n) {  // a key tile without a real node: no K, no V (wave-uniform)
-          if (part == 1) kf[nt].f[0][0] = kf[nt].f[0][1] = kf[nt].f[0][2] = kf[nt].f[0][3] = 0.0f;
-          else vb[nt] = zero4();
+          if (part == 1) kf[nt] = L::zero();
+          else vbo[nt] = L::zero();
           continue;
         }
         if (part < 2) {
           // (c = 4g + r, node = lq): four consecutive features of one node per lane
-          f32x4 t = dot_rows<D>(wf, xf[nt], zero4());
+          f32x4 t = dot_row_ops<T, D>(wf, xf[nt], zero4());
           t[0] += bv4.x; t[1] += bv4.y; t[2] += bv4.z; t[3] += bv4.w;
           if (node < a.N) {
             const int64_t row = (int64_t)b * a.row_sb + (int64_t)node * a.row_sn;
-            *reinterpret_cast<float4*>(a.qkv + row * 3 * D + part * D + DH * h + 4 * g) =
-                make_float4(t[0], t[1], t[2], t[3]);
+            L::st4(gqkv + row * 3 * D + part * D + DH * h + 4 * g, t[0], t[1], t[2], t[3]);
           }
-          Feat<DH>& dst = part == 0 ? qf[nt] : kf[nt];
-#pragma unroll
-          for (int s = 0; s < 4; ++s) dst.f[0][s] = t[s];
+          if (part == 0) {
+            qs[nt] = L::mk(t[0] * a.scale, t[1] * a.scale, t[2] * a.scale, t[3] * a.scale);
+            if (a.tie_qk) kf[nt] = L::mk(t);   // K tied to Q: tiles beyond n_real are never used
+          } else {
+            kf[nt] = L::mk(t);
+          }
         } else {
           // (node = 4g + r, c' = lq)
-          f32x4 t = dot_rows<D>(xf[nt], wf, zero4());
+          f32x4 t = dot_row_ops<T, D>(xf[nt], wf, zero4());
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             t[r] += bv1;
             const int nd = 16 * nt + 4 * g + r;
             if (nd < a.N) {
               const int64_t row = (int64_t)b * a.row_sb + (int64_t)nd * a.row_sn;
-              a.qkv[row * 3 * D + 2 * D + DH * h + lq] = t[r];
+              L::st1(gqkv + row * 3 * D + 2 * D + DH * h + lq, t[r]);
             }
             if (nd >= n) t[r] = 0.0f;  // padded keys carry no value
           }
-          vb[nt] = t;
+          vbo[nt] = L::mk(t);
         }
       }
     }
-  }
-  if (a.tie_qk) {  // K tied to Q: tiles beyond n_real are never used
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) kf[nt] = qf[nt];
   }
 
   FETA_STAMP(2);
@@ -268,12 +282,7 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
     for (int qb = 0; qb < NT; ++qb) acc[qb][kt] = zero4();
     if (16 * kt < n) {
 #pragma unroll
-      for (int qb = 0; qb < NT; ++qb) {
-        Feat<DH> qs;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) qs.f[0][s] = qf[qb].f[0][s] * a.scale;
-        acc[qb][kt] = dot_rows<DH>(kf[kt], qs, zero4());  // (key 4g+r, query lq)
-      }
+      for (int qb = 0; qb < NT; ++qb) acc[qb][kt] = L::mma(kf[kt], qs[qb], zero4());  // (key 4g+r, query lq)
     }
   }
   float mx[NT], zs[NT], rinv[NT];
@@ -338,17 +347,16 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
   for (int kt = 0; kt < NT; ++kt) {
     if (16 * kt >= n) continue;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int qb = 0; qb < NT; ++qb) {
 #pragma unroll
-      for (int qb = 0; qb < NT; ++qb) {
-        acc[qb][kt][r] *= rinv[qb];
-        o[qb] = mfma16(acc[qb][kt][r], vb[kt][r], o[qb]);  // (query 4g+r, c' lq)
-      }
+      for (int r = 0; r < 4; ++r) acc[qb][kt][r] *= rinv[qb];
+      o[qb] = L::mma(L::mk(acc[qb][kt]), vbo[kt], o[qb]);  // (query 4g+r, c' lq)
+    }
   }
 #pragma unroll
   for (int qb = 0; qb < NT; ++qb)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Os[(16 * qb + 4 * g + r) * P + DH * h + lq] = o[qb][r];
+    for (int r = 0; r < 4; ++r) L::st1(Os + (16 * qb + 4 * g + r) * P + DH * h + lq, o[qb][r]);
   if (a.attn != nullptr) {
 #pragma unroll
     for (int qb = 0; qb < NT; ++qb) {
@@ -372,16 +380,16 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
 
   // ---- concat to HBM (whole rows) and out_proj: wave w owns output columns 16w .. 16w+15 ----------
 #pragma unroll
-  for (int i = 0; i < NT; ++i) {
-    const int idx = tid + kRowThreads * i, node = idx >> 4, q = idx & 15;
+  for (int i = 0; i < XI; ++i) {
+    const int idx = tid + kRowThreads * i, node = idx / RV, q = idx % RV;
     if (node < a.N) {
       const int64_t row = (int64_t)b * a.row_sb + (int64_t)node * a.row_sn;
-      *reinterpret_cast<float4*>(a.out + row * D + 4 * q) = *reinterpret_cast<const float4*>(Os + node * P + 4 * q);
+      L::stv(gout + row * D + L::VEC * q, L::ldv(Os + node * P + L::VEC * q));
     }
   }
   {
-    Feat<D> wf;
-    load_row<D>(wf, Wo + (DH * h + lq) * P, g);
+    RowOp<T, D> wf;
+    load_row_op<T, D>(wf, Wo + (DH * h + lq) * P, g);
     const int o0 = DH * h + 4 * g;
     float s1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -391,13 +399,14 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
       const bool rok = node < a.N;
       const int64_t row = (int64_t)b * a.row_sb + (int64_t)min(node, a.N - 1) * a.row_sn;
       const float rs = rsv[nt];
-      Feat<D> of;
-      load_row<D>(of, Os + node * P, g);
-      const f32x4 t = dot_rows<D>(wf, of, zero4());  // (o = 16h + 4g + r, node lq)
-      const float4 res = *reinterpret_cast<const float4*>(Xs + node * P + o0);
-      float v[4] = {(t[0] + bo.x) * rs + res.x, (t[1] + bo.y) * rs + res.y, (t[2] + bo.z) * rs + res.z,
-                    (t[3] + bo.w) * rs + res.w};
-      if (rok) *reinterpret_cast<float4*>(a.y + row * D + o0) = make_float4(v[0], v[1], v[2], v[3]);
+      RowOp<T, D> of;
+      load_row_op<T, D>(of, Os + node * P, g);
+      const f32x4 t = dot_row_ops<T, D>(wf, of, zero4());  // (o = 16h + 4g + r, node lq)
+      float res[4];
+      L::ld4(Xs + node * P + o0, res);
+      float v[4] = {(t[0] + bo.x) * rs + res[0], (t[1] + bo.y) * rs + res[1], (t[2] + bo.z) * rs + res[2],
+                    (t[3] + bo.w) * rs + res[3]};
+      if (rok) L::st4(gy + row * D + o0, v[0], v[1], v[2], v[3]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float x1 = rok ? v[r] : 0.0f;
@@ -416,10 +425,10 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
   FETA_RT_LAUNCH_DONE(feta_block_launch);
 }
 
-template <int NT>
+template <class T, int NT>
 int launch_block_fwd(const BlockArgs& a, const feta_colsum_seg* segs, int nseg, hipStream_t stream) {
-  const size_t lds = sizeof(float) * block_lds_floats(NT, a.attn != nullptr);
-  auto kern = attn_block_fwd_kernel<NT>;
+  const size_t lds = block_lds_bytes<T>(NT, a.attn != nullptr);
+  auto kern = attn_block_fwd_kernel<T, NT>;
   static LdsSeen lds_seen;
   allow_dynamic_lds(kern, lds, lds_seen);
   int cap = kBlkMaxGrid;   // one resident workgroup per CU (LDS); FETA_BLOCK_MAX_GRID: tests force the loop
@@ -429,6 +438,16 @@ int launch_block_fwd(const BlockArgs& a, const feta_colsum_seg* segs, int nseg, 
   const int tiles = plan_colsum(segs, nseg, plan);
   hipLaunchKernelGGL(kern, dim3(grid + tiles), dim3(kRowThreads), lds, stream, a, plan, grid);
   return check_launch("feta_attn_block_fwd");
+}
+
+template <class T>
+int dispatch_block_fwd(const BlockArgs& a, const feta_colsum_seg* segs, int nseg, hipStream_t stream) {
+  switch ((a.N + 15) / 16) {
+    case 1: return launch_block_fwd<T, 1>(a, segs, nseg, stream);
+    case 2: return launch_block_fwd<T, 2>(a, segs, nseg, stream);
+    case 3: return launch_block_fwd<T, 3>(a, segs, nseg, stream);
+    default: return launch_block_fwd<T, 4>(a, segs, nseg, stream);
+  }
 }
 
 }  // namespace feta
@@ -465,11 +484,7 @@ extern "C" int feta_attn_block_fwd_sums(const feta_attn_block* d, const feta_col
   FETA_REQUIRE(aligned16(a.x) && aligned16(a.w_in) && aligned16(a.w_out) && aligned16(a.qkv) && aligned16(a.out) &&
                aligned16(a.y) && aligned16(a.y_stats) && aligned16(a.x_stats) && aligned16(a.b_in) && aligned16(a.b_out),
                "attn_block_fwd: tensors must be 16-byte aligned");
-  const int nt = (a.N + 15) / 16;
-  switch (nt) {
-    case 1: return launch_block_fwd<1>(a, segs, nseg, (hipStream_t)stream);
-    case 2: return launch_block_fwd<2>(a, segs, nseg, (hipStream_t)stream);
-    case 3: return launch_block_fwd<3>(a, segs, nseg, (hipStream_t)stream);
-    default: return launch_block_fwd<4>(a, segs, nseg, (hipStream_t)stream);
-  }
+  FETA_REQUIRE(a.dtype == FETA_F32 || a.dtype == FETA_BF16, "attn_block_fwd: dtype %d", a.dtype);
+  if (a.dtype == FETA_BF16) return dispatch_block_fwd<bf16_t>(a, segs, nseg, (hipStream_t)stream);
+  return dispatch_block_fwd<float>(a, segs, nseg, (hipStream_t)stream);
 }

@@ -23,9 +23,11 @@ struct LdsSeen {
   }
 };
 void note_attr_error(const char* what);
+void clear_attr_error();   // a note belongs to the launch that follows it, never to a later one
 
 template <class K>
 inline void allow_dynamic_lds(K kern, size_t bytes, LdsSeen& seen) {
+  clear_attr_error();
   if (bytes <= 64 * 1024) return;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = -1;

@@ -50,6 +50,33 @@ __device__ __forceinline__ f32x4 mfma16_bf16(const float (&a)[4], const float (&
   return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bv, c, 0, 0, 0);
 }
 
+// Four k-consecutive bf16 operand values of one lane, already packed (two VGPRs): what the fused bf16 stack kernels
+// keep in LDS / registers, so that an operand is rounded ONCE however many products it enters (feta_lp.h).
+struct __attribute__((aligned(8))) bf16x4_pk {
+  bf16x4_mfma v;
+};
+// two v_cvt_pk_bf16_f32 (round to nearest even, NaN stays NaN)
+__device__ __forceinline__ bf16x4_pk pack_bf16x4(float a, float b, float c, float d) {
+  typedef __bf16 bf16x4_native __attribute__((ext_vector_type(4)));
+  const f32x4 v = {a, b, c, d};
+  bf16x4_pk r;
+  r.v = __builtin_bit_cast(bf16x4_mfma, __builtin_convertvector(v, bf16x4_native));
+  return r;
+}
+__device__ __forceinline__ bf16x4_pk pack_bf16x4_raw(bf16_t a, bf16_t b, bf16_t c, bf16_t d) {
+  bf16x4_pk r;
+  r.v[0] = (short)a.bits; r.v[1] = (short)b.bits; r.v[2] = (short)c.bits; r.v[3] = (short)d.bits;
+  return r;
+}
+__device__ __forceinline__ float bf16x4_get(const bf16x4_pk& p, int i) {
+  bf16_t t;
+  t.bits = (unsigned short)p.v[i];
+  return bf2f(t);
+}
+__device__ __forceinline__ f32x4 mfma16_bf16_pk(const bf16x4_pk& a, const bf16x4_pk& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.v, b.v, c, 0, 0, 0);
+}
+
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }
 

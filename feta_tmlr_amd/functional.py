@@ -148,8 +148,8 @@ class FilterCoefficientsFn(torch.autograd.Function):
             # workgroups (feta_ffn_bwd_coeff), its reduction launch the sums
             pend.coeff_bwd_req = (cj, n_real, s, gb, dpooled.contiguous(), partial, b, n, h)
             p2 = partial.view(groups, 2 * c)
-            pend.add(p2[:, :c], ds, dw)
-            pend.add(p2[:, c:], db)
+            pend.add(p2[:, :c], ds, dw, owners=[(ctx.params[0], dw)])
+            pend.add(p2[:, c:], db, owners=[(ctx.params[1], db)])
             return None, None, dw, db, None
         waiting = pend.take() if pend is not None else []
         if waiting:
@@ -243,6 +243,7 @@ class PendingSums:
         self.stack_armed = False   # the fused layer stack will, in the same backward pass (set by the encoder), and
         self.stack_done = False    # ... has not yet: its one reduction launch takes what the stage's last node leaves
         self.items = []
+        self.owners = []
         self._callback_queued = False
         # forward direction: column sums of parameters that a launch of the layer stack carries in trailing workgroups
         # (s = colsum(gcn.weight) of the coefficient generator); whoever needs them first runs them if nobody did
@@ -260,6 +261,11 @@ class PendingSums:
     def untouched(*params):
         """A gradient may be completed after its node returned only if nothing reads it before the flush: the
         parameter has no .grad to accumulate into (autograd then keeps the returned tensor itself) and no hooks."""
+        # AccumulateGrad keeps the returned tensor without copying it only while grad mode is off (an ordinary
+        # backward pass): under create_graph=True it accumulates a copy, and anomaly mode reads the buffer when the
+        # node returns - both would see the un-reduced buffer
+        if torch.is_grad_enabled() or torch.is_anomaly_enabled():
+            return False
         for p in params:
             if p is None:
                 continue
@@ -267,10 +273,16 @@ class PendingSums:
                 return False
         return True
 
-    def add(self, partial, out, bcast=None):
+    def add(self, partial, out, bcast=None, owners=()):
+        """owners: [(parameter, the gradient tensor its node returns)] whose storage this sum completes later: checked
+        when the backward pass ends (_finish_pass) - had autograd copied the returned tensor after all (a hook on the
+        AccumulateGrad node, which untouched() cannot see), the finished values are copied over that copy."""
         # (a second tensor object on the same storage: autograd keeps a returned gradient without copying it only
         # if nobody else holds a reference to that tensor object)
         self.items.append((partial, out.detach(), None if bcast is None else bcast.detach()))
+        for p, g in owners:
+            if p is not None and g is not None:
+                self.owners.append((p, g.detach()))
         if not self._callback_queued:
             # safety net: whatever no later node took (autograd pruned it from this pass) is reduced when the
             # backward pass ends
@@ -311,6 +323,12 @@ class PendingSums:
                 cj, n_real, s, gb, dpooled, partial, b, n, h = req
                 abi.coeff_bwd(cj, n_real, s, gb, dpooled, partial, None, None, b, n, h, stream)
             abi.colsum_multi(items, stream)
+        owners, self.owners = self.owners, []
+        for p, g in owners:
+            # .grad is None: torch.autograd.grad() handed the tensor itself to the caller - nothing to repair
+            if p.grad is not None and p.grad.data_ptr() != g.data_ptr():
+                with torch.no_grad():
+                    p.grad.copy_(g.view_as(p.grad))
 
 
 class FilterFromPooledFn(torch.autograd.Function):
@@ -395,6 +413,8 @@ class FilterFromPooledFn(torch.autograd.Function):
             if ctx.defer and PendingSums.untouched(*ctx.params):
                 for pr in sums:
                     ctx.pending.add(*pr)
+                ctx.pending.owners += [(p_, g_.detach()) for p_, g_ in ((ctx.params[0], db_lin), (ctx.params[1], dbias))
+                                       if p_ is not None]
             else:
                 abi.colsum_multi(sums, stream)
             dpooled, dw_lin = dcoeff.mm(lin_w), dcoeff.t().mm(pooled)
@@ -494,7 +514,8 @@ class RowLinearCatFn(torch.autograd.Function):
                           partial_ld=(no * ki + no if ctx.defer is not None else 0))
         if ctx.defer is not None:     # the filter's backward reduces the partials inside its own launch
             abi.rowlin_bwd_ex(d, None, stream)
-            ctx.defer.add(partial, dwdb)
+            ctx.defer.add(partial, dwdb, owners=[(ctx.params[0], dwdb[:no * ki].view(no, ki)),
+                                                 (ctx.params[1], dwdb[no * ki:] if ctx.has_bias else None)])
         else:
             abi.rowlin_bwd_ex(d, dwdb, stream)
         return dx1, dx2, dwdb[:no * ki].view(no, ki), (dwdb[no * ki:] if ctx.has_bias else None), None
@@ -543,7 +564,8 @@ class RowLinearCatBNFn(torch.autograd.Function):
                           partial_ld=(no * ki + no if ctx.defer is not None else 0), sum_y=y2, sum_bn=prm2, sum_out=gs)
         if ctx.defer is not None:     # the filter's backward reduces the partials inside its own launch
             abi.rowlin_bwd_ex(d, None, stream)
-            ctx.defer.add(partial, dwdb)
+            ctx.defer.add(partial, dwdb, owners=[(ctx.params[0], dwdb[:no * ki].view(no, ki)),
+                                                 (ctx.params[1], dwdb[no * ki:] if ctx.has_bias else None)])
         else:
             abi.rowlin_bwd_ex(d, dwdb, stream)
         ctx.tail.gs = gs
@@ -661,6 +683,14 @@ class DropoutState:
             cls.manual_seed(torch.initial_seed())
         cls.offset += 1
         return cls.seed, cls.offset
+
+    @classmethod
+    def snapshot(cls):
+        return cls.seed, cls.offset
+
+    @classmethod
+    def restore(cls, snap):
+        cls.seed, cls.offset = snap
 
 
 def attention_core(qkv, pe, n_real, num_heads, need_attn=True, tie_qk=False, batch_first=False, dropout_p=0.0):

@@ -110,9 +110,15 @@ class FlatGradAllReduce:
         if not self.views:
             self.pack()
         if self.wire is not None:
+            # pre-scaled by 1 / world in fp32, then rounded ONCE to bf16 and SUMMED by the collective (ReduceOp.AVG on
+            # bf16 is not there on every backend, and a sum of pre-scaled addends cannot overflow where the mean fits).
+            # The running sum travels in bf16: each of the world - 1 additions rounds to 8 bits, so the result is
+            # within ~(1 + log2(world)) * 2^-9 relative of the fp32 bucket per element for like-signed addends
+            # (tests/test_parallel_gloo.py checks 2^-7 * max|g| at world 2 and 4)
+            self.flat.mul_(1.0 / self.world_size)
             self.wire.copy_(self.flat)
-        return dist.all_reduce(self.flat if self.wire is None else self.wire, op=self._op(), group=self.group,
-                               async_op=True)
+            return dist.all_reduce(self.wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return dist.all_reduce(self.flat, op=self._op(), group=self.group, async_op=True)
 
     def _op(self):
         return dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM
@@ -122,8 +128,8 @@ class FlatGradAllReduce:
             return
         work.wait()
         if self.wire is not None:
-            self.flat.copy_(self.wire)     # widened to fp32 before the scale and the scatter
-        if not self.avg_in_collective:
+            self.flat.copy_(self.wire)     # widened to fp32 before the scatter (already the mean)
+        elif not self.avg_in_collective:
             self.flat.mul_(1.0 / self.world_size)
         if not self.views:
             self.unpack()

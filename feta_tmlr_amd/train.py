@@ -183,15 +183,26 @@ class GraphedTrainStep:
         opt = {}
         for p, st in self.optimizer.state.items():
             opt[p] = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()}
-        return [t.detach().clone() for t in tensors], opt
+        # ... and the random streams the warm-up steps draw from: torch's generators (nn.Dropout) and the
+        # (seed, offset) of the attention-probability dropout masks
+        from .functional import DropoutState
+        dev = tensors[0].device if tensors else None
+        rng = (torch.get_rng_state(), torch.cuda.get_rng_state(dev) if (dev is not None and dev.type == 'cuda') else None,
+               DropoutState.snapshot())
+        return [t.detach().clone() for t in tensors], opt, rng
 
     @torch.no_grad()
     def _restore(self, snap):
         """In place: the captured graph holds the addresses of these tensors."""
-        saved, opt = snap
+        saved, opt, rng = snap
         tensors = list(self.model.parameters()) + list(self.model.buffers())
         for t, s in zip(tensors, saved):
             t.copy_(s)
+        from .functional import DropoutState
+        torch.set_rng_state(rng[0])
+        if rng[1] is not None:
+            torch.cuda.set_rng_state(rng[1], tensors[0].device)
+        DropoutState.restore(rng[2])
         for p, st in self.optimizer.state.items():
             before = opt.get(p)
             for k, v in st.items():

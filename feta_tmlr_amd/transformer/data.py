@@ -347,6 +347,10 @@ class BatchStager:
             self.sets.append((h, d))
         self.turn = 0
         self.copy_stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+        # one event per buffer set, recorded behind that set's H2D copies: the pinned host buffers of a set are the
+        # SOURCE of asynchronous copies, so a host that runs two or more batches ahead must not refill them before
+        # the copy engine has read them (stream-side ordering alone does not stop the host)
+        self.copied = [None, None]
 
     def stage(self, graph_ids):
         """-> (batch9, cache) on the device; the copies are enqueued on the copy stream and the current stream is
@@ -355,8 +359,11 @@ class BatchStager:
         ids = np.asarray(graph_ids, np.int64)
         bsz = len(ids)
         assert 0 < bsz <= self.bmax
-        h, d = self.sets[self.turn]
+        turn = self.turn
+        h, d = self.sets[turn]
         self.turn ^= 1
+        if self.copied[turn] is not None:
+            self.copied[turn].synchronize()     # the copies enqueued from this set two calls ago have been read
         ns = pk.n[ids]
         assert int(ns.max()) <= n_pad, 'graph with %d nodes in a batch padded to %d' % (int(ns.max()), n_pad)
         n_tot = int(ns.sum())
@@ -410,6 +417,9 @@ class BatchStager:
                         continue
                     out[k] = d[k][sl]
                     out[k].copy_(h[k][sl], non_blocking=True)
+                if self.copied[turn] is None:
+                    self.copied[turn] = torch.cuda.Event()
+                self.copied[turn].record(self.copy_stream)
             cur.wait_stream(self.copy_stream)
         else:
             for k, sl in views.items():

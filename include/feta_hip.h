@@ -12,7 +12,8 @@
  *  - every pointer is a DEVICE pointer owned by the caller and valid until the
  *    given stream reaches the enqueue point; nothing is allocated or synchronised
  *    inside; kernels are stream-ordered and graph-capturable;
- *  - all floating-point data is fp32, row-major; `stream` is a hipStream_t;
+ *  - floating-point data is fp32 unless an entry point or a descriptor's `dtype` says bf16, row-major; `stream` is a
+ *    hipStream_t;
  *  - "token tensors" (q/k/v, per-head outputs, filter input/output) are addressed
  *    as ptr[b*sb + i*sn + h*dh + c] with element strides sb (graph) and sn (node),
  *    so seq-first [N,B,d] and batch-first [B,N,d] storage both work without copies;
@@ -31,13 +32,22 @@
 extern "C" {
 #endif
 
-#define FETA_ABI_VERSION 6
+#define FETA_ABI_VERSION 7
 
 #define FETA_OK 0
 #define FETA_E_ARG (-1)     /* bad shape / stride / alignment / unsupported size */
 #define FETA_E_LAUNCH (-2)  /* the HIP runtime rejected a launch */
 
 typedef void* feta_stream_t;
+
+/* Storage type of the token tensors of the fused layer-stack descriptors (feta_attn_block, feta_attn_block_grad,
+ * feta_ffn, feta_ffn_grad; ABI 7).  FETA_BF16: the tensors marked [T] in each descriptor hold bf16 (the pointers stay
+ * typed float* in the structs; rows must be 16-byte aligned), the kernels stage bf16 tiles and run their contractions
+ * on v_mfma_f32_16x16x16_bf16; weights, biases, BatchNorm parameter blocks and partial sums, softmax statistics, the
+ * attention matrix, and every weight / bias gradient stay fp32.  The reference has no reduced-precision mode
+ * (experiments/run_transformer_gengcn.py:115-164): this is the storage path of BASELINE configs 3 and 5. */
+#define FETA_F32 0
+#define FETA_BF16 1
 
 int feta_version(void);
 const char* feta_last_error(void);
@@ -384,6 +394,7 @@ typedef struct feta_attn_block {
   int B, N, M;
   int64_t row_sb, row_sn;
   int tie_qk;
+  int dtype;           /* FETA_F32 | FETA_BF16: storage type of x, pe, qkv, out, y [T] (ABI 7) */
 } feta_attn_block;
 
 int feta_attn_block_supported(int N, int d_model, int heads);
@@ -437,6 +448,7 @@ typedef struct feta_attn_block_grad {
   float scale;
   int B, N, M;
   int64_t row_sb, row_sn;
+  int dtype;         /* FETA_F32 | FETA_BF16: storage type of dy, y1, qkv, out, dout2, pe, x0, dx, dx_b [T] (ABI 7) */
 } feta_attn_block_grad;
 
 int feta_attn_block_bwd_supported(int N, int d_model, int heads);
@@ -468,6 +480,7 @@ typedef struct feta_ffn {
   float* y;
   float* y_stats;   /* or NULL */
   int M, FF;
+  int dtype;        /* FETA_F32 | FETA_BF16: storage type of x, h, y [T] (ABI 7) */
 } feta_ffn;
 
 int feta_ffn_supported(int d_model, int ff);
@@ -516,6 +529,7 @@ typedef struct feta_ffn_grad {
   float* partial;
   int partial_ld;
   int M, FF;
+  int dtype;         /* FETA_F32 | FETA_BF16: storage type of dy, dy_b, g_y, h, x, dx [T] (ABI 7) */
 } feta_ffn_grad;
 
 int feta_ffn_bwd_supported(int d_model, int ff);

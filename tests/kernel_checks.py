@@ -644,3 +644,61 @@ class poisoned_scratch:
     def __exit__(self, *exc):
         torch.empty, torch.empty_like = self._e, self._el
         return False
+
+
+# ---- fused layer-stack kernels on bf16 storage (include/feta_hip.h: dtype = FETA_BF16) ---------------------------------
+def _lp_case(bsz, n_pad, n_min, seed, dev, with_pe=True):
+    """Inputs of an attention sub-block at d = 64 / 4 heads, values representable in bf16 (the fp64 oracle consumes the
+    same rounded values), seq-first rows."""
+    g = torch.Generator().manual_seed(seed)
+    d, heads = 64, 4
+    n_real = torch.randint(n_min, n_pad + 1, (bsz,), generator=g)
+    n_real[0] = n_pad
+    mask = torch.arange(n_pad)[None, :] >= n_real[:, None]                     # [B,N] True = pad
+    x = torch.randn(n_pad, bsz, d, generator=g).double()
+    x = round_to(x * (~mask).t().unsqueeze(-1), BF16)                           # zero rows on pads (the embedding's)
+    pe = None
+    if with_pe:
+        pe = torch.rand(bsz, n_pad, n_pad, generator=g).double() + 0.1
+        pe = round_to(pe * (~mask).unsqueeze(1) * (~mask).unsqueeze(2), BF16)
+    degree = (torch.rand(bsz, n_pad, generator=g).double() * 0.5 + 0.5) * (~mask)
+    p = dict(w_in=torch.randn(3 * d, d, generator=g).double() / 8, b_in=torch.randn(3 * d, generator=g).double() * 0.1,
+             w_out=torch.randn(d, d, generator=g).double() / 8, b_out=torch.randn(d, generator=g).double() * 0.1)
+    return d, heads, n_real.to(torch.int32), mask, x, pe, degree, p
+
+
+def check_attn_block_lp(abi, dev, stream, bsz=5, n_pad=21, n_min=3, seed=0, with_pe=True, need_attn=True):
+    """feta_attn_block_fwd with dtype = FETA_BF16 against the fp64 oracle of the same sub-block (in_proj -> attention
+    -> out_proj -> degree -> residual; oracle.diff_attention) on bf16-representable inputs: qkv, per-head outputs, y,
+    the (fp32) attention matrix and softmax statistics, and the BatchNorm partial sums of y."""
+    d, heads, n_real, mask, x, pe, degree, p = _lp_case(bsz, n_pad, n_min, seed, dev, with_pe)
+    m = n_pad * bsz
+    f32 = lambda t: t.float().to(dev).contiguous()
+    b16 = lambda t: t.to(BF16).to(dev).contiguous()
+    new = lambda *s: torch.full(s, float('nan'), dtype=BF16, device=dev)
+    qkv, out, y = new(m, 3 * d), new(m, d), new(m, d)
+    ast = torch.full((bsz, heads, n_pad, 2), float('nan'), device=dev)
+    attn = torch.full((bsz, heads, n_pad, n_pad), float('nan'), device=dev) if need_attn else None
+    st = torch.full((bsz, 2, d), float('nan'), device=dev)
+    rows = degree.t().reshape(m)
+    abi.attn_block_fwd(bsz, n_pad, float(d // heads) ** -0.5, stream, x=b16(x).view(m, d), w_in=f32(p['w_in']),
+                       b_in=f32(p['b_in']), w_out=f32(p['w_out']), b_out=f32(p['b_out']),
+                       pe=None if pe is None else b16(pe), n_real=n_real.to(dev), rowscale=f32(rows), qkv=qkv, out=out,
+                       attn_stats=ast, attn=attn, y=y, y_stats=st)
+    w32 = {k: v.float().double() for k, v in p.items()}
+    qkv_ref = torch.nn.functional.linear(x, w32['w_in'], w32['b_in'])
+    concat, a_ref, _ = O.attention_core(qkv_ref, pe, mask, heads)
+    y_ref = x + degree.t().unsqueeze(-1) * torch.nn.functional.linear(concat, w32['w_out'], w32['b_out'])
+    real = (~mask).t().unsqueeze(-1)       # k / v rows of key tiles without a real node are never written
+    zero = torch.zeros((), dtype=torch.float64)
+    assert_close('lp qkv', torch.where(real, qkv.view(n_pad, bsz, 3 * d).cpu().double(), zero),
+                 torch.where(real, qkv_ref, zero), tol=BF16_TOL)
+    assert_close('lp out', out.view(n_pad, bsz, d), concat, tol=BF16_TOL)
+    assert_close('lp y', y.view(n_pad, bsz, d), y_ref, tol=BF16_TOL)
+    if need_attn:
+        assert_close('lp attn', attn, a_ref, tol=BF16_TOL)
+    yf = y.view(m, d).float().cpu().double()
+    # statistics are sums of the fp32 values BEFORE the bf16 store: compare with the stored values up to their rounding
+    assert_close('lp y_stats sum', st[:, 0].sum(0), yf.sum(0), tol=BF16_TOL)
+    assert_close('lp y_stats sumsq', st[:, 1].sum(0), (yf * yf).sum(0), tol=BF16_TOL)
+    return dict(qkv=qkv, out=out, y=y, ast=ast, attn=attn)

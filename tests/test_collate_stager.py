@@ -61,3 +61,31 @@ def test_stager_on_device_with_spectrum():
         assert float((b9[2].cpu() - ref9[2]).abs().max()) < 2e-5
         assert float((cache.lam.cpu() - refc.lam).abs().max()) < 5e-6
         assert cache.u.shape == refc.u.shape
+
+
+@pytest.mark.gpu
+def test_stager_back_to_back_without_host_sync():
+    """A host that runs several batches ahead of the device (no synchronisation between stage() calls; the stream is
+    kept busy so that the copies really are pending when the next call refills the pinned buffers): every batch must
+    arrive intact - the pinned source buffers of a set are guarded by an event."""
+    dev = torch.device('cuda:0')
+    ds = D.SyntheticGraphDataset('zinc', 400, in_dim=28, seed=5)
+    pk = D.PackedGraphs(ds.samples)
+    st = D.BatchStager(pk, max_batch=128, n_pad=37, device=dev)
+    rng = np.random.default_rng(7)
+    busy = torch.randn(4096, 4096, device=dev)
+    all_ids, kept = [], []
+    for it in range(5):
+        for _ in range(8):
+            busy = busy @ busy * 1e-4      # the current stream (which the copy stream waits for) is behind the host
+        ids = rng.choice(len(ds), size=128, replace=False)
+        b9, cache = st.stage(ids)
+        all_ids.append(ids)
+        # consume on the device at once: the device buffers of a set are reused two calls later by design
+        kept.append([b9[i].clone() for i in (0, 1, 4, 5, 6, 7, 8)] + [cache.n_real.clone()])
+    torch.cuda.synchronize()
+    for ids, got in zip(all_ids, kept):
+        ref9, refc = D.collate([ds[i] for i in ids], n_pad=37)
+        for t, i in zip(got[:-1], (0, 1, 4, 5, 6, 7, 8)):
+            _same(t, ref9[i])
+        _same(got[-1], refc.n_real)

@@ -143,10 +143,10 @@ def test_encoder_without_graph_cache(emu):
     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize('scalar_mode', [False, True])
-def test_chebconvdynamic_operator_api(emu, scalar_mode):
+def check_chebconvdynamic_operator_api(dev, hook, scalar_mode):
     """ChebConvDynamic.forward(x, edge_index, filter_coeff, batch=) on the gathered node list,
-    including groups that edge_index does not cover (the stacked-heads quirk)."""
+    including groups that edge_index does not cover (the stacked-heads quirk); scalar_mode =
+    learn_only_filter_order_coeff (transformer/ChebNetDynamic.py:91-92,150-153)."""
     torch.manual_seed(1)
     bsz, heads, dh, order = 3, 2, 8, 4
     ds = D.SyntheticGraphDataset('mutag', bsz, in_dim=4, seed=3, n_min=4, n_max=15)
@@ -156,22 +156,29 @@ def test_chebconvdynamic_operator_api(emu, scalar_mode):
     conv = ChebConvDynamic(dh, dh, order, learn_only_filter_order_coeff=scalar_mode)
     with torch.no_grad():
         conv.bias.normal_(0, 0.1)
-    x = torch.randn(heads * n_tot, dh, requires_grad=True)
+    x = torch.randn(heads * n_tot, dh)
     groups = heads * bsz
-    fc = torch.randn(order, groups, requires_grad=True) if scalar_mode else \
-        (torch.randn(order, groups, dh, dh) / dh ** 0.5).requires_grad_(True)
+    fc = torch.randn(order, groups) if scalar_mode else torch.randn(order, groups, dh, dh) / dh ** 0.5
     batch_all = torch.cat([batch + i * bsz for i in range(heads)])
-    with _lib.override_for_tests(emu):
-        y = conv(x, edge_index, fc, batch=batch_all)       # edge_index covers head 0 only
+    conv_d = conv.to(dev)
+    xd = x.clone().to(dev).requires_grad_(True)
+    fcd = fc.clone().to(dev).requires_grad_(True)
+    with hook():
+        y = conv_d(xd, edge_index.to(dev), fcd, batch=batch_all.to(dev))       # edge_index covers head 0 only
         y.pow(2).sum().backward()
-    x64 = x.detach().double().requires_grad_(True)
-    fc64 = fc.detach().double().requires_grad_(True)
-    w64 = fc64 if not scalar_mode else fc64[:, :, None, None] * conv.weight.detach().double()[:, None]
-    y_ref = O.cheb_conv_dynamic_edges(x64, edge_index, w64, batch_all, conv.bias.detach().double())
+    x64 = x.double().requires_grad_(True)
+    fc64 = fc.double().requires_grad_(True)
+    w64 = fc64 if not scalar_mode else fc64[:, :, None, None] * conv.weight.detach().cpu().double()[:, None]
+    y_ref = O.cheb_conv_dynamic_edges(x64, edge_index, w64, batch_all, conv.bias.detach().cpu().double())
     y_ref.pow(2).sum().backward()
     KC.assert_close('y', y, y_ref)
-    KC.assert_close('dx', x.grad, x64.grad, tol=2e-5)
-    KC.assert_close('dcoeff', fc.grad, fc64.grad, tol=2e-5)
+    KC.assert_close('dx', xd.grad, x64.grad, tol=2e-5)
+    KC.assert_close('dcoeff', fcd.grad, fc64.grad, tol=2e-5)
+
+
+@pytest.mark.parametrize('scalar_mode', [False, True])
+def test_chebconvdynamic_operator_api(emu, scalar_mode):
+    check_chebconvdynamic_operator_api(CPU, lambda: _lib.override_for_tests(emu), scalar_mode)
 
 
 def test_ops_refuse_cpu_tensors_without_hook():
@@ -215,24 +222,29 @@ def test_fused_batchnorm_stack_matches_oracle(emu, monkeypatch, share, mode, pe_
         KC.assert_close('grad ' + name, p.grad, p64[name].grad, tol=3e-5)
 
 
-def test_fused_stack_updates_running_statistics(emu):
+def check_fused_stack_updates_running_statistics(dev, hook):
     model, batch9, cache = _model_case(True, 0, 'cheb', True, bsz=3, d=64, heads=4, layers=2, order=2)
     ref, _, _ = _model_case(True, 0, 'cheb', True, bsz=3, d=64, heads=4, layers=2, order=2)
     ref.encoder.fused_stack = False
-    x, mask, pe, _, degree, _, edge_index, batch, fi = batch9
-    with _lib.override_for_tests(emu):
+    model, ref, cache = model.to(dev), ref.to(dev), cache.to(dev)
+    x, mask, pe, _, degree, _, edge_index, batch, fi = [None if t is None else t.to(dev) for t in batch9]
+    with hook():
         model(x, edge_index, batch, fi, mask, pe, degree=degree, graph_cache=cache)
         ref(x, edge_index, batch, fi, mask, pe, degree=degree, graph_cache=cache)
     for l, lr in zip(model.encoder.layers, ref.encoder.layers):
         for nm in ('norm1', 'norm2'):
-            KC.assert_close(nm + '.running_mean', getattr(l, nm).running_mean, getattr(lr, nm).running_mean)
-            KC.assert_close(nm + '.running_var', getattr(l, nm).running_var, getattr(lr, nm).running_var)
+            KC.assert_close(nm + '.running_mean', getattr(l, nm).running_mean, getattr(lr, nm).running_mean.cpu())
+            KC.assert_close(nm + '.running_var', getattr(l, nm).running_var, getattr(lr, nm).running_var.cpu())
             # nn.BatchNorm1d advances num_batches_tracked once per training forward: both paths do (in the
             # kernel that finalizes the statistics), so state dicts stay interchangeable with PyTorch's
             assert int(getattr(l, nm).num_batches_tracked) == 1 and int(getattr(lr, nm).num_batches_tracked) == 1
-    with _lib.override_for_tests(emu):
+    with hook():
         model(x, edge_index, batch, fi, mask, pe, degree=degree, graph_cache=cache)
     assert all(int(getattr(l, nm).num_batches_tracked) == 2 for l in model.encoder.layers for nm in ('norm1', 'norm2'))
+
+
+def test_fused_stack_updates_running_statistics(emu):
+    check_fused_stack_updates_running_statistics(CPU, lambda: _lib.override_for_tests(emu))
 
 
 def test_two_phase_backward_equals_single_backward(emu):
@@ -320,6 +332,17 @@ def test_deferred_column_sums_and_gradient_accumulation(emu, monkeypatch, own_ge
             got = torch.autograd.grad((out * out).sum() + 0.01 * coeff.pow(2).sum(), heads)
             for nme, gg in zip(names, got):
                 KC.assert_close('pruned pass ' + nme, gg, once[nme].double(), tol=1e-6)
+            # create_graph=True: grad mode stays on inside backward, AccumulateGrad accumulates a COPY of what a node
+            # returns - nothing may be deferred
+            model.zero_grad(set_to_none=True)
+            taken.clear()
+            out, _, coeff = model(x, edge_index, batch, fi, mask, pe, degree=degree, return_filter_coeff=True,
+                                  graph_cache=cache)
+            ((out * out).sum() + 0.01 * coeff.pow(2).sum()).backward(create_graph=True)
+            assert max(taken) == 0, taken
+            for n, p in model.named_parameters():
+                if p.grad is not None:
+                    KC.assert_close('create_graph ' + n, p.grad.detach(), once[n].double(), tol=1e-6)
             model.zero_grad(set_to_none=True)
             h = model.encoder.linear.bias.register_hook(lambda g: seen.append(g.clone()))
             run()

@@ -90,10 +90,11 @@ def test_flat_bucket_allreduce_world2(emu, views):
     assert names[-6:-4] == ['gcn.weight', 'gcn.bias'] or 'gcn.weight' in names
 
 
-def test_bf16_wire_bucket_world2(emu):
+@pytest.mark.parametrize('world', [2, 4])
+def test_bf16_wire_bucket(emu, world):
     """FlatGradAllReduce(bucket_dtype=bfloat16) (BASELINE config 3): the collective moves bf16, the gradients that
-    come back are fp32, identical on both ranks and within bf16 rounding (2^-8 relative per addend) of the fp32 bucket"""
-    world = 2
+    come back are fp32, identical on every rank and within bf16 rounding (2^-8 relative per addend; the addends are
+    pre-scaled by 1 / world and SUMMED) of the fp32 bucket"""
     mgr = mp.Manager()
     ret16, ret32 = mgr.dict(), mgr.dict()
     port = 29500 + (os.getpid() % 1000) + 3

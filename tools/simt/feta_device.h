@@ -83,6 +83,31 @@ inline f32x4 mfma16_bf16(const float (&a)[4], const float (&b)[4], f32x4 c) {
   return d;
 }
 
+// packed operands (same API as the device header)
+struct alignas(8) bf16x4_pk {
+  short v[4];
+};
+inline bf16x4_pk pack_bf16x4(float a, float b, float c, float d) {
+  bf16x4_pk r;
+  r.v[0] = (short)f2bf(a).bits; r.v[1] = (short)f2bf(b).bits; r.v[2] = (short)f2bf(c).bits; r.v[3] = (short)f2bf(d).bits;
+  return r;
+}
+inline bf16x4_pk pack_bf16x4_raw(bf16_t a, bf16_t b, bf16_t c, bf16_t d) {
+  bf16x4_pk r;
+  r.v[0] = (short)a.bits; r.v[1] = (short)b.bits; r.v[2] = (short)c.bits; r.v[3] = (short)d.bits;
+  return r;
+}
+inline float bf16x4_get(const bf16x4_pk& p, int i) {
+  bf16_t t;
+  t.bits = (unsigned short)p.v[i];
+  return bf2f(t);
+}
+inline f32x4 mfma16_bf16_pk(const bf16x4_pk& a, const bf16x4_pk& b, f32x4 c) {
+  const float av[4] = {bf16x4_get(a, 0), bf16x4_get(a, 1), bf16x4_get(a, 2), bf16x4_get(a, 3)};
+  const float bv[4] = {bf16x4_get(b, 0), bf16x4_get(b, 1), bf16x4_get(b, 2), bf16x4_get(b, 3)};
+  return mfma16_bf16(av, bv, c);
+}
+
 inline float shfl_xor(float v, int mask) {
   simt::WaveScratch& s = simt::wave_scratch();
   const int l = lane_id();
