@@ -146,6 +146,11 @@ def make_batch(args, rank, dev):
     cpu = dict(src=src, mask=mask, pe=pe, degree=degree, edge_index=edge_index, batch=batch, fi=fi,
                dout=dout, cache=cache)
     gpu = {k: (v.to(dev) if v is not None else None) for k, v in cpu.items()}
+    if args.dtype == 'bf16':
+        # bf16 STORAGE: the resident batch holds its token rows and the positional kernel in the storage type (what
+        # a collate for this path emits); everything else (degree, U / lambda, node counts, upstream gradient) as before
+        gpu['src'] = gpu['src'].to(torch.bfloat16)
+        gpu['pe'] = None if gpu['pe'] is None else gpu['pe'].to(torch.bfloat16)
     return cpu, gpu
 
 
@@ -173,7 +178,9 @@ def make_step(args, enc, gpu, world, dev):
     as one hipGraph replay (two for the split backward) unless --no-graph / --dry-cpu."""
     params = [p for p in enc.parameters()]
     lowp = getattr(enc, 'storage_dtype', torch.float32) != torch.float32
-    two_phase = (args.two_phase or world > 1) and not lowp   # the split backward needs the fused (fp32) stack
+    # the split backward needs the fused stack (fp32, or the bf16 instantiations of its kernels where the shape has them)
+    two_phase = (args.two_phase or world > 1) and (not lowp or bool(getattr(enc, 'fused_stack', False)
+                                                                      and not args.layer_norm))
     fwd_args = (gpu['src'], gpu['pe'], gpu['edge_index'], gpu['fi'], gpu['batch'])
     fwd_kw = dict(degree=gpu['degree'], src_key_padding_mask=gpu['mask'], graph_cache=gpu['cache'])
     use_graph = not args.no_graph and dev.type == 'cuda'

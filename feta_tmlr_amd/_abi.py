@@ -123,7 +123,7 @@ class AttnBlock(C.Structure):
         ('w_in', _F), ('b_in', _F), ('w_out', _F), ('b_out', _F), ('pe', _F), ('n_real', _I),
         ('rowscale', _F), ('qkv', _F), ('out', _F), ('attn_stats', _F), ('attn', _F), ('y', _F),
         ('y_stats', _F), ('scale', C.c_float), ('B', C.c_int), ('N', C.c_int), ('M', C.c_int),
-        ('row_sb', C.c_int64), ('row_sn', C.c_int64), ('tie_qk', C.c_int), ('dtype', C.c_int),
+        ('row_sb', C.c_int64), ('row_sn', C.c_int64), ('tie_qk', C.c_int), ('dtype', C.c_int), ('out_f32', _F),
     ]
 
 
@@ -154,7 +154,7 @@ class Ffn(C.Structure):
         ('x_gamma', _F), ('x_beta', _F), ('x_bn_out', _F), ('x_rmean', _F), ('x_rvar', _F), ('x_nbt', _I),
         ('momentum', C.c_float), ('eps', C.c_float),
         ('w1', _F), ('b1', _F), ('w2', _F), ('b2', _F), ('h', _F), ('y', _F), ('y_stats', _F),
-        ('M', C.c_int), ('FF', C.c_int), ('dtype', C.c_int),
+        ('M', C.c_int), ('FF', C.c_int), ('dtype', C.c_int), ('y_f32', C.c_int),
     ]
 
 
@@ -172,7 +172,7 @@ class AttnBlockGrad(C.Structure):
         ('dbeta', _F), ('rowscale', _F), ('w_out', _F), ('w_in', _F), ('qkv', _F), ('out', _F), ('dout2', _F),
         ('pe', _F), ('n_real', _I), ('attn_stats', _F), ('x0', _F), ('bn0', _F), ('dx', _F), ('dx_b', _F), ('sum_out', _F),
         ('partial', _F), ('partial_ld', C.c_int), ('scale', C.c_float), ('B', C.c_int), ('N', C.c_int), ('M', C.c_int),
-        ('row_sb', C.c_int64), ('row_sn', C.c_int64), ('dtype', C.c_int),
+        ('row_sb', C.c_int64), ('row_sn', C.c_int64), ('dtype', C.c_int), ('dout2_f32', C.c_int),
     ]
 
 
@@ -188,7 +188,7 @@ class FfnGrad(C.Structure):
     _fields_ = [
         ('dy', _F), ('dy_b', _F), ('g_y', _F), ('g_bn', _F), ('g_sum', _F), ('Gs', C.c_int), ('g_fin', _F), ('g_fin_out', _F),
         ('dgamma', _F), ('dbeta', _F), ('h', _F), ('w2', _F), ('w1', _F), ('x', _F), ('x_bn', _F), ('dx', _F),
-        ('sum_out', _F), ('partial', _F), ('partial_ld', C.c_int), ('M', C.c_int), ('FF', C.c_int), ('dtype', C.c_int),
+        ('sum_out', _F), ('partial', _F), ('partial_ld', C.c_int), ('M', C.c_int), ('FF', C.c_int), ('dtype', C.c_int), ('g_f32', C.c_int),
     ]
 
 
@@ -216,18 +216,20 @@ def _same_dtype(dtype, *tensors):
             raise TypeError('expected %s operands, got %s' % (dtype, t.dtype))
 
 
-def _stack_dtype(ptrs, names):
+def _stack_dtype(ptrs, names, f32_ok=()):
     """FETA_F32 | FETA_BF16 of a fused-stack descriptor: the token tensors `names` ([T] in include/feta_hip.h) share
     one storage type; everything else (weights, statistics, partial sums) is fp32."""
     dt = None
     for k in names:
         t = ptrs.get(k)
-        if t is None:
+        if t is None or k in f32_ok and t.dtype == torch.float32:
             continue
         if dt is None:
             dt = t.dtype
         elif t.dtype != dt:
             raise TypeError('%s is %s, the other token tensors are %s' % (k, t.dtype, dt))
+    if dt is None:
+        dt = torch.float32
     if dt not in (torch.float32, torch.bfloat16):
         raise TypeError('token tensors must be float32 or bfloat16, got %s' % dt)
     for k, t in ptrs.items():
@@ -513,7 +515,8 @@ class Abi:
         d.row_sb, d.row_sn = (1, b) if seq_first else (n, 1)
         if partial_ptr is not None:
             d.partial = partial_ptr
-        d.dtype = _stack_dtype(ptrs, ('dy', 'y1', 'qkv', 'out', 'dout2', 'pe', 'x0', 'dx', 'dx_b'))
+        d.dtype = _stack_dtype(ptrs, ('dy', 'y1', 'qkv', 'out', 'dout2', 'pe', 'x0', 'dx', 'dx_b'), f32_ok=('dout2',))
+        d.dout2_f32 = int(ptrs.get('dout2') is not None and ptrs['dout2'].dtype == torch.float32)
         for k, t in ptrs.items():
             if t is not None:
                 setattr(d, k, t.data_ptr())
@@ -533,7 +536,8 @@ class Abi:
     def ffn_desc(self, m, ff, momentum=0.1, eps=1e-5, Gx=0, **ptrs):
         d = Ffn()
         d.M, d.FF, d.momentum, d.eps, d.Gx = m, ff, momentum, eps, Gx
-        d.dtype = _stack_dtype(ptrs, ('x', 'h', 'y'))
+        d.dtype = _stack_dtype(ptrs, ('x', 'h', 'y'), f32_ok=('y',))
+        d.y_f32 = int(ptrs['y'].dtype == torch.float32)
         for k, t in ptrs.items():
             if t is not None:
                 setattr(d, k, t.data_ptr())
@@ -561,7 +565,10 @@ class Abi:
         d.M, d.FF, d.Gs, d.partial_ld = m, ff, Gs, partial_ld
         if partial_ptr is not None:
             d.partial = partial_ptr
-        d.dtype = _stack_dtype(ptrs, ('dy', 'dy_b', 'g_y', 'h', 'x', 'dx'))
+        d.dtype = _stack_dtype(ptrs, ('dy', 'dy_b', 'g_y', 'h', 'x', 'dx'), f32_ok=('dy', 'g_y'))
+        d.g_f32 = int(ptrs['dy'].dtype == torch.float32)
+        if ptrs.get('g_y') is not None and ptrs['g_y'].dtype != ptrs['dy'].dtype:
+            raise TypeError('dy and g_y must share a dtype')
         for k, t in ptrs.items():
             if t is not None:
                 setattr(d, k, t.data_ptr())

@@ -384,7 +384,15 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
     const int idx = tid + kRowThreads * i, node = idx / RV, q = idx % RV;
     if (node < a.N) {
       const int64_t row = (int64_t)b * a.row_sb + (int64_t)node * a.row_sn;
-      L::stv(gout + row * D + L::VEC * q, L::ldv(Os + node * P + L::VEC * q));
+      const Vec ov = L::ldv(Os + node * P + L::VEC * q);
+      L::stv(gout + row * D + L::VEC * q, ov);
+      if (a.out_f32 != nullptr) {   // the same rows as fp32: operand of the fp32 filter stage behind a bf16 stack
+        float f[L::VEC];
+        L::unpack(ov, f);
+#pragma unroll
+        for (int e = 0; e < L::VEC; e += 4)
+          *reinterpret_cast<float4*>(a.out_f32 + row * D + L::VEC * q + e) = make_float4(f[e], f[e + 1], f[e + 2], f[e + 3]);
+      }
     }
   }
   {
@@ -482,7 +490,8 @@ extern "C" int feta_attn_block_fwd_sums(const feta_attn_block* d, const feta_col
   FETA_REQUIRE(a.x_stats == nullptr || (a.x_gamma && a.x_beta && a.x_bn_out && a.Gx > 0),
                "attn_block_fwd: x_stats needs x_gamma, x_beta, x_bn_out, Gx");
   FETA_REQUIRE(aligned16(a.x) && aligned16(a.w_in) && aligned16(a.w_out) && aligned16(a.qkv) && aligned16(a.out) &&
-               aligned16(a.y) && aligned16(a.y_stats) && aligned16(a.x_stats) && aligned16(a.b_in) && aligned16(a.b_out),
+               aligned16(a.y) && aligned16(a.y_stats) && aligned16(a.x_stats) && aligned16(a.b_in) && aligned16(a.b_out) &&
+               aligned16(a.out_f32),
                "attn_block_fwd: tensors must be 16-byte aligned");
   FETA_REQUIRE(a.dtype == FETA_F32 || a.dtype == FETA_BF16, "attn_block_fwd: dtype %d", a.dtype);
   if (a.dtype == FETA_BF16) return dispatch_block_fwd<bf16_t>(a, segs, nseg, (hipStream_t)stream);

@@ -25,6 +25,7 @@
 #include <cstdlib>
 
 #include "feta_abi_common.h"
+#include "feta_lp.h"
 #include "feta_rowops.h"
 
 namespace feta {
@@ -36,12 +37,15 @@ constexpr int kBbP = kBbD + 4;   // pitch of a staged 64-float row
 constexpr int kBbThreads = 512;
 constexpr int kBbMaxGrid = 256;
 
-__host__ __device__ inline int block_bwd_lds_floats(int nt, bool gbn) {
-  const int nr = 16 * nt;
-  return 7 * nr * kBbP          // q, k, v (later dq, dk, dv), dconcat, out, g1, x0
-         + nr * (nr + 1)        // pe
-         + kBbH * nr * 2 + nr   // softmax statistics, row scale
-         + (gbn ? 5 * kBbD + reduce_scratch_floats(kBbD) : 0);
+// LDS bytes of a workgroup: seven [NR][64 + pad] tiles of T, fp32 for everything else
+template <class T>
+__host__ __device__ inline int block_bwd_lds_bytes(int nt, bool gbn) {
+  const int nr = 16 * nt, P = kBbD + Lp<T>::PAD;
+  return (int)sizeof(T) * 7 * nr * P    // q, k, v (later dq, dk, dv), dconcat, out, g1, x0
+         + 4 * (nr * (nr + 1)           // pe
+                + kBbH * nr * 2 + nr    // softmax statistics, row scale
+                + 8 * kBbD + 8 * 2 * 16 // fp32 column sums of the bias gradients: db_out per wave, dq | dk | dv per wave
+                + (gbn ? 5 * kBbD + reduce_scratch_floats(kBbD) : 0));
 }
 
 #ifdef FETA_TIMING
@@ -50,9 +54,15 @@ __device__ unsigned int feta_bbwd_launch;
 #endif
 #define BB_STAMP(i) FETA_RT_STAMP(feta_bbwd_stamps, feta_bbwd_launch, i)
 
-template <int NT, bool SPLIT>
+// T: storage type of dy, y1, qkv, out, dout2, pe, x0, dx, dx_b and of the LDS tiles (feta_lp.h); weights, BatchNorm
+// parameter blocks and partial sums, softmax statistics, row scale and the weight-gradient partial rows: fp32.
+template <class T, int NT, bool SPLIT>
 __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
-  constexpr int D = kBbD, DH = kBbDH, H = kBbH, P = kBbP, NR = 16 * NT, PEP = NR + 1;
+  typedef Lp<T> L;
+  typedef typename L::Op Op;
+  typedef typename L::Vec Vec;
+  constexpr int D = kBbD, DH = kBbDH, H = kBbH, P = kBbD + L::PAD, NR = 16 * NT, PEP = NR + 1;
+  constexpr int VEC = L::VEC, RV = D / VEC;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lq = lane & 15, g = lane >> 4;
   // pair of heads of this workgroup: workgroups b and b + B share a graph - and, workgroups being dealt round-robin to
   // the 8 XCDs, an L2 when B is a multiple of 8 (adjacent workgroups never do: both would fetch the graph's tiles from
@@ -67,21 +77,31 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
   const int ktile = wv & 3;
   auto mine_dc = [&](int rt) { return SPLIT ? rt == (wv >> 1) : (rt & 1) == (wv >> 2); };
   auto mine_dx = [&](int rt) { return (rt & 1) == (wv >> 2); };
-  float* Qs = feta_lds;        // [NR][P] q, later dq
-  float* Ks = Qs + NR * P;     // k, later dk
-  float* Vs = Ks + NR * P;     // v, later dv
-  float* Ds = Vs + NR * P;     // dconcat
-  float* Os = Ds + NR * P;     // out (per-head outputs, concatenated)
-  float* Gt = Os + NR * P;     // g1 (BatchNorm-1 backward of dy; un-scaled)
-  float* X0 = Gt + NR * P;     // x0 (raw: seen through bn0 on use)
-  float* PE = X0 + NR * P;     // [NR][PEP]
+  T* Qs = reinterpret_cast<T*>(lds_bytes());   // [NR][P] q, later dq
+  T* Ks = Qs + NR * P;     // k, later dk   (rows >= n_real: zero)
+  T* Vs = Ks + NR * P;     // v, later dv   (rows >= n_real: zero)
+  T* Ds = Vs + NR * P;     // dconcat
+  T* Os = Ds + NR * P;     // out (per-head outputs, concatenated)
+  T* Gt = Os + NR * P;     // g1 (BatchNorm-1 backward of dy; un-scaled)
+  T* X0 = Gt + NR * P;     // x0 (raw: seen through bn0 on use)
+  float* PE = reinterpret_cast<float*>(X0 + NR * P);   // [NR][PEP]
   float* ST = PE + NR * PEP;   // [H][NR][2]
   float* RS = ST + H * NR * 2; // [NR] degree scale of the rows
-  float* gv = RS + NR;         // [5][64] scale, mean, rstd, m1, m2 of BatchNorm 1
+  float* DBO = RS + NR;        // [8 waves][64] fp32 column sums of (degree g1) over the rows each wave staged
+  float* DBS = DBO + 8 * D;    // [8 waves][2][16] fp32 column sums of the wave's dq | dk, dv accumulators
+  float* gv = DBS + 8 * 2 * 16;   // [5][64] scale, mean, rstd, m1, m2 of BatchNorm 1
+  const T* gdy = reinterpret_cast<const T*>(a.dy);
+  const T* gy1 = reinterpret_cast<const T*>(a.y1);
+  const T* gqkv = reinterpret_cast<const T*>(a.qkv);
+  const T* gout = reinterpret_cast<const T*>(a.out);
+  const T* gd2 = reinterpret_cast<const T*>(a.dout2);
+  const T* gpe = reinterpret_cast<const T*>(a.pe);
+  const T* gx0 = reinterpret_cast<const T*>(a.x0);
   const bool gbn = a.y1 != nullptr;
   const bool has_pe = a.pe != nullptr;
   const bool want_sums = a.sum_out != nullptr;
   const bool xbn = a.bn0 != nullptr;
+  const bool d2_f32 = a.dout2 != nullptr && a.dout2_f32 != 0 && sizeof(T) != sizeof(float);
   BB_STAMP(0);
 
   // ---- once per workgroup: BatchNorm-1 backward parameters, weight column slices ----------------------------------
@@ -129,30 +149,42 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
     float sum1[4] = {0.f, 0.f, 0.f, 0.f}, sum2[4] = {0.f, 0.f, 0.f, 0.f};
     auto grow = [&](int node) { return (int64_t)b * a.row_sb + (int64_t)min(node, nm1) * a.row_sn; };
 
-    // ---- cooperative loads of the graph: NR * 16 float4 per 64-wide tensor ------------------------------------------
-    constexpr int RI = (NR * 16 + kBbThreads - 1) / kBbThreads;
-    float4 qv[RI], kv[RI], vv[RI], ov[RI], dyv[RI], y1v[RI], x0v[RI], d2v[RI];
+    // ---- cooperative loads of the graph: NR * RV 16-byte vectors per 64-wide tensor --------------------------------
+    constexpr int RI = (NR * RV + kBbThreads - 1) / kBbThreads;
+    Vec qv[RI], kv[RI], vv[RI], ov[RI], dyv[RI], y1v[RI], x0v[RI], d2v[RI];
+    float rsn[RI];
 #pragma unroll
     for (int i = 0; i < RI; ++i) {
-      const int idx = min(tid + kBbThreads * i, NR * 16 - 1), c4 = 4 * (idx & 15);
-      const int64_t row = grow(idx >> 4);
-      qv[i] = *reinterpret_cast<const float4*>(a.qkv + row * 3 * D + c4);
-      kv[i] = *reinterpret_cast<const float4*>(a.qkv + row * 3 * D + D + c4);
-      vv[i] = *reinterpret_cast<const float4*>(a.qkv + row * 3 * D + 2 * D + c4);
-      ov[i] = *reinterpret_cast<const float4*>(a.out + row * D + c4);
-      dyv[i] = *reinterpret_cast<const float4*>(a.dy + row * D + c4);
-      // (no ternary on a whole float4: it is lowered to a private-memory select - the operands are read through a
+      const int idx = min(tid + kBbThreads * i, NR * RV - 1), c4 = VEC * (idx % RV);
+      const int64_t row = grow(idx / RV);
+      qv[i] = L::ldv(gqkv + row * 3 * D + c4);
+      kv[i] = L::ldv(gqkv + row * 3 * D + D + c4);
+      vv[i] = L::ldv(gqkv + row * 3 * D + 2 * D + c4);
+      ov[i] = L::ldv(gout + row * D + c4);
+      dyv[i] = L::ldv(gdy + row * D + c4);
+      // (no ternary on a whole vector: it is lowered to a private-memory select - the operands are read through a
       // pointer that falls back to a tensor which is always there)
-      y1v[i] = *reinterpret_cast<const float4*>((gbn ? a.y1 : a.dy) + row * D + c4);
-      x0v[i] = *reinterpret_cast<const float4*>(a.x0 + row * D + c4);
-      d2v[i] = *reinterpret_cast<const float4*>((a.dout2 != nullptr ? a.dout2 : a.dy) + row * D + c4);
+      y1v[i] = L::ldv((gbn ? gy1 : gdy) + row * D + c4);
+      x0v[i] = L::ldv(gx0 + row * D + c4);
+      if (d2_f32) {   // the filter branch's gradient arrives as fp32 behind a bf16 stack: rounded here
+        float f[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; e += 4) {
+          const float4 t4 = *reinterpret_cast<const float4*>(a.dout2 + row * D + c4 + e);
+          f[e] = t4.x; f[e + 1] = t4.y; f[e + 2] = t4.z; f[e + 3] = t4.w;
+        }
+        d2v[i] = L::pack(f);
+      } else {
+        d2v[i] = L::ldv((a.dout2 != nullptr ? gd2 : gdy) + row * D + c4);
+      }
+      rsn[i] = a.rowscale != nullptr ? a.rowscale[row] : 1.0f;
     }
     constexpr int PEI = (NR * NR + kBbThreads - 1) / kBbThreads;
     float pev[PEI];
 #pragma unroll
     for (int i = 0; i < PEI; ++i) {
       const int idx = tid + kBbThreads * i, qq = idx / NR, kk = idx - qq * NR;
-      const float v = has_pe ? a.pe[((int64_t)b * a.N + min(qq, nm1)) * a.N + min(kk, nm1)] : 1.0f;
+      const float v = has_pe ? L::ld1(gpe + ((int64_t)b * a.N + min(qq, nm1)) * a.N + min(kk, nm1)) : 1.0f;
       pev[i] = (idx < NR * NR && qq < a.N && kk < a.N) ? v : 0.0f;
     }
     {
@@ -161,34 +193,60 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
       if (tid < H * NR * 2) ST[tid] = sv;
       if (tid < NR) RS[tid] = (a.rowscale != nullptr && tid < a.N) ? a.rowscale[grow(tid)] : (tid < a.N ? 1.0f : 0.0f);
     }
+    // db_out = column sums of (degree g1): taken here from the fp32 values, BEFORE g1 is rounded into its tile (behind a
+    // BatchNorm backward the true column sums of g1 are zero when degree = 1: a sum over a bf16 tile would be noise)
+    float dbo[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) dbo[e] = 0.0f;
 #pragma unroll
     for (int i = 0; i < RI; ++i) {
       const int idx = tid + kBbThreads * i;
-      if (idx < NR * 16) {
-        const int node = idx >> 4, c4 = 4 * (idx & 15), off = node * P + c4;
-        const float rk = node < a.N ? 1.0f : 0.0f;      // rows beyond the padded length: zero everywhere
-        const float dk2 = (node < a.N && a.dout2 != nullptr) ? 1.0f : 0.0f;
-        auto put = [&](float* dst, const float4& v, float m) {
-          *reinterpret_cast<float4*>(dst + off) = make_float4(m * v.x, m * v.y, m * v.z, m * v.w);
+      if (idx < NR * RV) {
+        const int node = idx / RV, c4 = VEC * (idx % RV), off = node * P + c4;
+        const bool rk = node < a.N;       // rows beyond the padded length: zero everywhere
+        const bool rkv = node < n;        // k / v rows of padded nodes: zero (the forward pass never wrote some of them)
+        const bool dk2 = node < a.N && a.dout2 != nullptr;
+        auto put = [&](T* dst, const Vec& v, bool keep) {
+          float f[VEC];
+          L::unpack(v, f);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) f[e] = keep ? f[e] : 0.0f;
+          L::stv(dst + off, L::pack(f));
         };
         put(Qs, qv[i], rk);
-        put(Ks, kv[i], rk);
-        put(Vs, vv[i], rk);
+        put(Ks, kv[i], rkv);
+        put(Vs, vv[i], rkv);
         put(Os, ov[i], rk);
         put(X0, x0v[i], rk);
         put(Ds, d2v[i], dk2);     // dout2; the product is added below
-        float v[4] = {dyv[i].x, dyv[i].y, dyv[i].z, dyv[i].w};
+        float v[VEC];
+        L::unpack(dyv[i], v);
         if (gbn) {
-          const float yy[4] = {y1v[i].x, y1v[i].y, y1v[i].z, y1v[i].w};
+          float yy[VEC];
+          L::unpack(y1v[i], yy);
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
+          for (int s = 0; s < VEC; ++s) {
             const int o = c4 + s;
             const float xh = (yy[s] - gv[D + o]) * gv[2 * D + o];
             v[s] = gv[o] * (v[s] - gv[3 * D + o] - xh * gv[4 * D + o]);
           }
         }
-        *reinterpret_cast<float4*>(Gt + off) = make_float4(rk * v[0], rk * v[1], rk * v[2], rk * v[3]);
+#pragma unroll
+        for (int s = 0; s < VEC; ++s) {
+          v[s] = rk ? v[s] : 0.0f;
+          dbo[s] += rsn[i] * v[s];
+        }
+        L::stv(Gt + off, L::pack(v));
       }
+    }
+    // lanes l, l + RV, ... of a wave hold the same columns: one row per wave
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float sv = dbo[e];
+      if (RV <= 8) sv += shfl_xor(sv, 8);
+      sv += shfl_xor(sv, 16);
+      sv += shfl_xor(sv, 32);
+      if (lane < RV) DBO[wv * D + VEC * lane + e] = sv;
     }
 #pragma unroll
     for (int i = 0; i < PEI; ++i) {
@@ -197,29 +255,38 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
     }
     __syncthreads();
     BB_STAMP(2);
+    float* prow = a.partial + (int64_t)b * (a.partial_ld > 0 ? (int64_t)a.partial_ld : (int64_t)(4 * D * D + 4 * D));
+    if (hp == 0 && tid < D) {
+      float sv = 0.0f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) sv += DBO[w8 * D + tid];
+      prow[D * D + tid] = sv;
+    }
 
     // ---- dconcat^T tiles (c = 16h + 4g + r, row = 16 rt + lq) = sum_o W_out[o][c] (degree g1)[row][o] (+ dout2) ----
     // (the wave's weight column slices are requested where they are used: held over the whole kernel they cost 64
     // registers that the attention phase needs - the kernel spilled)
-    float woA[4][4];    // W_out[o = 16j+4g+s][c = 16 ct + lq]: dconcat columns of head ct
+    {
+      Op woA[4];    // W_out[o = 16j+4g+s][c = 16 ct + lq]: dconcat columns of head ct
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j) {
+        const float* p = a.w_out + (int64_t)(16 * j + 4 * g) * D + 16 * ct + lq;
+        woA[j] = L::mk(p[0], p[D], p[2 * D], p[3 * D]);
+      }
 #pragma unroll
-      for (int s = 0; s < 4; ++s) woA[j][s] = a.w_out[(int64_t)(16 * j + 4 * g + s) * D + 16 * ct + lq];
+      for (int rt = 0; rt < NT; ++rt) {
+        if (!mine_dc(rt)) continue;
+        const int rowl = 16 * rt + lq;
+        RowOp<T, D> gf;
+        load_row_op_scaled<T, D>(gf, Gt + rowl * P, g, RS[rowl]);
+        f32x4 acc = zero4();
 #pragma unroll
-    for (int rt = 0; rt < NT; ++rt) {
-      if (!mine_dc(rt)) continue;
-      const int rowl = 16 * rt + lq;
-      Feat<D> gf;
-      load_row<D>(gf, Gt + rowl * P, g, RS[rowl]);
-      f32x4 acc = zero4();
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc = mfma16(woA[j][s], gf.f[j][s], acc);
-      float4* dst = reinterpret_cast<float4*>(Ds + rowl * P + 16 * ct + 4 * g);
-      const float4 d2 = *dst;
-      *dst = make_float4(acc[0] + d2.x, acc[1] + d2.y, acc[2] + d2.z, acc[3] + d2.w);
+        for (int j = 0; j < 4; ++j) acc = L::mma(woA[j], gf.o[j], acc);
+        T* dst = Ds + rowl * P + 16 * ct + 4 * g;
+        float d2[4];
+        L::ld4(dst, d2);
+        L::st4(dst, acc[0] + d2[0], acc[1] + d2[1], acc[2] + d2[2], acc[3] + d2[3]);
+      }
     }
     __syncthreads();
     BB_STAMP(3);
@@ -233,37 +300,22 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
       r1[t] = zero4();
     }
     if (role == 0) {
-      Feat<DH> kf[NT], vf[NT];
-      float kb[NT][4];
+      Op kf[NT], vf[NT], kb[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int rowl = 16 * t + lq;
-        load_row<DH>(kf[t], Ks + rowl * P + co, g);
-        load_row<DH>(vf[t], Vs + rowl * P + co, g);
-        if (rowl >= n) {
-#pragma unroll
-          for (int s = 0; s < 4; ++s) kf[t].f[0][s] = vf[t].f[0][s] = 0.0f;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int rr = 16 * t + 4 * g + r;
-          kb[t][r] = rr < n ? Ks[rr * P + co + lq] : 0.0f;
-        }
+        kf[t] = L::ld(Ks + rowl * P + co + 4 * g);
+        vf[t] = L::ld(Vs + rowl * P + co + 4 * g);
+        kb[t] = L::gather(Ks + (16 * t + 4 * g) * P + co + lq, P);
       }
 #pragma unroll
       for (int qb = 0; qb < NT; ++qb) {
         const int q = 16 * qb + lq;
-        const bool qok = q < a.N;
-        Feat<DH> qf, dof, of;
-        load_row<DH>(qf, Qs + q * P + co, g, a.scale);
-        load_row<DH>(dof, Ds + q * P + co, g);
-        load_row<DH>(of, Os + q * P + co, g);
-        if (!qok) {
-#pragma unroll
-          for (int s = 0; s < 4; ++s) qf.f[0][s] = dof.f[0][s] = 0.0f;
-        }
-        float delta = dof.f[0][0] * of.f[0][0] + dof.f[0][1] * of.f[0][1] + dof.f[0][2] * of.f[0][2] +
-                      dof.f[0][3] * of.f[0][3];
+        const Op qf = L::ld_scaled(Qs + q * P + co + 4 * g, a.scale);   // (rows >= N of the tiles are zero)
+        const Op dof = L::ld(Ds + q * P + co + 4 * g);
+        const Op of = L::ld(Os + q * P + co + 4 * g);
+        float delta = L::get(dof, 0) * L::get(of, 0) + L::get(dof, 1) * L::get(of, 1) + L::get(dof, 2) * L::get(of, 2) +
+                      L::get(dof, 3) * L::get(of, 3);
         delta += shfl_xor(delta, 16);
         delta += shfl_xor(delta, 32);
         const float m = ST[(h * NR + q) * 2], z = ST[(h * NR + q) * 2 + 1];
@@ -273,36 +325,37 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
         for (int kt = 0; kt < NT; ++kt) {
           if (16 * kt >= n) continue;
           if (SPLIT && ((qb * NT + kt) & 1) != half) continue;   // the partner wave takes the other tile pairs
-          const f32x4 s = dot_rows<DH>(kf[kt], qf, zero4());
-          const f32x4 da = dot_rows<DH>(vf[kt], dof, zero4());
+          const f32x4 s = L::mma(kf[kt], qf, zero4());
+          const f32x4 da = L::mma(vf[kt], dof, zero4());
+          float pd[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int key = 16 * kt + 4 * g + r;
             const float p = key < n ? fast_exp(s[r] - m) * PE[q * PEP + key] * rinv : 0.0f;
-            r0[qb] = mfma16(p * (da[r] - delta), kb[kt][r], r0[qb]);  // (query 4g+r, c lq)
+            pd[r] = p * (da[r] - delta);
           }
+          r0[qb] = L::mma(L::mk(pd[0], pd[1], pd[2], pd[3]), kb[kt], r0[qb]);  // (query 4g+r, c lq)
         }
       }
     } else {
-      Feat<DH> qf[NT], dof[NT];
-      float qb4[NT][4], dob[NT][4], sd[NT][4], mq[NT][4], rz[NT][4];
+      Op qf[NT], dof[NT], qb4[NT], dob[NT];
+      float sd[NT][4], mq[NT][4], rz[NT][4];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int rowl = 16 * t + lq;
-        load_row<DH>(qf[t], Qs + rowl * P + co, g, a.scale);
-        load_row<DH>(dof[t], Ds + rowl * P + co, g);
-        if (rowl >= a.N) {
-#pragma unroll
-          for (int s = 0; s < 4; ++s) qf[t].f[0][s] = dof[t].f[0][s] = 0.0f;
-        }
+        qf[t] = L::ld_scaled(Qs + rowl * P + co + 4 * g, a.scale);
+        dof[t] = L::ld(Ds + rowl * P + co + 4 * g);
+        const T* colq = Qs + (16 * t + 4 * g) * P + co + lq;
+        const T* cold = Ds + (16 * t + 4 * g) * P + co + lq;
+        const T* colo = Os + (16 * t + 4 * g) * P + co + lq;
+        float qv4[4], dv4[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int rr = 16 * t + 4 * g + r;
           const bool ok = rr < a.N;
-          const float dvv = Ds[rr * P + co + lq];
-          qb4[t][r] = ok ? Qs[rr * P + co + lq] * a.scale : 0.0f;
-          dob[t][r] = ok ? dvv : 0.0f;
-          sd[t][r] = row16_sum(ok ? dvv * Os[rr * P + co + lq] : 0.0f);   // delta[q = 4g + r]
+          dv4[r] = L::ld1(cold + r * P);
+          qv4[r] = L::ld1(colq + r * P) * a.scale;
+          sd[t][r] = row16_sum(dv4[r] * L::ld1(colo + r * P));   // delta[q = 4g + r]
           // softmax statistics of the query: once per query, not once per (query, key tile) - the division alone is
           // a dozen instructions and this role is the one the other waves wait for
           const float z = ST[(h * NR + rr) * 2 + 1];
@@ -310,61 +363,78 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
           rz[t][r] = ok ? 1.0f / fmaxf(z, 1e-6f) : 0.0f;
           if (z < 1e-6f) sd[t][r] = 0.0f;
         }
+        qb4[t] = L::mk(qv4[0], qv4[1], qv4[2], qv4[3]);
+        dob[t] = L::mk(dv4[0], dv4[1], dv4[2], dv4[3]);
       }
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) {
         if (16 * kt >= n) continue;
         const int key = 16 * kt + lq;
-        Feat<DH> kf, vf;
-        load_row<DH>(kf, Ks + key * P + co, g);
-        load_row<DH>(vf, Vs + key * P + co, g);
-        if (key >= n) {
-#pragma unroll
-          for (int s = 0; s < 4; ++s) kf.f[0][s] = vf.f[0][s] = 0.0f;
-        }
+        const Op kf = L::ld(Ks + key * P + co + 4 * g);   // (rows >= n_real of the k / v tiles are zero)
+        const Op vf = L::ld(Vs + key * P + co + 4 * g);
 #pragma unroll
         for (int qb = 0; qb < NT; ++qb) {
           if (SPLIT && ((kt * NT + qb) & 1) != half) continue;
-          const f32x4 s = dot_rows<DH>(qf[qb], kf, zero4());
-          const f32x4 da = dot_rows<DH>(dof[qb], vf, zero4());
+          const f32x4 s = L::mma(qf[qb], kf, zero4());
+          const f32x4 da = L::mma(dof[qb], vf, zero4());
+          float pp[4], ds[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int q = 16 * qb + 4 * g + r;
-            const float p = key < n ? fast_exp(s[r] - mq[qb][r]) * PE[q * PEP + key] * rz[qb][r] : 0.0f;   // rz = 0: q >= N
-            const float ds = p * (da[r] - sd[qb][r]);
-            r1[kt] = mfma16(p, dob[qb][r], r1[kt]);    // dv (key 4g+r, c lq)
-            r0[kt] = mfma16(ds, qb4[qb][r], r0[kt]);   // dk
+            pp[r] = key < n ? fast_exp(s[r] - mq[qb][r]) * PE[q * PEP + key] * rz[qb][r] : 0.0f;   // rz = 0: q >= N
+            ds[r] = pp[r] * (da[r] - sd[qb][r]);
           }
+          r1[kt] = L::mma(L::mk(pp[0], pp[1], pp[2], pp[3]), dob[qb], r1[kt]);    // dv (key 4g+r, c lq)
+          r0[kt] = L::mma(L::mk(ds[0], ds[1], ds[2], ds[3]), qb4[qb], r0[kt]);    // dk
         }
       }
     }
-    // ---- dW_out = (degree g1)^T out and db_out: independent of the attention results, so the dq waves - which finish
-    // well before the dk / dv waves (their set-up alone is twice as long) - take them while they would otherwise wait
+    // fp32 column sums of this wave's dq | dk, dv accumulators (rows beyond the real / padded length are zero): the
+    // bias gradient of in_proj, before the accumulators are rounded into the tiles
+    {
+      float c0 = 0.0f, c1 = 0.0f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          c0 += r0[t][r];
+          c1 += r1[t][r];
+        }
+      c0 += shfl_xor(c0, 16);
+      c0 += shfl_xor(c0, 32);
+      c1 += shfl_xor(c1, 16);
+      c1 += shfl_xor(c1, 32);
+      if (g == 0) {
+        DBS[(wv * 2 + 0) * 16 + lq] = role == 0 ? c0 * a.scale : c0;
+        DBS[(wv * 2 + 1) * 16 + lq] = c1;
+      }
+    }
+    // ---- dW_out = (degree g1)^T out: independent of the attention results, so the dq waves - which finish
+    // well before the dk / dv waves (their set-up alone is twice as long) - take it while they would otherwise wait
     // at the barrier: o tile `ot` per wave, every column tile of this workgroup's heads
+    // (contraction over the graph's rows: k-step s of group q4 is row 16 q4 + 4 s + g)
     constexpr int NWO = SPLIT ? 2 : 4;
-    float* prow = a.partial + (int64_t)b * (a.partial_ld > 0 ? (int64_t)a.partial_ld : (int64_t)(4 * D * D + 4 * D));
     if (role == 0) {
       const int ot = SPLIT ? (wv & 1) + 2 * (wv >> 2) : (wv & 3);
       f32x4 aWo[NWO];
 #pragma unroll
       for (int i = 0; i < NWO; ++i) aWo[i] = zero4();
-      float dbo = 0.0f;
-#pragma unroll 2
-      for (int st = 0; st < NR / 4; ++st) {
-        const int rr = 4 * st + g;
-        const float ga = RS[rr] * Gt[rr * P + 16 * ot + lq];   // (degree g1)[row][o = 16 ot + lq]
-        dbo += ga;
+#pragma unroll 1
+      for (int q4 = 0; q4 < NT; ++q4) {
+        const int rr = 16 * q4 + g;
+        float gvv[4];
 #pragma unroll
-        for (int i = 0; i < NWO; ++i) aWo[i] = mfma16(ga, Os[rr * P + 16 * (SPLIT ? 2 * hp + i : i) + lq], aWo[i]);
+        for (int s4 = 0; s4 < 4; ++s4) gvv[s4] = RS[rr + 4 * s4] * L::ld1(Gt + (rr + 4 * s4) * P + 16 * ot + lq);
+        const Op ga = L::mk(gvv[0], gvv[1], gvv[2], gvv[3]);   // (degree g1)[row][o = 16 ot + lq]
+#pragma unroll
+        for (int i = 0; i < NWO; ++i)
+          aWo[i] = L::mma(ga, L::gather(Os + rr * P + 16 * (SPLIT ? 2 * hp + i : i) + lq, 4 * P), aWo[i]);
       }
 #pragma unroll
       for (int i = 0; i < NWO; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           prow[(int64_t)(16 * ot + 4 * g + r) * D + 16 * (SPLIT ? 2 * hp + i : i) + lq] = aWo[i][r];
-      dbo += shfl_xor(dbo, 16);
-      dbo += shfl_xor(dbo, 32);
-      if (hp == 0 && g == 0) prow[D * D + 16 * ot + lq] = dbo;
     }
     BB_STAMP(4);
     __syncthreads();   // every wave has taken its operands: the q / k / v tiles become dq / dk / dv
@@ -372,20 +442,20 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
 #pragma unroll
     for (int pass = 0; pass < (SPLIT ? 2 : 1); ++pass) {
       if (!SPLIT || half == pass) {
-        // (pass 0 overwrites: k / v rows of padded nodes were never written by the forward pass)
+        // (pass 0 overwrites)
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int rr = 16 * t + 4 * g + r;
             if (role == 0) {
-              float* dq = Qs + rr * P + co + lq;
-              *dq = (pass == 0 ? 0.0f : *dq) + r0[t][r] * a.scale;
+              T* dq = Qs + rr * P + co + lq;
+              L::st1(dq, (pass == 0 ? 0.0f : L::ld1(dq)) + r0[t][r] * a.scale);
             } else {
-              float* dk = Ks + rr * P + co + lq;
-              float* dv = Vs + rr * P + co + lq;
-              *dk = (pass == 0 ? 0.0f : *dk) + r0[t][r];
-              *dv = (pass == 0 ? 0.0f : *dv) + r1[t][r];
+              T* dk = Ks + rr * P + co + lq;
+              T* dv = Vs + rr * P + co + lq;
+              L::st1(dk, (pass == 0 ? 0.0f : L::ld1(dk)) + r0[t][r]);
+              L::st1(dv, (pass == 0 ? 0.0f : L::ld1(dv)) + r1[t][r]);
             }
           }
         }
@@ -403,40 +473,35 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
     for (int rt = 0; rt < NT; ++rt) dxa[rt] = zero4();
 #pragma unroll
     for (int part = 0; part < 3; ++part) {
-      float wiA[NJX][4];   // W_in[o = 64 part + 16 jc + 4g+s][k = 16 ktile + lq], jc = this pair's (or every) head
+      Op wiA[NJX];   // W_in[o = 64 part + 16 jc + 4g+s][k = 16 ktile + lq], jc = this pair's (or every) head
 #pragma unroll
-      for (int j = 0; j < NJX; ++j)
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-          wiA[j][s] = a.w_in[(int64_t)(64 * part + 16 * (SPLIT ? 2 * hp + j : j) + 4 * g + s) * D + 16 * ktile + lq];
+      for (int j = 0; j < NJX; ++j) {
+        const float* p = a.w_in + (int64_t)(64 * part + 16 * (SPLIT ? 2 * hp + j : j) + 4 * g) * D + 16 * ktile + lq;
+        wiA[j] = L::mk(p[0], p[D], p[2 * D], p[3 * D]);
+      }
 #pragma unroll
       for (int rt = 0; rt < NT; ++rt) {
         if (!mine_dx(rt)) continue;
-        const float* drow = (part == 0 ? Qs : (part == 1 ? Ks : Vs)) + (16 * rt + lq) * P + (SPLIT ? 32 * hp : 0);
+        const T* drow = (part == 0 ? Qs : (part == 1 ? Ks : Vs)) + (16 * rt + lq) * P + (SPLIT ? 32 * hp : 0);
 #pragma unroll
-        for (int j = 0; j < NJX; ++j) {
-          const float4 dq4 = *reinterpret_cast<const float4*>(drow + 16 * j + 4 * g);
-          dxa[rt] = mfma16(wiA[j][0], dq4.x, dxa[rt]);
-          dxa[rt] = mfma16(wiA[j][1], dq4.y, dxa[rt]);
-          dxa[rt] = mfma16(wiA[j][2], dq4.z, dxa[rt]);
-          dxa[rt] = mfma16(wiA[j][3], dq4.w, dxa[rt]);
-        }
+        for (int j = 0; j < NJX; ++j) dxa[rt] = L::mma(wiA[j], L::ld(drow + 16 * j + 4 * g), dxa[rt]);
       }
     }
-    float* dxo = (SPLIT && hp == 1) ? a.dx_b : a.dx;
+    T* dxo = reinterpret_cast<T*>((SPLIT && hp == 1) ? a.dx_b : a.dx);
     const float resw = (SPLIT && hp == 1) ? 0.0f : 1.0f;
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) {
       if (!mine_dx(rt)) continue;
       const int rowl = 16 * rt + lq;
       const f32x4 acc = dxa[rt];
-      const float4 res = *reinterpret_cast<const float4*>(Gt + rowl * P + 16 * ktile + 4 * g);
-      const float v[4] = {acc[0] + resw * res.x, acc[1] + resw * res.y, acc[2] + resw * res.z, acc[3] + resw * res.w};
+      float res[4];
+      L::ld4(Gt + rowl * P + 16 * ktile + 4 * g, res);
+      const float v[4] = {acc[0] + resw * res[0], acc[1] + resw * res[1], acc[2] + resw * res[2], acc[3] + resw * res[3]};
       const bool rok = rowl < a.N;
-      if (rok) *reinterpret_cast<float4*>(dxo + grow(rowl) * D + 16 * ktile + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+      if (rok) L::st4(dxo + grow(rowl) * D + 16 * ktile + 4 * g, v[0], v[1], v[2], v[3]);
       if (want_sums) {
-        const float4 xr = *reinterpret_cast<const float4*>(X0 + rowl * P + 16 * ktile + 4 * g);
-        const float xx[4] = {xr.x, xr.y, xr.z, xr.w};
+        float xx[4];
+        L::ld4(X0 + rowl * P + 16 * ktile + 4 * g, xx);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float s1 = rok ? v[r] : 0.0f;
@@ -472,11 +537,11 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
           }
         }
       } else if (lq == 0) {
-        const int64_t prow = (int64_t)blockIdx.x * 2 + (wv >> 2);
+        const int64_t prow2 = (int64_t)blockIdx.x * 2 + (wv >> 2);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          a.sum_out[(prow * 2 + 0) * D + 16 * ktile + 4 * g + r] = s1v[r];
-          a.sum_out[(prow * 2 + 1) * D + 16 * ktile + 4 * g + r] = s2v[r];
+          a.sum_out[(prow2 * 2 + 0) * D + 16 * ktile + 4 * g + r] = s1v[r];
+          a.sum_out[(prow2 * 2 + 1) * D + 16 * ktile + 4 * g + r] = s2v[r];
         }
       }
     }
@@ -487,24 +552,22 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
     constexpr int NWI = SPLIT ? 3 : 6;
     const int grp = wv >> 2;
     f32x4 aWi[NWI];
-    float dbi[NWI];
 #pragma unroll
-    for (int i = 0; i < NWI; ++i) {
-      aWi[i] = zero4();
-      dbi[i] = 0.0f;
-    }
+    for (int i = 0; i < NWI; ++i) aWi[i] = zero4();
     auto wi_part = [&](int i) { return SPLIT ? (3 * grp + i) >> 1 : (6 * grp + i) >> 2; };
     auto wi_head = [&](int i) { return SPLIT ? 2 * hp + ((3 * grp + i) & 1) : ((6 * grp + i) & 3); };
-    for (int st = 0; st < NR / 4; ++st) {
-      const int rr = 4 * st + g;
-      const float xb = X0[rr * P + 16 * ktile + lq] * sc0 + sh0;    // x0 through its BatchNorm, [row][k = 16 ktile + lq]
+#pragma unroll 1
+    for (int q4 = 0; q4 < NT; ++q4) {
+      const int rr = 16 * q4 + g;
+      float xv4[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) xv4[s4] = L::ld1(X0 + (rr + 4 * s4) * P + 16 * ktile + lq) * sc0 + sh0;
+      const Op xb = L::mk(xv4[0], xv4[1], xv4[2], xv4[3]);    // x0 through its BatchNorm, [row][k = 16 ktile + lq]
 #pragma unroll
       for (int i = 0; i < NWI; ++i) {
         const int part = wi_part(i);
-        const float* src = part == 0 ? Qs : (part == 1 ? Ks : Vs);
-        const float da = src[rr * P + 16 * wi_head(i) + lq];
-        dbi[i] += da;
-        aWi[i] = mfma16(da, xb, aWi[i]);
+        const T* src = part == 0 ? Qs : (part == 1 ? Ks : Vs);
+        aWi[i] = L::mma(L::gather(src + rr * P + 16 * wi_head(i) + lq, 4 * P), xb, aWi[i]);
       }
     }
     // ---- partial row of this graph: [dW_out (64 x 64) | db_out (64) | dW_in (192 x 64) | db_in (192)] --------------
@@ -515,33 +578,49 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         pWi[(int64_t)(64 * wi_part(i) + 16 * wi_head(i) + 4 * g + r) * D + 16 * ktile + lq] = aWi[i][r];
-#pragma unroll
-    for (int i = 0; i < NWI; ++i) {
-      float s = dbi[i];
-      s += shfl_xor(s, 16);
-      s += shfl_xor(s, 32);
-      if (ktile == 0 && g == 0) pbi[64 * wi_part(i) + 16 * wi_head(i) + lq] = s;
+    // db_in from the fp32 column sums the attention waves left (DBS: written before two barriers ago)
+    if (tid < 3 * D) {
+      const int part = tid >> 6, hh = (tid >> 4) & 3, c = tid & 15;
+      const int rl = part == 0 ? 0 : 1, which = part == 2 ? 1 : 0;
+      if (SPLIT) {
+        if ((hh >> 1) == hp) {
+          const int wa = (hh & 1) + 2 * rl;
+          pbi[tid] = DBS[(wa * 2 + which) * 16 + c] + DBS[((wa + 4) * 2 + which) * 16 + c];
+        }
+      } else {
+        pbi[tid] = DBS[((hh + 4 * rl) * 2 + which) * 16 + c];
+      }
     }
   }
   BB_STAMP(7);
   FETA_RT_LAUNCH_DONE(feta_bbwd_launch);
 }
 
-template <int NT>
+template <class T, int NT>
 int launch_block_bwd(const BwdArgs& a, hipStream_t stream) {
-  const size_t lds = sizeof(float) * block_bwd_lds_floats(NT, a.y1 != nullptr);
+  const size_t lds = block_bwd_lds_bytes<T>(NT, a.y1 != nullptr);
   if (a.dx_b != nullptr) {   // two workgroups per graph
-    auto kern = attn_block_bwd_kernel<NT, true>;
+    auto kern = attn_block_bwd_kernel<T, NT, true>;
     static LdsSeen lds_seen;
     allow_dynamic_lds(kern, lds, lds_seen);
     hipLaunchKernelGGL(kern, dim3(2 * a.B), dim3(kBbThreads), lds, stream, a);
   } else {
-    auto kern = attn_block_bwd_kernel<NT, false>;
+    auto kern = attn_block_bwd_kernel<T, NT, false>;
     static LdsSeen lds_seen;
     allow_dynamic_lds(kern, lds, lds_seen);
     hipLaunchKernelGGL(kern, dim3(a.B), dim3(kBbThreads), lds, stream, a);
   }
   return check_launch("feta_attn_block_bwd");
+}
+
+template <class T>
+int dispatch_block_bwd(const BwdArgs& a, hipStream_t stream) {
+  switch ((a.N + 15) / 16) {
+    case 1: return launch_block_bwd<T, 1>(a, stream);
+    case 2: return launch_block_bwd<T, 2>(a, stream);
+    case 3: return launch_block_bwd<T, 3>(a, stream);
+    default: return launch_block_bwd<T, 4>(a, stream);
+  }
 }
 
 }  // namespace feta
@@ -573,11 +652,7 @@ extern "C" int feta_attn_block_bwd(const feta_attn_block_grad* d, feta_stream_t 
   FETA_REQUIRE(aligned16(a.dy) && aligned16(a.qkv) && aligned16(a.out) && aligned16(a.x0) && aligned16(a.dx) &&
                aligned16(a.y1) && aligned16(a.dout2) && aligned16(a.g_sum) && aligned16(a.dx_b),
                "attn_block_bwd: tensors must be 16-byte aligned");
-  const int nt = (a.N + 15) / 16;
-  switch (nt) {
-    case 1: return launch_block_bwd<1>(a, (hipStream_t)stream);
-    case 2: return launch_block_bwd<2>(a, (hipStream_t)stream);
-    case 3: return launch_block_bwd<3>(a, (hipStream_t)stream);
-    default: return launch_block_bwd<4>(a, (hipStream_t)stream);
-  }
+  FETA_REQUIRE(a.dtype == FETA_F32 || a.dtype == FETA_BF16, "attn_block_bwd: dtype %d", a.dtype);
+  if (a.dtype == FETA_BF16) return dispatch_block_bwd<bf16_t>(a, (hipStream_t)stream);
+  return dispatch_block_bwd<float>(a, (hipStream_t)stream);
 }

@@ -15,6 +15,7 @@
 
 #include "feta_abi_common.h"
 #include "feta_coeff.h"
+#include "feta_lp.h"
 #include "feta_rowops.h"
 
 namespace feta {
@@ -24,11 +25,14 @@ typedef feta_ffn FfnArgs;  // include/feta_hip.h
 constexpr int kFfnD = 64;
 constexpr int kFfnRows = 32;  // rows per workgroup
 
-__host__ __device__ inline int ffn_lds_floats(int ff) {
-  return ff * (kFfnD + 4) + kFfnD * (ff + 4)  // W1 [FF][68], W2 [64][FF+4]
-         + 2 * kFfnD                            // scale / shift of BN1
-         + reduce_scratch_floats(kFfnD)         // finalize scratch, later: partial-tile exchange + stats
-         + 4 * 2 * 4 * 64;                      // exchange [wave][2 tiles][4 regs][64 lanes]
+// LDS bytes of a workgroup: W1 / W2 tiles of T, fp32 for everything else
+template <class T>
+__host__ __device__ inline int ffn_lds_bytes(int ff) {
+  const int pad = Lp<T>::PAD;
+  return (int)sizeof(T) * (ff * (kFfnD + pad) + kFfnD * (ff + pad))  // W1 [FF][64+pad], W2 [64][FF+pad]
+         + 4 * (2 * kFfnD                                              // scale / shift of BN1
+                + reduce_scratch_floats(kFfnD)                        // finalize scratch, later: partial-tile exchange + stats
+                + 4 * 2 * 4 * 64);                                    // exchange [wave][2 tiles][4 regs][64 lanes]
 }
 
 // workgroups of a launch = partial rows of y_stats: every 32-row block up to 512 of them (two resident
@@ -47,9 +51,12 @@ __device__ unsigned long long feta_ffn_stamps[16];
 
 // Workgroups beyond main_grid run the forward of the coefficient generator (feta_coeff.h), one (head, graph) block each:
 // it depends on the attention matrix of the last layer only, so it shares the launch of that layer's feed-forward half.
-template <int FF>
+// T: storage type of x, h, y and of the weight tiles in LDS (feta_lp.h); weights in HBM, biases, statistics: fp32.
+template <class T, int FF>
 __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a, CoeffFwdRole cf, int main_grid) {
-  constexpr int D = kFfnD, P1 = D + 4, P2 = FF + 4, HT = FF / 32;  // HT hidden tiles per half
+  typedef Lp<T> L;
+  typedef typename L::Op Op;
+  constexpr int D = kFfnD, P1 = D + L::PAD, P2 = FF + L::PAD, HT = FF / 32;  // HT hidden tiles per half
   if ((int)blockIdx.x >= main_grid) {
     coeff_fwd_body(cf.attn, cf.n_real, cf.s, cf.gbias, cf.cj, cf.pooled, cf.B, cf.N, cf.H, cf.C, coeff_fwd_stage(cf.N),
                    (int)blockIdx.x - main_grid);
@@ -57,11 +64,14 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a, CoeffFw
   }
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lq = lane & 15, g = lane >> 4;
   const int rt = wv >> 1, hh = wv & 1;
-  float* W1 = feta_lds;            // [FF][P1]
-  float* W2 = W1 + FF * P1;        // [64][P2]
-  float* xss = W2 + D * P2;        // [2][64]
+  T* W1 = reinterpret_cast<T*>(lds_bytes());   // [FF][P1]
+  T* W2 = W1 + FF * P1;                         // [64][P2]
+  float* xss = reinterpret_cast<float*>(W2 + D * P2);   // [2][64]
   float* scr = xss + 2 * D;        // finalize scratch
   float* xch = scr + reduce_scratch_floats(D);  // [4 waves][2][4][64]
+  const T* gx = reinterpret_cast<const T*>(a.x);
+  T* gh = reinterpret_cast<T*>(a.h);
+  T* gy = reinterpret_cast<T*>(a.y);
   FFN_STAMP(0);
   const int nblk = (a.M + kFfnRows - 1) / kFfnRows;
   // a workgroup stages the weights ONCE and walks its row blocks (blockIdx.x, + gridDim.x, ...): at large
@@ -71,8 +81,12 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a, CoeffFw
   int rowc = min(row, a.M - 1);
 
   // ---- requests: the wave's first x rows, biases, then the weights ----------------------------------------
-  Feat<D> xf;
-  load_row_sel<D>(xf, a.x + (int64_t)rowc * D, true, g);
+  float xr[4][4];   // the wave's x row chunks (features 16j + 4g ..), fp32: operand of the first product AND the residual
+  auto load_x = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) L::ld4(gx + (int64_t)rowc * D + 16 * j + 4 * g, xr[j]);
+  };
+  load_x();
   float4 b1v[HT], b2v[2];
 #pragma unroll
   for (int t = 0; t < HT; ++t)
@@ -83,7 +97,7 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a, CoeffFw
     b2v[t] = a.b2 != nullptr ? *reinterpret_cast<const float4*>(a.b2 + 16 * (2 * hh + t) + 4 * g)
                              : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   {
-    constexpr int NV = 2 * FF * D / 4 / kRowThreads;  // float4 per thread: W1 then W2
+    constexpr int NV = 2 * FF * D / 4 / kRowThreads;  // float4 per thread: W1 then W2 (fp32 masters)
     float4 wv4[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -95,10 +109,10 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a, CoeffFw
     for (int i = 0; i < NV; ++i) {
       const int idx = tid + kRowThreads * i;
       if (idx < FF * D / 4) {
-        *reinterpret_cast<float4*>(W1 + (idx / (D / 4)) * P1 + 4 * (idx % (D / 4))) = wv4[i];
+        L::st4(W1 + (idx / (D / 4)) * P1 + 4 * (idx % (D / 4)), wv4[i].x, wv4[i].y, wv4[i].z, wv4[i].w);
       } else {
         const int j = idx - FF * D / 4;
-        *reinterpret_cast<float4*>(W2 + (j / (FF / 4)) * P2 + 4 * (j % (FF / 4))) = wv4[i];
+        L::st4(W2 + (j / (FF / 4)) * P2 + 4 * (j % (FF / 4)), wv4[i].x, wv4[i].y, wv4[i].z, wv4[i].w);
       }
     }
   }
@@ -142,32 +156,34 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a, CoeffFw
     row = blk * kFfnRows + 16 * rt + lq;
     rok = row < a.M;
     rowc = min(row, a.M - 1);
-    load_row_sel<D>(xf, a.x + (int64_t)rowc * D, true, g);
+    load_x();
   }
+  RowOp<T, D> xf;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const float4 sc = *reinterpret_cast<const float4*>(xss + 16 * j + 4 * g);
     const float4 sh = *reinterpret_cast<const float4*>(xss + D + 16 * j + 4 * g);
-    xf.f[j][0] = xf.f[j][0] * sc.x + sh.x;
-    xf.f[j][1] = xf.f[j][1] * sc.y + sh.y;
-    xf.f[j][2] = xf.f[j][2] * sc.z + sh.z;
-    xf.f[j][3] = xf.f[j][3] * sc.w + sh.w;
+    xr[j][0] = xr[j][0] * sc.x + sh.x;
+    xr[j][1] = xr[j][1] * sc.y + sh.y;
+    xr[j][2] = xr[j][2] * sc.z + sh.z;
+    xr[j][3] = xr[j][3] * sc.w + sh.w;
+    xf.o[j] = L::mk(xr[j][0], xr[j][1], xr[j][2], xr[j][3]);
   }
 
   // ---- h (this half of the hidden units) = relu(x W1^T + b1): (hidden 4g+r, row lq) ------------------
-  f32x4 hacc[HT];
+  Op ho[HT];
 #pragma unroll
   for (int t = 0; t < HT; ++t) {
     const int o = hh * (FF / 2) + 16 * t;
-    Feat<D> wf;
-    load_row<D>(wf, W1 + (o + lq) * P1, g);
-    f32x4 v = dot_rows<D>(wf, xf, zero4());
+    RowOp<T, D> wf;
+    load_row_op<T, D>(wf, W1 + (o + lq) * P1, g);
+    f32x4 v = dot_row_ops<T, D>(wf, xf, zero4());
     v[0] = fmaxf(v[0] + b1v[t].x, 0.0f);
     v[1] = fmaxf(v[1] + b1v[t].y, 0.0f);
     v[2] = fmaxf(v[2] + b1v[t].z, 0.0f);
     v[3] = fmaxf(v[3] + b1v[t].w, 0.0f);
-    hacc[t] = v;
-    if (rok) *reinterpret_cast<float4*>(a.h + (int64_t)row * FF + o + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+    ho[t] = L::mk(v);   // the accumulator tile of the first product IS the B operand of the second
+    if (rok) L::st4(gh + (int64_t)row * FF + o + 4 * g, v[0], v[1], v[2], v[3]);
   }
   FFN_STAMP(3);
   // ---- partial y2^T tiles over this half: (output 4g+r, row lq) --------------------------------------
@@ -176,13 +192,8 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a, CoeffFw
   for (int t2 = 0; t2 < 4; ++t2) {
     f32x4 acc = zero4();
 #pragma unroll
-    for (int t = 0; t < HT; ++t) {
-      const float4 w4 = *reinterpret_cast<const float4*>(W2 + (16 * t2 + lq) * P2 + hh * (FF / 2) + 16 * t + 4 * g);
-      acc = mfma16(w4.x, hacc[t][0], acc);
-      acc = mfma16(w4.y, hacc[t][1], acc);
-      acc = mfma16(w4.z, hacc[t][2], acc);
-      acc = mfma16(w4.w, hacc[t][3], acc);
-    }
+    for (int t = 0; t < HT; ++t)
+      acc = L::mma(L::ld(W2 + (16 * t2 + lq) * P2 + hh * (FF / 2) + 16 * t + 4 * g), ho[t], acc);
     yp[t2] = acc;
   }
   FFN_STAMP(4);
@@ -206,14 +217,17 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a, CoeffFw
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float own = hh ? yp[2 + t][r] : yp[t][r];
-      // (the empty asm makes both candidates plain register values: a select between two LOADS of xf is
-      // folded into one load at a selected address, which puts xf in private memory)
-      float x_hi = xf.f[2 + t][r], x_lo = xf.f[t][r];
+      // (the empty asm makes both candidates plain register values: a select between two LOADS of xr is
+      // folded into one load at a selected address, which puts xr in private memory)
+      float x_hi = xr[2 + t][r], x_lo = xr[t][r];
       asm volatile("" : "+v"(x_hi), "+v"(x_lo));
       const float res = hh ? x_hi : x_lo;
       v[r] = own + theirs[(t * 4 + r) * 64 + lane] + bb[r] + res;
     }
-    if (rok) *reinterpret_cast<float4*>(a.y + (int64_t)row * D + o2) = make_float4(v[0], v[1], v[2], v[3]);
+    if (rok) {
+      if (a.y_f32) *reinterpret_cast<float4*>(a.y + (int64_t)row * D + o2) = make_float4(v[0], v[1], v[2], v[3]);
+      else L::st4(gy + (int64_t)row * D + o2, v[0], v[1], v[2], v[3]);
+    }
     if (want_stats) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -235,18 +249,26 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a, CoeffFw
   if (want_stats && tid < 2 * D) a.y_stats[(int64_t)blockIdx.x * 2 * D + tid] = tot1[0];
 }
 
-template <int FF>
+template <class T, int FF>
 int launch_ffn_fwd(const FfnArgs& a, const CoeffFwdRole& cf, hipStream_t stream) {
-  size_t floats = ffn_lds_floats(FF);
+  size_t lds = ffn_lds_bytes<T>(FF);
   const int role = cf.attn != nullptr ? cf.B * cf.H : 0;
-  if (role > 0 && (size_t)coeff_fwd_lds_floats(cf.N) > floats) floats = coeff_fwd_lds_floats(cf.N);
-  const size_t lds = sizeof(float) * floats;
-  auto kern = ffn_fwd_kernel<FF>;
+  if (role > 0 && sizeof(float) * (size_t)coeff_fwd_lds_floats(cf.N) > lds) lds = sizeof(float) * coeff_fwd_lds_floats(cf.N);
+  auto kern = ffn_fwd_kernel<T, FF>;
   static LdsSeen lds_seen;
   allow_dynamic_lds(kern, lds, lds_seen);
   const int grid = ffn_grid(a.M);
   hipLaunchKernelGGL(kern, dim3(grid + role), dim3(kRowThreads), lds, stream, a, cf, grid);
   return check_launch("feta_ffn_fwd");
+}
+
+template <class T>
+int dispatch_ffn_fwd(const FfnArgs& a, const CoeffFwdRole& cf, hipStream_t stream) {
+  switch (a.FF) {
+    case 64: return launch_ffn_fwd<T, 64>(a, cf, stream);
+    case 128: return launch_ffn_fwd<T, 128>(a, cf, stream);
+    default: return launch_ffn_fwd<T, 256>(a, cf, stream);
+  }
 }
 
 }  // namespace feta
@@ -284,9 +306,7 @@ extern "C" int feta_ffn_fwd_coeff(const feta_ffn* d, const feta_coeff_fwd_role* 
   FETA_REQUIRE(aligned16(a.x) && aligned16(a.w1) && aligned16(a.w2) && aligned16(a.h) && aligned16(a.y) &&
                    aligned16(a.b1) && aligned16(a.b2) && aligned16(a.x_stats) && aligned16(a.y_stats),
                "ffn_fwd: tensors must be 16-byte aligned");
-  switch (a.FF) {
-    case 64: return launch_ffn_fwd<64>(a, cf, (hipStream_t)stream);
-    case 128: return launch_ffn_fwd<128>(a, cf, (hipStream_t)stream);
-    default: return launch_ffn_fwd<256>(a, cf, (hipStream_t)stream);
-  }
+  FETA_REQUIRE(a.dtype == FETA_F32 || a.dtype == FETA_BF16, "ffn_fwd: dtype %d", a.dtype);
+  if (a.dtype == FETA_BF16) return dispatch_ffn_fwd<bf16_t>(a, cf, (hipStream_t)stream);
+  return dispatch_ffn_fwd<float>(a, cf, (hipStream_t)stream);
 }

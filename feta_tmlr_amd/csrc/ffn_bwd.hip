@@ -21,6 +21,7 @@
 
 #include "feta_abi_common.h"
 #include "feta_coeff.h"
+#include "feta_lp.h"
 #include "feta_rowops.h"
 
 namespace feta {
@@ -47,23 +48,38 @@ inline int ffn_bwd_xblocks(int M) {
   return nblk < cap ? nblk : cap;
 }
 
-// g2(row, o..o+3) from dy (and y2 when the BatchNorm backward is folded in); gv = [5][64]: scale, mean, rstd, m1, m2
-__device__ __forceinline__ float4 g2_of(const float4& dv, const float4& yv, const float* gv, int o, bool gbn) {
-  float v[4] = {dv.x, dv.y, dv.z, dv.w};
+// g2(row, o .. o+NV-1) from dy (and y2 when the BatchNorm backward is folded in), in place in v;
+// gv = [5][64]: scale, mean, rstd, m1, m2
+template <int NV>
+__device__ __forceinline__ void g2_of(float (&v)[NV], const float (&yy)[NV], const float* gv, int o, bool gbn) {
   if (gbn) {
-    const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < NV; ++s) {
       const float xh = (yy[s] - gv[kFbD + o + s]) * gv[2 * kFbD + o + s];
       v[s] = gv[o + s] * (v[s] - gv[3 * kFbD + o + s] - xh * gv[4 * kFbD + o + s]);
     }
   }
-  return make_float4(v[0], v[1], v[2], v[3]);
 }
 
-template <int FF>
+// LDS row paddings of the W role's tiles (elements): their operands are read down columns as well as along rows
+template <class T> struct FbPad { static constexpr int W = 16; };
+template <> struct FbPad<bf16_t> { static constexpr int W = 8; };
+
+template <class T>
+inline size_t ffn_bwd_lds_bytes(int FF, bool gbn) {
+  const size_t x_lds = kFbRows * (kFbD + Lp<T>::PAD) + kFbRows * (FF + Lp<T>::PAD);
+  const size_t w_lds = 2 * 64 * (kFbD + FbPad<T>::W) + 2 * 64 * (kFbSlice + FbPad<T>::W);
+  return sizeof(T) * (x_lds > w_lds ? x_lds : w_lds) + sizeof(float) * (gbn ? 5 * kFbD + reduce_scratch_floats(kFbD) : 0);
+}
+
+// T: storage type of dy, dy_b, g_y, h, x, dx and of the LDS tiles (feta_lp.h); weights, parameter blocks, partial
+// sums and the weight-gradient partial rows: fp32.
+template <class T, int FF>
 __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, FfnBwdGeom ge, CoeffBwdRole cb) {
-  constexpr int D = kFbD, NJ2 = FF / 16;
+  typedef Lp<T> L;
+  typedef typename L::Op Op;
+  typedef typename L::Vec Vec;
+  constexpr int D = kFbD, NJ2 = FF / 16, VEC = L::VEC, RV = D / VEC;
   if ((int)blockIdx.x >= ge.main_grid) {
     // trailing workgroups: the backward of the coefficient generator (feta_coeff.h) - it depends on the filter stage
     // only, and this is the first launch of the layer stack's backward
@@ -72,6 +88,12 @@ __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, Ffn
     return;
   }
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lq = lane & 15, g = lane >> 4;
+  const T* gdy = reinterpret_cast<const T*>(a.dy);
+  const T* gdyb = reinterpret_cast<const T*>(a.dy_b);
+  const T* ggy = reinterpret_cast<const T*>(a.g_y);
+  const T* ghh = reinterpret_cast<const T*>(a.h);
+  const T* gxx = reinterpret_cast<const T*>(a.x);
+  T* gdx = reinterpret_cast<T*>(a.dx);
   // Which piece of work this workgroup is.  A 64-row chunk is touched by six workgroups (its two X-role blocks and the
   // four hidden-unit slices of the W role), and workgroups are dealt round-robin to the 8 XCDs, each with its own L2:
   // in launch order (X blocks, then W slices) the six sat on up to six XCDs and the chunk's rows of dy, y2, y1 left HBM
@@ -121,25 +143,54 @@ __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, Ffn
     }
     __syncthreads();
   }
+  // gradient vector `idx` of a row tile: dy (+ dy_b) and y2, as fp32
+  // (captures local pointers only: a lambda that captures the argument struct `a` by reference here made the compiler
+  // keep a copy of the whole struct in private memory)
+  const bool two_parts = a.dy_b != nullptr;
+  const bool g_f32 = a.g_f32 != 0 && sizeof(T) != sizeof(float);   // dy, g_y fp32 behind a bf16 stack (its last layer)
+  const float* fdy = a.dy;
+  const float* fgy = a.g_y;
+  auto load_g = [gdy, gdyb, ggy, gbn, two_parts, g_f32, fdy, fgy](int64_t off, float (&dv)[VEC], float (&yv)[VEC]) {
+    if (g_f32) {
+#pragma unroll
+      for (int e = 0; e < VEC; e += 4) {
+        const float4 d4 = *reinterpret_cast<const float4*>(fdy + off + e);
+        const float4 y4 = *reinterpret_cast<const float4*>((gbn ? fgy : fdy) + off + e);
+        dv[e] = d4.x; dv[e + 1] = d4.y; dv[e + 2] = d4.z; dv[e + 3] = d4.w;
+        yv[e] = y4.x; yv[e + 1] = y4.y; yv[e + 2] = y4.z; yv[e + 3] = y4.w;
+      }
+      return;
+    }
+    L::unpack(L::ldv(gdy + off), dv);
+    if (two_parts) {   // the gradient arrives in two parts (feta_attn_block_bwd, SPLIT form)
+      float d2[VEC];
+      L::unpack(L::ldv(gdyb + off), d2);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) dv[e] += d2[e];
+    }
+    L::unpack(L::ldv((gbn ? ggy : gdy) + off), yv);
+  };
 
   if (xblk >= 0) {
     // ================================ X role: dh tile -> dx1 ================================================
-    constexpr int GP = D + 4, DP = FF + 4, CT2 = FF / 64;   // CT2 column tiles of dh per wave
-    float* gt = after;              // [32][GP]  g2
-    float* dht = gt + kFbRows * GP; // [32][DP]  dh
+    constexpr int GP = D + L::PAD, DP = FF + L::PAD, CT2 = FF / 64;   // CT2 column tiles of dh per wave
+    T* gt = reinterpret_cast<T*>(after);   // [32][GP]  g2
+    T* dht = gt + kFbRows * GP;            // [32][DP]  dh
     // weight slices of this wave, for the whole launch
-    float wA2[CT2][4][4];           // W2[o = 16j+4g+s][c = 16 (w CT2 + t) + lq]
+    Op wA2[CT2][4];                 // W2[o = 16j+4g+s][c = 16 (w CT2 + t) + lq]
 #pragma unroll
     for (int t = 0; t < CT2; ++t)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j) {
+        const float* p = a.w2 + (int64_t)(16 * j + 4 * g) * FF + 16 * (w * CT2 + t) + lq;
+        wA2[t][j] = L::mk(p[0], p[FF], p[2 * FF], p[3 * FF]);
+      }
+    Op wA1[NJ2];                    // W1[c = 16j+4g+s][k = 16w + lq]
 #pragma unroll
-        for (int s = 0; s < 4; ++s) wA2[t][j][s] = a.w2[(int64_t)(16 * j + 4 * g + s) * FF + 16 * (w * CT2 + t) + lq];
-    float wA1[NJ2][4];              // W1[c = 16j+4g+s][k = 16w + lq]
-#pragma unroll
-    for (int j = 0; j < NJ2; ++j)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) wA1[j][s] = a.w1[(int64_t)(16 * j + 4 * g + s) * D + 16 * w + lq];
+    for (int j = 0; j < NJ2; ++j) {
+      const float* p = a.w1 + (int64_t)(16 * j + 4 * g) * D + 16 * w + lq;
+      wA1[j] = L::mk(p[0], p[D], p[2 * D], p[3 * D]);
+    }
     const bool want_sums = a.sum_out != nullptr;
     float mean1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, rstd1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (want_sums) {
@@ -152,79 +203,69 @@ __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, Ffn
     float sum1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, sum2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const int nblk = (a.M + kFbRows - 1) / kFbRows;
     const int row_last = a.M - 1;
+    constexpr int NU = kFbRows * RV / kRowThreads;   // vectors of the gradient tile per thread
     for (int blk = xblk; blk < nblk; blk += ge.XB) {
       const int r0 = blk * kFbRows;
       if (blk != xblk) __syncthreads();   // the tiles of the previous block have been consumed
-      // requests of the block: gradient tile (2 items per thread), relu operands, residual rows of the sums
-      float4 dv[2], yv[2];
+      // requests of the block: gradient tile, relu operands, residual rows of the sums
+      float dv[NU][VEC], yv[NU][VEC];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int idx = tid + u * kRowThreads, rr = idx >> 4, c4 = idx & 15;
-        const int64_t off = (int64_t)min(r0 + rr, row_last) * D + 4 * c4;
-        dv[u] = *reinterpret_cast<const float4*>(a.dy + off);
-        if (a.dy_b != nullptr) {   // the gradient arrives in two parts (feta_attn_block_bwd, SPLIT form)
-          const float4 d2 = *reinterpret_cast<const float4*>(a.dy_b + off);
-          dv[u] = make_float4(dv[u].x + d2.x, dv[u].y + d2.y, dv[u].z + d2.z, dv[u].w + d2.w);
-        }
-        yv[u] = *reinterpret_cast<const float4*>((gbn ? a.g_y : a.dy) + off);
+      for (int u = 0; u < NU; ++u) {
+        const int idx = tid + u * kRowThreads, rr = idx / RV, c4 = idx % RV;
+        load_g((int64_t)min(r0 + rr, row_last) * D + VEC * c4, dv[u], yv[u]);
       }
-      float4 hv[2][CT2], sy[2];
+      float hv[2][CT2][4], sy[2][4];
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
         const int64_t rowc = min(r0 + 16 * rt + lq, row_last);
 #pragma unroll
-        for (int t = 0; t < CT2; ++t)
-          hv[rt][t] = *reinterpret_cast<const float4*>(a.h + rowc * FF + 16 * (w * CT2 + t) + 4 * g);
-        sy[rt] = *reinterpret_cast<const float4*>(a.x + rowc * D + 16 * w + 4 * g);
+        for (int t = 0; t < CT2; ++t) L::ld4(ghh + rowc * FF + 16 * (w * CT2 + t) + 4 * g, hv[rt][t]);
+        L::ld4(gxx + rowc * D + 16 * w + 4 * g, sy[rt]);
       }
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int idx = tid + u * kRowThreads, rr = idx >> 4, c4 = idx & 15;
-        const float4 v = g2_of(dv[u], yv[u], gv, 4 * c4, gbn);
+      for (int u = 0; u < NU; ++u) {
+        const int idx = tid + u * kRowThreads, rr = idx / RV, c4 = idx % RV;
+        g2_of<VEC>(dv[u], yv[u], gv, VEC * c4, gbn);
         const bool ok = r0 + rr < a.M;
-        *reinterpret_cast<float4*>(gt + rr * GP + 4 * c4) =
-            make_float4(ok ? v.x : 0.0f, ok ? v.y : 0.0f, ok ? v.z : 0.0f, ok ? v.w : 0.0f);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) dv[u][e] = ok ? dv[u][e] : 0.0f;
+        L::stv(gt + rr * GP + VEC * c4, L::pack(dv[u]));
       }
       __syncthreads();
       // dh^T tiles (c = 16 ct + 4g + r, row = 16 rt + lq) = sum_o W2[o][c] g2[row][o], masked by h > 0
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
-        Feat<D> gf;
-        load_row<D>(gf, gt + (16 * rt + lq) * GP, g);
+        RowOp<T, D> gf;
+        load_row_op<T, D>(gf, gt + (16 * rt + lq) * GP, g);
 #pragma unroll
         for (int t = 0; t < CT2; ++t) {
           f32x4 acc = zero4();
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) acc = mfma16(wA2[t][j][s], gf.f[j][s], acc);
-          const float4 hh = hv[rt][t];
-          *reinterpret_cast<float4*>(dht + (16 * rt + lq) * DP + 16 * (w * CT2 + t) + 4 * g) =
-              make_float4(hh.x > 0.0f ? acc[0] : 0.0f, hh.y > 0.0f ? acc[1] : 0.0f, hh.z > 0.0f ? acc[2] : 0.0f,
-                          hh.w > 0.0f ? acc[3] : 0.0f);
+          for (int j = 0; j < 4; ++j) acc = L::mma(wA2[t][j], gf.o[j], acc);
+          L::st4(dht + (16 * rt + lq) * DP + 16 * (w * CT2 + t) + 4 * g,
+                 hv[rt][t][0] > 0.0f ? acc[0] : 0.0f, hv[rt][t][1] > 0.0f ? acc[1] : 0.0f,
+                 hv[rt][t][2] > 0.0f ? acc[2] : 0.0f, hv[rt][t][3] > 0.0f ? acc[3] : 0.0f);
         }
       }
       __syncthreads();
       // dx1^T tiles (k = 16w + 4g + r, row) = sum_c W1[c][k] dh[row][c]  + g2[row][k]
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
-        Feat<FF> df;
-        load_row<FF>(df, dht + (16 * rt + lq) * DP, g);
+        RowOp<T, FF> df;
+        load_row_op<T, FF>(df, dht + (16 * rt + lq) * DP, g);
         f32x4 acc = zero4();
 #pragma unroll
-        for (int j = 0; j < NJ2; ++j)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) acc = mfma16(wA1[j][s], df.f[j][s], acc);
-        const float4 res = *reinterpret_cast<const float4*>(gt + (16 * rt + lq) * GP + 16 * w + 4 * g);
-        const float v[4] = {acc[0] + res.x, acc[1] + res.y, acc[2] + res.z, acc[3] + res.w};
+        for (int j = 0; j < NJ2; ++j) acc = L::mma(wA1[j], df.o[j], acc);
+        float res[4];
+        L::ld4(gt + (16 * rt + lq) * GP + 16 * w + 4 * g, res);
+        const float v[4] = {acc[0] + res[0], acc[1] + res[1], acc[2] + res[2], acc[3] + res[3]};
         const int row = r0 + 16 * rt + lq;
         const bool rok = row < a.M;
-        if (rok) *reinterpret_cast<float4*>(a.dx + (int64_t)row * D + 16 * w + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+        if (rok) L::st4(gdx + (int64_t)row * D + 16 * w + 4 * g, v[0], v[1], v[2], v[3]);
         if (want_sums) {
-          const float yy[4] = {sy[rt].x, sy[rt].y, sy[rt].z, sy[rt].w};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float xh = (yy[r] - mean1[r]) * rstd1[r];
+            const float xh = (sy[rt][r] - mean1[r]) * rstd1[r];
             const float s1 = rok ? v[r] : 0.0f;
             sum1[r] += s1;
             sum2[r] += s1 * xh;
@@ -246,104 +287,124 @@ __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, Ffn
   }
 
   // ================================== W role: dW2 | db2 | dW1 | db1 of one (chunk, hidden slice) ===================
-  constexpr int GPW = D + 16, HP = kFbSlice + 16;
+  constexpr int GPW = D + FbPad<T>::W, HP = kFbSlice + FbPad<T>::W, HV = kFbSlice / VEC;
   const int bi = wbi;
   const int si = bi % ge.NS, rc = bi / ge.NS;
   const int c0 = kFbSlice * si;
-  float* gt = after;             // [64][GPW] g2
-  float* xt = gt + 64 * GPW;     // [64][GPW] x1 (seen through its BatchNorm)
-  float* hs = xt + 64 * GPW;     // [64][HP]  h slice
-  float* dhs = hs + 64 * HP;     // [64][HP]  dh slice
-  float wA2[2][4][4];            // W2[o = 16j+4g+s][c = c0 + 16t + lq]
+  T* gt = reinterpret_cast<T*>(after);   // [64][GPW] g2
+  T* xt = gt + 64 * GPW;     // [64][GPW] x1 (seen through its BatchNorm)
+  T* hs = xt + 64 * GPW;     // [64][HP]  h slice
+  T* dhs = hs + 64 * HP;     // [64][HP]  dh slice
+  Op wA2[2][4];              // W2[o = 16j+4g+s][c = c0 + 16t + lq]
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) wA2[t][j][s] = a.w2[(int64_t)(16 * j + 4 * g + s) * FF + c0 + 16 * t + lq];
+    for (int j = 0; j < 4; ++j) {
+      const float* p = a.w2 + (int64_t)(16 * j + 4 * g) * FF + c0 + 16 * t + lq;
+      wA2[t][j] = L::mk(p[0], p[FF], p[2 * FF], p[3 * FF]);
+    }
   const int row_lo = rc * ge.per * 16, row_hi = min((rc + 1) * ge.per * 16, a.M);
   const int row_last = max(row_hi - 1, 0);
   f32x4 aW2[2] = {zero4(), zero4()}, aW1[2] = {zero4(), zero4()};
-  float db2 = 0.0f, db1[2] = {0.0f, 0.0f};
+  // bias gradients = column sums of g2 / dh: taken from the fp32 values BEFORE they are rounded into the tiles (behind a
+  // BatchNorm backward the true column sum of g2 is zero: the rounding errors of a bf16 tile would be all that is left)
+  float cs2[VEC], cs1[2][4];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) cs2[e] = 0.0f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cs1[t][r] = 0.0f;
   const bool xbn = a.x_bn != nullptr;
+  constexpr int NG = 64 * RV / kRowThreads, NH = 64 * HV / kRowThreads;   // vectors per thread: g2 / x1 tiles, h slice
   for (int r0 = row_lo; r0 < row_hi; r0 += 64) {
     if (r0 > row_lo) __syncthreads();
-    // stage g2 [64 x 64], x1 [64 x 64] (4 items per thread each) and the h slice [64 x 32] (2 per thread): every
-    // load of the pass is issued before the first LDS store
-    float4 dv[4], yv[4], xv[4], hq[2];
+    // stage g2 [64 x 64], x1 [64 x 64] and the h slice [64 x 32]: every load of the pass is issued before the first
+    // LDS store
+    float dv[NG][VEC], yv[NG][VEC];
+    Vec xv[NG], hq[NH];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = tid + u * kRowThreads, rr = idx >> 4, c4 = idx & 15;
-      const int64_t off = (int64_t)min(r0 + rr, row_last) * D + 4 * c4;
-      dv[u] = *reinterpret_cast<const float4*>(a.dy + off);
-      if (a.dy_b != nullptr) {
-        const float4 d2 = *reinterpret_cast<const float4*>(a.dy_b + off);
-        dv[u] = make_float4(dv[u].x + d2.x, dv[u].y + d2.y, dv[u].z + d2.z, dv[u].w + d2.w);
-      }
-      yv[u] = *reinterpret_cast<const float4*>((gbn ? a.g_y : a.dy) + off);
-      xv[u] = *reinterpret_cast<const float4*>(a.x + off);
+    for (int u = 0; u < NG; ++u) {
+      const int idx = tid + u * kRowThreads, rr = idx / RV, c4 = idx % RV;
+      const int64_t off = (int64_t)min(r0 + rr, row_last) * D + VEC * c4;
+      load_g(off, dv[u], yv[u]);
+      xv[u] = L::ldv(gxx + off);
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int idx = tid + u * kRowThreads, rr = idx >> 3, c4 = idx & 7;
-      hq[u] = *reinterpret_cast<const float4*>(a.h + (int64_t)min(r0 + rr, row_last) * FF + c0 + 4 * c4);
+    for (int u = 0; u < NH; ++u) {
+      const int idx = tid + u * kRowThreads, rr = idx / HV, c4 = idx % HV;
+      hq[u] = L::ldv(ghh + (int64_t)min(r0 + rr, row_last) * FF + c0 + VEC * c4);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = tid + u * kRowThreads, rr = idx >> 4, c4 = idx & 15;
+    for (int u = 0; u < NG; ++u) {
+      const int idx = tid + u * kRowThreads, rr = idx / RV, c4 = idx % RV;
       const bool ok = r0 + rr < row_hi;
-      const float4 v = g2_of(dv[u], yv[u], gv, 4 * c4, gbn);
-      *reinterpret_cast<float4*>(gt + rr * GPW + 4 * c4) =
-          make_float4(ok ? v.x : 0.0f, ok ? v.y : 0.0f, ok ? v.z : 0.0f, ok ? v.w : 0.0f);
-      float4 x = xv[u];
+      g2_of<VEC>(dv[u], yv[u], gv, VEC * c4, gbn);
+      float x[VEC];
+      L::unpack(xv[u], x);
       if (xbn) {
-        const float4 sc = *reinterpret_cast<const float4*>(a.x_bn + 4 * c4);
-        const float4 sh = *reinterpret_cast<const float4*>(a.x_bn + D + 4 * c4);
-        x = make_float4(x.x * sc.x + sh.x, x.y * sc.y + sh.y, x.z * sc.z + sh.z, x.w * sc.w + sh.w);
+#pragma unroll
+        for (int e4 = 0; e4 < VEC; e4 += 4) {
+          const float4 sc = *reinterpret_cast<const float4*>(a.x_bn + VEC * c4 + e4);
+          const float4 sh = *reinterpret_cast<const float4*>(a.x_bn + D + VEC * c4 + e4);
+          x[e4] = x[e4] * sc.x + sh.x;
+          x[e4 + 1] = x[e4 + 1] * sc.y + sh.y;
+          x[e4 + 2] = x[e4 + 2] * sc.z + sh.z;
+          x[e4 + 3] = x[e4 + 3] * sc.w + sh.w;
+        }
       }
-      *reinterpret_cast<float4*>(xt + rr * GPW + 4 * c4) =
-          make_float4(ok ? x.x : 0.0f, ok ? x.y : 0.0f, ok ? x.z : 0.0f, ok ? x.w : 0.0f);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        dv[u][e] = ok ? dv[u][e] : 0.0f;
+        cs2[e] += dv[u][e];
+        x[e] = ok ? x[e] : 0.0f;
+      }
+      L::stv(gt + rr * GPW + VEC * c4, L::pack(dv[u]));
+      L::stv(xt + rr * GPW + VEC * c4, L::pack(x));
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int idx = tid + u * kRowThreads, rr = idx >> 3, c4 = idx & 7;
+    for (int u = 0; u < NH; ++u) {
+      const int idx = tid + u * kRowThreads, rr = idx / HV, c4 = idx % HV;
       const bool ok = r0 + rr < row_hi;
-      *reinterpret_cast<float4*>(hs + rr * HP + 4 * c4) =
-          make_float4(ok ? hq[u].x : 0.0f, ok ? hq[u].y : 0.0f, ok ? hq[u].z : 0.0f, ok ? hq[u].w : 0.0f);
+      float hf[VEC];
+      L::unpack(hq[u], hf);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) hf[e] = ok ? hf[e] : 0.0f;
+      L::stv(hs + rr * HP + VEC * c4, L::pack(hf));
     }
     __syncthreads();
     // this wave's row tile of the dh slice: (c = c0 + 16t + 4g + r, row = 16w + lq)
     {
-      Feat<D> gf;
-      load_row<D>(gf, gt + (16 * w + lq) * GPW, g);
+      RowOp<T, D> gf;
+      load_row_op<T, D>(gf, gt + (16 * w + lq) * GPW, g);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         f32x4 acc = zero4();
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) acc = L::mma(wA2[t][j], gf.o[j], acc);
+        float hh[4];
+        L::ld4(hs + (16 * w + lq) * HP + 16 * t + 4 * g, hh);
+        const float dm[4] = {hh[0] > 0.0f ? acc[0] : 0.0f, hh[1] > 0.0f ? acc[1] : 0.0f, hh[2] > 0.0f ? acc[2] : 0.0f,
+                             hh[3] > 0.0f ? acc[3] : 0.0f};
+        L::st4(dhs + (16 * w + lq) * HP + 16 * t + 4 * g, dm[0], dm[1], dm[2], dm[3]);
 #pragma unroll
-          for (int s = 0; s < 4; ++s) acc = mfma16(wA2[t][j][s], gf.f[j][s], acc);
-        const float4 hh = *reinterpret_cast<const float4*>(hs + (16 * w + lq) * HP + 16 * t + 4 * g);
-        *reinterpret_cast<float4*>(dhs + (16 * w + lq) * HP + 16 * t + 4 * g) =
-            make_float4(hh.x > 0.0f ? acc[0] : 0.0f, hh.y > 0.0f ? acc[1] : 0.0f, hh.z > 0.0f ? acc[2] : 0.0f,
-                        hh.w > 0.0f ? acc[3] : 0.0f);
+        for (int r = 0; r < 4; ++r) cs1[t][r] += dm[r];
       }
     }
     __syncthreads();
     // dW2[o = 16w + 4g' + r][c = c0 + 16ct + lq] += g2[row][o] h[row][c];  dW1[c][k = 16w + lq] += dh[row][c] x1[row][k]
-#pragma unroll 4
-    for (int st = 0; st < 16; ++st) {
-      const int rr = 4 * st + g;
-      const float ga = gt[rr * GPW + 16 * w + lq];
-      const float xb = xt[rr * GPW + 16 * w + lq];
-      db2 += ga;
+    // (contraction over the 64 rows of the pass: k-step s of group q is row 16 q + 4 s + g)
+#pragma unroll 2
+    for (int q = 0; q < 4; ++q) {
+      const int rr = 16 * q + g;
+      const Op ga = L::gather(gt + rr * GPW + 16 * w + lq, 4 * GPW);
+      const Op xb = L::gather(xt + rr * GPW + 16 * w + lq, 4 * GPW);
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
-        const float hb = hs[rr * HP + 16 * ct + lq];
-        const float da = dhs[rr * HP + 16 * ct + lq];
-        db1[ct] += da;
-        aW2[ct] = mfma16(ga, hb, aW2[ct]);
-        aW1[ct] = mfma16(da, xb, aW1[ct]);
+        const Op hb = L::gather(hs + rr * HP + 16 * ct + lq, 4 * HP);
+        const Op da = L::gather(dhs + rr * HP + 16 * ct + lq, 4 * HP);
+        aW2[ct] = L::mma(ga, hb, aW2[ct]);
+        aW1[ct] = L::mma(da, xb, aW1[ct]);
       }
     }
   }
@@ -359,21 +420,36 @@ __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, Ffn
       pW2[(int64_t)(16 * w + 4 * g + r) * FF + c0 + 16 * ct + lq] = aW2[ct][r];
       pW1[(int64_t)(c0 + 16 * ct + 4 * g + r) * D + 16 * w + lq] = aW1[ct][r];
     }
-  db2 += shfl_xor(db2, 16);
-  db2 += shfl_xor(db2, 32);
-  if (g == 0 && si == 0) pb2[16 * w + lq] = db2;
+  // db2 | db1: the per-thread fp32 column sums meet in LDS (the tiles are no longer needed), fixed order
+  __syncthreads();
+  float* red2 = after;                        // [256][VEC]: thread tid holds columns VEC (tid % RV) ..
+  float* red1 = after + kRowThreads * VEC;    // [4 waves][2 tiles][16]
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-    float s = db1[ct];
-    s += shfl_xor(s, 16);
-    s += shfl_xor(s, 32);
-    if (g == 0 && w == 0) pb1[c0 + 16 * ct + lq] = s;
+  for (int e = 0; e < VEC; ++e) red2[tid * VEC + e] = cs2[e];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float sv = row16_sum(cs1[t][r]);
+      if (lq == 0) red1[(w * 2 + t) * 16 + 4 * g + r] = sv;
+    }
+  __syncthreads();
+  if (si == 0 && tid < D) {
+    const int c4 = tid / VEC, e = tid % VEC;
+    float sv = 0.0f;
+    for (int k = 0; k < kRowThreads / RV; ++k) sv += red2[(c4 + RV * k) * VEC + e];
+    pb2[tid] = sv;
+  }
+  if (tid < kFbSlice) {
+    const int t = tid >> 4, cc = tid & 15;
+    pb1[c0 + tid] = (red1[(0 * 2 + t) * 16 + cc] + red1[(1 * 2 + t) * 16 + cc]) +
+                    (red1[(2 * 2 + t) * 16 + cc] + red1[(3 * 2 + t) * 16 + cc]);
   }
 }
 
 extern int row_chunks(int M);   // rowwise.hip
 
-template <int FF>
+template <class T, int FF>
 int launch_ffn_bwd(const FfnGradArgs& a, const CoeffBwdRole& cb, hipStream_t stream) {
   FfnBwdGeom ge{};
   ge.XB = ffn_bwd_xblocks(a.M);
@@ -381,13 +457,10 @@ int launch_ffn_bwd(const FfnGradArgs& a, const CoeffBwdRole& cb, hipStream_t str
   const int nrb16 = (a.M + 15) / 16;
   ge.per = (nrb16 + ge.RC - 1) / ge.RC;
   ge.NS = FF / kFbSlice;
-  const size_t x_lds = kFbRows * (kFbD + 4) + kFbRows * (FF + 4);
-  const size_t w_lds = 2 * 64 * (kFbD + 16) + 2 * 64 * (kFbSlice + 16);
-  size_t floats = (x_lds > w_lds ? x_lds : w_lds) + (a.g_y ? 5 * kFbD + reduce_scratch_floats(kFbD) : 0);
+  size_t lds = ffn_bwd_lds_bytes<T>(FF, a.g_y != nullptr);
   const int role = cb.cj != nullptr ? ((cb.C + kCoeffThreads - 1) / kCoeffThreads) * cb.G : 0;
-  if (role > 0 && (size_t)(kCoeffPass * cb.N) > floats) floats = kCoeffPass * cb.N;
-  const size_t lds = sizeof(float) * floats;
-  auto kern = ffn_bwd_kernel<FF>;
+  if (role > 0 && sizeof(float) * (size_t)(kCoeffPass * cb.N) > lds) lds = sizeof(float) * (size_t)(kCoeffPass * cb.N);
+  auto kern = ffn_bwd_kernel<T, FF>;
   static LdsSeen seen;
   allow_dynamic_lds(kern, lds, seen);
   // XCD-aware order: every 32-row block has its own X-role workgroup and a chunk is exactly two of them
@@ -427,6 +500,11 @@ extern "C" int feta_ffn_bwd_coeff(const feta_ffn_grad* d, const feta_coeff_bwd_r
   FETA_REQUIRE(!a.sum_out || a.x_bn, "ffn_bwd: sum_out needs x_bn (the BatchNorm that produced x)");
   FETA_REQUIRE(aligned16(a.dy_b) && aligned16(a.dy) && aligned16(a.h) && aligned16(a.x) && aligned16(a.dx) && aligned16(a.g_y) &&
                aligned16(a.x_bn) && aligned16(a.g_sum), "ffn_bwd: pointers must be 16-byte aligned");
-  if (a.FF == 64) return launch_ffn_bwd<64>(a, cb, (hipStream_t)stream);
-  return launch_ffn_bwd<128>(a, cb, (hipStream_t)stream);
+  FETA_REQUIRE(a.dtype == FETA_F32 || a.dtype == FETA_BF16, "ffn_bwd: dtype %d", a.dtype);
+  if (a.dtype == FETA_BF16) {
+    if (a.FF == 64) return launch_ffn_bwd<bf16_t, 64>(a, cb, (hipStream_t)stream);
+    return launch_ffn_bwd<bf16_t, 128>(a, cb, (hipStream_t)stream);
+  }
+  if (a.FF == 64) return launch_ffn_bwd<float, 64>(a, cb, (hipStream_t)stream);
+  return launch_ffn_bwd<float, 128>(a, cb, (hipStream_t)stream);
 }

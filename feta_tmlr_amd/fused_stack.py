@@ -56,6 +56,22 @@ def layer_params(layer):
 USE_LN_STACK = os.environ.get('FETA_LN_STACK', '1') != '0'   # 0: LayerNorm layers run op by op (A/B timing)
 
 
+def lowp_stack_supported(abi, layers, n, b, d_model):
+    """bf16 storage (layers.set_storage_dtype): the stack runs iff every launch of it is one of the four fused kernels
+    (csrc/block.hip, ffn.hip, ffn_bwd.hip, block_bwd.hip - the only ones instantiated for bf16 tiles); BatchNorm stacks."""
+    if not (USE_ATTN_BLOCK and USE_FFN_FUSED and USE_FFN_BWD and USE_ATTN_BLOCK_BWD):
+        return False
+    l0 = layers[0]
+    heads = l0.self_attn.num_heads
+    if not l0.batch_norm or l0.self_attn.tie_qk:
+        return False
+    if not (abi.attn_block_supported(n, d_model, heads) and abi.attn_block_bwd_supported(n, d_model, heads)
+            and abi.attn_block_bwd_blocks(b) > 0):
+        return False
+    return all(abi.ffn_supported(d_model, l.linear1.out_features) and abi.ffn_bwd_supported(d_model, l.linear1.out_features)
+               for l in layers)
+
+
 def stack_supported(layers, d_model):
     """BatchNorm stack (training mode: batch statistics) or LayerNorm stack (any mode), no dropout."""
     from .functional import ROWLIN_DIMS, layer_norm_rows_supported
@@ -153,22 +169,38 @@ class FusedEncoderStackFn(torch.autograd.Function):
         scale = float(dh) ** -0.5
         dev = src.device
         new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        # bf16 storage (layers.set_storage_dtype; BASELINE configs 3 / 5): src and pe arrive as bf16, every token tensor
+        # of the stack is bf16 (qkv, out, y1, h, y2 and the gradients in backward), the kernels run their bf16
+        # instantiations (include/feta_hip.h: dtype = FETA_BF16).  Statistics, parameter blocks, attn, every parameter
+        # gradient: fp32.  What LEAVES the stack is fp32 again - the last layer writes its y2 as fp32 (feta_ffn.y_f32) and
+        # its per-head outputs once more as fp32 (feta_attn_block.out_f32) - so the filter stage behind it (coefficient
+        # generator, spectral filter, linear_cat with the folded BatchNorm) runs unchanged and there is no cast launch.
+        dt = src.dtype
+        lowp = dt != torch.float32
+        newt = lambda *s: torch.empty(s, dtype=dt, device=dev)
+        if lowp and (pe is not None and pe.dtype != dt):
+            raise TypeError('bf16 stack: pe must be %s as well' % dt)
         G = abi.rowlin_blocks(m)
         x_in = src.contiguous().view(m, d)
         pe_c = None if pe is None else pe.contiguous()
         block = USE_ATTN_BLOCK and abi.attn_block_supported(n, d, heads)
+        if lowp and not lowp_stack_supported(abi, layers, n, b, d):
+            raise NotImplementedError('bf16 storage: the fused stack needs d_model = 64, 4 heads, N <= 64, BatchNorm')
         saved = []
         y_prev, st_prev, prm_prev = x_in, None, None
         attn = None
+        out32 = None
         for li, layer in enumerate(layers):
             (w_in, b_in, w_o, b_o, g1, be1, w1, bb1, w2, bb2, g2, be2) = params[li * PER_LAYER:(li + 1) * PER_LAYER]
             ff = w1.shape[0]
             want = need_attn and li == nl - 1
             attn = new(b, heads, n, n) if want else None
             ast = new(b, heads, n, 2)
-            qkv = new(m, 3 * d)
-            out = torch.empty((n, b, heads, dh), dtype=torch.float32, device=dev)
-            y1 = new(m, d)
+            qkv = newt(m, 3 * d)
+            out = torch.empty((n, b, heads, dh), dtype=dt, device=dev)
+            if lowp and li == nl - 1:
+                out32 = new(n, b, heads, dh)
+            y1 = newt(m, d)
             bn_prev = {}
             if li > 0:
                 pl = layers[li - 1].norm2
@@ -185,6 +217,7 @@ class FusedEncoderStackFn(torch.autograd.Function):
                 abi.attn_block_fwd(b, n, scale, stream, tie_qk=tie, x=y_prev, w_in=w_in, b_in=b_in, w_out=w_o,
                                    b_out=b_o, pe=pe_c, n_real=n_real, rowscale=degree_rows, qkv=qkv, out=out,
                                    attn_stats=ast, attn=attn, y=y1, y_stats=st1,
+                                   out_f32=(out32 if li == nl - 1 else None),
                                    sums=(pending.take_fwd() if (pending is not None and li == 0) else ()), **bn_prev)
                 st1, G1 = _cap_partials(abi, stream, st1, new)
             else:
@@ -202,11 +235,11 @@ class FusedEncoderStackFn(torch.autograd.Function):
                 dsc = abi.rowlin_ex(m, d, d, x=out.view(m, d), w=w_o, bias=b_o, rowscale=degree_rows,
                                     residual=y_prev, res_bn=prm_prev, y=y1, stats=st1)
                 abi.rowlin_fwd_ex(dsc, stream)
-            h, prm1 = new(m, ff), new(4, d)
+            h, prm1 = newt(m, ff), new(4, d)
             n1 = layer.norm1
             bn1 = dict(x_stats=st1, Gx=G1, x_gamma=g1, x_beta=be1, x_bn_out=prm1, x_rmean=n1.running_mean,
                        x_rvar=n1.running_var, x_nbt=n1.num_batches_tracked, momentum=float(n1.momentum), eps=float(n1.eps))
-            y2 = new(m, d)
+            y2 = new(m, d) if li == nl - 1 else newt(m, d)    # (the stack's output is fp32 whatever the storage type)
             if USE_FFN_FUSED and abi.ffn_supported(d, ff):
                 # F4 + F5 in one launch: the hidden activations stay in registers (csrc/ffn.hip)
                 G2 = abi.ffn_blocks(m)
@@ -249,7 +282,7 @@ class FusedEncoderStackFn(torch.autograd.Function):
         ctx.owner = layers[0] if len(layers) else None
         if attn is not None:
             ctx.mark_non_differentiable(attn)
-        concat_last = saved[-1]['out'].view(n, b, d)
+        concat_last = (out32 if lowp else saved[-1]['out']).view(n, b, d)
         return final.view(n, b, d), concat_last, attn
 
     @staticmethod
@@ -260,7 +293,9 @@ class FusedEncoderStackFn(torch.autograd.Function):
         abi, stream = _lib.backend(saved[0]['qkv'])
         m = n * b
         dev = saved[0]['qkv'].device
+        dt = saved[0]['qkv'].dtype      # storage type of the stack's token tensors (forward)
         new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        newt = lambda *s: torch.empty(s, dtype=dt, device=dev)
         grads = [None] * len(params)
         ff0 = params[6].shape[0]
         fused_attn = (USE_ATTN_BLOCK_BWD and not tie and abi.attn_block_bwd_supported(n, d, heads)
@@ -279,6 +314,8 @@ class FusedEncoderStackFn(torch.autograd.Function):
         slots = {}
         if d_final is None:   # only the per-head output of the last layer was used
             d_final = torch.zeros(n, b, d, dtype=torch.float32, device=dev)
+        if dt != torch.float32 and d_final.dtype != torch.float32:
+            d_final = d_final.float()      # (the stack's output is fp32: so is its gradient)
         dcur, dcur_b = d_final.contiguous().view(m, d), None
         if ctx.tail is not None:
             # (StackTail contract) d_final is the gradient w.r.t. BN2(y2); its partial sums came with it
@@ -300,7 +337,7 @@ class FusedEncoderStackFn(torch.autograd.Function):
             slots[base + 8] = (off, d, ff)
             pp1, off1 = wslot('f', ff, d)
             slots[base + 6] = (off1, ff, d)
-            dx1 = new(m, d)
+            dx1 = newt(m, d)
             if USE_FFN_BWD and abi.ffn_bwd_supported(d, ff):
                 # B1 + B2 in one launch (csrc/ffn_bwd.hip): the hidden gradient never leaves the chip
                 G1s = abi.ffn_bwd_blocks(m)
@@ -334,11 +371,11 @@ class FusedEncoderStackFn(torch.autograd.Function):
             d2 = d_concat_last if (li == nl - 1 and d_concat_last is not None) else None
             if fused_attn:
                 # B3 + B4 + B5 in one launch, one workgroup per graph (csrc/block_bwd.hip): dconcat and dqkv stay on chip
-                dx0 = new(m, d)
+                dx0 = newt(m, d)
                 # the layer below takes the gradient in two parts iff its FFN backward is the fused kernel
                 split = (USE_ATTN_BLOCK_SPLIT and li > 0 and USE_FFN_BWD
                          and abi.ffn_bwd_supported(d, params[(li - 1) * PER_LAYER + 6].shape[0]))
-                dx0b = new(m, d) if split else None
+                dx0b = newt(m, d) if split else None
                 GB = abi.attn_block_bwd_blocks(b)
                 gs_prev = new(2 * GB, 2, d) if li > 0 else None
                 abi.attn_block_bwd(b, n, scale, stream, Gs=G1s, partial_ptr=ppo, partial_ld=ta, dy=dx1, y1=s['y1'],

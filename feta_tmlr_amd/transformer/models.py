@@ -229,8 +229,16 @@ class DiffTransformerEncoderGenGCN(nn.Module):
                 raise NotImplementedError("the bf16 storage path runs filter_mode='spectral' with matrix coefficients")
             output = output.to(self.storage_dtype)
             pe = None if pe is None else pe.to(self.storage_dtype)    # once for all layers
-        fused = (not lowp and self.fused_stack and self.last_layer_filter and mask is None
+        fused = (self.fused_stack and self.last_layer_filter and mask is None
                  and stack_supported(self.layers, src.shape[-1]))
+        if lowp and fused:
+            # bf16 storage: the stack runs the bf16 instantiations of the four fused kernels where the shape has them
+            # (fused_stack.lowp_stack_supported) and hands fp32 tensors to the filter stage, which is the fp32 path
+            # below, unchanged; other shapes take the op-by-op bf16 path (general bf16 kernels + library bf16 GEMMs)
+            from .. import _lib
+            from ..fused_stack import lowp_stack_supported
+            fused = lowp_stack_supported(_lib.backend(output)[0], self.layers, n, src.shape[1], src.shape[-1])
+        lowp = lowp and not fused      # from here on: the op-by-op bf16 path
         # BatchNorm stack whose only consumer is linear_cat: the last BatchNorm is applied inside linear_cat's kernels
         tail = None
         if (fused and self.layers[0].batch_norm and self.use_skip_conn and self.norm is None

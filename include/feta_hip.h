@@ -395,6 +395,8 @@ typedef struct feta_attn_block {
   int64_t row_sb, row_sn;
   int tie_qk;
   int dtype;           /* FETA_F32 | FETA_BF16: storage type of x, pe, qkv, out, y [T] (ABI 7) */
+  float* out_f32;      /* nullable: `out` once more, as fp32 [M,64] - the fp32 filter stage behind a bf16 stack reads it
+                          (out_each_head of the last layer, transformer/models.py:179) without a cast launch */
 } feta_attn_block;
 
 int feta_attn_block_supported(int N, int d_model, int heads);
@@ -449,6 +451,7 @@ typedef struct feta_attn_block_grad {
   int B, N, M;
   int64_t row_sb, row_sn;
   int dtype;         /* FETA_F32 | FETA_BF16: storage type of dy, y1, qkv, out, dout2, pe, x0, dx, dx_b [T] (ABI 7) */
+  int dout2_f32;     /* 1: dout2 is fp32 whatever dtype says (it comes from the fp32 filter stage) */
 } feta_attn_block_grad;
 
 int feta_attn_block_bwd_supported(int N, int d_model, int heads);
@@ -481,6 +484,8 @@ typedef struct feta_ffn {
   float* y_stats;   /* or NULL */
   int M, FF;
   int dtype;        /* FETA_F32 | FETA_BF16: storage type of x, h, y [T] (ABI 7) */
+  int y_f32;        /* 1: y is written as fp32 whatever dtype says (last layer of a bf16 stack: its consumer, linear_cat
+                       with the folded BatchNorm, transformer/models.py:223-224, is an fp32 kernel) */
 } feta_ffn;
 
 int feta_ffn_supported(int d_model, int ff);
@@ -530,6 +535,7 @@ typedef struct feta_ffn_grad {
   int partial_ld;
   int M, FF;
   int dtype;         /* FETA_F32 | FETA_BF16: storage type of dy, dy_b, g_y, h, x, dx [T] (ABI 7) */
+  int g_f32;         /* 1: dy and g_y are fp32 whatever dtype says (last layer of a bf16 stack, see feta_ffn.y_f32) */
 } feta_ffn_grad;
 
 int feta_ffn_bwd_supported(int d_model, int ff);

@@ -702,3 +702,174 @@ def check_attn_block_lp(abi, dev, stream, bsz=5, n_pad=21, n_min=3, seed=0, with
     assert_close('lp y_stats sum', st[:, 0].sum(0), yf.sum(0), tol=BF16_TOL)
     assert_close('lp y_stats sumsq', st[:, 1].sum(0), (yf * yf).sum(0), tol=BF16_TOL)
     return dict(qkv=qkv, out=out, y=y, ast=ast, attn=attn)
+
+
+def check_ffn_lp(abi, dev, stream, m=75, ff=128, seed=0, with_bn=True):
+    """feta_ffn_fwd with dtype = FETA_BF16: x = y1 seen through a BatchNorm parameter block, h = relu(x W1^T + b1),
+    y = x + h W2^T + b2 against fp64 on bf16-representable y1 (the kernel rounds the weights when it stages them,
+    the hidden activations when they are stored and handed to the second product)."""
+    g = torch.Generator().manual_seed(seed)
+    d = 64
+    y1 = round_to(torch.randn(m, d, generator=g).double(), BF16)
+    w1, b1 = torch.randn(ff, d, generator=g) / 8, torch.randn(ff, generator=g) * 0.1
+    w2, b2 = torch.randn(d, ff, generator=g) / 8, torch.randn(d, generator=g) * 0.1
+    prm = torch.zeros(4, d)
+    prm[0] = torch.rand(d, generator=g) + 0.5
+    prm[1] = torch.randn(d, generator=g) * 0.2
+    h = torch.full((m, ff), float('nan'), dtype=BF16, device=dev)
+    y = torch.full((m, d), float('nan'), dtype=BF16, device=dev)
+    st = torch.full((abi.ffn_blocks(m), 2, d), float('nan'), device=dev)
+    abi.ffn_fwd(m, ff, stream, x=y1.to(BF16).to(dev), x_bn=prm.to(dev) if with_bn else None, w1=w1.to(dev), b1=b1.to(dev),
+                w2=w2.to(dev), b2=b2.to(dev), h=h, y=y, y_stats=st)
+    x = y1 * prm[0].double() + prm[1].double() if with_bn else y1
+    h_ref = torch.relu(x @ w1.double().t() + b1.double())
+    y_ref = x + h_ref @ w2.double().t() + b2.double()
+    assert_close('lp h', h, h_ref, tol=BF16_TOL)
+    assert_close('lp y2', y, y_ref, tol=BF16_TOL)
+    yf = y.float().cpu().double()
+    assert_close('lp y2 stats sum', st[:, 0].sum(0), yf.sum(0), tol=BF16_TOL)
+    assert_close('lp y2 stats sumsq', st[:, 1].sum(0), (yf * yf).sum(0), tol=BF16_TOL)
+
+
+def check_ffn_bwd_lp(abi, dev, stream, m=150, ff=128, seed=0, with_bn=True):
+    """feta_ffn_bwd with dtype = FETA_BF16 (LayerNorm form: dy is the gradient w.r.t. y2; with_bn: BatchNorm form, the
+    backward of BN2 folded into the gradient loads) against fp64 autograd of y2 = x + linear2(relu(linear1(x))),
+    x = BN1-affine(y1), on bf16-representable saved tensors."""
+    g = torch.Generator().manual_seed(seed)
+    d = 64
+    y1 = round_to(torch.randn(m, d, generator=g).double(), BF16)
+    w1, b1 = (torch.randn(ff, d, generator=g) / 8).double(), (torch.randn(ff, generator=g) * 0.1).double()
+    w2, b2 = (torch.randn(d, ff, generator=g) / 8).double(), (torch.randn(d, generator=g) * 0.1).double()
+    prm1 = torch.zeros(4, d, dtype=torch.float64)
+    prm1[0] = torch.rand(d, generator=g) + 0.5          # scale, shift of BN1 as the forward published them
+    prm1[1] = torch.randn(d, generator=g) * 0.2
+    prm1[2] = torch.randn(d, generator=g) * 0.1         # mean, rstd (for the partial sums of BN1's backward)
+    prm1[3] = torch.rand(d, generator=g) + 0.5
+    dy = round_to(torch.randn(m, d, generator=g).double(), BF16)
+    x = (y1 * prm1[0] + prm1[1]).requires_grad_(True)
+    w1r, w2r = w1.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+    b1r, b2r = b1.clone().requires_grad_(True), b2.clone().requires_grad_(True)
+    h_ref = torch.relu(x @ w1r.t() + b1r)
+    y2 = x + h_ref @ w2r.t() + b2r
+    if with_bn:
+        gamma2 = (torch.rand(d, generator=g) + 0.5).double().requires_grad_(True)
+        beta2 = torch.zeros(d, dtype=torch.float64, requires_grad=True)
+        out = torch.nn.functional.batch_norm(y2, None, None, gamma2, beta2, True, 0.1, 1e-5)
+        out.backward(dy)
+        mean2, var2 = y2.detach().mean(0), y2.detach().var(0, unbiased=False)
+        rstd2 = (var2 + 1e-5).rsqrt()
+        prm2 = torch.stack([gamma2.detach() * rstd2, -mean2 * gamma2.detach() * rstd2, mean2, rstd2])
+        y2s = round_to(y2.detach(), BF16)      # what the forward stored
+        xh = (y2s - mean2) * rstd2
+        gsum = torch.stack([dy.sum(0), (dy * xh).sum(0)]).unsqueeze(0)   # one partial row
+    else:
+        y2.backward(dy)
+    hs = round_to(h_ref.detach(), BF16)
+    f32 = lambda t: t.float().to(dev).contiguous()
+    b16 = lambda t: t.to(BF16).to(dev).contiguous()
+    rc = abi.rowlin_chunks(m)
+    ld = 2 * d * ff + d + ff
+    partial = torch.full((rc, ld), float('nan'), device=dev)
+    dx = torch.full((m, d), float('nan'), dtype=BF16, device=dev)
+    so = torch.full((abi.ffn_bwd_blocks(m), 2, d), float('nan'), device=dev)
+    kw = {}
+    if with_bn:
+        kw = dict(g_y=b16(y2s), g_bn=f32(prm2), g_sum=f32(gsum), Gs=1, g_fin_out=torch.empty(2, d, device=dev),
+                  dgamma=torch.empty(d, device=dev), dbeta=torch.empty(d, device=dev))
+    abi.ffn_bwd(m, ff, stream, partial=partial, dy=b16(dy), h=b16(hs), w2=f32(w2), w1=f32(w1), x=b16(y1), x_bn=f32(prm1),
+                dx=dx, sum_out=so, **kw)
+    dwdb = partial.double().sum(0).cpu()
+    gx = x.grad                                 # gradient w.r.t. x (the kernel's dx: BN1's backward is the consumer's)
+    assert_close('lp ffn dx', dx, gx, tol=BF16_TOL)
+    assert_close('lp ffn dW2', dwdb[:d * ff].view(d, ff), w2r.grad, tol=BF16_TOL)
+    assert_close('lp ffn db2', dwdb[d * ff:d * ff + d], b2r.grad, tol=BF16_TOL)
+    assert_close('lp ffn dW1', dwdb[d * ff + d:d * ff + d + ff * d].view(ff, d), w1r.grad, tol=BF16_TOL)
+    assert_close('lp ffn db1', dwdb[d * ff + d + ff * d:], b1r.grad, tol=BF16_TOL)
+    xh1 = (y1 - prm1[2]) * prm1[3]
+    assert_close('lp ffn sum dx', so[:, 0].sum(0), gx.sum(0), tol=BF16_TOL)
+    assert_close('lp ffn sum dx xhat', so[:, 1].sum(0), (gx * xh1).sum(0), tol=BF16_TOL)
+    if with_bn:
+        assert_close('lp ffn dgamma2', kw['dgamma'], gamma2.grad, tol=BF16_TOL)
+        assert_close('lp ffn dbeta2', kw['dbeta'], beta2.grad, tol=BF16_TOL)
+
+
+def check_attn_block_bwd_lp(abi, dev, stream, bsz=5, n_pad=21, n_min=3, seed=0, with_pe=True, split=False, with_bn=False):
+    """feta_attn_block_bwd with dtype = FETA_BF16 on the tensors its own forward (feta_attn_block_fwd, bf16) saved,
+    against fp64 autograd of y1 = x + degree * out_proj(attention(in_proj(x))), x = x0 seen through a BatchNorm block:
+    dx, both weight / bias gradients (per-graph partial rows summed), the partial sums for the previous BatchNorm;
+    with_bn: the incoming gradient is the one w.r.t. BatchNorm-1(y1) and its backward is folded into the loads."""
+    d, heads, n_real, mask, x0, pe, degree, p = _lp_case(bsz, n_pad, n_min, seed, dev, with_pe)
+    g = torch.Generator().manual_seed(seed + 100)
+    m = n_pad * bsz
+    f32 = lambda t: t.float().to(dev).contiguous()
+    b16 = lambda t: t.to(BF16).to(dev).contiguous()
+    bn0 = torch.zeros(4, d, dtype=torch.float64)
+    bn0[0] = torch.rand(d, generator=g) + 0.5
+    bn0[1] = torch.randn(d, generator=g) * 0.2
+    bn0[2] = torch.randn(d, generator=g) * 0.1
+    bn0[3] = torch.rand(d, generator=g) + 0.5
+    new = lambda *s: torch.full(s, float('nan'), dtype=BF16, device=dev)
+    qkv, out, y = new(m, 3 * d), new(m, d), new(m, d)
+    ast = torch.full((bsz, heads, n_pad, 2), float('nan'), device=dev)
+    st = torch.empty((bsz, 2, d), device=dev)
+    rows = degree.t().reshape(m)
+    scale = float(d // heads) ** -0.5
+    pe_d = None if pe is None else b16(pe)
+    abi.attn_block_fwd(bsz, n_pad, scale, stream, x=b16(x0).view(m, d), x_bn=f32(bn0), w_in=f32(p['w_in']),
+                       b_in=f32(p['b_in']), w_out=f32(p['w_out']), b_out=f32(p['b_out']), pe=pe_d, n_real=n_real.to(dev),
+                       rowscale=f32(rows), qkv=qkv, out=out, attn_stats=ast, attn=None, y=y, y_stats=st)
+    # fp64 reference
+    w = {k: v.float().double().requires_grad_(True) for k, v in p.items()}
+    x = (x0 * bn0[0] + bn0[1]).requires_grad_(True)
+    qkv_ref = torch.nn.functional.linear(x, w['w_in'], w['b_in'])
+    concat, _, _ = O.attention_core(qkv_ref, pe, mask, heads, detach_max=True)
+    y1 = x + degree.t().unsqueeze(-1) * torch.nn.functional.linear(concat, w['w_out'], w['b_out'])
+    dy = round_to(torch.randn(n_pad, bsz, d, generator=g).double(), BF16)
+    dout2 = round_to(torch.randn(n_pad, bsz, d, generator=g).double() * (~mask).t().unsqueeze(-1), BF16)
+    kw = {}
+    if with_bn:
+        gamma1 = (torch.rand(d, generator=g) + 0.5).double().requires_grad_(True)
+        beta1 = torch.zeros(d, dtype=torch.float64, requires_grad=True)
+        o1 = torch.nn.functional.batch_norm(y1.reshape(m, d), None, None, gamma1, beta1, True, 0.1, 1e-5)
+        ((o1 * dy.reshape(m, d)).sum() + (concat * dout2).sum()).backward()
+        y1s = y.float().cpu().double()                       # what the forward stored
+        mean1, var1 = y1.detach().reshape(m, d).mean(0), y1.detach().reshape(m, d).var(0, unbiased=False)
+        rstd1 = (var1 + 1e-5).rsqrt()
+        bn1 = torch.stack([gamma1.detach() * rstd1, -mean1 * gamma1.detach() * rstd1, mean1, rstd1])
+        xh = (y1s - mean1) * rstd1
+        dyf = dy.reshape(m, d)
+        gsum = torch.stack([dyf.sum(0), (dyf * xh).sum(0)]).unsqueeze(0)
+        kw = dict(y1=y, bn1=f32(bn1), g_sum=f32(gsum), Gs=1, fin_out=torch.empty(2, d, device=dev),
+                  dgamma=torch.empty(d, device=dev), dbeta=torch.empty(d, device=dev))
+    else:
+        ((y1 * dy).sum() + (concat * dout2).sum()).backward()
+    gb = abi.attn_block_bwd_blocks(bsz)
+    ld = 4 * d * d + 4 * d
+    partial = torch.full((gb, ld), float('nan'), device=dev)
+    dx = new(m, d)
+    dxb = new(m, d) if split else None
+    so = torch.full((2 * gb, 2, d), float('nan'), device=dev)
+    abi.attn_block_bwd(bsz, n_pad, scale, stream, partial=partial, dy=b16(dy).view(m, d), rowscale=f32(rows),
+                       w_out=f32(p['w_out']), w_in=f32(p['w_in']), qkv=qkv, out=out, dout2=b16(dout2).view(m, d), pe=pe_d,
+                       n_real=n_real.to(dev), attn_stats=ast, x0=b16(x0).view(m, d), bn0=f32(bn0), dx=dx, dx_b=dxb,
+                       sum_out=so, **kw)
+    real = (~mask).t().unsqueeze(-1)
+    got = dx.view(n_pad, bsz, d).float().cpu().double()
+    if split:
+        got = got + dxb.view(n_pad, bsz, d).float().cpu().double()
+    zero = torch.zeros((), dtype=torch.float64)
+    # rows of padded nodes: their dx exists (residual + projections of zero-probability keys) and is compared too
+    rowsN = torch.ones_like(real)
+    assert_close('lp block dx', torch.where(rowsN, got, zero), x.grad, tol=BF16_TOL)
+    pw = partial.double().sum(0).cpu()
+    assert_close('lp block dW_out', pw[:d * d].view(d, d), w['w_out'].grad, tol=BF16_TOL)
+    assert_close('lp block db_out', pw[d * d:d * d + d], w['b_out'].grad, tol=BF16_TOL)
+    assert_close('lp block dW_in', pw[d * d + d:d * d + d + 3 * d * d].view(3 * d, d), w['w_in'].grad, tol=BF16_TOL)
+    assert_close('lp block db_in', pw[d * d + d + 3 * d * d:], w['b_in'].grad, tol=BF16_TOL)
+    xh0 = (x0 - bn0[2]) * bn0[3]
+    gx = x.grad
+    assert_close('lp block sum dx', so[:, 0].sum(0), gx.reshape(m, d).sum(0), tol=BF16_TOL)
+    assert_close('lp block sum dx xhat', so[:, 1].sum(0), (gx * xh0).reshape(m, d).sum(0), tol=BF16_TOL)
+    if with_bn:
+        assert_close('lp block dgamma1', kw['dgamma'], gamma1.grad, tol=BF16_TOL)
+        assert_close('lp block dbeta1', kw['dbeta'], beta1.grad, tol=BF16_TOL)

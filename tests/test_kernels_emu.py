@@ -206,3 +206,26 @@ def test_layernorm_rejects_unsupported_width(emu):
     y = torch.zeros(4, 6)
     with pytest.raises(ValueError):
         emu.layernorm_fwd(y, torch.ones(6), torch.zeros(6), 1e-5, torch.empty_like(y), torch.empty(4, 2), None)
+
+
+# ---- fused layer-stack kernels on bf16 storage (dtype = FETA_BF16: BASELINE configs 3 / 5) --------------------------------
+@pytest.mark.parametrize('kw', [dict(), dict(bsz=3, n_pad=37, n_min=9, with_pe=False),
+                                dict(bsz=2, n_pad=16, n_min=1, need_attn=False), dict(bsz=2, n_pad=64, n_min=40)])
+def test_attn_block_fwd_bf16(emu, kw):
+    KC.check_attn_block_lp(emu, CPU, None, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(), dict(split=True), dict(bsz=3, n_pad=37, n_min=9, with_pe=False, with_bn=True),
+                                dict(bsz=2, n_pad=16, n_min=1, split=True, with_bn=True), dict(bsz=2, n_pad=64, n_min=40)])
+def test_attn_block_bwd_bf16(emu, kw):
+    KC.check_attn_block_bwd_lp(emu, CPU, None, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(), dict(m=33, ff=64, with_bn=False), dict(m=130, ff=256, seed=3)])
+def test_ffn_fwd_bf16(emu, kw):
+    KC.check_ffn_lp(emu, CPU, None, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(), dict(m=70, ff=64, with_bn=False), dict(m=300, ff=128, seed=3)])
+def test_ffn_bwd_bf16(emu, kw):
+    KC.check_ffn_bwd_lp(emu, CPU, None, **kw)

@@ -228,3 +228,33 @@ def test_attn_dropout(hip, bsz, n, h, dh, p, dtype):
     """feta_attn_fwd_drop / feta_attn_bwd_drop: the oracle holds the mask the kernels derive from (seed, offset)"""
     abi, dev, stream = hip
     KC.check_attn(abi, dev, stream, bsz, n, h, dh, True, drop=(p, 1234567891011, 7), dtype=dtype)
+
+
+# ---- fused layer-stack kernels on bf16 storage (dtype = FETA_BF16: BASELINE configs 3 / 5) --------------------------------
+@pytest.mark.parametrize('kw', [dict(), dict(bsz=3, n_pad=37, n_min=9, with_pe=False),
+                                dict(bsz=2, n_pad=16, n_min=1, need_attn=False), dict(bsz=2, n_pad=64, n_min=40),
+                                dict(bsz=128, n_pad=37, n_min=9), dict(bsz=300, n_pad=37, n_min=9, seed=2)])
+def test_attn_block_fwd_bf16(hip, kw):
+    abi, dev, stream = hip
+    KC.check_attn_block_lp(abi, dev, stream, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(), dict(split=True), dict(bsz=3, n_pad=37, n_min=9, with_pe=False, with_bn=True),
+                                dict(bsz=2, n_pad=16, n_min=1, split=True, with_bn=True), dict(bsz=2, n_pad=64, n_min=40),
+                                dict(bsz=128, n_pad=37, n_min=9, split=True, with_bn=True),
+                                dict(bsz=128, n_pad=37, n_min=9, split=False, with_bn=True, seed=4)])
+def test_attn_block_bwd_bf16(hip, kw):
+    abi, dev, stream = hip
+    KC.check_attn_block_bwd_lp(abi, dev, stream, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(), dict(m=33, ff=64, with_bn=False), dict(m=130, ff=256, seed=3), dict(m=4736, ff=128)])
+def test_ffn_fwd_bf16(hip, kw):
+    abi, dev, stream = hip
+    KC.check_ffn_lp(abi, dev, stream, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(), dict(m=70, ff=64, with_bn=False), dict(m=300, ff=128, seed=3), dict(m=4736, ff=128)])
+def test_ffn_bwd_bf16(hip, kw):
+    abi, dev, stream = hip
+    KC.check_ffn_bwd_lp(abi, dev, stream, **kw)
