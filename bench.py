@@ -179,8 +179,14 @@ def make_step(args, enc, gpu, world, dev):
     params = [p for p in enc.parameters()]
     lowp = getattr(enc, 'storage_dtype', torch.float32) != torch.float32
     # the split backward needs the fused stack (fp32, or the bf16 instantiations of its kernels where the shape has them)
-    two_phase = (args.two_phase or world > 1) and (not lowp or bool(getattr(enc, 'fused_stack', False)
-                                                                      and not args.layer_norm))
+    fused_lowp = False
+    if lowp:
+        from feta_tmlr_amd import _lib
+        from feta_tmlr_amd.fused_stack import lowp_stack_supported, stack_supported
+        n_, b_, d_ = gpu['src'].shape
+        fused_lowp = (bool(getattr(enc, 'fused_stack', False)) and stack_supported(enc.layers, d_)
+                      and lowp_stack_supported(_lib.backend(gpu['src'])[0], enc.layers, n_, b_, d_))
+    two_phase = (args.two_phase or world > 1) and (not lowp or fused_lowp)
     fwd_args = (gpu['src'], gpu['pe'], gpu['edge_index'], gpu['fi'], gpu['batch'])
     fwd_kw = dict(degree=gpu['degree'], src_key_padding_mask=gpu['mask'], graph_cache=gpu['cache'])
     use_graph = not args.no_graph and dev.type == 'cuda'

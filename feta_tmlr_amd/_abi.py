@@ -51,6 +51,9 @@ SIGNATURES = {
     'feta_layernorm_blocks': ([C.c_int], C.c_int),
     'feta_layernorm_fwd': ([_F, _F, _F, C.c_float, _F, _F, C.c_int, C.c_int, _S], C.c_int),
     'feta_layernorm_bwd': ([_F, _F, _F, _F, _F, _F, C.c_int, _F, C.c_int, C.c_int, _S], C.c_int),
+    'feta_layernorm_fwd_ex': ([_F, _F, _F, C.c_float, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, _S], C.c_int),
+    'feta_layernorm_bwd_ex': ([_F, _F, _F, _F, _F, _F, C.c_int, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _S],
+                              C.c_int),
     'feta_eigh_sym_supported': ([C.c_int], C.c_int),
     'feta_eigh_sym_workspace_bytes': ([C.c_int, C.c_int], C.c_int64),
     'feta_eigh_sym': ([_F, _I, C.c_float, _F, _F, _I, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _S],
@@ -84,6 +87,9 @@ SIGNATURES['feta_lin_supported'] = ([C.c_int, C.c_int, C.c_int], C.c_int)
 SIGNATURES['feta_lin_fwd'] = ([_F, _F, _F, _F, C.c_int, C.c_int, C.c_int, _S], C.c_int)
 SIGNATURES['feta_lin_bwd'] = ([_F, _F, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.POINTER(ColsumSeg), C.c_int, _S],
                               C.c_int)
+SIGNATURES['feta_lin_fwd_ex'] = ([_F, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, _S], C.c_int)
+SIGNATURES['feta_lin_bwd_ex'] = ([_F, _F, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.POINTER(ColsumSeg), C.c_int, C.c_int,
+                                  _S], C.c_int)
 
 
 class RowLinEx(C.Structure):
@@ -358,16 +364,18 @@ class Abi:
     def lin_supported(self, r, k, n):
         return bool(self.lib.feta_lin_supported(r, k, n))
 
-    def lin_fwd(self, x, w, bias, y, stream):
+    def lin_fwd(self, x, w, bias, y, stream, bf16=False):
+        """bf16: operands rounded to bf16 when staged, bf16 MFMA, fp32 accumulate (feta_lin_fwd_ex)"""
         r, k = x.shape
-        self._check(self.lib.feta_lin_fwd(_p(x), _p(w), _p(bias), _p(y), r, k, w.shape[0], stream), 'feta_lin_fwd')
+        self._check(self.lib.feta_lin_fwd_ex(_p(x), _p(w), _p(bias), _p(y), r, k, w.shape[0], int(bool(bf16)), stream),
+                    'feta_lin_fwd')
 
-    def lin_bwd(self, x, w, dy, dx, dw, db, stream, pairs=()):
-        """dx = dy w, dw = dy^T x, db = colsum(dy) in one launch; pairs: [(in [R, C], out [C])] pending column sums
-        that ride along in trailing workgroups."""
+    def lin_bwd(self, x, w, dy, dx, dw, db, stream, pairs=(), bf16=False):
+        """pairs: [(in [R, C], out [C])] pending column sums that ride in trailing workgroups of the launch"""
         r, k = x.shape
-        self._check(self.lib.feta_lin_bwd(_p(x), _p(w), _p(dy), _p(dx), _p(dw), _p(db), r, k, w.shape[0],
-                                          self._colsum_segs(pairs), len(pairs), stream), 'feta_lin_bwd')
+        self._check(self.lib.feta_lin_bwd_ex(_p(x), _p(w), _p(dy), _p(dx), _p(dw), _p(db), r, k, w.shape[0],
+                                             self._colsum_segs(pairs), len(pairs), int(bool(bf16)), stream),
+                    'feta_lin_bwd')
 
     def colsum(self, x, out, stream):
         r, c = x.shape
@@ -613,18 +621,28 @@ class Abi:
     def layernorm_blocks(self, m):
         return self.lib.feta_layernorm_blocks(m)
 
+    @staticmethod
+    def _dt(t):
+        if t.dtype == torch.float32:
+            return 0
+        if t.dtype == torch.bfloat16:
+            return 1
+        raise TypeError('float32 or bfloat16 rows, got %s' % t.dtype)
+
     def layernorm_fwd(self, y, gamma, beta, eps, out, stats, stream):
+        """y, out: float32 or bfloat16 rows (independently: feta_layernorm_fwd_ex)"""
         m, d = y.shape
-        self._check(self.lib.feta_layernorm_fwd(_p(y), _p(gamma), _p(beta), eps, _p(out), _p(stats), m, d, stream),
-                    'feta_layernorm_fwd')
+        self._check(self.lib.feta_layernorm_fwd_ex(_p(y), _p(gamma), _p(beta), eps, _p(out), _p(stats), m, d,
+                                                   self._dt(y), self._dt(out), stream), 'feta_layernorm_fwd')
 
     def layernorm_bwd(self, dout, y, stats, gamma, dy, partial, dgdb, stream, partial_ld=0, partial_ptr=None):
         """partial_ptr / partial_ld: this LayerNorm's columns inside a shared [blocks, total] partial buffer
-        (dgdb None: the caller reduces it)."""
+        (dgdb None: the caller reduces it).  dout, y, dy: float32 or bfloat16 rows, independently."""
         m, d = y.shape
         pp = _p(partial) if partial_ptr is None else C.c_void_p(partial_ptr)
-        self._check(self.lib.feta_layernorm_bwd(_p(dout), _p(y), _p(stats), _p(gamma), _p(dy), pp, partial_ld,
-                                                _p(dgdb), m, d, stream), 'feta_layernorm_bwd')
+        self._check(self.lib.feta_layernorm_bwd_ex(_p(dout), _p(y), _p(stats), _p(gamma), _p(dy), pp, partial_ld,
+                                                   _p(dgdb), m, d, self._dt(dout), self._dt(y), self._dt(dy), stream),
+                    'feta_layernorm_bwd')
 
     def eigh_sym_supported(self, n):
         return bool(self.lib.feta_eigh_sym_supported(n))

@@ -7,13 +7,20 @@ Every entry: (name, launches per layer, fn, algorithmic bytes per launch, kernel
 import torch
 
 
-def stack_layer_cases(abi, st, dev, b, n, d, heads, ff, pe, n_real, last_layer_attn=True, seed=0):
+def stack_layer_cases(abi, st, dev, b, n, d, heads, ff, pe, n_real, last_layer_attn=True, seed=0, dtype=torch.float32):
+    """dtype: storage type of the token tensors (torch.bfloat16: the bf16 instantiations of the four fused kernels;
+    the row-wise cases stay fp32 - they have no bf16 form); byte counts: ft bytes per token element, 4 per other"""
     m = b * n
     dh = d // heads
     g = torch.Generator().manual_seed(seed)
     rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
     new = lambda *s: torch.empty(*s, device=dev)
+    rndt = lambda *s: torch.randn(*s, generator=g).to(dev).to(dtype)
+    newt = lambda *s: torch.empty(*s, device=dev, dtype=dtype)
     f4 = 4
+    ft = 2 if dtype == torch.bfloat16 else 4
+    if pe is not None:
+        pe = pe.to(dtype)
     G = abi.rowlin_blocks(m)
     RC = abi.rowlin_chunks(m)
     cases = []
@@ -23,42 +30,44 @@ def stack_layer_cases(abi, st, dev, b, n, d, heads, ff, pe, n_real, last_layer_a
         return prm[:, :c].contiguous()
 
     if abi.attn_block_supported(n, d, heads):
-        x, w_in, b_in = rnd(m, d), rnd(3 * d, d) / d ** 0.5, rnd(3 * d)
+        x, w_in, b_in = rndt(m, d), rnd(3 * d, d) / d ** 0.5, rnd(3 * d)
         w_o, b_o, deg = rnd(d, d) / d ** 0.5, rnd(d), torch.rand(m, generator=g).to(dev)
-        qkv, out, y1, st1 = new(m, 3 * d), new(m, d), new(m, d), new(b, 2, d)
+        qkv, out, y1, st1 = newt(m, 3 * d), newt(m, d), newt(m, d), new(b, 2, d)
         ast, attn = new(b, heads, n, 2), new(b, heads, n, n)
         stats_prev = rnd(G, 2, d).abs()
         common = dict(x=x, w_in=w_in, b_in=b_in, w_out=w_o, b_out=b_o, pe=pe, n_real=n_real, rowscale=deg,
                       qkv=qkv, out=out, attn_stats=ast, y=y1, y_stats=st1, x_stats=stats_prev, Gx=G,
                       x_gamma=prm_of(d)[0], x_beta=prm_of(d)[1], x_bn_out=new(4, d))
-        base = b * (n * d + (n * n if pe is not None else 0) + 3 * n * d + n * d + 2 * heads * n + n * d) + 4 * d * d
+        base_t = b * (n * d + (n * n if pe is not None else 0) + 3 * n * d + n * d + n * d)   # token elements
+        base_o = b * 2 * heads * n + 4 * d * d                                                    # fp32 elements
         scale = dh ** -0.5
         # descriptors are built once: the eager timing loop must not be bound by Python
         d0 = abi.attn_block_desc(b, n, scale, attn=None, **common)
         d1 = abi.attn_block_desc(b, n, scale, attn=attn, **common)
         cases.append(('attn_block_fwd (no attn write)', 1.0,
-                      lambda: (abi.attn_block_launch(d0, st), common)[0], f4 * base, ['attn_block_fwd']))
+                      lambda: (abi.attn_block_launch(d0, st), common)[0], ft * base_t + f4 * base_o,
+                      ['attn_block_fwd']))
         if last_layer_attn:
             cases.append(('attn_block_fwd (+attn write)', 0.0,
                           lambda: (abi.attn_block_launch(d1, st), common)[0],
-                          f4 * (base + b * heads * n * n), ['attn_block_fwd']))
+                          ft * base_t + f4 * (base_o + b * heads * n * n), ['attn_block_fwd']))
     if abi.ffn_supported(d, ff):
-        x, w1, b1, w2, b2 = rnd(m, d), rnd(ff, d) / d ** 0.5, rnd(ff), rnd(d, ff) / ff ** 0.5, rnd(d)
-        hbuf, y2, st2 = new(m, ff), new(m, d), new(abi.ffn_blocks(m), 2, d)
+        x, w1, b1, w2, b2 = rndt(m, d), rnd(ff, d) / d ** 0.5, rnd(ff), rnd(d, ff) / ff ** 0.5, rnd(d)
+        hbuf, y2, st2 = newt(m, ff), newt(m, d), new(abi.ffn_blocks(m), 2, d)
         g1 = min(b, 256)      # the stack caps the partial rows a consumer re-reduces (fused_stack.MAX_STAT_ROWS)
         stats1 = rnd(g1, 2, d).abs()
         fkw = dict(x=x, w1=w1, b1=b1, w2=w2, b2=b2, h=hbuf, y=y2, y_stats=st2, x_stats=stats1,
                    x_gamma=prm_of(d)[0], x_beta=prm_of(d)[1], x_bn_out=new(4, d))
         fd = abi.ffn_desc(m, ff, Gx=g1, **fkw)
         cases.append(('ffn_fwd', 1.0, lambda: (abi.ffn_launch(fd, st), fkw)[0],
-                      f4 * (m * d + 2 * d * ff + m * ff + m * d), ['ffn_fwd']))
+                      ft * (m * d + m * ff + m * d) + f4 * 2 * d * ff, ['ffn_fwd']))
         # the last layer's launch carries the coefficient generator's forward in trailing workgroups
         # (feta_ffn_fwd_coeff): C = P dh^2 channels at the reference's filter order 4
         cgen = 4 * (d // heads) ** 2
         attn_in = torch.rand(b, heads, n, n, generator=g).to(dev)
         crole = (attn_in, n_real, rnd(cgen), rnd(cgen), new(heads * b, n), new(heads * b, cgen))
         cases.append(('ffn_fwd (+ coefficient generator)', 1.0, lambda: (abi.ffn_launch(fd, st, crole), fkw)[0],
-                      f4 * (m * d + 2 * d * ff + m * ff + m * d + b * (heads * n * n + heads * cgen + heads * n)),
+                      ft * (m * d + m * ff + m * d) + f4 * (2 * d * ff + b * (heads * n * n + heads * cgen + heads * n)),
                       ['ffn_fwd']))
 
     def bwd_case(name, ki, no, extras):
@@ -87,7 +96,7 @@ def stack_layer_cases(abi, st, dev, b, n, d, heads, ff, pe, n_real, last_layer_a
     fused_a = abi.attn_block_bwd_supported(n, d, heads) and abi.attn_block_bwd_blocks(b) > 0
     if fused_f:
         # backward of the FFN half in one launch (csrc/ffn_bwd.hip), BatchNorm stack variant
-        dy, y2, hh, y1, dx = rnd(m, d), rnd(m, d), rnd(m, ff), rnd(m, d), new(m, d)
+        dy, y2, hh, y1, dx = rndt(m, d), rndt(m, d), rndt(m, ff), rndt(m, d), newt(m, d)
         w2, w1 = rnd(d, ff) / ff ** 0.5, rnd(ff, d) / d ** 0.5
         cols = 2 * d * ff + d + ff
         part = new(RC, cols)
@@ -97,50 +106,51 @@ def stack_layer_cases(abi, st, dev, b, n, d, heads, ff, pe, n_real, last_layer_a
         fdsc = abi.ffn_bwd_desc(m, ff, Gs=G, partial_ld=cols, partial_ptr=part.data_ptr(), **kw)
         keep_f = (kw, part)
         cases.append(('ffn_bwd', 1.0, lambda: (abi.ffn_bwd_launch(fdsc, st), keep_f)[0],
-                      f4 * (4 * m * d + m * ff + 2 * d * ff + RC * cols), ['ffn_bwd']))
+                      ft * (4 * m * d + m * ff) + f4 * (2 * d * ff + RC * cols), ['ffn_bwd']))
         # the last layer's launch (the first of the stack's backward) carries the coefficient generator's backward
         # kernel in trailing workgroups (feta_ffn_bwd_coeff)
         cgen = 4 * (d // heads) ** 2
         cgrp = abi.coeff_bwd_groups(b, heads)
         brole = (rnd(heads * b, n), n_real, rnd(cgen), rnd(cgen), rnd(heads * b, cgen), new(cgrp, 2, cgen), b, n, heads)
         cases.append(('ffn_bwd (+ coefficient generator)', 1.0, lambda: (abi.ffn_bwd_launch(fdsc, st, brole), keep_f)[0],
-                      f4 * (4 * m * d + m * ff + 2 * d * ff + RC * cols + b * (heads * cgen + heads * n) + cgrp * 2 * cgen),
+                      ft * (4 * m * d + m * ff) + f4 * (2 * d * ff + RC * cols + b * (heads * cgen + heads * n) + cgrp * 2 * cgen),
                       ['ffn_bwd']))
         if fused_a:
             # ... below a layer whose attention backward ran as two workgroups per graph: the gradient in two parts
-            kw2 = dict(kw, dy_b=rnd(m, d))
+            kw2 = dict(kw, dy_b=rndt(m, d))
             fdsc2 = abi.ffn_bwd_desc(m, ff, Gs=G, partial_ld=cols, partial_ptr=part.data_ptr(), **kw2)
             keep_f2 = (kw2, part)
             cases.append(('ffn_bwd (gradient in two parts)', 1.0, lambda: (abi.ffn_bwd_launch(fdsc2, st), keep_f2)[0],
-                          f4 * (5 * m * d + m * ff + 2 * d * ff + RC * cols), ['ffn_bwd']))
+                          ft * (5 * m * d + m * ff) + f4 * (2 * d * ff + RC * cols), ['ffn_bwd']))
     else:
         bwd_case('rowlin_bwd linear2 (stack: BN-backward gradient)', ff, d, 'g')
         bwd_case('rowlin_bwd linear1 (stack: relu, add, sums)', d, ff, 'ras')
     if fused_a:
         # backward of the attention sub-block in one launch (csrc/block_bwd.hip), BatchNorm stack variant
-        dy, y1, x0, qkv, out, dx = rnd(m, d), rnd(m, d), rnd(m, d), rnd(m, 3 * d), rnd(m, d), new(m, d)
+        dy, y1, x0, qkv, out, dx = rndt(m, d), rndt(m, d), rndt(m, d), rndt(m, 3 * d), rndt(m, d), newt(m, d)
         w_o, w_in = rnd(d, d) / d ** 0.5, rnd(3 * d, d) / d ** 0.5
         ast = torch.rand(b, heads, n, 2, generator=g).to(dev) + 1.0
         deg = torch.rand(m, generator=g).to(dev)
         cols = 4 * d * d + 4 * d
-        part = new(b, cols)
+        gb = abi.attn_block_bwd_blocks(b)     # partial rows = workgroups (they walk the graphs beyond 256)
+        part = new(gb, cols)
         kw = dict(dy=dy, y1=y1, bn1=prm_of(d), g_sum=rnd(G, 2, d), fin_out=new(2, d), dgamma=new(d), dbeta=new(d),
                   rowscale=deg, w_out=w_o, w_in=w_in, qkv=qkv, out=out, pe=pe, n_real=n_real, attn_stats=ast, x0=x0,
-                  bn0=prm_of(d), dx=dx, sum_out=new(2 * b, 2, d))
+                  bn0=prm_of(d), dx=dx, sum_out=new(2 * gb, 2, d))
         keep_a = (kw, part)
         cases.append(('attn_block_bwd', 1.0,
                       lambda: (abi.attn_block_bwd(b, n, dh ** -0.5, st, Gs=G, partial_ptr=part.data_ptr(), partial_ld=cols,
                                                   **kw), keep_a)[0],
-                      f4 * (8 * m * d + (b * n * n if pe is not None else 0) + 2 * b * heads * n + 4 * d * d + b * cols),
+                      ft * (8 * m * d + (b * n * n if pe is not None else 0)) + f4 * (2 * b * heads * n + 4 * d * d + gb * cols),
                       ['attn_block_bwd<false>']))
-        if fused_f:
+        if fused_f and gb == b:
             # two workgroups per graph (layers whose consumer is the fused FFN backward): dx in two parts
-            kws = dict(kw, dx_b=new(m, d))
+            kws = dict(kw, dx_b=newt(m, d))
             keep_s = (kws, part)
             cases.append(('attn_block_bwd (two workgroups per graph)', 1.0,
                           lambda: (abi.attn_block_bwd(b, n, dh ** -0.5, st, Gs=G, partial_ptr=part.data_ptr(),
                                                       partial_ld=cols, **kws), keep_s)[0],
-                          f4 * (9 * m * d + (b * n * n if pe is not None else 0) + 2 * b * heads * n + 4 * d * d + b * cols),
+                          ft * (9 * m * d + (b * n * n if pe is not None else 0)) + f4 * (2 * b * heads * n + 4 * d * d + b * cols),
                           ['attn_block_bwd<true>']))
     else:
         bwd_case('rowlin_bwd out_proj (stack: BN-backward gradient)', d, d, 'g')

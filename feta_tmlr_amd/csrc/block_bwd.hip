@@ -54,9 +54,20 @@ __device__ unsigned int feta_bbwd_launch;
 #endif
 #define BB_STAMP(i) FETA_RT_STAMP(feta_bbwd_stamps, feta_bbwd_launch, i)
 
+// One element of a workgroup's partial row: the first graph it walks stores, every later one adds.  The add is a
+// no-return float atomic - not for atomicity (only this thread ever touches the element, in program order) but because
+// it has no result: a load-add-store would give the scheduler 40 independent loads per lane to hoist above the
+// attention phase (the kernel spilled 0.5 - 1 KB per lane that way).
+__device__ __forceinline__ void acc_to(float* p, float v, bool first) {
+  if (first) *p = v;
+  else atomicAdd(p, v);
+}
+
 // T: storage type of dy, y1, qkv, out, dout2, pe, x0, dx, dx_b and of the LDS tiles (feta_lp.h); weights, BatchNorm
 // parameter blocks and partial sums, softmax statistics, row scale and the weight-gradient partial rows: fp32.
-template <class T, int NT, bool SPLIT>
+// LOOP: more graphs than workgroups - a separate instantiation, because the graph loop costs registers (the single-graph
+// forms are spill-free; the compiler treats everything invariant in the loop as hoistable).
+template <class T, int NT, bool SPLIT, bool LOOP>
 __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
   typedef Lp<T> L;
   typedef typename L::Op Op;
@@ -142,11 +153,27 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
     }
   }
   const int nm1 = a.N - 1;
-  {
-    const int b = (int)blockIdx.x - hp * a.B;   // one graph per workgroup (SPLIT: per two)
+  float sum1[4] = {0.f, 0.f, 0.f, 0.f}, sum2[4] = {0.f, 0.f, 0.f, 0.f};
+  // one graph per workgroup (SPLIT: per two) up to kBbMaxGrid graphs; beyond that the workgroups walk the graphs
+  // b, b + gridDim.x, ... and ADD each graph's weight-gradient tiles to their own partial row (read-modify-write by the
+  // thread that wrote it: the row stays in the XCD's L2), the partial sums for the previous BatchNorm stay in registers
+  const int nwg = (int)gridDim.x;
+  int b = (int)blockIdx.x - hp * a.B;
+  do {
+    const bool first = !LOOP || b < nwg;
+    if (LOOP && !first) __syncthreads();   // the tiles of the previous graph have been consumed
+    // The weight column slices below are loop-invariant loads: hoisted out of the graph loop they would be held across
+    // the attention phase (112 registers per lane: the kernel spilled up to 1 KB per lane).  The pointers are
+    // laundered once per graph so that the loads stay where they are used.
+    const float* w_out_l = a.w_out;
+    const float* w_in_l = a.w_in;
+    if (LOOP) {
+      FETA_OPAQUE_PTR(w_out_l);
+      FETA_OPAQUE_PTR(w_in_l);
+    }
+    const feta_gcf w_out_p = (feta_gcf)w_out_l, w_in_p = (feta_gcf)w_in_l;
     const int n = a.n_real[b];
     BB_STAMP(1);
-    float sum1[4] = {0.f, 0.f, 0.f, 0.f}, sum2[4] = {0.f, 0.f, 0.f, 0.f};
     auto grow = [&](int node) { return (int64_t)b * a.row_sb + (int64_t)min(node, nm1) * a.row_sn; };
 
     // ---- cooperative loads of the graph: NR * RV 16-byte vectors per 64-wide tensor --------------------------------
@@ -255,12 +282,13 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
     }
     __syncthreads();
     BB_STAMP(2);
-    float* prow = a.partial + (int64_t)b * (a.partial_ld > 0 ? (int64_t)a.partial_ld : (int64_t)(4 * D * D + 4 * D));
+    float* prow = a.partial + (int64_t)(SPLIT ? b : (int)blockIdx.x) *
+                                  (a.partial_ld > 0 ? (int64_t)a.partial_ld : (int64_t)(4 * D * D + 4 * D));
     if (hp == 0 && tid < D) {
       float sv = 0.0f;
 #pragma unroll
       for (int w8 = 0; w8 < 8; ++w8) sv += DBO[w8 * D + tid];
-      prow[D * D + tid] = sv;
+      acc_to(prow + D * D + tid, sv, first);
     }
 
     // ---- dconcat^T tiles (c = 16h + 4g + r, row = 16 rt + lq) = sum_o W_out[o][c] (degree g1)[row][o] (+ dout2) ----
@@ -270,7 +298,7 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
       Op woA[4];    // W_out[o = 16j+4g+s][c = 16 ct + lq]: dconcat columns of head ct
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float* p = a.w_out + (int64_t)(16 * j + 4 * g) * D + 16 * ct + lq;
+        const feta_gcf p = w_out_p + (int64_t)(16 * j + 4 * g) * D + 16 * ct + lq;
         woA[j] = L::mk(p[0], p[D], p[2 * D], p[3 * D]);
       }
 #pragma unroll
@@ -434,7 +462,9 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
       for (int i = 0; i < NWO; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          prow[(int64_t)(16 * ot + 4 * g + r) * D + 16 * (SPLIT ? 2 * hp + i : i) + lq] = aWo[i][r];
+        {
+          acc_to(prow + (int64_t)(16 * ot + 4 * g + r) * D + 16 * (SPLIT ? 2 * hp + i : i) + lq, aWo[i][r], first);
+        }
     }
     BB_STAMP(4);
     __syncthreads();   // every wave has taken its operands: the q / k / v tiles become dq / dk / dv
@@ -476,7 +506,7 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
       Op wiA[NJX];   // W_in[o = 64 part + 16 jc + 4g+s][k = 16 ktile + lq], jc = this pair's (or every) head
 #pragma unroll
       for (int j = 0; j < NJX; ++j) {
-        const float* p = a.w_in + (int64_t)(64 * part + 16 * (SPLIT ? 2 * hp + j : j) + 4 * g) * D + 16 * ktile + lq;
+        const feta_gcf p = w_in_p + (int64_t)(64 * part + 16 * (SPLIT ? 2 * hp + j : j) + 4 * g) * D + 16 * ktile + lq;
         wiA[j] = L::mk(p[0], p[D], p[2 * D], p[3 * D]);
       }
 #pragma unroll
@@ -536,7 +566,7 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
             a.sum_out[((int64_t)blockIdx.x * 2 + 1) * D + 16 * ktile + 4 * g + r] = s2v[r] + red[(ktile * 2 + 1) * 16 + 4 * g + r];
           }
         }
-      } else if (lq == 0) {
+      } else if (lq == 0 && (!LOOP || b + nwg >= a.B)) {   // (the last graph of this workgroup: sum1 / sum2 ran over all)
         const int64_t prow2 = (int64_t)blockIdx.x * 2 + (wv >> 2);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -577,7 +607,9 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
     for (int i = 0; i < NWI; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        pWi[(int64_t)(64 * wi_part(i) + 16 * wi_head(i) + 4 * g + r) * D + 16 * ktile + lq] = aWi[i][r];
+      {
+        acc_to(pWi + (int64_t)(64 * wi_part(i) + 16 * wi_head(i) + 4 * g + r) * D + 16 * ktile + lq, aWi[i][r], first);
+      }
     // db_in from the fp32 column sums the attention waves left (DBS: written before two barriers ago)
     if (tid < 3 * D) {
       const int part = tid >> 6, hh = (tid >> 4) & 3, c = tid & 15;
@@ -585,13 +617,14 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
       if (SPLIT) {
         if ((hh >> 1) == hp) {
           const int wa = (hh & 1) + 2 * rl;
-          pbi[tid] = DBS[(wa * 2 + which) * 16 + c] + DBS[((wa + 4) * 2 + which) * 16 + c];
+          pbi[tid] = DBS[(wa * 2 + which) * 16 + c] + DBS[((wa + 4) * 2 + which) * 16 + c];   // (one graph per pair)
         }
       } else {
-        pbi[tid] = DBS[((hh + 4 * rl) * 2 + which) * 16 + c];
+        acc_to(pbi + tid, DBS[((hh + 4 * rl) * 2 + which) * 16 + c], first);
       }
     }
-  }
+    b += nwg;
+  } while (LOOP && b < a.B);
   BB_STAMP(7);
   FETA_RT_LAUNCH_DONE(feta_bbwd_launch);
 }
@@ -599,16 +632,22 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
 template <class T, int NT>
 int launch_block_bwd(const BwdArgs& a, hipStream_t stream) {
   const size_t lds = block_bwd_lds_bytes<T>(NT, a.y1 != nullptr);
+  const int grid = feta_attn_block_bwd_blocks(a.B);
   if (a.dx_b != nullptr) {   // two workgroups per graph
-    auto kern = attn_block_bwd_kernel<T, NT, true>;
+    auto kern = attn_block_bwd_kernel<T, NT, true, false>;
     static LdsSeen lds_seen;
     allow_dynamic_lds(kern, lds, lds_seen);
     hipLaunchKernelGGL(kern, dim3(2 * a.B), dim3(kBbThreads), lds, stream, a);
-  } else {
-    auto kern = attn_block_bwd_kernel<T, NT, false>;
+  } else if (grid == a.B) {
+    auto kern = attn_block_bwd_kernel<T, NT, false, false>;
     static LdsSeen lds_seen;
     allow_dynamic_lds(kern, lds, lds_seen);
-    hipLaunchKernelGGL(kern, dim3(a.B), dim3(kBbThreads), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBbThreads), lds, stream, a);
+  } else {
+    auto kern = attn_block_bwd_kernel<T, NT, false, true>;
+    static LdsSeen lds_seen;
+    allow_dynamic_lds(kern, lds, lds_seen);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBbThreads), lds, stream, a);
   }
   return check_launch("feta_attn_block_bwd");
 }
@@ -637,15 +676,23 @@ extern "C" int feta_attn_block_bwd_supported(int N, int d_model, int heads) {
   return (d_model == kBbD && heads == kBbH && N >= 1 && N <= 64) ? 1 : 0;
 }
 
-/* partial rows of a launch (= graphs), 0 if the batch is beyond the one-workgroup-per-graph form */
-extern "C" int feta_attn_block_bwd_blocks(int B) { return (B >= 1 && B <= kBbMaxGrid) ? B : 0; }
+/* partial rows of a launch = its workgroups: one per graph up to kBbMaxGrid (FETA_BLOCK_BWD_MAX_GRID: tests force the
+ * loop), beyond that the workgroups walk several graphs */
+extern "C" int feta_attn_block_bwd_blocks(int B) {
+  int cap = kBbMaxGrid;
+  if (const char* e = getenv("FETA_BLOCK_BWD_MAX_GRID")) cap = atoi(e) > 0 ? atoi(e) : cap;
+  return B < 1 ? 0 : (B < cap ? B : cap);
+}
 
 extern "C" int feta_attn_block_bwd(const feta_attn_block_grad* d, feta_stream_t stream) {
   FETA_REQUIRE(d != nullptr, "attn_block_bwd: null descriptor");
   const BwdArgs& a = *d;
   FETA_REQUIRE(a.dy && a.w_out && a.w_in && a.qkv && a.out && a.n_real && a.attn_stats && a.x0 && a.dx && a.partial,
                "attn_block_bwd: null pointer");
-  FETA_REQUIRE(a.B > 0 && a.B <= kBbMaxGrid, "attn_block_bwd: B=%d outside [1,%d] (feta_attn_block_bwd_blocks)", a.B, kBbMaxGrid);
+  FETA_REQUIRE(a.B > 0, "attn_block_bwd: B=%d", a.B);
+  FETA_REQUIRE(a.dx_b == nullptr || feta_attn_block_bwd_blocks(a.B) == a.B,
+               "attn_block_bwd: the two-workgroup form (dx_b) needs one workgroup per graph (B=%d > %d)", a.B,
+               feta_attn_block_bwd_blocks(a.B));
   FETA_REQUIRE(a.N >= 1 && a.N <= 64 && a.M == a.B * a.N, "attn_block_bwd: N=%d outside [1,64] or M != B*N", a.N);
   FETA_REQUIRE(!a.y1 || (a.bn1 && a.g_sum && a.Gs > 0), "attn_block_bwd: y1 needs bn1, g_sum, Gs");
   FETA_REQUIRE(!a.sum_out || a.bn0, "attn_block_bwd: sum_out needs bn0");

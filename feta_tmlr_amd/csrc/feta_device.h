@@ -11,6 +11,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // __shared__ object can serialise LDS-DMA waits); kernels carve it by hand.
 extern __shared__ __attribute__((aligned(16))) float feta_lds[];
 
+// Makes a (wave-uniform) pointer opaque to the optimizer at this point: loads through it are not hoisted above it.
+// (the laundered value comes back as a generic pointer: FETA_GLOBAL restores the global address space, without which
+// every access through it becomes a flat_load / flat_store and waits on both memory counters)
+#define FETA_OPAQUE_PTR(p) asm volatile("" : "+s"(p))
+typedef const float __attribute__((address_space(1)))* feta_gcf;   // keep accesses through a laundered pointer global_*
+
 namespace feta {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }

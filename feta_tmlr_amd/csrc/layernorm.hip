@@ -6,7 +6,7 @@
 // workgroup of 256 threads walks row blocks of 16 and keeps the dgamma / dbeta column partials in
 // registers until its last block.
 #include "feta_abi_common.h"
-#include <feta_device.h>
+#include "feta_lp.h"
 
 namespace feta {
 
@@ -28,7 +28,20 @@ struct LnArgs {
   float* partial;       // [gridDim.x, 2, D] dgamma | dbeta partial sums (row pitch partial_ld)
   float eps;
   int M, D, partial_ld;
+  int y_bf16, out_bf16, dout_bf16, dy_bf16;   // storage type per tensor (feta_layernorm_*_ex): 1 = bf16
 };
+
+// four consecutive elements of a row of fp32 or bf16 storage (the pointer is typed float* in LnArgs either way)
+__device__ __forceinline__ float4 ln_ld4(const float* base, int64_t idx, bool bf16) {
+  float v[4];
+  if (bf16) Lp<bf16_t>::ld4(reinterpret_cast<const bf16_t*>(base) + idx, v);
+  else Lp<float>::ld4(base + idx, v);
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void ln_st4(float* base, int64_t idx, bool bf16, const float4& o) {
+  if (bf16) Lp<bf16_t>::st4(reinterpret_cast<bf16_t*>(base) + idx, o.x, o.y, o.z, o.w);
+  else Lp<float>::st4(base + idx, o.x, o.y, o.z, o.w);
+}
 
 template <int NV>
 __global__ __launch_bounds__(kLnThreads) void ln_fwd_kernel(LnArgs a) {
@@ -51,7 +64,7 @@ __global__ __launch_bounds__(kLnThreads) void ln_fwd_kernel(LnArgs a) {
     for (int v = 0; v < NV; ++v) {
       const int c = 64 * v + 4 * l;
       const bool ok = c < a.D;
-      x[v] = *reinterpret_cast<const float4*>(a.y + (int64_t)rowc * a.D + (ok ? c : 0));
+      x[v] = ln_ld4(a.y, (int64_t)rowc * a.D + (ok ? c : 0), a.y_bf16 != 0);
       if (!ok) x[v].x = x[v].y = x[v].z = x[v].w = 0.0f;
       s += (x[v].x + x[v].y) + (x[v].z + x[v].w);
     }
@@ -75,7 +88,7 @@ __global__ __launch_bounds__(kLnThreads) void ln_fwd_kernel(LnArgs a) {
           o.y = (x[v].y - mean) * rstd * gm[v].y + bt[v].y;
           o.z = (x[v].z - mean) * rstd * gm[v].z + bt[v].z;
           o.w = (x[v].w - mean) * rstd * gm[v].w + bt[v].w;
-          *reinterpret_cast<float4*>(a.out + (int64_t)row * a.D + c) = o;
+          ln_st4(a.out, (int64_t)row * a.D + c, a.out_bf16 != 0, o);
         }
       }
       if (l == 0) {
@@ -111,8 +124,8 @@ __global__ __launch_bounds__(kLnThreads) void ln_bwd_kernel(LnArgs a) {
     for (int v = 0; v < NV; ++v) {
       const int c = 64 * v + 4 * l;
       const bool ok = c < a.D && rok;
-      const float4 yv = *reinterpret_cast<const float4*>(a.y + (int64_t)rowc * a.D + (c < a.D ? c : 0));
-      const float4 dv = *reinterpret_cast<const float4*>(a.dout + (int64_t)rowc * a.D + (c < a.D ? c : 0));
+      const float4 yv = ln_ld4(a.y, (int64_t)rowc * a.D + (c < a.D ? c : 0), a.y_bf16 != 0);
+      const float4 dv = ln_ld4(a.dout, (int64_t)rowc * a.D + (c < a.D ? c : 0), a.dout_bf16 != 0);
       const float m = ok ? 1.0f : 0.0f;
       xh[v].x = (yv.x - mean) * rstd * m;  xh[v].y = (yv.y - mean) * rstd * m;
       xh[v].z = (yv.z - mean) * rstd * m;  xh[v].w = (yv.w - mean) * rstd * m;
@@ -135,7 +148,7 @@ __global__ __launch_bounds__(kLnThreads) void ln_bwd_kernel(LnArgs a) {
           o.y = rstd * (g[v].y - s1 - xh[v].y * s2);
           o.z = rstd * (g[v].z - s1 - xh[v].z * s2);
           o.w = rstd * (g[v].w - s1 - xh[v].w * s2);
-          *reinterpret_cast<float4*>(a.dy + (int64_t)row * a.D + c) = o;
+          ln_st4(a.dy, (int64_t)row * a.D + c, a.dy_bf16 != 0, o);
         }
       }
     }
@@ -176,19 +189,28 @@ extern "C" int feta_layernorm_blocks(int M) { return M > 0 ? ln_blocks(M) : 0; }
 
 extern "C" int feta_layernorm_fwd(const float* y, const float* gamma, const float* beta, float eps, float* out,
                                   float* stats, int M, int D, feta_stream_t stream) {
+  return feta_layernorm_fwd_ex(y, gamma, beta, eps, out, stats, M, D, FETA_F32, FETA_F32, stream);
+}
+
+extern "C" int feta_layernorm_fwd_ex(const void* y, const float* gamma, const float* beta, float eps, void* out,
+                                     float* stats, int M, int D, int y_dtype, int out_dtype, feta_stream_t stream) {
   FETA_REQUIRE(y && gamma && beta && out && stats && M > 0, "layernorm_fwd: bad arguments");
   FETA_REQUIRE(ln_dim_ok(D), "layernorm_fwd: D = %d (multiple of 4, <= 256)", D);
+  FETA_REQUIRE((y_dtype == FETA_F32 || y_dtype == FETA_BF16) && (out_dtype == FETA_F32 || out_dtype == FETA_BF16),
+               "layernorm_fwd: dtypes %d, %d", y_dtype, out_dtype);
   FETA_REQUIRE(aligned16(y) && aligned16(gamma) && aligned16(beta) && aligned16(out),
                "layernorm_fwd: pointers must be 16-byte aligned");
   LnArgs a{};
-  a.y = y;
+  a.y = static_cast<const float*>(y);
   a.gamma = gamma;
   a.beta = beta;
-  a.out = out;
+  a.out = static_cast<float*>(out);
   a.stats = stats;
   a.eps = eps;
   a.M = M;
   a.D = D;
+  a.y_bf16 = y_dtype == FETA_BF16;
+  a.out_bf16 = out_dtype == FETA_BF16;
   const int nblk = (M + kLnRows - 1) / kLnRows;
   const dim3 grid(nblk < 8 * kLnMaxBlocks ? nblk : 8 * kLnMaxBlocks), block(kLnThreads);
 #define CALL(NVV) { auto kern = ln_fwd_kernel<NVV>; hipLaunchKernelGGL(kern, grid, block, 0, (hipStream_t)stream, a); }
@@ -200,22 +222,34 @@ extern "C" int feta_layernorm_fwd(const float* y, const float* gamma, const floa
 extern "C" int feta_layernorm_bwd(const float* dout, const float* y, const float* stats, const float* gamma,
                                   float* dy, float* partial, int partial_ld, float* dgamma_dbeta, int M, int D,
                                   feta_stream_t stream) {
+  return feta_layernorm_bwd_ex(dout, y, stats, gamma, dy, partial, partial_ld, dgamma_dbeta, M, D, FETA_F32, FETA_F32,
+                               FETA_F32, stream);
+}
+
+extern "C" int feta_layernorm_bwd_ex(const void* dout, const void* y, const float* stats, const float* gamma,
+                                     void* dy, float* partial, int partial_ld, float* dgamma_dbeta, int M, int D,
+                                     int dout_dtype, int y_dtype, int dy_dtype, feta_stream_t stream) {
   FETA_REQUIRE(dout && y && stats && gamma && dy && partial && M > 0, "layernorm_bwd: bad arguments");
   FETA_REQUIRE(partial_ld == 0 || partial_ld >= 2 * D, "layernorm_bwd: partial_ld = %d < 2 D", partial_ld);
   FETA_REQUIRE(dgamma_dbeta || partial_ld > 0, "layernorm_bwd: dgamma_dbeta may only be NULL with a caller-reduced partial_ld");
   FETA_REQUIRE(ln_dim_ok(D), "layernorm_bwd: D = %d (multiple of 4, <= 256)", D);
+  FETA_REQUIRE((dout_dtype | y_dtype | dy_dtype) >= 0 && (dout_dtype | y_dtype | dy_dtype) <= 1,
+               "layernorm_bwd: dtypes %d, %d, %d", dout_dtype, y_dtype, dy_dtype);
   FETA_REQUIRE(aligned16(dout) && aligned16(y) && aligned16(gamma) && aligned16(dy),
                "layernorm_bwd: pointers must be 16-byte aligned");
   LnArgs a{};
-  a.y = y;
+  a.y = static_cast<const float*>(y);
   a.gamma = gamma;
   a.stats = const_cast<float*>(stats);
-  a.dout = dout;
-  a.dy = dy;
+  a.dout = static_cast<const float*>(dout);
+  a.dy = static_cast<float*>(dy);
   a.partial = partial;
   a.partial_ld = partial_ld > 0 ? partial_ld : 2 * D;
   a.M = M;
   a.D = D;
+  a.dout_bf16 = dout_dtype == FETA_BF16;
+  a.y_bf16 = y_dtype == FETA_BF16;
+  a.dy_bf16 = dy_dtype == FETA_BF16;
   const int G = ln_blocks(M);
   const size_t lds = sizeof(float) * kLnRows * 2 * D;
 #define CALL(NVV) { auto kern = ln_bwd_kernel<NVV>; hipLaunchKernelGGL(kern, dim3(G), dim3(kLnThreads), lds, (hipStream_t)stream, a); }

@@ -12,9 +12,11 @@
 //
 // Arithmetic: v_mfma_f32_16x16x4_f32, k-ordered exact fp32 - the same contraction order for every output element
 // (k ascending in steps of 16, inside a step the four k-quads of the MFMA), deterministic.
+#include <cstdlib>
+
 #include "feta_abi_common.h"
 #include "feta_colsum.h"
-#include "feta_tiles.h"
+#include "feta_lp.h"
 
 namespace feta {
 
@@ -165,6 +167,261 @@ __global__ __launch_bounds__(kLinThreads) void lin_bwd_kernel(LinBwdArgs a) {
   colsum_role<kLinThreads>(a.segs, blk - a.nw);
 }
 
+
+// ---- LDS-tiled form for shapes whose dims are multiples of 64 (the BASELINE shape: R = H*B = 512, K = N = C = 1024, one
+// GFLOP per product - compute-bound, where the one-tile-per-wave form above is L2-bound: every wave re-reads a whole
+// operand slab).  D[i][j] = sum_kk P[i][kk] Q[kk][j], 64 x 32 output tile per workgroup, 4 waves = (32-row half, 16-column
+// tile), contraction staged through LDS in chunks of 64 with the next chunk's global loads in flight under the current
+// chunk's MFMAs (double buffer, ONE barrier per chunk).
+//   forward  i = r, j = n, kk = k :  P = x  [i][kk],  Q = w  [j][kk]
+//   dX       i = r, j = k, kk = n :  P = dy [i][kk],  Q = w  [kk][j]
+//   dW       i = n, j = k, kk = r :  P = dy [kk][i],  Q = x  [kk][j]      (+ db[i] = sum_kk P: fp32, from the staged values)
+// An operand whose tile is [outer][kk] is read as a row operand (one 16-byte LDS read per four k-steps), one whose tile
+// is [kk][outer] as a gather down a column (four scalar reads): no tile is transposed in memory.
+// T = float: k-ordered exact fp32 MFMA (deterministic, the same contraction order for every element); T = bf16_t (bf16
+// storage legs, layers.set_storage_dtype): the fp32 operands are rounded to bf16 when they are staged, fp32 accumulate.
+constexpr int kLtI = 64, kLtJ = 32, kLtK = 64;
+
+template <class T>
+__host__ __device__ inline int lin_tiled_lds_bytes() {
+  // P tile 64 x 64 (+ pad), Q tile 32 x 64 or 64 x 32 (+ pad), two buffers
+  return 2 * (int)sizeof(T) * (64 * (64 + Lp<T>::PAD) + 64 * (64 + Lp<T>::PAD));
+}
+
+struct LinTiledArgs {
+  const float* p;   // P source matrix
+  const float* q;   // Q source matrix
+  const float* bias;
+  float* d;         // [I][J]
+  float* rowsum;    // db (dW role), nullable
+  int ldp, ldq, ldd;
+  int I, J, KK;
+};
+
+// stage a [ROWS][COLS] fp32 block of a row-major matrix (leading dimension ld) into registers / into an LDS tile of T
+template <int ROWS, int COLS>
+struct LtStage {
+  static constexpr int NV = ROWS * COLS / 4 / kLinThreads;   // float4 per thread
+  float4 v[NV];
+  __device__ __forceinline__ void load(const float* src, int64_t ld, int r0, int c0) {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int idx = threadIdx.x + u * kLinThreads, rr = idx / (COLS / 4), c4 = idx % (COLS / 4);
+      v[u] = *reinterpret_cast<const float4*>(src + (int64_t)(r0 + rr) * ld + c0 + 4 * c4);
+    }
+  }
+  template <class T>
+  __device__ __forceinline__ void store(T* tile, int pitch) const {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int idx = threadIdx.x + u * kLinThreads, rr = idx / (COLS / 4), c4 = idx % (COLS / 4);
+      Lp<T>::st4(tile + rr * pitch + 4 * c4, v[u].x, v[u].y, v[u].z, v[u].w);
+    }
+  }
+};
+
+// PKK: P tile is [i][kk] (kk contiguous in memory) else [kk][i];  QKK: Q tile is [j][kk] else [kk][j]
+template <class T, bool PKK, bool QKK, bool ROWSUM>
+__device__ __forceinline__ void lin_tiled_body(const LinTiledArgs& a, int ti, int tj) {
+  typedef Lp<T> L;
+  typedef typename L::Op Op;
+  constexpr int PP = 64 + L::PAD;                       // pitch of the P tile (64 x 64 either way)
+  constexpr int QP = (QKK ? kLtK : kLtJ) + L::PAD;      // Q tile: [32 j][64 kk] or [64 kk][32 j]
+  constexpr int QROWS = QKK ? kLtJ : kLtK, QCOLS = QKK ? kLtK : kLtJ;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lq = lane & 15, g = lane >> 4;
+  const int ih = wv & 1, jt = wv >> 1;
+  // (tile addresses are computed from the buffer index, never read from an array of pointers: a pointer loaded from a
+  // dynamically indexed array loses its LDS address space, the tile reads become flat loads, and a flat load makes the
+  // compiler wait for vmcnt(0) - i.e. for the next chunk's global loads - in front of every MFMA group)
+  T* base = reinterpret_cast<T*>(lds_bytes());
+  constexpr int PSZ = 64 * PP, QSZ = 64 * (64 + L::PAD);
+  const int i0 = kLtI * ti, j0 = kLtJ * tj;
+  // Two register sets of staged chunks in flight (A: chunk c + 1, B: chunk c + 2) in front of the LDS double buffer: at
+  // one workgroup per CU a single chunk in flight (24 KB per CU) left the kernel bound by the L2 round trip, ~1 us per
+  // chunk against 0.45 us of fp32 MFMAs - and with bf16 MFMAs there is nothing else to hide it under.
+  LtStage<64, 64> psA, psB;
+  LtStage<QROWS, QCOLS> qsA, qsB;
+  // (locals, not `a`, inside the lambdas: a lambda that captures a kernel-argument struct by reference can make the
+  // compiler keep a copy of the struct in private memory - ffn_bwd.hip)
+  const float* gp = a.p;
+  const float* gq = a.q;
+  const int ldp = a.ldp, ldq = a.ldq;
+  auto request = [gp, gq, ldp, ldq, i0, j0](LtStage<64, 64>& ps, LtStage<QROWS, QCOLS>& qs, int c) {
+    const int k0 = kLtK * c;
+    if (PKK) ps.load(gp, ldp, i0, k0);
+    else ps.load(gp, ldp, k0, i0);
+    if (QKK) qs.load(gq, ldq, j0, k0);
+    else qs.load(gq, ldq, k0, j0);
+  };
+  // fp32 row sums of P over kk (db of the dW role), from the staged values before they are rounded: this thread's
+  // float4 covers four consecutive i of one kk row
+  float rs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  auto commit = [&rs, base](const LtStage<64, 64>& ps, const LtStage<QROWS, QCOLS>& qs, int buf) {
+    ps.template store<T>(base + buf * PSZ, PP);
+    qs.template store<T>(base + 2 * PSZ + buf * QSZ, QP);
+    if (ROWSUM) {
+#pragma unroll
+      for (int u = 0; u < LtStage<64, 64>::NV; ++u) {
+        rs[0] += ps.v[u].x; rs[1] += ps.v[u].y; rs[2] += ps.v[u].z; rs[3] += ps.v[u].w;
+      }
+    }
+  };
+  f32x4 acc[2] = {zero4(), zero4()};
+  auto compute = [&acc, base, ih, jt, lq, g](int buf) {
+    const T* pt = base + buf * PSZ;
+    const T* qt = base + 2 * PSZ + buf * QSZ;
+#pragma unroll
+    for (int q4 = 0; q4 < kLtK / 16; ++q4) {
+      const Op qo = QKK ? L::ld(qt + (16 * jt + lq) * QP + 16 * q4 + 4 * g)
+                        : L::gather(qt + (16 * q4 + 4 * g) * QP + 16 * jt + lq, QP);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int il = 32 * ih + 16 * t + lq;
+        const Op po = PKK ? L::ld(pt + il * PP + 16 * q4 + 4 * g) : L::gather(pt + (16 * q4 + 4 * g) * PP + il, PP);
+        acc[t] = L::mma(po, qo, acc[t]);
+      }
+    }
+  };
+  const int nc = a.KK / kLtK;
+  request(psA, qsA, 0);
+  commit(psA, qsA, 0);
+  if (1 < nc) request(psA, qsA, 1);
+  if (2 < nc) request(psB, qsB, 2);
+  __syncthreads();
+  for (int c = 0; c < nc; c += 2) {
+    // LDS buffer 0 holds chunk c; A: chunk c + 1, B: chunk c + 2 (in flight)
+    compute(0);
+    if (c + 1 < nc) commit(psA, qsA, 1);
+    if (c + 3 < nc) request(psA, qsA, c + 3);
+    __syncthreads();
+    if (c + 1 < nc) {
+      compute(1);
+      if (c + 2 < nc) commit(psB, qsB, 0);
+      if (c + 4 < nc) request(psB, qsB, c + 4);
+      __syncthreads();
+    }
+  }
+  // D[i][j] (+ bias[j])
+  const int col = j0 + 16 * jt + lq;
+  const float bv = a.bias != nullptr ? a.bias[col] : 0.0f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a.d[(int64_t)(i0 + 32 * ih + 16 * t + 4 * g + r) * a.ldd + col] = acc[t][r] + bv;
+  if (ROWSUM && a.rowsum != nullptr && tj == 0) {
+    // thread (rr = idx / 16, c4 = idx % 16) of vector u summed rows kk = rr + 16 u' ... of columns i0 + 4 c4 ..: the 16
+    // threads x NV vectors that share c4 meet in LDS (fixed order)
+    float* red = reinterpret_cast<float*>(lds_bytes());     // [256][4] (the tiles are no longer needed)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[threadIdx.x * 4 + e] = rs[e];
+    __syncthreads();
+    if (threadIdx.x < kLtI) {
+      const int c4 = threadIdx.x >> 2, e = threadIdx.x & 3;
+      float sv = 0.0f;
+      for (int k = 0; k < kLinThreads / 16; ++k) sv += red[(c4 + 16 * k) * 4 + e];
+      a.rowsum[i0 + threadIdx.x] = sv;
+    }
+  }
+}
+
+// XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2); the 8 consecutive
+// workgroups of a group get 8 different j tiles of ONE i tile... and the next group the next j tiles: an XCD keeps
+// meeting the same j tiles (its slice of Q) while the P rows stream through.
+__device__ __forceinline__ void lin_tile_of(int blk, int TI, int TJ, int& ti, int& tj) {
+  // blk = (tj_hi * TI + ti) * 8 + tj_lo with tj = tj_hi * 8 + tj_lo  (TJ a multiple of 8)
+  const int lo = blk & 7, rest = blk >> 3;
+  ti = rest % TI;
+  tj = (rest / TI) * 8 + lo;
+  (void)TJ;
+}
+
+template <class T>
+__global__ __launch_bounds__(kLinThreads) void lin_fwd_tiled_kernel(LinTiledArgs a) {
+  int ti, tj;
+  lin_tile_of((int)blockIdx.x, a.I / kLtI, a.J / kLtJ, ti, tj);
+  lin_tiled_body<T, true, true, false>(a, ti, tj);
+}
+
+struct LinBwdTiledArgs {
+  LinTiledArgs dx, dw;
+  int nx, nw;
+  ColsumPlan segs;
+};
+
+template <class T>
+__global__ __launch_bounds__(kLinThreads) void lin_bwd_tiled_kernel(LinBwdTiledArgs a) {
+  int blk = (int)blockIdx.x, ti, tj;
+  // the two gradient products interleaved in groups of 8 workgroups, so that both kinds are resident on every CU
+  // from the start (two workgroups fit a CU: the dW role's gathers and the dX role's row reads share its LDS pipe)
+  const int pairs = a.nx < a.nw ? a.nx : a.nw;
+  if (blk < 2 * pairs) {
+    const int grp = blk >> 4, in = blk & 15;
+    const int sub = grp * 8 + (in & 7);
+    if (in < 8) {
+      lin_tile_of(sub, a.dx.I / kLtI, a.dx.J / kLtJ, ti, tj);
+      lin_tiled_body<T, true, false, false>(a.dx, ti, tj);
+    } else {
+      lin_tile_of(sub, a.dw.I / kLtI, a.dw.J / kLtJ, ti, tj);
+      lin_tiled_body<T, false, false, true>(a.dw, ti, tj);
+    }
+    return;
+  }
+  blk -= 2 * pairs;
+  if (blk < a.nx - pairs) {
+    lin_tile_of(pairs + blk, a.dx.I / kLtI, a.dx.J / kLtJ, ti, tj);
+    lin_tiled_body<T, true, false, false>(a.dx, ti, tj);
+    return;
+  }
+  blk -= a.nx - pairs;
+  if (blk < a.nw - pairs) {
+    lin_tile_of(pairs + blk, a.dw.I / kLtI, a.dw.J / kLtJ, ti, tj);
+    lin_tiled_body<T, false, false, true>(a.dw, ti, tj);
+    return;
+  }
+  colsum_role<kLinThreads>(a.segs, blk - (a.nw - pairs));
+}
+
+inline bool lin_tiled_ok(int R, int K, int N) {
+  // every dim a multiple of 64 and the tile counts over the j dims multiples of 8 (lin_tile_of); FETA_LIN_TILED=0: the
+  // one-tile-per-wave form everywhere (A/B timing)
+  int64_t min_macs = (int64_t)1 << 24;
+  if (const char* e = getenv("FETA_LIN_TILED")) {
+    if (atoi(e) == 0) return false;
+    if (atoi(e) == 2) min_macs = 0;     // tests: the tiled kernels at the smallest shape they take
+  }
+  return R % 64 == 0 && K % 256 == 0 && N % 256 == 0 && (int64_t)R * K * N >= min_macs;
+}
+
+template <class T>
+int launch_lin_fwd_tiled(const float* x, const float* w, const float* bias, float* y, int R, int K, int N,
+                         hipStream_t stream) {
+  LinTiledArgs a{x, w, bias, y, nullptr, K, K, N, R, N, K};
+  auto kern = lin_fwd_tiled_kernel<T>;
+  const size_t lds = lin_tiled_lds_bytes<T>();
+  static LdsSeen seen;
+  allow_dynamic_lds(kern, lds, seen);
+  hipLaunchKernelGGL(kern, dim3((R / kLtI) * (N / kLtJ)), dim3(kLinThreads), lds, stream, a);
+  return check_launch("feta_lin_fwd");
+}
+
+template <class T>
+int launch_lin_bwd_tiled(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int R, int K,
+                         int N, const ColsumPlan& plan, int tiles, hipStream_t stream) {
+  LinBwdTiledArgs a{};
+  a.dx = LinTiledArgs{dy, w, nullptr, dx, nullptr, N, K, K, R, K, N};     // i = r, j = k, kk = n
+  a.dw = LinTiledArgs{dy, x, nullptr, dw, db, N, K, K, N, K, R};          // i = n, j = k, kk = r
+  a.nx = dx != nullptr ? (R / kLtI) * (K / kLtJ) : 0;
+  a.nw = (N / kLtI) * (K / kLtJ);
+  a.segs = plan;
+  auto kern = lin_bwd_tiled_kernel<T>;
+  size_t lds = lin_tiled_lds_bytes<T>();
+  if (lds < kLinThreads * sizeof(float) * 4) lds = kLinThreads * sizeof(float) * 4;
+  static LdsSeen seen;
+  allow_dynamic_lds(kern, lds, seen);
+  hipLaunchKernelGGL(kern, dim3(a.nx + a.nw + tiles), dim3(kLinThreads), lds, stream, a);
+  return check_launch("feta_lin_bwd");
+}
+
 }  // namespace feta
 
 using namespace feta;
@@ -175,9 +432,19 @@ extern "C" int feta_lin_supported(int R, int K, int N) {
 
 extern "C" int feta_lin_fwd(const float* x, const float* w, const float* bias, float* y, int R, int K, int N,
                             feta_stream_t stream) {
+  return feta_lin_fwd_ex(x, w, bias, y, R, K, N, FETA_F32, stream);
+}
+
+extern "C" int feta_lin_fwd_ex(const float* x, const float* w, const float* bias, float* y, int R, int K, int N,
+                               int compute, feta_stream_t stream) {
   FETA_REQUIRE(x && w && y, "lin_fwd: null pointer");
   FETA_REQUIRE(feta_lin_supported(R, K, N), "lin_fwd: need R, K, N multiples of 4, K, N >= 16 (R=%d K=%d N=%d)", R, K, N);
   FETA_REQUIRE(aligned16(x) && aligned16(w), "lin_fwd: x and w must be 16-byte aligned");
+  FETA_REQUIRE(compute == FETA_F32 || compute == FETA_BF16, "lin_fwd: compute type %d", compute);
+  if (lin_tiled_ok(R, K, N)) {
+    if (compute == FETA_BF16) return launch_lin_fwd_tiled<bf16_t>(x, w, bias, y, R, K, N, (hipStream_t)stream);
+    return launch_lin_fwd_tiled<float>(x, w, bias, y, R, K, N, (hipStream_t)stream);
+  }
   LinFwdArgs a{x, w, bias, y, R, K, N, (N + 31) / 32};
   const int grid = ((R + 31) / 32) * a.tn;
   auto kern = lin_fwd_kernel;
@@ -187,18 +454,32 @@ extern "C" int feta_lin_fwd(const float* x, const float* w, const float* bias, f
 
 extern "C" int feta_lin_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int R,
                             int K, int N, const feta_colsum_seg* segs, int nseg, feta_stream_t stream) {
+  return feta_lin_bwd_ex(x, w, dy, dx, dw, db, R, K, N, segs, nseg, FETA_F32, stream);
+}
+
+extern "C" int feta_lin_bwd_ex(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int R,
+                               int K, int N, const feta_colsum_seg* segs, int nseg, int compute, feta_stream_t stream) {
   FETA_REQUIRE(x && w && dy && dw, "lin_bwd: null pointer");
   FETA_REQUIRE(feta_lin_supported(R, K, N), "lin_bwd: need R, K, N multiples of 4, K, N >= 16 (R=%d K=%d N=%d)", R, K, N);
   FETA_REQUIRE(aligned16(dy), "lin_bwd: dy must be 16-byte aligned");
   FETA_REQUIRE(nseg >= 0 && nseg <= FETA_COLSUM_MAX_SEGS && (nseg == 0 || segs != nullptr),
                "lin_bwd: 0..%d column-sum segments", FETA_COLSUM_MAX_SEGS);
+  FETA_REQUIRE(compute == FETA_F32 || compute == FETA_BF16, "lin_bwd: compute type %d", compute);
+  for (int i = 0; i < nseg; ++i) FETA_REQUIRE(colsum_seg_ok(segs[i]), "lin_bwd: bad segment %d", i);
+  if (lin_tiled_ok(R, K, N)) {
+    FETA_REQUIRE(aligned16(x) && aligned16(w), "lin_bwd: x and w must be 16-byte aligned");
+    ColsumPlan plan{};
+    const int tiles = plan_colsum(segs, nseg, plan);
+    if (compute == FETA_BF16)
+      return launch_lin_bwd_tiled<bf16_t>(x, w, dy, dx, dw, db, R, K, N, plan, tiles, (hipStream_t)stream);
+    return launch_lin_bwd_tiled<float>(x, w, dy, dx, dw, db, R, K, N, plan, tiles, (hipStream_t)stream);
+  }
   LinBwdArgs a{};
   a.x = x; a.w = w; a.dy = dy; a.dx = dx; a.dw = dw; a.db = db;
   a.R = R; a.K = K; a.N = N;
   a.tk = (K + 31) / 32;
   a.nx = dx != nullptr ? ((R + 31) / 32) * a.tk : 0;
   a.nw = ((N + 31) / 32) * a.tk;
-  for (int i = 0; i < nseg; ++i) FETA_REQUIRE(colsum_seg_ok(segs[i]), "lin_bwd: bad segment %d", i);
   const int tiles = plan_colsum(segs, nseg, a.segs);
   auto kern = lin_bwd_kernel;
   hipLaunchKernelGGL(kern, dim3(a.nx + a.nw + tiles), dim3(kLinThreads), kLinThreads * sizeof(float),

@@ -226,7 +226,10 @@ class _FilterFn(torch.autograd.Function):
         return dx, dcoeff, dbias, None, None, None, None, None, None, None
 
 
-LIN_OWN_GEMM_MAX_MACS = 1 << 27
+import os as _os
+# above this many multiply-adds per product the C x C linear runs as library GEMMs (A/B switch: since round 3 the
+# LDS-tiled kernels of csrc/lin.hip take the BASELINE shape, 2^29 MACs per product)
+LIN_OWN_GEMM_MAX_MACS = int(_os.environ.get('FETA_LIN_OWN_MAX_MACS', str(1 << 31)))
 
 
 class PendingSums:
@@ -340,8 +343,10 @@ class FilterFromPooledFn(torch.autograd.Function):
     available together) instead of two, and no dcoeff hand-over through autograd."""
 
     @staticmethod
-    def forward(ctx, x, pooled, lin_w, lin_b, bias, n_real, g0, g1, mode, order, share, batch_first, pending):
+    def forward(ctx, x, pooled, lin_w, lin_b, bias, n_real, g0, g1, mode, order, share, batch_first, pending,
+                gemm_bf16=False):
         abi, stream = _lib.backend(x, pooled)
+        ctx.gemm_bf16 = bool(gemm_bf16)
         b, n, h, dh = x.shape
         xs = _dense_like(x, batch_first)
         # fp32 master precision (also what a regulariser sees)
@@ -353,7 +358,7 @@ class FilterFromPooledFn(torch.autograd.Function):
         ctx.own_gemm = abi.lin_supported(r_, k_, n_) and r_ * k_ * n_ <= LIN_OWN_GEMM_MAX_MACS
         if ctx.own_gemm:
             coeff = torch.empty((pooled.shape[0], lin_w.shape[0]), dtype=torch.float32, device=pooled.device)
-            abi.lin_fwd(pooled, lin_w, lin_b, coeff, stream)
+            abi.lin_fwd(pooled, lin_w, lin_b, coeff, stream, bf16=ctx.gemm_bf16)
         else:
             coeff = torch.addmm(lin_b, pooled, lin_w.t())
         ctx.pending = pending
@@ -407,7 +412,7 @@ class FilterFromPooledFn(torch.autograd.Function):
             # dpooled, dW_lin, db_lin and every pending column sum in ONE launch (csrc/lin.hip)
             dpooled = torch.empty_like(pooled) if ctx.needs_input_grad[1] else None
             dw_lin = torch.empty_like(lin_w)
-            abi.lin_bwd(pooled, lin_w, dcoeff, dpooled, dw_lin, db_lin, stream, pairs=sums)
+            abi.lin_bwd(pooled, lin_w, dcoeff, dpooled, dw_lin, db_lin, stream, pairs=sums, bf16=ctx.gemm_bf16)
         else:
             sums.append((dcoeff, db_lin))
             if ctx.defer and PendingSums.untouched(*ctx.params):
@@ -420,11 +425,11 @@ class FilterFromPooledFn(torch.autograd.Function):
             dpooled, dw_lin = dcoeff.mm(lin_w), dcoeff.t().mm(pooled)
         if not has_bias:
             dbias = None
-        return (dx, dpooled, dw_lin, db_lin, dbias) + (None,) * 8
+        return (dx, dpooled, dw_lin, db_lin, dbias) + (None,) * 9
 
 
 def filter_from_pooled(x, pooled, lin_w, lin_b, bias, n_real, graph, mode, order, heads_share_graph=False,
-                       batch_first=False, pending=None):
+                       batch_first=False, pending=None, gemm_bf16=False):
     """x [B,N,H,dh] view, pooled [H*B, C] -> (y, coeff [H*B, C]); graph = (lhat,) | (u, lam)."""
     g0 = graph[0].contiguous()
     g1 = graph[1].contiguous() if len(graph) > 1 else None
@@ -433,7 +438,7 @@ def filter_from_pooled(x, pooled, lin_w, lin_b, bias, n_real, graph, mode, order
             raise NotImplementedError("the bf16 storage path runs the eigenbasis filter (filter_mode='spectral')")
         g0 = g0.to(x.dtype)      # U travels as bf16; lambda and t_k(lambda) stay fp32
     return FilterFromPooledFn.apply(x, pooled, lin_w, lin_b, bias, n_real, g0, g1, mode, order,
-                                    bool(heads_share_graph), batch_first, pending)
+                                    bool(heads_share_graph), batch_first, pending, bool(gemm_bf16))
 
 
 class RowLinearFn(torch.autograd.Function):

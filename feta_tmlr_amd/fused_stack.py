@@ -45,6 +45,18 @@ USE_ATTN_BLOCK_BWD = os.environ.get('FETA_ATTN_BLOCK_BWD', '1') != '0'
 # two workgroups per graph (one per pair of heads) where the consumer of dx is the fused FFN backward, which adds the
 # two parts on load (feta_attn_block_grad.dx_b); 0: one workgroup per graph everywhere (A/B timing)
 USE_ATTN_BLOCK_SPLIT = os.environ.get('FETA_ATTN_BLOCK_SPLIT', '1') != '0'
+# more graphs than workgroups (B > 256): the fused attention-block backward walks several graphs per workgroup.  That
+# instantiation spills (the graph loop costs registers, csrc/block_bwd.hip) and measured SLOWER than the three-launch
+# form on fp32 (molhiv B = 1024, N_pad = 64: 533 k vs 649 k graphs/s), so fp32 stacks take it only on request; bf16
+# stacks always do (the three-launch kernels have no bf16 form)
+USE_ATTN_BLOCK_BWD_LOOP = os.environ.get('FETA_BLOCK_BWD_LOOP', '0') != '0'
+
+
+def _fused_attn_bwd(abi, b, n, d, heads, tie, dt):
+    if not (USE_ATTN_BLOCK_BWD and not tie and abi.attn_block_bwd_supported(n, d, heads)):
+        return False
+    gb = abi.attn_block_bwd_blocks(b)
+    return gb > 0 and (gb == b or dt != torch.float32 or USE_ATTN_BLOCK_BWD_LOOP)
 
 def layer_params(layer):
     a = layer.self_attn
@@ -58,12 +70,13 @@ USE_LN_STACK = os.environ.get('FETA_LN_STACK', '1') != '0'   # 0: LayerNorm laye
 
 def lowp_stack_supported(abi, layers, n, b, d_model):
     """bf16 storage (layers.set_storage_dtype): the stack runs iff every launch of it is one of the four fused kernels
-    (csrc/block.hip, ffn.hip, ffn_bwd.hip, block_bwd.hip - the only ones instantiated for bf16 tiles); BatchNorm stacks."""
+    (csrc/block.hip, ffn.hip, ffn_bwd.hip, block_bwd.hip - the ones instantiated for bf16 tiles - and, LayerNorm stacks,
+    feta_layernorm_*_ex)."""
     if not (USE_ATTN_BLOCK and USE_FFN_FUSED and USE_FFN_BWD and USE_ATTN_BLOCK_BWD):
         return False
     l0 = layers[0]
     heads = l0.self_attn.num_heads
-    if not l0.batch_norm or l0.self_attn.tie_qk:
+    if l0.self_attn.tie_qk or (not l0.batch_norm and not USE_LN_STACK):
         return False
     if not (abi.attn_block_supported(n, d_model, heads) and abi.attn_block_bwd_supported(n, d_model, heads)
             and abi.attn_block_bwd_blocks(b) > 0):
@@ -298,8 +311,7 @@ class FusedEncoderStackFn(torch.autograd.Function):
         newt = lambda *s: torch.empty(s, dtype=dt, device=dev)
         grads = [None] * len(params)
         ff0 = params[6].shape[0]
-        fused_attn = (USE_ATTN_BLOCK_BWD and not tie and abi.attn_block_bwd_supported(n, d, heads)
-                      and abi.attn_block_bwd_blocks(b) > 0)
+        fused_attn = _fused_attn_bwd(abi, b, n, d, heads, tie, dt)
         # every weight/bias gradient of the stack goes through the split-K partial buffers and ONE deterministic
         # reduction at the end (instead of one reduction launch per linear)
         part_f, part_a, tf, ta, wslot = _partial_buffers(abi, new, m, b, n, d, heads, ff0, nl, fused_attn)
@@ -373,7 +385,7 @@ class FusedEncoderStackFn(torch.autograd.Function):
                 # B3 + B4 + B5 in one launch, one workgroup per graph (csrc/block_bwd.hip): dconcat and dqkv stay on chip
                 dx0 = newt(m, d)
                 # the layer below takes the gradient in two parts iff its FFN backward is the fused kernel
-                split = (USE_ATTN_BLOCK_SPLIT and li > 0 and USE_FFN_BWD
+                split = (USE_ATTN_BLOCK_SPLIT and li > 0 and USE_FFN_BWD and abi.attn_block_bwd_blocks(b) == b
                          and abi.ffn_bwd_supported(d, params[(li - 1) * PER_LAYER + 6].shape[0]))
                 dx0b = newt(m, d) if split else None
                 GB = abi.attn_block_bwd_blocks(b)
@@ -469,24 +481,34 @@ class FusedLayerNormStackFn(torch.autograd.Function):
         scale = float(dh) ** -0.5
         dev = src.device
         new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        # bf16 storage: as in the BatchNorm stack - bf16 token tensors inside, fp32 out of the last layer
+        dt = src.dtype
+        lowp = dt != torch.float32
+        newt = lambda *s: torch.empty(s, dtype=dt, device=dev)
         x_in = src.contiguous().view(m, d)
         pe_c = None if pe is None else pe.contiguous()
         block = USE_ATTN_BLOCK and abi.attn_block_supported(n, d, heads)
+        if lowp and not lowp_stack_supported(abi, layers, n, b, d):
+            raise NotImplementedError('bf16 storage: the fused stack needs d_model = 64, 4 heads, N <= 64')
         saved = []
         attn = None
+        out32 = None
         for li, layer in enumerate(layers):
             (w_in, b_in, w_o, b_o, g1, be1, w1, bb1, w2, bb2, g2, be2) = params[li * PER_LAYER:(li + 1) * PER_LAYER]
             ff = w1.shape[0]
             want = need_attn and li == nl - 1
             attn = new(b, heads, n, n) if want else None
             ast = new(b, heads, n, 2)
-            qkv = new(m, 3 * d)
-            out = torch.empty((n, b, heads, dh), dtype=torch.float32, device=dev)
-            y1 = new(m, d)
+            qkv = newt(m, 3 * d)
+            out = torch.empty((n, b, heads, dh), dtype=dt, device=dev)
+            if lowp and li == nl - 1:
+                out32 = new(n, b, heads, dh)
+            y1 = newt(m, d)
             if block:
                 abi.attn_block_fwd(b, n, scale, stream, tie_qk=tie, x=x_in, w_in=w_in, b_in=b_in, w_out=w_o,
                                    b_out=b_o, pe=pe_c, n_real=n_real, rowscale=degree_rows, qkv=qkv, out=out,
                                    attn_stats=ast, attn=attn, y=y1, y_stats=new(b, 2, d),   # (statistics unused)
+                                   out_f32=(out32 if li == nl - 1 else None),
                                    sums=(pending.take_fwd() if (pending is not None and li == 0) else ()))
             else:
                 dsc = abi.rowlin_ex(m, d, 3 * d, x=x_in, w=w_in, bias=b_in, y=qkv)
@@ -498,9 +520,9 @@ class FusedLayerNormStackFn(torch.autograd.Function):
                 dsc = abi.rowlin_ex(m, d, d, x=out.view(m, d), w=w_o, bias=b_o, rowscale=degree_rows,
                                     residual=x_in, y=y1)
                 abi.rowlin_fwd_ex(dsc, stream)
-            x1, lst1 = new(m, d), new(m, 2)
+            x1, lst1 = newt(m, d), new(m, 2)
             abi.layernorm_fwd(y1, g1, be1, float(layer.norm1.eps), x1, lst1, stream)
-            h, y2 = new(m, ff), new(m, d)
+            h, y2 = newt(m, ff), newt(m, d)
             if USE_FFN_FUSED and abi.ffn_supported(d, ff):
                 abi.ffn_fwd(m, ff, stream, x=x1, w1=w1, b1=bb1, w2=w2, b2=bb2, h=h, y=y2,
                             coeff=_coeff_fwd_role(pending, li, nl, attn, n_real))
@@ -509,7 +531,7 @@ class FusedLayerNormStackFn(torch.autograd.Function):
                 abi.rowlin_fwd_ex(dsc, stream)
                 dsc = abi.rowlin_ex(m, ff, d, x=h, w=w2, bias=bb2, residual=x1, y=y2)
                 abi.rowlin_fwd_ex(dsc, stream)
-            x2, lst2 = new(m, d), new(m, 2)
+            x2, lst2 = (new(m, d) if li == nl - 1 else newt(m, d)), new(m, 2)   # (the stack's output is fp32)
             abi.layernorm_fwd(y2, g2, be2, float(layer.norm2.eps), x2, lst2, stream)
             saved.append(dict(x0=x_in, qkv=qkv, out=out, ast=ast, y1=y1, lst1=lst1, x1=x1, h=h, y2=y2, lst2=lst2))
             x_in = x2
@@ -520,7 +542,7 @@ class FusedLayerNormStackFn(torch.autograd.Function):
         ctx.owner = layers[0] if len(layers) else None
         if attn is not None:
             ctx.mark_non_differentiable(attn)
-        concat_last = saved[-1]['out'].view(n, b, d)
+        concat_last = (out32 if lowp else saved[-1]['out']).view(n, b, d)
         # (a fresh tensor object for the output: the saved x2 of the last layer is not handed out)
         return x_in.view(n, b, d), concat_last, attn
 
@@ -532,12 +554,13 @@ class FusedLayerNormStackFn(torch.autograd.Function):
         abi, stream = _lib.backend(saved[0]['qkv'])
         m = n * b
         dev = saved[0]['qkv'].device
+        dt = saved[0]['qkv'].dtype
         new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        newt = lambda *s: torch.empty(s, dtype=dt, device=dev)
         GL = abi.layernorm_blocks(m)
         grads = [None] * len(params)
         ff0 = params[6].shape[0]
-        fused_attn = (USE_ATTN_BLOCK_BWD and not tie and abi.attn_block_bwd_supported(n, d, heads)
-                      and abi.attn_block_bwd_blocks(b) > 0)
+        fused_attn = _fused_attn_bwd(abi, b, n, d, heads, tie, dt)
         part_f, part_a, tf, ta, wslot = _partial_buffers(abi, new, m, b, n, d, heads, ff0, nl, fused_attn)
         coeff_req = _coeff_bwd_request(ctx, abi, stream, d, params[(nl - 1) * PER_LAYER + 6].shape[0])
         total = tf + ta
@@ -546,7 +569,7 @@ class FusedLayerNormStackFn(torch.autograd.Function):
         ln_tail = dwdb_all[total:].view(nl, 4, d)   # dgamma1, dbeta1, dgamma2, dbeta2 per layer
 
         def ln_bwd(dout, y, stats, gamma, li, which):
-            dy = new(m, d)
+            dy = newt(m, d)
             abi.layernorm_bwd(dout, y, stats, gamma, dy, None, None, stream, partial_ld=nl * 4 * d,
                               partial_ptr=ln_part.data_ptr() + 4 * (li * 4 + 2 * which) * d)
             return dy
@@ -554,6 +577,8 @@ class FusedLayerNormStackFn(torch.autograd.Function):
         slots = {}
         if d_final is None:
             d_final = torch.zeros(n, b, d, dtype=torch.float32, device=dev)
+        if dt != torch.float32 and d_final.dtype != torch.float32:
+            d_final = d_final.float()
         dcur = d_final.contiguous().view(m, d)
         for li in range(nl - 1, -1, -1):
             s = saved[li]
@@ -566,7 +591,7 @@ class FusedLayerNormStackFn(torch.autograd.Function):
             slots[base + 8] = (off, d, ff)
             pp1, off1 = wslot('f', ff, d)
             slots[base + 6] = (off1, ff, d)
-            dx1 = new(m, d)
+            dx1 = newt(m, d)
             if USE_FFN_BWD and abi.ffn_bwd_supported(d, ff):
                 # linear2 + linear1 backward in one launch (csrc/ffn_bwd.hip), dx1 = dy2 + dh W1
                 abi.ffn_bwd(m, ff, stream, coeff=(coeff_req if li == nl - 1 else None), partial_ptr=pp, partial_ld=tf,
@@ -589,7 +614,7 @@ class FusedLayerNormStackFn(torch.autograd.Function):
             d2 = d_concat_last if (li == nl - 1 and d_concat_last is not None) else None
             if fused_attn:
                 # out_proj + attention + in_proj backward in one launch, one workgroup per graph (csrc/block_bwd.hip)
-                dx0 = new(m, d)
+                dx0 = newt(m, d)
                 abi.attn_block_bwd(b, n, scale, stream, partial_ptr=ppo, partial_ld=ta, dy=dy1, rowscale=degree_rows,
                                    w_out=w_o, w_in=w_in, qkv=s['qkv'], out=s['out'],
                                    dout2=None if d2 is None else d2.contiguous().view(m, d), pe=pe_c, n_real=n_real,

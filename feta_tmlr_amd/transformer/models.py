@@ -132,7 +132,8 @@ class DiffTransformerEncoderGenGCN(nn.Module):
             graph, mode = (cache.u, cache.lam), 'spec'
         y, coeff = FF.filter_from_pooled(out_each_head, pooled, self.linear.weight, self.linear.bias,
                                          self.spectral_gnns.bias, cache.n_real, graph, mode, self.order,
-                                         self.heads_share_graph, pending=pending)
+                                         self.heads_share_graph, pending=pending,
+                                         gemm_bf16=self.storage_dtype != torch.float32)
         return coeff.reshape(h, bsz, -1), y.permute(1, 0, 2, 3).reshape(n, bsz, h * dh)
 
     # -- A3 ---------------------------------------------------------------------------------

@@ -145,6 +145,14 @@ int feta_lin_fwd(const float* x, const float* w, const float* bias, float* y, in
                  feta_stream_t stream);
 int feta_lin_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int R, int K,
                  int N, const feta_colsum_seg* segs, int nseg, feta_stream_t stream);
+/* the same with a compute type (ABI 7): FETA_BF16 = the fp32 operands are rounded to bf16 when they are staged and the
+ * products run on v_mfma_f32_16x16x16_bf16 with fp32 accumulation (bf16 storage legs); outputs, bias gradient and the
+ * pending column sums stay fp32.  Shapes whose dims are multiples of 64 (256 for K, N) take the LDS-tiled kernels -
+ * one GFLOP per product at the BASELINE shape (R = 512, K = N = C = 1024), where they replace the library GEMMs. */
+int feta_lin_fwd_ex(const float* x, const float* w, const float* bias, float* y, int R, int K, int N, int compute,
+                    feta_stream_t stream);
+int feta_lin_bwd_ex(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int R, int K,
+                    int N, const feta_colsum_seg* segs, int nseg, int compute, feta_stream_t stream);
 
 /* ---- A3: dynamic Chebyshev filter, direct recursion on a dense scaled Laplacian ----
  * Replaces ChebConvDynamic.forward + __norm__ (transformer/ChebNetDynamic.py:108-189)
@@ -416,7 +424,8 @@ int feta_attn_block_fwd_sums(const feta_attn_block* d, const feta_colsum_seg* se
  *   dq|dk|dv from q|k|v (qkv [M,192]), out [M,64], pe, attn_stats (feta_attn_bwd's arithmetic);
  *   dx [M,64] = dqkv W_in + g1;  sum_out (nullable) [2 * feta_attn_block_bwd_blocks(B)][2][64]: partial
  *        (sum dx, sum dx * xhat0), xhat0 from x0 (pre-norm) and bn0 [4][64];
- *   partial: one row per workgroup (feta_attn_block_bwd_blocks(B) rows, pitch partial_ld, 0: 4*64*64 + 4*64),
+ *   partial: one row per workgroup (feta_attn_block_bwd_blocks(B) rows: one workgroup per graph up to 256 graphs, beyond
+ *        that the workgroups walk several graphs and add into their row; pitch partial_ld, 0: 4*64*64 + 4*64),
  *        columns [dW_out (64 x 64) | db_out (64) | dW_in (192 x 64) | db_in (192)], reduced by the caller;
  *        dW_in contracts dqkv with x0 seen through bn0 (scale, shift rows) when given.
  * Rows are addressed as in feta_attn_block: row(b, i) = b*row_sb + i*row_sn. */
@@ -579,6 +588,14 @@ int feta_layernorm_fwd(const float* y, const float* gamma, const float* beta, fl
 int feta_layernorm_bwd(const float* dout, const float* y, const float* stats, const float* gamma,
                        float* dy, float* partial, int partial_ld, float* dgamma_dbeta, int M, int D,
                        feta_stream_t stream);
+/* the same kernels with a storage type per tensor (FETA_F32 | FETA_BF16; ABI 7): the LayerNorm stack on bf16 storage
+ * normalises bf16 rows into bf16 rows (fp32 into the filter stage behind the last layer), statistics and the
+ * dgamma / dbeta partials stay fp32. */
+int feta_layernorm_fwd_ex(const void* y, const float* gamma, const float* beta, float eps, void* out,
+                          float* stats, int M, int D, int y_dtype, int out_dtype, feta_stream_t stream);
+int feta_layernorm_bwd_ex(const void* dout, const void* y, const float* stats, const float* gamma,
+                          void* dy, float* partial, int partial_ld, float* dgamma_dbeta, int M, int D,
+                          int dout_dtype, int y_dtype, int dy_dtype, feta_stream_t stream);
 
 /* ---- spectrum producer ------------------------------------------------
  * Batched symmetric eigendecomposition, one workgroup per graph, the matrix in LDS (N <= 192) or, for

@@ -475,22 +475,25 @@ def check_colsum_multi_mixed(abi, dev, stream, seed=0):
     assert_close('small', o_small, small.double().sum(0))
 
 
-def check_lin(abi, dev, stream, r, k, n, seed=0, with_dx=True, segs=((40, 16), (9, 2048 + 64), (70, 100))):
+def check_lin(abi, dev, stream, r, k, n, seed=0, with_dx=True, segs=((40, 16), (9, 2048 + 64), (70, 100)), bf16=False):
     """feta_lin_fwd / feta_lin_bwd (csrc/lin.hip) against float64: y = x w^T + b; dx, dw, db in one launch together
-    with pending column sums (tall, few-rows-many-columns and odd-width segments)."""
+    with pending column sums (tall, few-rows-many-columns and odd-width segments).  bf16: the bf16 compute type
+    (feta_lin_*_ex) on bf16-representable operands - their products are exact in fp32, so the fp32 bound holds."""
     g = torch.Generator().manual_seed(seed)
     x, w, b, dy = torch.randn(r, k, generator=g), torch.randn(n, k, generator=g) / k ** 0.5, torch.randn(n, generator=g), \
         torch.randn(r, n, generator=g)
+    if bf16:
+        x, w, dy = (t.to(BF16).float() for t in (x, w, dy))
     assert abi.lin_supported(r, k, n)
     nan = lambda *s: torch.full(s, float('nan'), device=dev)
     xd, wd, bd, dyd = x.to(dev), w.to(dev), b.to(dev), dy.to(dev)
     y = nan(r, n)
-    abi.lin_fwd(xd, wd, bd, y, stream)
+    abi.lin_fwd(xd, wd, bd, y, stream, bf16=bf16)
     errs = {'y': assert_close('lin y', y, x.double() @ w.double().t() + b.double(), tol=2e-6)}
     dx, dw, db = (nan(r, k) if with_dx else None), nan(n, k), nan(n)
     ins = [torch.randn(sr, sc, generator=g) for sr, sc in segs]
     outs = [nan(sc) for _, sc in segs]
-    abi.lin_bwd(xd, wd, dyd, dx, dw, db, stream, pairs=[(i.to(dev), o) for i, o in zip(ins, outs)])
+    abi.lin_bwd(xd, wd, dyd, dx, dw, db, stream, pairs=[(i.to(dev), o) for i, o in zip(ins, outs)], bf16=bf16)
     if with_dx:
         errs['dx'] = assert_close('lin dx', dx, dy.double() @ w.double(), tol=2e-6)
     # (a fp32 accumulation chain over r terms: the rounding error grows ~ sqrt(r))

@@ -24,11 +24,21 @@ def test_bench_step_matches_oracle(emu, mode, share, two_phase):
                         replays=1, two_phase=two_phase)
 
 
-@pytest.mark.parametrize('share', [True, False])
-def test_bench_step_bf16_matches_oracle(emu, share):
-    """--dtype bf16 (BASELINE configs 3 / 5): bf16 storage, bf16 MFMA, fp32 statistics and master weights"""
-    errs, _ = BC.check_bench_step(CPU, lambda: _lib.override_for_tests(emu), SMALL + ['--dtype', 'bf16'],
-                                  share=share, replays=1)
+@pytest.mark.parametrize('share,extra', [(True, []), (False, []), (True, ['--layer-norm']), (True, ['--two-phase'])])
+def test_bench_step_bf16_matches_oracle(emu, share, extra):
+    """--dtype bf16 (BASELINE configs 3 / 5): bf16 storage, bf16 MFMA, fp32 statistics and master weights - the fused
+    stack's bf16 instantiations (BatchNorm and LayerNorm stacks, single-pass and split backward)"""
+    from feta_tmlr_amd import fused_stack
+    calls = []
+    orig_bn, orig_ln = fused_stack.FusedEncoderStackFn.apply, fused_stack.FusedLayerNormStackFn.apply
+    fused_stack.FusedEncoderStackFn.apply = staticmethod(lambda *a: (calls.append(a[0].dtype), orig_bn(*a))[1])
+    fused_stack.FusedLayerNormStackFn.apply = staticmethod(lambda *a: (calls.append(a[0].dtype), orig_ln(*a))[1])
+    try:
+        errs, _ = BC.check_bench_step(CPU, lambda: _lib.override_for_tests(emu), SMALL + ['--dtype', 'bf16'] + extra,
+                                      share=share, replays=1)
+    finally:
+        fused_stack.FusedEncoderStackFn.apply, fused_stack.FusedLayerNormStackFn.apply = orig_bn, orig_ln
+    assert calls and all(dt == torch.bfloat16 for dt in calls), 'the bf16 leg did not take the fused stack: %s' % calls
     print({k: '%.2e' % v for k, v in errs.items()})
 
 

@@ -229,3 +229,21 @@ def test_ffn_fwd_bf16(emu, kw):
 @pytest.mark.parametrize('kw', [dict(), dict(m=70, ff=64, with_bn=False), dict(m=300, ff=128, seed=3)])
 def test_ffn_bwd_bf16(emu, kw):
     KC.check_ffn_bwd_lp(emu, CPU, None, **kw)
+
+
+@pytest.mark.parametrize('dtype_check', ['bf16'])
+def test_attn_block_bwd_walks_several_graphs(emu, monkeypatch, dtype_check):
+    """more graphs than workgroups (FETA_BLOCK_BWD_MAX_GRID): a workgroup adds every graph it walks to its own partial
+    row and keeps the BatchNorm partial sums in registers"""
+    monkeypatch.setenv('FETA_BLOCK_BWD_MAX_GRID', '2')
+    KC.check_attn_block_bwd_lp(emu, CPU, None, bsz=5, n_pad=21, n_min=3, with_bn=True)
+    KC.check_attn_block_bwd_lp(emu, CPU, None, bsz=4, n_pad=37, n_min=9, with_pe=False)
+
+
+@pytest.mark.parametrize('r,k,n,with_dx,bf16', [(64, 256, 256, True, False), (128, 256, 512, True, True),
+                                                (64, 512, 256, False, False)])
+def test_lin_gemm_tiled(emu, monkeypatch, r, k, n, with_dx, bf16):
+    """the LDS-tiled kernels of csrc/lin.hip (the form the BASELINE shape R = 512, K = N = 1024 takes), forced at small
+    shapes: forward, dX and dW roles interleaved in one launch, fp32 row sums for db, pending column sums"""
+    monkeypatch.setenv('FETA_LIN_TILED', '2')
+    KC.check_lin(emu, CPU, None, r, k, n, with_dx=with_dx, bf16=bf16)

@@ -258,3 +258,14 @@ def test_ffn_fwd_bf16(hip, kw):
 def test_ffn_bwd_bf16(hip, kw):
     abi, dev, stream = hip
     KC.check_ffn_bwd_lp(abi, dev, stream, **kw)
+
+
+@pytest.mark.parametrize('r,k,n,with_dx,bf16', [(512, 1024, 1024, True, False), (512, 1024, 1024, True, True),
+                                                (64, 256, 256, True, False), (1024, 256, 512, False, True),
+                                                (4096, 1024, 1024, True, False)])
+def test_lin_gemm_tiled(hip, monkeypatch, r, k, n, with_dx, bf16):
+    """the LDS-tiled kernels of csrc/lin.hip at the BASELINE shape of ``self.linear`` (transformer/models.py:145,284:
+    R = H*B = 512 rows, C = 1024) in both compute types, at the smallest shape they take and at a large batch"""
+    monkeypatch.setenv('FETA_LIN_TILED', '2')
+    abi, dev, stream = hip
+    KC.check_lin(abi, dev, stream, r, k, n, with_dx=with_dx, bf16=bf16)

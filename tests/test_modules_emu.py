@@ -430,6 +430,7 @@ def test_attn_block_walks_several_graphs_per_workgroup(emu, monkeypatch):
     """large batches: a workgroup of the fused attention block stages the weights once and loops over its
     graphs; forced here with 2 workgroups for 5 graphs"""
     monkeypatch.setenv('FETA_BLOCK_MAX_GRID', '2')
+    monkeypatch.setenv('FETA_BLOCK_BWD_MAX_GRID', '2')     # (the backward block as well: partial rows accumulate)
     monkeypatch.setenv('FETA_FFN_MAX_GRID', '3')
     check_attn_block_equals_three_launches(CPU, lambda: _lib.override_for_tests(emu), monkeypatch, 'zinc',
                                            9, 30, False, True, bsz=5)

@@ -48,6 +48,7 @@ def main():
     ap.add_argument('--n-pad', type=int, default=37)
     ap.add_argument('--kernel', choices=sorted(KERNELS), default='fwd')
     ap.add_argument('--split', action='store_true', help='bwd: the two-workgroups-per-graph form')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help='storage type of the token tensors')
     ap.add_argument('--build-only', action='store_true')
     ap.add_argument('--lib', default=OUT, help='a diagnostic build to load instead (A/B timing of an older source)')
     a = ap.parse_args()
@@ -69,7 +70,8 @@ def main():
     s2 = torch.cuda.Stream()
     with torch.cuda.stream(s2):
         st = s2.cuda_stream
-        fn = {nm: f for nm, _, f, _, _ in stack_layer_cases(abi, st, dev, b, n, d, h, 2 * d, pe, nr)}[case]
+        fn = {nm: f for nm, _, f, _, _ in stack_layer_cases(abi, st, dev, b, n, d, h, 2 * d, pe, nr,
+                                                           dtype=torch.bfloat16 if a.dtype == 'bf16' else torch.float32)}[case]
         for _ in range(5):
             fn()
         torch.cuda.synchronize()

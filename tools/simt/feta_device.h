@@ -12,6 +12,9 @@ struct f32x4 {
 
 extern float* feta_lds;  // sized per launch, NaN-poisoned guard behind it (simt_runtime.cpp)
 
+#define FETA_OPAQUE_PTR(p) ((void)(p))
+typedef const float* feta_gcf;
+
 namespace feta {
 
 inline int lane_id() { return threadIdx.x & 63; }
