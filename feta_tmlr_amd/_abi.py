@@ -71,6 +71,11 @@ SIGNATURES.update({
     'feta_attn_bwd_drop': ([_F, _F, _F, C.c_int64, C.c_int64, _F, _I, _F, _F, C.c_int64, C.c_int64, _F, _F, _F, _F, _F,
                             C.c_float, C.c_float, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                             _S], C.c_int),
+    'feta_attn_fwd_drop_dev': ([_F, _F, _F, C.c_int64, C.c_int64, _F, _I, _F, C.c_int64, C.c_int64, _F, _F, C.c_float,
+                                C.c_float, _I, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _S], C.c_int),
+    'feta_attn_bwd_drop_dev': ([_F, _F, _F, C.c_int64, C.c_int64, _F, _I, _F, _F, C.c_int64, C.c_int64, _F, _F, _F, _F, _F,
+                                C.c_float, C.c_float, _I, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                _S], C.c_int),
     'feta_spec_filter_fwd_bf16': SIGNATURES['feta_spec_filter_fwd'],
     'feta_spec_filter_bwd_bf16': SIGNATURES['feta_spec_filter_bwd'],
 })
@@ -278,6 +283,15 @@ class Abi:
         sb, sn = tok_strides(q)
         assert tok_strides(k) == (sb, sn) and tok_strides(v) == (sb, sn)
         osb, osn = tok_strides(out)
+        if drop is not None and drop[0] > 0.0 and torch.is_tensor(drop[1]):
+            # device-resident key (functional.DropoutState in device mode): drop = (p, state int64[2], offset_add)
+            _same_dtype(q.dtype, k, v, pe, out, attn)
+            assert drop[1].dtype == torch.int64 and drop[1].numel() == 2 and drop[1].device == q.device
+            self._check(self.lib.feta_attn_fwd_drop_dev(_p(q), _p(k), _p(v), sb, sn, _p(pe), _p(n_real), _p(out), osb, osn,
+                                                        _p(attn), _p(stats), scale, float(drop[0]), _p(drop[1]),
+                                                        int(drop[2]), 1 if q.dtype == torch.bfloat16 else 0, b, n, h, dh,
+                                                        stream), 'feta_attn_fwd_drop_dev')
+            return
         if drop is not None and drop[0] > 0.0:
             _same_dtype(q.dtype, k, v, pe, out, attn)
             self._check(self.lib.feta_attn_fwd_drop(_p(q), _p(k), _p(v), sb, sn, _p(pe), _p(n_real), _p(out), osb, osn,
@@ -307,6 +321,15 @@ class Abi:
             assert tok_strides(t) == (sb, sn)
         osb, osn = tok_strides(out)
         assert tok_strides(dout) == (osb, osn)
+        if drop is not None and drop[0] > 0.0 and torch.is_tensor(drop[1]):
+            _same_dtype(q.dtype, k, v, pe, out, dout, dq, dk, dv)
+            assert dout2 is None
+            self._check(self.lib.feta_attn_bwd_drop_dev(_p(q), _p(k), _p(v), sb, sn, _p(pe), _p(n_real), _p(out), _p(dout),
+                                                        osb, osn, _p(stats), _p(delta), _p(dq), _p(dk), _p(dv), scale,
+                                                        float(drop[0]), _p(drop[1]), int(drop[2]),
+                                                        1 if q.dtype == torch.bfloat16 else 0, b, n, h, dh, stream),
+                        'feta_attn_bwd_drop_dev')
+            return
         if drop is not None and drop[0] > 0.0:
             _same_dtype(q.dtype, k, v, pe, out, dout, dq, dk, dv)
             assert dout2 is None

@@ -43,7 +43,21 @@ struct AttnArgsT {
   unsigned drop_thresh;   // keep iff bits >= drop_thresh; 0 = no dropout
   float drop_scale;       // 1 / (1 - p)
   unsigned seed_lo, seed_hi, off_lo, off_hi;
+  // device-resident (seed, offset) (feta_attn_*_drop_dev): when given, the mask is keyed by dstate[0] and counted from
+  // dstate[1] + (off_hi, off_lo) - read at RUN time, so a captured hipGraph draws a fresh mask on every replay
+  const unsigned long long* dstate;
 };
+
+// (kernel arguments are a by-value copy: the device-resident key is patched into it once per wave, scalar loads)
+template <class A>
+__device__ __forceinline__ void resolve_drop_state(A& a) {
+  if (a.dstate != nullptr) {
+    const unsigned long long seed = a.dstate[0];
+    const unsigned long long off = a.dstate[1] + (((unsigned long long)a.off_hi << 32) | a.off_lo);
+    a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32);
+    a.off_lo = (unsigned)off; a.off_hi = (unsigned)(off >> 32);
+  }
+}
 
 __device__ __forceinline__ unsigned mulhi32(unsigned a, unsigned b) {
   return (unsigned)(((unsigned long long)a * (unsigned long long)b) >> 32);
@@ -77,6 +91,7 @@ __device__ __forceinline__ void drop_scales(const A& a, int bh, int q, int kg, f
 // ---- forward: one wave per (b, h, 16-query block), S^T in registers ------------------------------------------
 template <class T, int DH, int KT_MAX>
 __global__ __launch_bounds__(64 * kLWaves) void attn_fwd_lp_kernel(AttnArgsT<T> a) {
+  resolve_drop_state(a);
   constexpr int CT = Feat<DH>::CT;
   constexpr int KP = 16 * KT_MAX + 1;
   const int lane = lane_id(), lq = lane & 15, g = lane >> 4;
@@ -204,6 +219,7 @@ __global__ __launch_bounds__(64 * kLWaves) void attn_fwd_lp_kernel(AttnArgsT<T> 
 // ---- dq for one 16-query block (+ delta = rowsum(dout * out)) -------------------------------------------------
 template <class T, int DH>
 __global__ __launch_bounds__(64 * kLWaves) void attn_bwd_dq_lp_kernel(AttnArgsT<T> a) {
+  resolve_drop_state(a);
   constexpr int CT = Feat<DH>::CT;
   const int lane = lane_id(), lq = lane & 15, g = lane >> 4;
   const int item = blockIdx.x * kLWaves + wave_id();
@@ -291,6 +307,7 @@ __global__ __launch_bounds__(64 * kLWaves) void attn_bwd_dq_lp_kernel(AttnArgsT<
 // ---- dk, dv for one 16-key block (rows = queries, column = key) ---------------------------------------------------
 template <class T, int DH>
 __global__ __launch_bounds__(64 * kLWaves) void attn_bwd_dkdv_lp_kernel(AttnArgsT<T> a) {
+  resolve_drop_state(a);
   constexpr int CT = Feat<DH>::CT;
   const int lane = lane_id(), lq = lane & 15, g = lane >> 4;
   const int item = blockIdx.x * kLWaves + wave_id();
@@ -918,7 +935,8 @@ extern "C" int feta_attn_bwd_bf16(const void* q, const void* k, const void* v, i
 
 namespace {
 template <class T>
-void set_drop(AttnArgsT<T>& a, float p_drop, uint64_t seed, uint64_t offset) {
+void set_drop(AttnArgsT<T>& a, float p_drop, uint64_t seed, uint64_t offset, const uint64_t* dstate = nullptr) {
+  a.dstate = reinterpret_cast<const unsigned long long*>(dstate);
   if (p_drop > 0.0f) {
     const double t = (double)p_drop * 4294967296.0;
     a.drop_thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)t;
@@ -935,12 +953,13 @@ void set_drop(AttnArgsT<T>& a, float p_drop, uint64_t seed, uint64_t offset) {
 template <class T>
 int attn_fwd_drop_t(const void* q, const void* k, const void* v, int64_t qkv_sb, int64_t qkv_sn, const void* pe,
                     const int32_t* n_real, void* out, int64_t o_sb, int64_t o_sn, void* attn, float* stats, float scale,
-                    float p_drop, uint64_t seed, uint64_t offset, int B, int N, int H, int dh, hipStream_t stream) {
+                    float p_drop, uint64_t seed, uint64_t offset, int B, int N, int H, int dh, hipStream_t stream,
+                    const uint64_t* dstate = nullptr) {
   AttnArgsT<T> a{};
   a.q = (const T*)q; a.k = (const T*)k; a.v = (const T*)v; a.pe = (const T*)pe; a.n_real = n_real;
   a.out_w = (T*)out; a.attn = (T*)attn; a.stats = stats; a.qsb = qkv_sb; a.qsn = qkv_sn; a.osb = o_sb;
   a.osn = o_sn; a.scale = scale; a.B = B; a.N = N; a.H = H; a.NB = (N + 15) / 16; a.total = B * H * a.NB;
-  set_drop(a, p_drop, seed, offset);
+  set_drop(a, p_drop, seed, offset, dstate);
   switch (dh) {
     case 16: return launch_attn_fwd_lp<T, 16>(a, stream);
     case 32: return launch_attn_fwd_lp<T, 32>(a, stream);
@@ -953,13 +972,14 @@ template <class T>
 int attn_bwd_drop_t(const void* q, const void* k, const void* v, int64_t qkv_sb, int64_t qkv_sn, const void* pe,
                     const int32_t* n_real, const void* out, const void* dout, int64_t o_sb, int64_t o_sn,
                     const float* stats, float* delta, void* dq, void* dk, void* dv, float scale, float p_drop,
-                    uint64_t seed, uint64_t offset, int B, int N, int H, int dh, hipStream_t stream) {
+                    uint64_t seed, uint64_t offset, int B, int N, int H, int dh, hipStream_t stream,
+                    const uint64_t* dstate = nullptr) {
   AttnArgsT<T> a{};
   a.q = (const T*)q; a.k = (const T*)k; a.v = (const T*)v; a.pe = (const T*)pe; a.n_real = n_real;
   a.out = (const T*)out; a.dout = (const T*)dout; a.stats_in = stats; a.delta = delta;
   a.dq = (T*)dq; a.dk = (T*)dk; a.dv = (T*)dv; a.qsb = qkv_sb; a.qsn = qkv_sn; a.osb = o_sb; a.osn = o_sn;
   a.scale = scale; a.B = B; a.N = N; a.H = H; a.NB = (N + 15) / 16; a.total = B * H * a.NB;
-  set_drop(a, p_drop, seed, offset);
+  set_drop(a, p_drop, seed, offset, dstate);
   switch (dh) {
     case 16: return launch_attn_bwd_lp<T, 16>(a, stream);
     case 32: return launch_attn_bwd_lp<T, 32>(a, stream);
@@ -969,10 +989,10 @@ int attn_bwd_drop_t(const void* q, const void* k, const void* v, int64_t qkv_sb,
 }
 }  // namespace
 
-extern "C" int feta_attn_fwd_drop(const void* q, const void* k, const void* v, int64_t qkv_sb, int64_t qkv_sn,
+static int attn_fwd_drop_any(const void* q, const void* k, const void* v, int64_t qkv_sb, int64_t qkv_sn,
                                   const void* pe, const int32_t* n_real, void* out, int64_t o_sb, int64_t o_sn,
                                   void* attn, float* stats, float scale, float p_drop, uint64_t seed, uint64_t offset,
-                                  int dtype, int B, int N, int H, int dh, feta_stream_t stream) {
+                                  int dtype, int B, int N, int H, int dh, feta_stream_t stream, const uint64_t* dstate) {
   FETA_REQUIRE(q && k && v && n_real && out && stats, "attn_fwd_drop: null pointer");
   FETA_REQUIRE(B > 0 && H > 0 && N >= 1 && N <= FETA_MAX_NODES, "attn_fwd_drop: N=%d outside [1,%d]", N, FETA_MAX_NODES);
   FETA_REQUIRE(dh == 16 || dh == 32 || dh == 64, "attn_fwd_drop: head dim %d not in {16,32,64}", dh);
@@ -984,16 +1004,33 @@ extern "C" int feta_attn_fwd_drop(const void* q, const void* k, const void* v, i
                "attn_fwd_drop: misaligned token tensors / strides");
   if (dtype == FETA_DTYPE_F32)
     return attn_fwd_drop_t<float>(q, k, v, qkv_sb, qkv_sn, pe, n_real, out, o_sb, o_sn, attn, stats, scale, p_drop, seed,
-                                  offset, B, N, H, dh, (hipStream_t)stream);
+                                  offset, B, N, H, dh, (hipStream_t)stream, dstate);
   return attn_fwd_drop_t<bf16_t>(q, k, v, qkv_sb, qkv_sn, pe, n_real, out, o_sb, o_sn, attn, stats, scale, p_drop, seed,
-                                 offset, B, N, H, dh, (hipStream_t)stream);
+                                 offset, B, N, H, dh, (hipStream_t)stream, dstate);
 }
 
-extern "C" int feta_attn_bwd_drop(const void* q, const void* k, const void* v, int64_t qkv_sb, int64_t qkv_sn,
+extern "C" int feta_attn_fwd_drop(const void* q, const void* k, const void* v, int64_t qkv_sb, int64_t qkv_sn,
+                                  const void* pe, const int32_t* n_real, void* out, int64_t o_sb, int64_t o_sn,
+                                  void* attn, float* stats, float scale, float p_drop, uint64_t seed, uint64_t offset,
+                                  int dtype, int B, int N, int H, int dh, feta_stream_t stream) {
+  return attn_fwd_drop_any(q, k, v, qkv_sb, qkv_sn, pe, n_real, out, o_sb, o_sn, attn, stats, scale, p_drop, seed, offset,
+                           dtype, B, N, H, dh, stream, nullptr);
+}
+
+extern "C" int feta_attn_fwd_drop_dev(const void* q, const void* k, const void* v, int64_t qkv_sb, int64_t qkv_sn,
+                                      const void* pe, const int32_t* n_real, void* out, int64_t o_sb, int64_t o_sn,
+                                      void* attn, float* stats, float scale, float p_drop, const uint64_t* state,
+                                      uint64_t offset_add, int dtype, int B, int N, int H, int dh, feta_stream_t stream) {
+  FETA_REQUIRE(state != nullptr, "attn_fwd_drop_dev: null state");
+  return attn_fwd_drop_any(q, k, v, qkv_sb, qkv_sn, pe, n_real, out, o_sb, o_sn, attn, stats, scale, p_drop, 0, offset_add,
+                           dtype, B, N, H, dh, stream, state);
+}
+
+static int attn_bwd_drop_any(const void* q, const void* k, const void* v, int64_t qkv_sb, int64_t qkv_sn,
                                   const void* pe, const int32_t* n_real, const void* out, const void* dout,
                                   int64_t o_sb, int64_t o_sn, const float* stats, float* delta, void* dq, void* dk,
                                   void* dv, float scale, float p_drop, uint64_t seed, uint64_t offset, int dtype,
-                                  int B, int N, int H, int dh, feta_stream_t stream) {
+                                  int B, int N, int H, int dh, feta_stream_t stream, const uint64_t* dstate) {
   FETA_REQUIRE(q && k && v && n_real && out && dout && stats && delta && dq && dk && dv, "attn_bwd_drop: null pointer");
   FETA_REQUIRE(B > 0 && H > 0 && N >= 1 && N <= FETA_MAX_NODES, "attn_bwd_drop: N=%d outside [1,%d]", N, FETA_MAX_NODES);
   FETA_REQUIRE(dh == 16 || dh == 32 || dh == 64, "attn_bwd_drop: head dim %d not in {16,32,64}", dh);
@@ -1003,9 +1040,28 @@ extern "C" int feta_attn_bwd_drop(const void* q, const void* k, const void* v, i
                "attn_bwd_drop: strides %% 4 == 0");
   if (dtype == FETA_DTYPE_F32)
     return attn_bwd_drop_t<float>(q, k, v, qkv_sb, qkv_sn, pe, n_real, out, dout, o_sb, o_sn, stats, delta, dq, dk, dv,
-                                  scale, p_drop, seed, offset, B, N, H, dh, (hipStream_t)stream);
+                                  scale, p_drop, seed, offset, B, N, H, dh, (hipStream_t)stream, dstate);
   return attn_bwd_drop_t<bf16_t>(q, k, v, qkv_sb, qkv_sn, pe, n_real, out, dout, o_sb, o_sn, stats, delta, dq, dk, dv,
-                                 scale, p_drop, seed, offset, B, N, H, dh, (hipStream_t)stream);
+                                 scale, p_drop, seed, offset, B, N, H, dh, (hipStream_t)stream, dstate);
+}
+
+extern "C" int feta_attn_bwd_drop(const void* q, const void* k, const void* v, int64_t qkv_sb, int64_t qkv_sn,
+                                  const void* pe, const int32_t* n_real, const void* out, const void* dout,
+                                  int64_t o_sb, int64_t o_sn, const float* stats, float* delta, void* dq, void* dk,
+                                  void* dv, float scale, float p_drop, uint64_t seed, uint64_t offset, int dtype,
+                                  int B, int N, int H, int dh, feta_stream_t stream) {
+  return attn_bwd_drop_any(q, k, v, qkv_sb, qkv_sn, pe, n_real, out, dout, o_sb, o_sn, stats, delta, dq, dk, dv, scale,
+                           p_drop, seed, offset, dtype, B, N, H, dh, stream, nullptr);
+}
+
+extern "C" int feta_attn_bwd_drop_dev(const void* q, const void* k, const void* v, int64_t qkv_sb, int64_t qkv_sn,
+                                      const void* pe, const int32_t* n_real, const void* out, const void* dout,
+                                      int64_t o_sb, int64_t o_sn, const float* stats, float* delta, void* dq, void* dk,
+                                      void* dv, float scale, float p_drop, const uint64_t* state, uint64_t offset_add,
+                                      int dtype, int B, int N, int H, int dh, feta_stream_t stream) {
+  FETA_REQUIRE(state != nullptr, "attn_bwd_drop_dev: null state");
+  return attn_bwd_drop_any(q, k, v, qkv_sb, qkv_sn, pe, n_real, out, dout, o_sb, o_sn, stats, delta, dq, dk, dv, scale,
+                           p_drop, 0, offset_add, dtype, B, N, H, dh, stream, state);
 }
 
 static int spec_args_bf16(FilterArgsT<bf16_t>& a, const void* x, int64_t x_sb, int64_t x_sn, const void* u,

@@ -227,9 +227,12 @@ class _FilterFn(torch.autograd.Function):
 
 
 import os as _os
-# above this many multiply-adds per product the C x C linear runs as library GEMMs (A/B switch: since round 3 the
-# LDS-tiled kernels of csrc/lin.hip take the BASELINE shape, 2^29 MACs per product)
-LIN_OWN_GEMM_MAX_MACS = int(_os.environ.get('FETA_LIN_OWN_MAX_MACS', str(1 << 31)))
+# fp32 compute: above this many multiply-adds per product the C x C linear runs as library GEMMs.  Round 3 measured the
+# LDS-tiled fp32 kernels of csrc/lin.hip at the BASELINE shape (2^29 MACs per product) against them: forward 15.7 vs
+# 12.8 us, dX + dW (+ db + pending sums, one launch) 32.8 vs 25.8 us - the chip holds ~1.6 GHz under fp32 MFMA load, so
+# the floor is 10.2 / 20.4 us and the library sits at 80 % of it; FETA_LIN_OWN_MAX_MACS=2147483648 selects ours (A/B).
+# bf16 compute (bf16 storage legs) always takes the tiled kernels: 9.3 / 16.5 us, no cast launches.
+LIN_OWN_GEMM_MAX_MACS = int(_os.environ.get('FETA_LIN_OWN_MAX_MACS', str(1 << 27)))
 
 
 class PendingSums:
@@ -355,7 +358,7 @@ class FilterFromPooledFn(torch.autograd.Function):
         # csrc/lin.hip (one 16 x 16 tile per wave straight from L2, gradient products and column sums in one launch)
         # where the products are launch-bound; the library GEMM where they are compute-bound (C = 1024 at the
         # BASELINE shape: 1 GFLOP each, ~12 us at half the fp32 matrix peak; lin.hip is L2-bound there, 31 us)
-        ctx.own_gemm = abi.lin_supported(r_, k_, n_) and r_ * k_ * n_ <= LIN_OWN_GEMM_MAX_MACS
+        ctx.own_gemm = abi.lin_supported(r_, k_, n_) and (r_ * k_ * n_ <= LIN_OWN_GEMM_MAX_MACS or ctx.gemm_bf16)
         if ctx.own_gemm:
             coeff = torch.empty((pooled.shape[0], lin_w.shape[0]), dtype=torch.float32, device=pooled.device)
             abi.lin_fwd(pooled, lin_w, lin_b, coeff, stream, bf16=ctx.gemm_bf16)
@@ -674,20 +677,70 @@ def layer_norm_rows(y, gamma, beta, eps):
 class DropoutState:
     """(seed, offset) of the attention-probability dropout masks: every masked forward takes the next offset, so
     masks differ between layers and steps and are reproducible from the seed (the kernels derive the mask from
-    (seed, offset, b, h, query, key): include/feta_hip.h, feta_attn_fwd_drop)."""
+    (seed, offset, b, h, query, key): include/feta_hip.h, feta_attn_fwd_drop).
+
+    Host mode (default): (seed, offset) are Python ints handed to the kernels as arguments.
+    Device mode (begin_device_mode; used by train.GraphedTrainStep): the key lives in an int64[2] DEVICE tensor which
+    the kernels read when they RUN (feta_attn_*_drop_dev); call k of a step uses offset state[1] + k and the step
+    itself advances state[1] by its number of masked calls (end_step, a captured in-place add) - a hipGraph replay
+    therefore draws the masks the eager loop would have drawn at that step."""
     seed = None
     offset = 0
+    _dev = None      # int64 [seed, offset] on the device of the captured step
+    _calls = 0       # masked calls so far in the current step (device mode)
 
     @classmethod
     def manual_seed(cls, seed):
         cls.seed, cls.offset = int(seed) & (2 ** 63 - 1), 0
+        cls._sync_device()
+
+    @classmethod
+    def _sync_device(cls):
+        if cls._dev is not None:
+            cls._dev.copy_(torch.tensor([cls.seed, cls.offset], dtype=torch.int64))
+            cls._calls = 0
+
+    @classmethod
+    def device_mode(cls):
+        return cls._dev is not None
+
+    @classmethod
+    def begin_device_mode(cls, device):
+        if cls.seed is None:
+            cls.manual_seed(torch.initial_seed())
+        cls._dev = torch.tensor([cls.seed, cls.offset], dtype=torch.int64).to(device)
+        cls._calls = 0
+
+    @classmethod
+    def end_device_mode(cls):
+        cls._dev = None
+        cls._calls = 0
 
     @classmethod
     def next(cls):
+        """-> (seed, offset) as ints, or (state tensor, offset_add) in device mode"""
+        if cls._dev is not None:
+            cls._calls += 1
+            return cls._dev, cls._calls
         if cls.seed is None:
             cls.manual_seed(torch.initial_seed())
         cls.offset += 1
         return cls.seed, cls.offset
+
+    @classmethod
+    def end_step(cls):
+        """Device mode: advance the device offset by the masked calls of this step (an in-place add on the current
+        stream: part of the captured step); the host mirror follows.  -> number of calls"""
+        n, cls._calls = cls._calls, 0
+        if cls._dev is not None and n:
+            cls._dev[1:2].add_(n)
+            cls.offset += n
+        return n
+
+    @classmethod
+    def replayed(cls, n):
+        """A captured step that made n masked calls was replayed: the host mirror follows the device offset."""
+        cls.offset += n
 
     @classmethod
     def snapshot(cls):
@@ -696,15 +749,20 @@ class DropoutState:
     @classmethod
     def restore(cls, snap):
         cls.seed, cls.offset = snap
+        if cls.seed is not None:
+            cls._sync_device()
 
 
 def attention_core(qkv, pe, n_real, num_heads, need_attn=True, tie_qk=False, batch_first=False, dropout_p=0.0):
-    """dropout_p > 0: attention-probability dropout with a mask regenerated in backward (no mask tensor).  The
-    (seed, offset) are host values: a captured hipGraph would replay ONE mask, so dropout runs eagerly."""
+    """dropout_p > 0: attention-probability dropout with a mask regenerated in backward (no mask tensor).  The key
+    (seed, offset) is a pair of host values, or - DropoutState in device mode - a device tensor the kernels read when
+    they run, which is what makes the op capturable."""
     drop = None
     if dropout_p > 0.0:
-        if qkv.is_cuda and torch.cuda.is_current_stream_capturing():
-            raise RuntimeError('attention dropout inside a captured hipGraph would replay one fixed mask')
+        if qkv.is_cuda and torch.cuda.is_current_stream_capturing() and not DropoutState.device_mode():
+            raise RuntimeError('attention dropout inside a captured hipGraph would replay one fixed mask: capture with '
+                               'the key on the device (functional.DropoutState.begin_device_mode; '
+                               'train.GraphedTrainStep does)')
         drop = (float(dropout_p),) + DropoutState.next()
     return AttentionCoreFn.apply(qkv, pe, n_real, num_heads, need_attn, tie_qk, batch_first, drop)
 

@@ -164,6 +164,10 @@ class GraphedTrainStep:
                                        clone(graph_cache.lam), clone(graph_cache.lhat),
                                        {k: (v.clone() if torch.is_tensor(v) else v)
                                         for k, v in graph_cache.extra.items()})
+        # attention-probability dropout inside the graph: the (seed, offset) key moves to the device, every replay
+        # reads it there and advances it (functional.DropoutState) - the masks of replay i are those of eager step i
+        from .functional import DropoutState
+        DropoutState.begin_device_mode(batch9[0].device)
         snap = self._snapshot()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -226,6 +230,8 @@ class GraphedTrainStep:
                             padded_node_labels=self.task == 'sbm')
         loss.backward()
         self.optimizer.step()
+        from .functional import DropoutState
+        self.drop_calls = DropoutState.end_step()     # (in-graph: the device offset moves past this step's masks)
         return loss.detach()
 
     def set_lr(self, lr):
@@ -245,6 +251,9 @@ class GraphedTrainStep:
             if torch.is_tensor(dst):
                 dst.copy_(graph_cache.extra[key], non_blocking=True)
         self.graph.replay()
+        if self.drop_calls:
+            from .functional import DropoutState
+            DropoutState.replayed(self.drop_calls)
         return self.loss
 
 

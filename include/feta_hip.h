@@ -250,6 +250,18 @@ int feta_attn_bwd_drop(const void* q, const void* k, const void* v, int64_t qkv_
                        int64_t o_sb, int64_t o_sn, const float* stats, float* delta,
                        void* dq, void* dk, void* dv, float scale, float p_drop, uint64_t seed, uint64_t offset,
                        int dtype, int B, int N, int H, int dh, feta_stream_t stream);
+/* the same with the key DEVICE-RESIDENT (ABI 7): state = {seed, offset} (two uint64 in device memory), the mask of this
+ * call is the one of (state[0], state[1] + offset_add), read when the kernel RUNS - a captured hipGraph (the reference's
+ * --dropout > 0 inside train.GraphedTrainStep) draws fresh masks on every replay; the step advances state[1] itself. */
+int feta_attn_fwd_drop_dev(const void* q, const void* k, const void* v, int64_t qkv_sb, int64_t qkv_sn,
+                           const void* pe, const int32_t* n_real, void* out, int64_t o_sb, int64_t o_sn,
+                           void* attn, float* stats, float scale, float p_drop, const uint64_t* state,
+                           uint64_t offset_add, int dtype, int B, int N, int H, int dh, feta_stream_t stream);
+int feta_attn_bwd_drop_dev(const void* q, const void* k, const void* v, int64_t qkv_sb, int64_t qkv_sn,
+                           const void* pe, const int32_t* n_real, const void* out, const void* dout,
+                           int64_t o_sb, int64_t o_sn, const float* stats, float* delta,
+                           void* dq, void* dk, void* dv, float scale, float p_drop, const uint64_t* state,
+                           uint64_t offset_add, int dtype, int B, int N, int H, int dh, feta_stream_t stream);
 
 /* ---- A1/A4: row-wise linears of the encoder layer and BatchNorm1d --------------------------
  * Replaces the F.linear / relu / degree scaling / residual / BatchNorm1d sequence of

@@ -12,14 +12,21 @@ from oracle import feta_oracle as O
 # bf16 storage leg (bench.py --dtype bf16): the whole encoder against the fp64 oracle on the SAME fp32 inputs and
 # master weights - so, unlike the kernel-level checks, the rounding of inputs and weights to bf16 is part of the
 # error: every tensor of the stack is stored with 8 significant bits.  Output: max-abs relative to max(1, max|ref|).
-# Parameter gradients: relative FROBENIUS error per parameter - with 8-bit activations a relu pre-activation near
-# zero takes the other branch for a few (row, unit) pairs, which moves single elements of dW1 / db1 by a whole
-# row contribution (any bf16 implementation does this); the norm-wise error is what stays bounded.  Measured on the
-# MI355X at the BASELINE batch: 0.3-2 % for most parameters, 5-9 % for linear1 and 8-13 % for norm1.bias - those are
-# column sums over all N*B rows of gradients whose residual part (a BatchNorm backward) sums to exactly zero, so
-# the bf16 rounding of 4.7 k large cancelling terms sits on top of a small true sum.
+# Parameter gradients: relative FROBENIUS error per parameter.  Round 3 (fused bf16 stack, every bias / affine column sum
+# taken from fp32 values before they are rounded into a tile), measured on the MI355X at the BASELINE batch: 0.4-3.5 %
+# for every parameter except the four per layer that sit behind the relu mask in backward - linear1.weight / .bias
+# (dW1, db1 = sums of dh = (g2 W2) * [h > 0]) and norm1.weight / .bias (sums of dx1 = g2 + dh W1): 4-11 %.  The cause is
+# the mask, not a reduction: with 8-bit operands ~400 of the 606 k pre-activations change sign against the fp64 run,
+# and each flip moves whole row contributions (tools/relu_flip_probe.py isolates it: 6 / 4 / 6 / 4 % from the flips alone,
+# 0.3-0.5 % from all roundings together once the mask is exact).  Any bf16 implementation has this; the bound for those
+# four stays loose, everything else is held to 5 %.
 BF16_MODEL_TOL = 3e-2
-BF16_GRAD_FRO_TOL = 1.6e-1
+BF16_GRAD_FRO_TOL = 5e-2
+BF16_GRAD_FRO_TOL_RELU = 1.5e-1      # linear1.*, norm1.*: behind the relu mask
+
+
+def bf16_grad_tol(name):
+    return BF16_GRAD_FRO_TOL_RELU if ('.linear1.' in name or '.norm1.' in name) else BF16_GRAD_FRO_TOL
 
 
 def rel_fro(got, ref):
@@ -79,7 +86,7 @@ def check_bench_step(dev, run_ctx, argv, filter_mode=None, share=None, replays=2
             continue
         errs[name] = KC.assert_close('grad ' + name, p.grad.detach().cpu(), g_ref, tol=grad_tol)
     if lowp:
-        bad = {k: '%.3e' % v for k, v in errs.items() if k != 'out' and v > BF16_GRAD_FRO_TOL}
-        assert not bad, 'relative Frobenius error of parameter gradients above %.2g: %s (all: %s)' % (
-            BF16_GRAD_FRO_TOL, bad, {k: '%.2e' % v for k, v in errs.items()})
+        bad = {k: '%.3e' % v for k, v in errs.items() if k != 'out' and v > bf16_grad_tol(k)}
+        assert not bad, 'relative Frobenius error of parameter gradients above %.2g (%.2g behind the relu mask): %s (all: %s)' % (
+            BF16_GRAD_FRO_TOL, BF16_GRAD_FRO_TOL_RELU, bad, {k: '%.2e' % v for k, v in errs.items()})
     return errs, used_graph

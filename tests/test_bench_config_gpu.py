@@ -24,10 +24,23 @@ def test_timed_configuration_matches_oracle(hip, mode, share, two_phase):
     print('max abs errors:', {k: '%.2e' % v for k, v in errs.items()})
 
 
-@pytest.mark.parametrize('argv', [[], ['--shape', 'molhiv', '--batch', '96', '--n-pad', '64', '--k-eig', '32', '--layer-norm']])
+@pytest.mark.parametrize('argv', [[], ['--two-phase'],
+                                  ['--shape', 'molhiv', '--batch', '96', '--n-pad', '64', '--k-eig', '32', '--layer-norm'],
+                                  ['--shape', 'molhiv', '--batch', '300', '--n-pad', '64', '--k-eig', '32']])
 def test_bf16_storage_leg_matches_oracle(hip, argv):
-    """bench.py --dtype bf16 (BASELINE config 3 shape, and a molhiv-shaped LayerNorm bucket of config 5) through the
-    captured hipGraph against the fp64 oracle, bf16 tolerance (bench_checks.BF16_MODEL_TOL)"""
-    errs, used_graph = BC.check_bench_step(hip[1], contextlib.nullcontext, argv + ['--dtype', 'bf16'], replays=2)
+    """bench.py --dtype bf16 through the captured hipGraph against the fp64 oracle, bf16 tolerances
+    (bench_checks.BF16_MODEL_TOL / bf16_grad_tol): the BASELINE config 3 shape, single-pass and with the split backward
+    of --gpus N; a molhiv-shaped LayerNorm bucket of config 5; a batch above 256 graphs (the attention-block backward
+    walks several graphs per workgroup).  Every one of them must run the fused stack's bf16 instantiations."""
+    from feta_tmlr_amd import fused_stack
+    calls = []
+    orig_bn, orig_ln = fused_stack.FusedEncoderStackFn.apply, fused_stack.FusedLayerNormStackFn.apply
+    fused_stack.FusedEncoderStackFn.apply = staticmethod(lambda *a: (calls.append(a[0].dtype), orig_bn(*a))[1])
+    fused_stack.FusedLayerNormStackFn.apply = staticmethod(lambda *a: (calls.append(a[0].dtype), orig_ln(*a))[1])
+    try:
+        errs, used_graph = BC.check_bench_step(hip[1], contextlib.nullcontext, argv + ['--dtype', 'bf16'], replays=2)
+    finally:
+        fused_stack.FusedEncoderStackFn.apply, fused_stack.FusedLayerNormStackFn.apply = orig_bn, orig_ln
+    assert calls and all(dt == torch.bfloat16 for dt in calls), calls
     assert used_graph
     print('max abs errors:', {k: '%.2e' % v for k, v in errs.items()})

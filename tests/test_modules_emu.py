@@ -70,7 +70,7 @@ def test_model_forward_backward_matches_oracle(emu, batch_norm, share, mode, pe_
         KC.assert_close('grad ' + name, p.grad, ref, tol=2e-5)
 
 
-def check_layer_attention_dropout(dev, hook, bf16=False):
+def check_layer_attention_dropout(dev, hook, bf16=False, device_key=False):
     """DiffTransformerEncoderLayer in training mode with attention-probability dropout (--dropout of the reference
     scripts, experiments/run_transformer_gengcn.py:47) against the oracle holding the same mask; eval mode is
     dropout-free; two forwards draw different masks."""
@@ -89,6 +89,8 @@ def check_layer_attention_dropout(dev, hook, bf16=False):
     src = x.permute(1, 0, 2).contiguous().requires_grad_(True)
     n, b = src.shape[0], src.shape[1]
     FF.DropoutState.manual_seed(4242)
+    if device_key:     # the key on the device (what a captured step uses): the same masks as the host key
+        FF.DropoutState.begin_device_mode(dev)
     with hook():
         out, attn, heads_out = layer(src, pe=pe, degree=degree, src_key_padding_mask=mask, need_heads=True)
         w = torch.linspace(0.5, 1.5, out.numel(), device=dev).view_as(out)
@@ -96,6 +98,10 @@ def check_layer_attention_dropout(dev, hook, bf16=False):
         out2, attn2, _ = layer(src, pe=pe, degree=degree, src_key_padding_mask=mask, need_heads=True)
         layer.eval()
         out_eval, attn_eval = layer(src, pe=pe, degree=degree, src_key_padding_mask=mask)
+    if device_key:
+        assert FF.DropoutState.end_step() == 2      # two masked forwards; the device offset moved past them
+        assert FF.DropoutState._dev.tolist() == [4242, 2] and FF.DropoutState.snapshot() == (4242, 2)
+        FF.DropoutState.end_device_mode()
     p64 = {'l.' + k: v.detach().cpu().double() for k, v in layer.state_dict().items()}
     src64 = src.detach().cpu().double().requires_grad_(True)
     scales = KC.dropout_scales(b, heads, n, p_drop, 4242, 1)
@@ -117,9 +123,9 @@ def check_layer_attention_dropout(dev, hook, bf16=False):
     KC.assert_close('eval output', out_eval, ref_eval, tol=tol)
 
 
-@pytest.mark.parametrize('bf16', [False, True])
-def test_layer_attention_dropout(emu, bf16):
-    check_layer_attention_dropout(CPU, lambda: _lib.override_for_tests(emu), bf16)
+@pytest.mark.parametrize('bf16,device_key', [(False, False), (True, False), (False, True)])
+def test_layer_attention_dropout(emu, bf16, device_key):
+    check_layer_attention_dropout(CPU, lambda: _lib.override_for_tests(emu), bf16, device_key)
 
 
 def test_unused_outer_gcn_has_no_grad(emu):

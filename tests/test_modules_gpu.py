@@ -110,11 +110,11 @@ def test_spectral_mode_without_eigenbasis(spectral_k):
     check_spectral_mode_without_eigenbasis(torch.device('cuda:0'), contextlib.nullcontext, spectral_k)
 
 
-@pytest.mark.parametrize('bf16', [False, True])
-def test_layer_attention_dropout(bf16):
+@pytest.mark.parametrize('bf16,device_key', [(False, False), (True, False), (False, True), (True, True)])
+def test_layer_attention_dropout(bf16, device_key):
     import contextlib
     from test_modules_emu import check_layer_attention_dropout
-    check_layer_attention_dropout(torch.device('cuda:0'), contextlib.nullcontext, bf16)
+    check_layer_attention_dropout(torch.device('cuda:0'), contextlib.nullcontext, bf16, device_key)
 
 
 @pytest.mark.parametrize('scalar_mode', [False, True])

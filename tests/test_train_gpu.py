@@ -78,3 +78,42 @@ def test_graphed_train_step_equals_eager_steps(hip, task):
         assert float((pa.detach() - pb.detach()).abs().max()) <= 3 * max(lrs) * 1.01, k
         if sig.any():
             KC.assert_close('param ' + k, pb.detach()[sig].cpu(), pa.detach()[sig].cpu().double(), tol=3e-5)
+
+
+def test_graphed_train_step_with_attention_dropout(hip):
+    """--dropout > 0 (experiments/run_transformer_gengcn.py:47) inside the captured step: the attention-probability
+    masks are keyed by a DEVICE-resident (seed, offset) which every replay reads and advances, so replay i draws the
+    masks of eager step i (same losses) and two replays differ (missing #4)."""
+    from feta_tmlr_amd import functional as FF
+    dev = hip[1]
+    task = 'tu'
+    model_a, batch9, cache = TC.build_case(task, dev, batch_norm=False)
+    model_b, _, _ = TC.build_case(task, dev, batch_norm=False)
+    model_b.load_state_dict(model_a.state_dict())
+    for m in (model_a, model_b):
+        for layer in m.encoder.layers:
+            layer.self_attn.dropout = 0.2       # (the activations' nn.Dropout modules stay at p = 0: torch's generator
+        m.train()                               #  is offset differently inside a graph)
+    crit = T.make_criterion(task, nb_class=3)
+    opt_a = T.make_optimizer(task, model_a.parameters(), lr=1e-3)
+    opt_b = T.make_optimizer(task, model_b.parameters(), lr=1e-3, capturable=True)
+    try:
+        FF.DropoutState.manual_seed(77)
+        eager = [float(T.train_step(task, model_a, crit, opt_a, batch9, T.prepare_cache(model_a, batch9, cache), lr=lr))
+                 for lr in (1e-3, 0.0, 0.0)]
+        assert eager[1] != eager[2]                 # lr = 0: only the masks changed between these two steps
+        FF.DropoutState.manual_seed(77)
+        graphed = T.GraphedTrainStep(task, model_b, crit, opt_b, batch9, cache)
+        assert graphed.drop_calls == len(model_b.encoder.layers)
+        assert FF.DropoutState.snapshot() == (77, 0)     # warm-up and capture left the key where it was
+        got = []
+        for lr in (1e-3, 0.0, 0.0):
+            graphed.set_lr(lr)
+            got.append(float(graphed(batch9, cache)))
+        for i, (a, b) in enumerate(zip(eager, got)):
+            assert abs(a - b) <= 3e-5 * max(1.0, abs(a)), (i, eager, got)
+        assert FF.DropoutState.snapshot() == (77, 3 * graphed.drop_calls)
+        torch.cuda.synchronize()
+        assert FF.DropoutState._dev.tolist() == [77, 3 * graphed.drop_calls]
+    finally:
+        FF.DropoutState.end_device_mode()
