@@ -283,6 +283,25 @@ def make_step(args, enc, gpu, world, dev):
     return step, two_phase, use_graph
 
 
+def grad_bucket_bytes(enc, two_phase, dtype):
+    """Bytes one rank hands to the gradient collectives per step: row-constant gradients (gcn.weight) travel as one row;
+    the split backward reduces the two C x C gradients in place and the stack's flat buffer in place, the single-pass
+    form packs everything into one bucket (bf16 on the wire for the bf16 storage leg)."""
+    head = stack = 0
+    stack_ids = {id(p) for p in enc.stack_parameters()}
+    for p in enc.parameters():
+        if not p.requires_grad:
+            continue
+        n = p.shape[1] if (getattr(p, '_feta_row_constant', False) and p.dim() == 2) else p.numel()
+        if id(p) in stack_ids:
+            stack += n
+        else:
+            head += n
+    if two_phase:
+        return {'head': 4 * head, 'stack': 4 * stack}
+    return {'all': (2 if dtype == 'bf16' else 4) * (head + stack)}
+
+
 def time_steps(step, args, world, dev):
     """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
     for _ in range(args.warmup):
@@ -330,17 +349,18 @@ def spec_bytes(b, n, h, dh, k_eig, p, sum_n, backward):
 
 
 def _load_json(*names):
+    """-> (content, 'profiles/<name>') of the first committed profile summary that exists, else ({}, None)"""
     for nm in names:
         p = os.path.join(ROOT, 'profiles', nm)
         if os.path.exists(p):
             try:
-                return json.load(open(p))
+                return json.load(open(p)), 'profiles/' + nm
             except Exception:
                 pass
-    return {}
+    return {}, None
 
 
-def roofline(args, gpu, dev):
+def roofline(args, gpu, dev, lowp=False):
     """Times the hand-written kernels of one step in isolation, in exactly the variants the fused stack
     issues (feta_tmlr_amd/benchcases.py; HIP events on the stream they are launched on - torch's
     current stream), groups the variants by KERNEL SYMBOL (what rocprofv3 --stats reports: e.g. the two
@@ -365,7 +385,8 @@ def roofline(args, gpu, dev):
                   and abi.ffn_bwd_supported(d, 2 * d) and abi.attn_block_bwd_supported(n, d, h)
                   and abi.attn_block_bwd_blocks(b) > 0)
     coeff_roles = args.filter_mode in ('spectral', 'cheb') and not args.two_phase and args.gpus == 1 and p == 4
-    for name, per_layer, fn, nbytes, syms in stack_layer_cases(abi, st, dev, b, n, d, h, 2 * d, gpu['pe'], nr):
+    for name, per_layer, fn, nbytes, syms in stack_layer_cases(abi, st, dev, b, n, d, h, 2 * d, gpu['pe'], nr,
+                                                               dtype=torch.bfloat16 if lowp else torch.float32):
         if name == 'attn_block_fwd (no attn write)':
             cnt = L - 1
         elif name == 'attn_block_fwd (+attn write)':
@@ -386,7 +407,9 @@ def roofline(args, gpu, dev):
             cnt = L
         if cnt == 0:
             continue
-        sym = syms[0]
+        # candidates are grouped by SOURCE kernel: the one- and two-workgroup instantiations of attn_block_bwd are one
+        # kernel, as are the variants of the others
+        sym = syms[0].split('<')[0]
         if sym == 'rowlin_bwd':   # one template instantiation (= one symbol) per (KI, NO)
             sym = 'rowlin_bwd<%s>' % name.split()[1]
         cand.append((name, sym, cnt, fn, nbytes))
@@ -420,7 +443,7 @@ def roofline(args, gpu, dev):
                      spec_bytes(b, n, h, dh, k_eig, p, sum_n, True)))
     r_ = h * b
     from feta_tmlr_amd import functional as FF
-    if abi.lin_supported(r_, c, c) and r_ * c * c <= FF.LIN_OWN_GEMM_MAX_MACS:
+    if abi.lin_supported(r_, c, c) and (r_ * c * c <= FF.LIN_OWN_GEMM_MAX_MACS or lowp):
         # the C x C linear of the coefficient generator runs as csrc/lin.hip at this size (else: library GEMMs, which
         # are not candidates - the roofline object prices the hand-written kernels)
         lw, lb, lx, ldy = rnd(c, c) / c ** 0.5, rnd(c), rnd(r_, c), rnd(r_, c)
@@ -428,11 +451,15 @@ def roofline(args, gpu, dev):
                              torch.empty(c, c, device=dev), torch.empty(c, device=dev))
         cat_part = rnd(abi.rowlin_chunks(b * n), d * 2 * d + d)
         pairs = [(rnd(r_, dh), torch.empty(dh, device=dev)), (cat_part, torch.empty(cat_part.shape[1], device=dev))]
-        cand.append(('lin_fwd', 'lin_fwd', 1, lambda: abi.lin_fwd(lx, lw, lb, ly, st), 4 * (2 * r_ * c + c * c)))
-        cand.append(('lin_bwd', 'lin_bwd', 1, lambda: abi.lin_bwd(lx, lw, ldy, ldx, ldw, ldb, st, pairs=pairs),
+        cand.append(('lin_fwd', 'lin_fwd', 1, lambda: abi.lin_fwd(lx, lw, lb, ly, st, bf16=lowp), 4 * (2 * r_ * c + c * c)))
+        cand.append(('lin_bwd', 'lin_bwd', 1, lambda: abi.lin_bwd(lx, lw, ldy, ldx, ldw, ldb, st, pairs=pairs, bf16=lowp),
                      4 * (3 * r_ * c + 2 * c * c + cat_part.numel())))
-    traffic = _load_json('r02_traffic_b128.json', 'traffic.json')
-    mfma = _load_json('r02_pmc_mfma_b128.json', 'r01_pmc_mfma_b128.json')
+    # NOT measured in this run: committed products of separate rocprofv3 --pmc passes (tools/profile_round.sh), named in
+    # the object so that nobody takes them for same-run counters
+    tfiles = ('r03_traffic_b128_bf16.json',) if lowp else ('r03_traffic_b128.json', 'r02_traffic_b128.json')
+    mfiles = ('r03_pmc_mfma_b128_bf16.json',) if lowp else ('r03_pmc_mfma_b128.json', 'r02_pmc_mfma_b128.json')
+    traffic, traffic_src = _load_json(*tfiles)
+    mfma, mfma_src = _load_json(*mfiles)
     groups = {}
     for name, sym, cnt, fn, nbytes in cand:
         t = time_kernel(fn, args.kernel_iters)
@@ -449,11 +476,11 @@ def roofline(args, gpu, dev):
         if all(r['traffic'] is not None for r in rows):
             tr = int(sum(r['launches_per_step'] * r['traffic'] for r in rows) / launches)
         busy = None
-        base, _, targ = sym.partition('<')
-        for key, val in mfma.items():   # keys: kernel names with template arguments
-            if base in key and (targ not in ('true>', 'false>') or key.rstrip().endswith(', ' + targ)):
-                busy = val.get('mfma_busy_pct')
-                break
+        base = sym.partition('<')[0]
+        hits = [val.get('mfma_busy_pct') for key, val in mfma.items()      # keys: kernel names with template arguments
+                if base in key and ('bf16' in key) == lowp and val.get('mfma_busy_pct') is not None]
+        if hits:
+            busy = round(sum(hits) / len(hits), 2)      # mean over the instantiations of the source kernel
         ach = bytes_step / t_step / 1e3       # bytes / us -> GB/s
         out_rows.append({'kernel': sym, 'launches_per_step': launches, 'launch_us': round(t_step / launches, 3),
                          'us_per_step': round(t_step, 2), 'algorithmic_bytes': int(bytes_step / launches),
@@ -464,7 +491,8 @@ def roofline(args, gpu, dev):
            'unit': 'GB/s', 'frac': dom['frac'], 'traffic': dom['traffic'],
            'algorithmic_bytes': dom['algorithmic_bytes'], 'launch_us': dom['launch_us'],
            'launches_per_step': dom['launches_per_step'], 'us_per_step': dom['us_per_step'],
-           'mfma_busy_pct': dom['mfma_busy_pct'], 'variants': dom['variants'],
+           'mfma_busy_pct': dom['mfma_busy_pct'], 'traffic_source': traffic_src, 'mfma_busy_source': mfma_src,
+           'timing': 'HIP events in this run, launch stream', 'variants': dom['variants'],
            'other_kernels': [{k_: v_ for k_, v_ in r.items() if k_ != 'variants'} for r in out_rows if r is not dom]}
     return res
 
@@ -501,7 +529,7 @@ def roofline_streaming(args, dev):
     return out
 
 
-def cpu_baseline(args, cpu, enc, spectral, share):
+def cpu_baseline(args, cpu, enc, spectral, share, primary=True):
     """CPU restatement of the SAME operator as the GPU leg it is reported beside, PyTorch CPU fp32, all host
     cores: the reference's algorithm for everything the reference has text for (attention layer as
     reconstructed, the un-collapsed GCNConv on ones with its Python loop over the H*B blocks, head stacking,
@@ -529,25 +557,34 @@ def cpu_baseline(args, cpu, enc, spectral, share):
                                      collapsed=collapsed, eig=eig)
         (out * cpu['dout'][:, :sub]).sum().backward()
 
-    def timed(collapsed):
-        step(collapsed)
-        t0 = time.perf_counter()
-        for _ in range(args.cpu_steps):
+    def timed(collapsed, warm, steps):
+        """warm-up steps, then the MEDIAN of the timed steps"""
+        for _ in range(warm):
             step(collapsed)
-        return (time.perf_counter() - t0) / args.cpu_steps
+        ts = []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            step(collapsed)
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return ts[len(ts) // 2]
 
-    dt = timed(False)
+    warm, steps = (5, 20) if primary else (1, max(3, args.cpu_steps // 2))
+    if args.cpu_steps != 8:     # an explicit --cpu-steps overrides the protocol (short runs)
+        warm, steps = 1, args.cpu_steps
+    dt = timed(False, warm, steps)
     log('cpu baseline (%s) timed' % ('eigenbasis K=%d' % args.k_eig if spectral else 'edge-list recursion'))
     # the same restatement with the exact GCNConv(ones) = c_j colsum(W) + b collapse (SURVEY F7), so that
     # the GPU/CPU ratio is not inflated by the reference's redundant ones @ W product alone
-    dt_opt = timed(True)
+    dt_opt = timed(True, 1, max(3, steps // 4))
     op = ('K=%d eigenbasis filter, every head on the graph' % args.k_eig) if spectral else \
         'order-%d Chebyshev edge-list recursion' % args.order
     if not spectral or not share:
         op += ', heads_share_graph=%s' % share
     return {'value': round(sub / dt, 2), 'unit': 'graphs/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d steps of fwd+bwd on the %d graphs of the batch (oracle.encoder_gengcn: %s; un-collapsed '
-                      'coefficient generator; torch CPU fp32, %d threads)' % (args.cpu_steps, sub, op, cores),
+            'sample': '%d warm-up + %d timed steps (median) of fwd+bwd on the %d graphs of the batch '
+                      '(oracle.encoder_gengcn: %s; un-collapsed coefficient generator; torch CPU fp32, %d threads)'
+                      % (warm, steps, sub, op, cores),
             'optimised_value': round(sub / dt_opt, 2),
             'optimised_sample': 'same, with the collapsed coefficient generator (no ones @ W, no dense edge list)'}
 
@@ -586,6 +623,37 @@ def main(argv=None):
     dt = time_steps(step, args, world, dev)
     log('timed region done: %.3f ms/step' % (dt / args.steps * 1e3))
 
+    # beside the headline leg (N = 1, fp32 run only): the bf16 storage leg of BASELINE configs 3 / 5 on the same batch,
+    # and the split backward --gpus N uses, so that the first SCALE run has its single-GPU baseline
+    extra = {}
+    if world == 1 and not args.dry_cpu and args.dtype == 'f32' and not args.no_literal:
+        import copy
+        a16 = copy.copy(args)
+        a16.dtype = 'bf16'
+        _, gpu16 = make_batch(a16, rank, dev)
+        enc16 = build_encoder(a16).to(dev)
+        enc16.train()
+        step16, _, _ = make_step(a16, enc16, gpu16, world, dev)
+        dt16 = time_steps(step16, args, world, dev)
+        log('bf16 storage leg: %.3f ms/step' % (dt16 / args.steps * 1e3))
+        extra['bf16_leg'] = {'value': round(args.batch * args.steps / dt16, 2), 'unit': 'graphs/s',
+                             'ms_per_step': round(dt16 / args.steps * 1e3, 4), 'dtype': 'bf16',
+                             'what': 'the same step on bf16 storage (python bench.py --dtype bf16): fused stack on '
+                                     'v_mfma_f32_16x16x16_bf16, fp32 statistics / parameter gradients / filter stage',
+                             'roofline': roofline(a16, gpu16, dev, lowp=True)}
+        if not two_phase:
+            a2 = copy.copy(args)
+            a2.two_phase = True
+            enc2 = build_encoder(a2).to(dev)
+            enc2.train()
+            step2, _, _ = make_step(a2, enc2, gpu, world, dev)
+            dt2 = time_steps(step2, args, world, dev)
+            log('split backward at N = 1: %.3f ms/step' % (dt2 / args.steps * 1e3))
+            extra['two_phase_n1'] = {'value': round(args.batch * args.steps / dt2, 2), 'unit': 'graphs/s',
+                                     'ms_per_step': round(dt2 / args.steps * 1e3, 4),
+                                     'what': 'python bench.py --two-phase: the backward --gpus N > 1 runs (head '
+                                             'gradients first, their all-reduce under the stack backward), on one GPU'}
+
     literal = None
     if (not args.no_literal and not args.dry_cpu and args.dtype == 'f32'
             and not (args.filter_mode == 'cheb' and args.no_share_graph)):
@@ -618,14 +686,20 @@ def main(argv=None):
                        'norm': 'layer' if args.layer_norm else 'batch(per-rank stats)',
                        'heads_share_graph': share, 'hip_graph': bool(use_graph),
                        'backward': 'two-phase (head all-reduce under stack backward)' if two_phase else 'single',
+                       'two_phase': bool(two_phase),
+                       'ranks': dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
+                       'grad_bucket_bytes': grad_bucket_bytes(enc, two_phase, args.dtype),
                        'parallelism': 'dp%d' % world},
         }
+        res.update(extra)
         if args.dry_cpu:
             res['invalid'] = 'dry-cpu launcher rehearsal on the host emulation of the kernels: not a measurement'
             res['data'] = 'synthetic (dry-cpu)'
         elif args.dtype != 'f32':
-            res['note'] = ('bf16 storage leg (BASELINE configs 3 / 5): general bf16 kernels + library bf16 GEMMs, not the '
-                           'fused fp32 stack; the headline line is --dtype f32')
+            res['note'] = ('bf16 storage leg (BASELINE configs 3 / 5): bf16 token tensors and LDS tiles, fused stack on '
+                           'v_mfma_f32_16x16x16_bf16, fp32 statistics / parameter gradients / filter stage; the headline '
+                           'line is --dtype f32 (the reference\'s arithmetic)')
+            res['roofline'] = roofline(args, gpu, dev, lowp=True)
         else:
             res['roofline'] = roofline(args, gpu, dev)
             if args.stream_batch > 0:
@@ -635,7 +709,7 @@ def main(argv=None):
                 res['cpu_baseline'] = cpu_baseline(args, cpu, enc, args.filter_mode == 'spectral', share)
             if literal is not None:
                 if world == 1 and not args.no_cpu_baseline:
-                    literal['cpu_baseline'] = cpu_baseline(args, cpu, enc, False, False)
+                    literal['cpu_baseline'] = cpu_baseline(args, cpu, enc, False, False, primary=False)
                 res['reference_literal'] = literal
         print(json.dumps(res))
         sys.stdout.flush()

@@ -92,8 +92,9 @@ def stack_layer_cases(abi, st, dev, b, n, d, heads, ff, pe, n_real, last_layer_a
         keep = (x, w, dy, dx, part, kw)
         cases.append((name, 1.0, lambda: (abi.rowlin_bwd_ex(dsc, None, st), keep)[0], f4 * nbytes, ['rowlin_bwd']))
 
+    from .fused_stack import _fused_attn_bwd
     fused_f = abi.ffn_bwd_supported(d, ff)
-    fused_a = abi.attn_block_bwd_supported(n, d, heads) and abi.attn_block_bwd_blocks(b) > 0
+    fused_a = _fused_attn_bwd(abi, b, n, d, heads, False, dtype)     # (what the stack issues at this batch / type)
     if fused_f:
         # backward of the FFN half in one launch (csrc/ffn_bwd.hip), BatchNorm stack variant
         dy, y2, hh, y1, dx = rndt(m, d), rndt(m, d), rndt(m, ff), rndt(m, d), newt(m, d)

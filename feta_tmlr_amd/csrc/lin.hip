@@ -324,15 +324,17 @@ __device__ __forceinline__ void lin_tiled_body(const LinTiledArgs& a, int ti, in
   }
 }
 
-// XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2); the 8 consecutive
-// workgroups of a group get 8 different j tiles of ONE i tile... and the next group the next j tiles: an XCD keeps
-// meeting the same j tiles (its slice of Q) while the P rows stream through.
+// XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  The 8 consecutive
+// workgroups of a group take 8 different j tiles of ONE i tile, the next group the next 8 j tiles of the same i tile,
+// and only then the next i tile: an XCD sees the P rows of an i tile TJ / 8 times in a row (they stay in its L2) and
+// keeps cycling over its own TJ / 8 j tiles (its slice of Q).  (Round 3, R = 65536: with the i tiles innermost the
+// four users of a P tile on an XCD were 1024 groups apart and the counters showed 8.9 GB for 0.54 GB algorithmic.)
 __device__ __forceinline__ void lin_tile_of(int blk, int TI, int TJ, int& ti, int& tj) {
-  // blk = (tj_hi * TI + ti) * 8 + tj_lo with tj = tj_hi * 8 + tj_lo  (TJ a multiple of 8)
-  const int lo = blk & 7, rest = blk >> 3;
-  ti = rest % TI;
-  tj = (rest / TI) * 8 + lo;
-  (void)TJ;
+  // blk = (ti * (TJ / 8) + tj_hi) * 8 + tj_lo with tj = tj_hi * 8 + tj_lo  (TJ a multiple of 8)
+  const int lo = blk & 7, rest = blk >> 3, nhi = TJ >> 3;
+  ti = rest / nhi;
+  tj = (rest - ti * nhi) * 8 + lo;
+  (void)TI;
 }
 
 template <class T>

@@ -43,6 +43,8 @@ def main():
     ap.add_argument('--k-eig', type=int, default=16)
     ap.add_argument('--iters', type=int, default=100)
     ap.add_argument('--json', action='store_true')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                    help='storage type of the fused-stack rows (the general-kernel rows stay fp32)')
     ap.add_argument('--batch-first', action='store_true',
                     help='token tensors stored [B,N,...] (a graph is contiguous) instead of the reference seq-first [N,B,...]')
     a = ap.parse_args()
@@ -148,7 +150,9 @@ def main():
 
     if not bf:   # the kernels of a fused-stack layer in the variants the stack issues
         from feta_tmlr_amd.benchcases import stack_layer_cases
-        for name, _, fn, nbytes, _ in stack_layer_cases(abi, st, dev, b, n, d, h, 2 * d, pe, nr):
+        lowp = a.dtype == 'bf16'
+        for name, _, fn, nbytes, _ in stack_layer_cases(abi, st, dev, b, n, d, h, 2 * d, pe, nr,
+                                                        dtype=torch.bfloat16 if lowp else torch.float32):
             add(name, fn, nbytes)
         # the C x C linear of the coefficient generator (csrc/lin.hip) with the column sums it carries in the step:
         # filter-bias partials and linear_cat's split-K weight-gradient partials
@@ -157,10 +161,10 @@ def main():
             lw, lb, lx, ldy = rnd(c, c) / c ** 0.5, rnd(c), rnd(r_, c), rnd(r_, c)
             ly, ldx, ldw, ldb = (torch.empty(r_, c, device=dev), torch.empty(r_, c, device=dev),
                                  torch.empty(c, c, device=dev), torch.empty(c, device=dev))
-            add('lin_fwd %dx%dx%d' % (r_, c, c), lambda: abi.lin_fwd(lx, lw, lb, ly, st), f4 * (2 * r_ * c + c * c))
+            add('lin_fwd %dx%dx%d' % (r_, c, c), lambda: abi.lin_fwd(lx, lw, lb, ly, st, bf16=lowp), f4 * (2 * r_ * c + c * c))
             cat_part = rnd(abi.rowlin_chunks(m), d * 2 * d + d)
             pairs = [(rnd(r_, dh), torch.empty(dh, device=dev)), (cat_part, torch.empty(cat_part.shape[1], device=dev))]
-            add('lin_bwd (dx, dw, db + 2 colsum)', lambda: abi.lin_bwd(lx, lw, ldy, ldx, ldw, ldb, st, pairs=pairs),
+            add('lin_bwd (dx, dw, db + 2 colsum)', lambda: abi.lin_bwd(lx, lw, ldy, ldx, ldw, ldb, st, pairs=pairs, bf16=lowp),
                 f4 * (3 * r_ * c + 2 * c * c + cat_part.numel()))
 
     if a.json:

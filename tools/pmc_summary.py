@@ -73,6 +73,12 @@ def main():
         for i, (row, _) in enumerate(ROWS):
             if row.startswith('attn_bwd'):
                 ROWS[i] = (row, ['attn_bwd_graph'])
+    if any('attn_block_bwd' in name for name, _ in f) and not any('Lb1ELb0' in name or ', true, false>' in name
+                                                                   for name, _ in f):
+        # beyond 256 graphs with the fused attention-block backward (bf16): no two-workgroup form, no two-part gradient
+        names = [r for r, _ in ROWS]
+        del ROWS[names.index('attn_block_bwd (two workgroups per graph)')]
+        del ROWS[[r for r, _ in ROWS].index('ffn_bwd (gradient in two parts)')]
     if not any('attn_block_bwd' in name for name, _ in f):   # batches beyond the fused attention-block backward
         i = [r for r, _ in ROWS].index('attn_block_bwd')
         del ROWS[i + 1]      # the two-workgroup form and the FFN backward that takes its two parts: not issued there
