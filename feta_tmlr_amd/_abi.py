@@ -43,6 +43,7 @@ SIGNATURES = {
     'feta_rowlin_fwd': ([_F, _F, _F, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, _S], C.c_int),
     'feta_rowlin_bwd': ([_F, _F, _F, _F, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int, _S], C.c_int),
     'feta_bn_stats': ([_F, _F, C.c_int, C.c_int, _S], C.c_int),
+    'feta_bn_stats_shift': ([_F, _F, _F, C.c_int, C.c_int, _S], C.c_int),
     'feta_bn_apply_fwd': ([_F, _F, _F, _F, _F, _F, _F, _F, _I, C.c_float, C.c_float, C.c_int, C.c_int, _S],
                           C.c_int),
     'feta_bn_bwd': ([_F, _F, _F, _F, _F, _F, _F, _F, C.c_int, C.c_int, _S], C.c_int),
@@ -76,6 +77,10 @@ SIGNATURES.update({
     'feta_attn_bwd_drop_dev': ([_F, _F, _F, C.c_int64, C.c_int64, _F, _I, _F, _F, C.c_int64, C.c_int64, _F, _F, _F, _F, _F,
                                 C.c_float, C.c_float, _I, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 _S], C.c_int),
+    'feta_attn_fwd_stab': ([_F, _F, _F, C.c_int64, C.c_int64, _F, _I, _F, C.c_int64, C.c_int64, _F, _F, C.c_float,
+                            C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _S], C.c_int),
+    'feta_attn_bwd_stab': ([_F, _F, _F, C.c_int64, C.c_int64, _F, _I, _F, _F, C.c_int64, C.c_int64, _F, _F, _F, _F, _F,
+                            C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _S], C.c_int),
     'feta_spec_filter_fwd_bf16': SIGNATURES['feta_spec_filter_fwd'],
     'feta_spec_filter_bwd_bf16': SIGNATURES['feta_spec_filter_bwd'],
 })
@@ -111,7 +116,7 @@ class RowLinEx(C.Structure):
         ('g_fin', _F), ('g_fin_out', _F), ('dgamma', _F), ('dbeta', _F),
         ('add_plain', _F), ('add_dout', _F), ('add_y', _F), ('add_bn', _F), ('add_fin', _F),
         ('x2', _F), ('x_split', C.c_int), ('dx2', _F),
-        ('sum_y', _F), ('sum_bn', _F), ('sum_out', _F),
+        ('sum_y', _F), ('sum_bn', _F), ('sum_out', _F), ('stats_shift', _F),
     ]
 
 
@@ -134,7 +139,8 @@ class AttnBlock(C.Structure):
         ('w_in', _F), ('b_in', _F), ('w_out', _F), ('b_out', _F), ('pe', _F), ('n_real', _I),
         ('rowscale', _F), ('qkv', _F), ('out', _F), ('attn_stats', _F), ('attn', _F), ('y', _F),
         ('y_stats', _F), ('scale', C.c_float), ('B', C.c_int), ('N', C.c_int), ('M', C.c_int),
-        ('row_sb', C.c_int64), ('row_sn', C.c_int64), ('tie_qk', C.c_int), ('dtype', C.c_int), ('out_f32', _F),
+        ('row_sb', C.c_int64), ('row_sn', C.c_int64), ('tie_qk', C.c_int), ('dtype', C.c_int), ('y_shift', _F),
+        ('out_f32', _F),
     ]
 
 
@@ -165,7 +171,7 @@ class Ffn(C.Structure):
         ('x_gamma', _F), ('x_beta', _F), ('x_bn_out', _F), ('x_rmean', _F), ('x_rvar', _F), ('x_nbt', _I),
         ('momentum', C.c_float), ('eps', C.c_float),
         ('w1', _F), ('b1', _F), ('w2', _F), ('b2', _F), ('h', _F), ('y', _F), ('y_stats', _F),
-        ('M', C.c_int), ('FF', C.c_int), ('dtype', C.c_int), ('y_f32', C.c_int),
+        ('M', C.c_int), ('FF', C.c_int), ('dtype', C.c_int), ('y_shift', _F), ('y_f32', C.c_int),
     ]
 
 
@@ -277,12 +283,20 @@ class Abi:
             raise FetaError('%s failed (%d): %s' % (what, rc, msg))
 
     # q,k,v,out,...: [B,N,H,dh] views (any B/N strides)
-    def attn_fwd(self, q, k, v, pe, n_real, out, attn, stats, scale, stream, drop=None):
-        """drop = (p, seed, offset): attention-probability dropout (feta_attn_fwd_drop)"""
+    def attn_fwd(self, q, k, v, pe, n_real, out, attn, stats, scale, stream, drop=None, clamp5=False):
+        """drop = (p, seed, offset): attention-probability dropout (feta_attn_fwd_drop); clamp5: exp(clamp(s, -5, 5))
+        instead of exp(s - rowmax) (feta_attn_fwd_stab)"""
         b, n, h, dh = q.shape
         sb, sn = tok_strides(q)
         assert tok_strides(k) == (sb, sn) and tok_strides(v) == (sb, sn)
         osb, osn = tok_strides(out)
+        if clamp5:
+            assert drop is None or drop[0] == 0.0, 'clamp5 with attention dropout is not instantiated'
+            _same_dtype(q.dtype, k, v, pe, out, attn)
+            self._check(self.lib.feta_attn_fwd_stab(_p(q), _p(k), _p(v), sb, sn, _p(pe), _p(n_real), _p(out), osb, osn,
+                                                    _p(attn), _p(stats), scale, 1, 1 if q.dtype == torch.bfloat16 else 0,
+                                                    b, n, h, dh, stream), 'feta_attn_fwd_stab')
+            return
         if drop is not None and drop[0] > 0.0 and torch.is_tensor(drop[1]):
             # device-resident key (functional.DropoutState in device mode): drop = (p, state int64[2], offset_add)
             _same_dtype(q.dtype, k, v, pe, out, attn)
@@ -314,13 +328,21 @@ class Abi:
         return n <= 64 and dh <= 16 and dtype == torch.float32
 
     def attn_bwd(self, q, k, v, pe, n_real, out, dout, stats, delta, dq, dk, dv, scale, stream, dout2=None,
-                 drop=None):
+                 drop=None, clamp5=False):
         b, n, h, dh = q.shape
         sb, sn = tok_strides(q)
         for t in (k, v, dq, dk, dv):
             assert tok_strides(t) == (sb, sn)
         osb, osn = tok_strides(out)
         assert tok_strides(dout) == (osb, osn)
+        if clamp5:
+            assert dout2 is None and (drop is None or drop[0] == 0.0)
+            _same_dtype(q.dtype, k, v, pe, out, dout, dq, dk, dv)
+            self._check(self.lib.feta_attn_bwd_stab(_p(q), _p(k), _p(v), sb, sn, _p(pe), _p(n_real), _p(out), _p(dout),
+                                                    osb, osn, _p(stats), _p(delta), _p(dq), _p(dk), _p(dv), scale, 1,
+                                                    1 if q.dtype == torch.bfloat16 else 0, b, n, h, dh, stream),
+                        'feta_attn_bwd_stab')
+            return
         if drop is not None and drop[0] > 0.0 and torch.is_tensor(drop[1]):
             _same_dtype(q.dtype, k, v, pe, out, dout, dq, dk, dv)
             assert dout2 is None
@@ -469,9 +491,11 @@ class Abi:
         self._check(self.lib.feta_rowlin_bwd(_p(x), _p(w), _p(dy), _p(rowscale), _p(ysaved), _p(dx),
                                              _p(partial), _p(dwdb), m, ki, no, stream), 'feta_rowlin_bwd')
 
-    def bn_stats(self, y, stats, stream):
+    def bn_stats(self, y, stats, stream, shift=None):
+        """stats [rowlin_blocks(M) + 1, 2, D]: shifted partial sums + the shift row (include/feta_hip.h)"""
         m, d = y.shape
-        self._check(self.lib.feta_bn_stats(_p(y), _p(stats), m, d, stream), 'feta_bn_stats')
+        assert stats.shape[0] == self.rowlin_blocks(m) + 1, 'stats needs rowlin_blocks(M) + 1 rows (shift row)'
+        self._check(self.lib.feta_bn_stats_shift(_p(y), _p(shift), _p(stats), m, d, stream), 'feta_bn_stats')
 
     def bn_apply_fwd(self, y, stats, gamma, beta, out, mean_rstd, running_mean, running_var, momentum,
                      eps, stream, nbt=None):
@@ -626,7 +650,7 @@ class Abi:
         m, d = y.shape
         self._check(self.lib.feta_bn_apply_fwd_prm(_p(y), _p(stats), _p(gamma), _p(beta), _p(out),
                                                    _p(bn_prm), _p(running_mean), _p(running_var), _p(nbt),
-                                                   momentum, eps, m, d, stats.shape[0], stream),
+                                                   momentum, eps, m, d, stats.shape[0] - 1, stream),   # (last row: shift)
                     'feta_bn_apply_fwd_prm')
 
     def bn_bwd_reduce(self, y, dout, bn_prm, partial, stream):

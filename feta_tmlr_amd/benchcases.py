@@ -32,9 +32,9 @@ def stack_layer_cases(abi, st, dev, b, n, d, heads, ff, pe, n_real, last_layer_a
     if abi.attn_block_supported(n, d, heads):
         x, w_in, b_in = rndt(m, d), rnd(3 * d, d) / d ** 0.5, rnd(3 * d)
         w_o, b_o, deg = rnd(d, d) / d ** 0.5, rnd(d), torch.rand(m, generator=g).to(dev)
-        qkv, out, y1, st1 = newt(m, 3 * d), newt(m, d), newt(m, d), new(b, 2, d)
+        qkv, out, y1, st1 = newt(m, 3 * d), newt(m, d), newt(m, d), new(b + 1, 2, d)
         ast, attn = new(b, heads, n, 2), new(b, heads, n, n)
-        stats_prev = rnd(G, 2, d).abs()
+        stats_prev = rnd(G + 1, 2, d).abs()      # (partial rows + the shift row)
         common = dict(x=x, w_in=w_in, b_in=b_in, w_out=w_o, b_out=b_o, pe=pe, n_real=n_real, rowscale=deg,
                       qkv=qkv, out=out, attn_stats=ast, y=y1, y_stats=st1, x_stats=stats_prev, Gx=G,
                       x_gamma=prm_of(d)[0], x_beta=prm_of(d)[1], x_bn_out=new(4, d))
@@ -53,9 +53,9 @@ def stack_layer_cases(abi, st, dev, b, n, d, heads, ff, pe, n_real, last_layer_a
                           ft * base_t + f4 * (base_o + b * heads * n * n), ['attn_block_fwd']))
     if abi.ffn_supported(d, ff):
         x, w1, b1, w2, b2 = rndt(m, d), rnd(ff, d) / d ** 0.5, rnd(ff), rnd(d, ff) / ff ** 0.5, rnd(d)
-        hbuf, y2, st2 = newt(m, ff), newt(m, d), new(abi.ffn_blocks(m), 2, d)
+        hbuf, y2, st2 = newt(m, ff), newt(m, d), new(abi.ffn_blocks(m) + 1, 2, d)
         g1 = min(b, 256)      # the stack caps the partial rows a consumer re-reduces (fused_stack.MAX_STAT_ROWS)
-        stats1 = rnd(g1, 2, d).abs()
+        stats1 = rnd(g1 + 1, 2, d).abs()
         fkw = dict(x=x, w1=w1, b1=b1, w2=w2, b2=b2, h=hbuf, y=y2, y_stats=st2, x_stats=stats1,
                    x_gamma=prm_of(d)[0], x_beta=prm_of(d)[1], x_bn_out=new(4, d))
         fd = abi.ffn_desc(m, ff, Gx=g1, **fkw)

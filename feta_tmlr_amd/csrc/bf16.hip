@@ -46,6 +46,11 @@ struct AttnArgsT {
   // device-resident (seed, offset) (feta_attn_*_drop_dev): when given, the mask is keyed by dstate[0] and counted from
   // dstate[1] + (off_hi, off_lo) - read at RUN time, so a captured hipGraph draws a fresh mask on every replay
   const unsigned long long* dstate;
+  // stabilisation of the exponent (stab = {rowmax, clamp5}): 0 = exp(s - rowmax) (upstream GraphiT), 1 = the
+  // in-tree witnesses' form exp(clamp(s, -5, 5)) (LSPE/layers/graphit_gt_layer.py:39-43,
+  // LPE/layers/graph_transformer_spectra_layer.py:239-243) - no row maximum (the stored one is 0), no gradient through
+  // a clamped score
+  int clamp5;
 };
 
 // (kernel arguments are a by-value copy: the device-resident key is patched into it once per wave, scalar loads)
@@ -123,12 +128,15 @@ __global__ __launch_bounds__(64 * kLWaves) void attn_fwd_lp_kernel(AttnArgsT<T> 
   for (int kt = 0; kt < KT_MAX; ++kt) {
     if (kt < KT) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < 4; ++r) {
+        if (a.clamp5) acc[kt][r] = fminf(fmaxf(acc[kt][r], -5.0f), 5.0f);
         if (16 * kt + 4 * g + r < n) m = fmaxf(m, acc[kt][r]);
+      }
     }
   }
   m = fmaxf(m, shfl_xor(m, 16));
   m = fmaxf(m, shfl_xor(m, 32));
+  if (a.clamp5) m = 0.0f;   // (wave-uniform flag; the shuffles above stay unconditional)
 
   const bool has_pe = a.pe != nullptr;
   const T* pe_row = has_pe ? a.pe + ((int64_t)b * a.N + qc) * a.N : nullptr;
@@ -287,8 +295,10 @@ __global__ __launch_bounds__(64 * kLWaves) void attn_bwd_dq_lp_kernel(AttnArgsT<
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int key = 16 * kt + 4 * g + r;
-      const float p = (key < n && qok) ? fast_exp(s[r] - m) * pv[r] * rinv : 0.0f;
+      const float sc = a.clamp5 ? fminf(fmaxf(s[r], -5.0f), 5.0f) : s[r];
+      const float p = (key < n && qok) ? fast_exp(sc - m) * pv[r] * rinv : 0.0f;
       ds[r] = p * (da[r] * ms[r] - delta);   // d(dropped probability) -> d(probability): the same keep-scale
+      if (a.clamp5 && sc != s[r]) ds[r] = 0.0f;   // a clamped score passes no gradient
     }
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) dq[ct] = Num<T>::mma4(ds, kb[ct], dq[ct]);
@@ -369,8 +379,10 @@ __global__ __launch_bounds__(64 * kLWaves) void attn_bwd_dkdv_lp_kernel(AttnArgs
           drop_scales(a, bh, min(qq, a.N - 1), keyc >> 2, ms);
           mk = (keyc & 3) == 0 ? ms[0] : ((keyc & 3) == 1 ? ms[1] : ((keyc & 3) == 2 ? ms[2] : ms[3]));
         }
-        const float pr = (qq < a.N && kok) ? fast_exp(s[r] - sm[r]) * pv[r] * (1.0f / fmaxf(zz, 1e-6f)) : 0.0f;
+        const float sc = a.clamp5 ? fminf(fmaxf(s[r], -5.0f), 5.0f) : s[r];
+        const float pr = (qq < a.N && kok) ? fast_exp(sc - sm[r]) * pv[r] * (1.0f / fmaxf(zz, 1e-6f)) : 0.0f;
         ds[r] = pr * (da[r] * mk - (zz < 1e-6f ? 0.0f : sd[r]));
+        if (a.clamp5 && sc != s[r]) ds[r] = 0.0f;
         p[r] = pr * mk;              // dV takes the dropped probabilities
       }
 #pragma unroll
@@ -935,8 +947,10 @@ extern "C" int feta_attn_bwd_bf16(const void* q, const void* k, const void* v, i
 
 namespace {
 template <class T>
-void set_drop(AttnArgsT<T>& a, float p_drop, uint64_t seed, uint64_t offset, const uint64_t* dstate = nullptr) {
+void set_drop(AttnArgsT<T>& a, float p_drop, uint64_t seed, uint64_t offset, const uint64_t* dstate = nullptr,
+              int clamp5 = 0) {
   a.dstate = reinterpret_cast<const unsigned long long*>(dstate);
+  a.clamp5 = clamp5;
   if (p_drop > 0.0f) {
     const double t = (double)p_drop * 4294967296.0;
     a.drop_thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)t;
@@ -954,12 +968,12 @@ template <class T>
 int attn_fwd_drop_t(const void* q, const void* k, const void* v, int64_t qkv_sb, int64_t qkv_sn, const void* pe,
                     const int32_t* n_real, void* out, int64_t o_sb, int64_t o_sn, void* attn, float* stats, float scale,
                     float p_drop, uint64_t seed, uint64_t offset, int B, int N, int H, int dh, hipStream_t stream,
-                    const uint64_t* dstate = nullptr) {
+                    const uint64_t* dstate = nullptr, int clamp5 = 0) {
   AttnArgsT<T> a{};
   a.q = (const T*)q; a.k = (const T*)k; a.v = (const T*)v; a.pe = (const T*)pe; a.n_real = n_real;
   a.out_w = (T*)out; a.attn = (T*)attn; a.stats = stats; a.qsb = qkv_sb; a.qsn = qkv_sn; a.osb = o_sb;
   a.osn = o_sn; a.scale = scale; a.B = B; a.N = N; a.H = H; a.NB = (N + 15) / 16; a.total = B * H * a.NB;
-  set_drop(a, p_drop, seed, offset, dstate);
+  set_drop(a, p_drop, seed, offset, dstate, clamp5);
   switch (dh) {
     case 16: return launch_attn_fwd_lp<T, 16>(a, stream);
     case 32: return launch_attn_fwd_lp<T, 32>(a, stream);
@@ -973,13 +987,13 @@ int attn_bwd_drop_t(const void* q, const void* k, const void* v, int64_t qkv_sb,
                     const int32_t* n_real, const void* out, const void* dout, int64_t o_sb, int64_t o_sn,
                     const float* stats, float* delta, void* dq, void* dk, void* dv, float scale, float p_drop,
                     uint64_t seed, uint64_t offset, int B, int N, int H, int dh, hipStream_t stream,
-                    const uint64_t* dstate = nullptr) {
+                    const uint64_t* dstate = nullptr, int clamp5 = 0) {
   AttnArgsT<T> a{};
   a.q = (const T*)q; a.k = (const T*)k; a.v = (const T*)v; a.pe = (const T*)pe; a.n_real = n_real;
   a.out = (const T*)out; a.dout = (const T*)dout; a.stats_in = stats; a.delta = delta;
   a.dq = (T*)dq; a.dk = (T*)dk; a.dv = (T*)dv; a.qsb = qkv_sb; a.qsn = qkv_sn; a.osb = o_sb; a.osn = o_sn;
   a.scale = scale; a.B = B; a.N = N; a.H = H; a.NB = (N + 15) / 16; a.total = B * H * a.NB;
-  set_drop(a, p_drop, seed, offset, dstate);
+  set_drop(a, p_drop, seed, offset, dstate, clamp5);
   switch (dh) {
     case 16: return launch_attn_bwd_lp<T, 16>(a, stream);
     case 32: return launch_attn_bwd_lp<T, 32>(a, stream);
@@ -992,7 +1006,7 @@ int attn_bwd_drop_t(const void* q, const void* k, const void* v, int64_t qkv_sb,
 static int attn_fwd_drop_any(const void* q, const void* k, const void* v, int64_t qkv_sb, int64_t qkv_sn,
                                   const void* pe, const int32_t* n_real, void* out, int64_t o_sb, int64_t o_sn,
                                   void* attn, float* stats, float scale, float p_drop, uint64_t seed, uint64_t offset,
-                                  int dtype, int B, int N, int H, int dh, feta_stream_t stream, const uint64_t* dstate) {
+                                  int dtype, int B, int N, int H, int dh, feta_stream_t stream, const uint64_t* dstate, int stab = 0) {
   FETA_REQUIRE(q && k && v && n_real && out && stats, "attn_fwd_drop: null pointer");
   FETA_REQUIRE(B > 0 && H > 0 && N >= 1 && N <= FETA_MAX_NODES, "attn_fwd_drop: N=%d outside [1,%d]", N, FETA_MAX_NODES);
   FETA_REQUIRE(dh == 16 || dh == 32 || dh == 64, "attn_fwd_drop: head dim %d not in {16,32,64}", dh);
@@ -1004,9 +1018,9 @@ static int attn_fwd_drop_any(const void* q, const void* k, const void* v, int64_
                "attn_fwd_drop: misaligned token tensors / strides");
   if (dtype == FETA_DTYPE_F32)
     return attn_fwd_drop_t<float>(q, k, v, qkv_sb, qkv_sn, pe, n_real, out, o_sb, o_sn, attn, stats, scale, p_drop, seed,
-                                  offset, B, N, H, dh, (hipStream_t)stream, dstate);
+                                  offset, B, N, H, dh, (hipStream_t)stream, dstate, stab);
   return attn_fwd_drop_t<bf16_t>(q, k, v, qkv_sb, qkv_sn, pe, n_real, out, o_sb, o_sn, attn, stats, scale, p_drop, seed,
-                                 offset, B, N, H, dh, (hipStream_t)stream, dstate);
+                                 offset, B, N, H, dh, (hipStream_t)stream, dstate, stab);
 }
 
 extern "C" int feta_attn_fwd_drop(const void* q, const void* k, const void* v, int64_t qkv_sb, int64_t qkv_sn,
@@ -1030,7 +1044,7 @@ static int attn_bwd_drop_any(const void* q, const void* k, const void* v, int64_
                                   const void* pe, const int32_t* n_real, const void* out, const void* dout,
                                   int64_t o_sb, int64_t o_sn, const float* stats, float* delta, void* dq, void* dk,
                                   void* dv, float scale, float p_drop, uint64_t seed, uint64_t offset, int dtype,
-                                  int B, int N, int H, int dh, feta_stream_t stream, const uint64_t* dstate) {
+                                  int B, int N, int H, int dh, feta_stream_t stream, const uint64_t* dstate, int stab = 0) {
   FETA_REQUIRE(q && k && v && n_real && out && dout && stats && delta && dq && dk && dv, "attn_bwd_drop: null pointer");
   FETA_REQUIRE(B > 0 && H > 0 && N >= 1 && N <= FETA_MAX_NODES, "attn_bwd_drop: N=%d outside [1,%d]", N, FETA_MAX_NODES);
   FETA_REQUIRE(dh == 16 || dh == 32 || dh == 64, "attn_bwd_drop: head dim %d not in {16,32,64}", dh);
@@ -1040,9 +1054,9 @@ static int attn_bwd_drop_any(const void* q, const void* k, const void* v, int64_
                "attn_bwd_drop: strides %% 4 == 0");
   if (dtype == FETA_DTYPE_F32)
     return attn_bwd_drop_t<float>(q, k, v, qkv_sb, qkv_sn, pe, n_real, out, dout, o_sb, o_sn, stats, delta, dq, dk, dv,
-                                  scale, p_drop, seed, offset, B, N, H, dh, (hipStream_t)stream, dstate);
+                                  scale, p_drop, seed, offset, B, N, H, dh, (hipStream_t)stream, dstate, stab);
   return attn_bwd_drop_t<bf16_t>(q, k, v, qkv_sb, qkv_sn, pe, n_real, out, dout, o_sb, o_sn, stats, delta, dq, dk, dv,
-                                 scale, p_drop, seed, offset, B, N, H, dh, (hipStream_t)stream, dstate);
+                                 scale, p_drop, seed, offset, B, N, H, dh, (hipStream_t)stream, dstate, stab);
 }
 
 extern "C" int feta_attn_bwd_drop(const void* q, const void* k, const void* v, int64_t qkv_sb, int64_t qkv_sn,
@@ -1062,6 +1076,25 @@ extern "C" int feta_attn_bwd_drop_dev(const void* q, const void* k, const void* 
   FETA_REQUIRE(state != nullptr, "attn_bwd_drop_dev: null state");
   return attn_bwd_drop_any(q, k, v, qkv_sb, qkv_sn, pe, n_real, out, dout, o_sb, o_sn, stats, delta, dq, dk, dv, scale,
                            p_drop, 0, offset_add, dtype, B, N, H, dh, stream, state);
+}
+
+extern "C" int feta_attn_fwd_stab(const void* q, const void* k, const void* v, int64_t qkv_sb, int64_t qkv_sn,
+                                  const void* pe, const int32_t* n_real, void* out, int64_t o_sb, int64_t o_sn,
+                                  void* attn, float* stats, float scale, int stab, int dtype, int B, int N, int H,
+                                  int dh, feta_stream_t stream) {
+  FETA_REQUIRE(stab == FETA_STAB_ROWMAX || stab == FETA_STAB_CLAMP5, "attn_fwd_stab: stab %d", stab);
+  return attn_fwd_drop_any(q, k, v, qkv_sb, qkv_sn, pe, n_real, out, o_sb, o_sn, attn, stats, scale, 0.0f, 0, 0, dtype, B,
+                           N, H, dh, stream, nullptr, stab);
+}
+
+extern "C" int feta_attn_bwd_stab(const void* q, const void* k, const void* v, int64_t qkv_sb, int64_t qkv_sn,
+                                  const void* pe, const int32_t* n_real, const void* out, const void* dout,
+                                  int64_t o_sb, int64_t o_sn, const float* stats, float* delta, void* dq, void* dk,
+                                  void* dv, float scale, int stab, int dtype, int B, int N, int H, int dh,
+                                  feta_stream_t stream) {
+  FETA_REQUIRE(stab == FETA_STAB_ROWMAX || stab == FETA_STAB_CLAMP5, "attn_bwd_stab: stab %d", stab);
+  return attn_bwd_drop_any(q, k, v, qkv_sb, qkv_sn, pe, n_real, out, dout, o_sb, o_sn, stats, delta, dq, dk, dv, scale, 0.0f,
+                           0, 0, dtype, B, N, H, dh, stream, nullptr, stab);
 }
 
 static int spec_args_bf16(FilterArgsT<bf16_t>& a, const void* x, int64_t x_sb, int64_t x_sn, const void* u,

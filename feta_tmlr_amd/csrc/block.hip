@@ -155,8 +155,8 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
     // deterministically); workgroup 0 publishes the parameter block and the running statistics
     reduce_partials_finish(a.x_stats, a.Gx, D, pb, scr + 2 * D, scr);
     for (int c = tid; c < D; c += kRowThreads) {
-      const float mean = scr[c] / (float)a.M;
-      const float var = fmaxf(scr[D + c] / (float)a.M - mean * mean, 0.0f);
+      float mean, var;
+      bn_moments(a.x_stats, a.Gx, D, a.M, scr, c, mean, var);
       const float rstd = rsqrtf(var + a.eps);
       const float scale = xg * rstd;
       const float shift = xb - mean * scale;
@@ -400,6 +400,10 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
     load_row_op<T, D>(wf, Wo + (DH * h + lq) * P, g);
     const int o0 = DH * h + 4 * g;
     float s1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    // shift of the statistics (feta_rowops.h): the running mean of the BatchNorm that will normalise y, as it is now
+    float4 ks = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (a.y_shift != nullptr) ks = *reinterpret_cast<const float4*>(a.y_shift + o0);
+    const float kv[4] = {ks.x, ks.y, ks.z, ks.w};
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       if (16 * nt >= a.N) break;
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
       if (rok) L::st4(gy + row * D + o0, v[0], v[1], v[2], v[3]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float x1 = rok ? v[r] : 0.0f;
+        const float x1 = rok ? v[r] - kv[r] : 0.0f;
         s1[r] += row16_sum(x1);
         s2[r] += row16_sum(x1 * x1);
       }
@@ -426,6 +430,7 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
       float* st = a.y_stats + (int64_t)b * 2 * D;
       *reinterpret_cast<float4*>(st + o0) = make_float4(s1[0], s1[1], s1[2], s1[3]);
       *reinterpret_cast<float4*>(st + D + o0) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+      if (b == 0) *reinterpret_cast<float4*>(a.y_stats + (int64_t)a.B * 2 * D + o0) = ks;   // row B: the shift
     }
   }
   }  // graphs of this workgroup
@@ -491,7 +496,7 @@ extern "C" int feta_attn_block_fwd_sums(const feta_attn_block* d, const feta_col
                "attn_block_fwd: x_stats needs x_gamma, x_beta, x_bn_out, Gx");
   FETA_REQUIRE(aligned16(a.x) && aligned16(a.w_in) && aligned16(a.w_out) && aligned16(a.qkv) && aligned16(a.out) &&
                aligned16(a.y) && aligned16(a.y_stats) && aligned16(a.x_stats) && aligned16(a.b_in) && aligned16(a.b_out) &&
-               aligned16(a.out_f32),
+               aligned16(a.out_f32) && aligned16(a.y_shift),
                "attn_block_fwd: tensors must be 16-byte aligned");
   FETA_REQUIRE(a.dtype == FETA_F32 || a.dtype == FETA_BF16, "attn_block_fwd: dtype %d", a.dtype);
   if (a.dtype == FETA_BF16) return dispatch_block_fwd<bf16_t>(a, segs, nseg, (hipStream_t)stream);

@@ -151,6 +151,24 @@ __device__ __forceinline__ void reduce_partials(const float* part, int G, int D,
   reduce_partials_finish(part, G, D, pb, red, tot);
 }
 
+// BatchNorm partial statistics are SHIFTED sums (round 3): a producer accumulates sum (y - K) and sum (y - K)^2 per
+// column, K = the running mean of the BatchNorm that will consume them as the producer saw it (or 0), and records K in
+// one extra row behind its G partial rows - layout [G + 1][2][D], row G = [K | unused].  mean = K + S1 / M and
+// var = S2 / M - (S1 / M)^2 then cancel at the scale of |batch mean - K| (what the running mean tracks) instead of
+// |batch mean|: E[y^2] - mean^2 in fp32 loses the variance of a column whose mean is 10^3 standard deviations away,
+// nn.BatchNorm1d (what the reference calls, Welford) does not.  The consumer reads K from the partial buffer, never
+// from the running mean itself: workgroup 0 of the consumer updates that while the others may still be starting.
+__device__ __forceinline__ float partials_shift(const float* part, int G, int D, int c) {
+  return part[(int64_t)G * 2 * D + c];
+}
+// tot: [2][D] totals of the shifted sums over M rows -> batch mean and biased variance of column c
+__device__ __forceinline__ void bn_moments(const float* part, int G, int D, int M, const float* tot, int c, float& mean,
+                                           float& var) {
+  const float m1 = tot[c] / (float)M;
+  mean = partials_shift(part, G, D, c) + m1;
+  var = fmaxf(tot[D + c] / (float)M - m1 * m1, 0.0f);
+}
+
 __host__ __device__ inline int reduce_red_floats(int D) {
   const int nq = 2 * D / 4;
   const int slices = kRowThreads / nq > 0 ? kRowThreads / nq : 1;

@@ -87,15 +87,19 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a, CoeffFw
     for (int j = 0; j < 4; ++j) L::ld4(gx + (int64_t)rowc * D + 16 * j + 4 * g, xr[j]);
   };
   load_x();
-  float4 b1v[HT], b2v[2];
+  float4 b1v[HT], b2v[2], ksv[2];   // ksv: shift of the y statistics (feta_rowops.h) for this wave's two output tiles
 #pragma unroll
   for (int t = 0; t < HT; ++t)
     b1v[t] = a.b1 != nullptr ? *reinterpret_cast<const float4*>(a.b1 + hh * (FF / 2) + 16 * t + 4 * g)
                              : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < 2; ++t) {
     b2v[t] = a.b2 != nullptr ? *reinterpret_cast<const float4*>(a.b2 + 16 * (2 * hh + t) + 4 * g)
                              : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    ksv[t] = (a.y_shift != nullptr && a.y_stats != nullptr)
+                 ? *reinterpret_cast<const float4*>(a.y_shift + 16 * (2 * hh + t) + 4 * g)
+                 : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  }
   {
     constexpr int NV = 2 * FF * D / 4 / kRowThreads;  // float4 per thread: W1 then W2 (fp32 masters)
     float4 wv4[NV];
@@ -123,8 +127,8 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a, CoeffFw
     // weights behind that hot spot)
     reduce_partials(a.x_stats, a.Gx, D, scr + 2 * D, scr);
     for (int c = tid; c < D; c += kRowThreads) {
-      const float mean = scr[c] / (float)a.M;
-      const float var = fmaxf(scr[D + c] / (float)a.M - mean * mean, 0.0f);
+      float mean, var;
+      bn_moments(a.x_stats, a.Gx, D, a.M, scr, c, mean, var);
       const float rstd = rsqrtf(var + a.eps);
       const float scale = a.x_gamma[c] * rstd;
       const float shift = a.x_beta[c] - mean * scale;
@@ -229,9 +233,10 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a, CoeffFw
       else L::st4(gy + (int64_t)row * D + o2, v[0], v[1], v[2], v[3]);
     }
     if (want_stats) {
+      const float kk[4] = {ksv[t].x, ksv[t].y, ksv[t].z, ksv[t].w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float x1 = rok ? v[r] : 0.0f;
+        const float x1 = rok ? v[r] - kk[r] : 0.0f;
         const float s1 = row16_sum(x1), s2 = row16_sum(x1 * x1);
         if (lq == 0) {
           red[(rt * 2 + 0) * D + o2 + r] = s1;
@@ -247,6 +252,8 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a, CoeffFw
   FFN_STAMP(5);
   }  // row blocks of this workgroup
   if (want_stats && tid < 2 * D) a.y_stats[(int64_t)blockIdx.x * 2 * D + tid] = tot1[0];
+  if (want_stats && blockIdx.x == 0 && tid < D)   // row main_grid: the shift these sums are relative to
+    a.y_stats[(int64_t)main_grid * 2 * D + tid] = a.y_shift != nullptr ? a.y_shift[tid] : 0.0f;
 }
 
 template <class T, int FF>

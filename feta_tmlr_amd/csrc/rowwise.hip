@@ -134,8 +134,8 @@ __global__ __launch_bounds__(kRowThreads) void rowlin_fwd_kernel(RowLinArgs a, R
     // deterministically); block 0 publishes the parameter block and the running statistics
     reduce_partials(a.x_stats, a.Gx, DS, scr + 2 * DS, scr);
     for (int c = threadIdx.x; c < DS; c += kRowThreads) {
-      const float mean = scr[c] / (float)a.M;
-      const float var = fmaxf(scr[DS + c] / (float)a.M - mean * mean, 0.0f);
+      float mean, var;
+      bn_moments(a.x_stats, a.Gx, DS, a.M, scr, c, mean, var);
       const float rstd = rsqrtf(var + a.eps);
       const float scale = a.x_gamma[c] * rstd;
       const float shift = a.x_beta[c] - mean * scale;
@@ -204,9 +204,13 @@ __global__ __launch_bounds__(kRowThreads) void rowlin_fwd_kernel(RowLinArgs a, R
       if (rok)
         *reinterpret_cast<float4*>(a.y + (int64_t)row * a.NO + o) = make_float4(v[0], v[1], v[2], v[3]);
       if (want_stats) {
+        // (shifted sums, feta_rowops.h: relative to the consumer BatchNorm's running mean)
+        float4 ks = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (a.stats_shift != nullptr) ks = *reinterpret_cast<const float4*>(a.stats_shift + o);
+        const float kv[4] = {ks.x, ks.y, ks.z, ks.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float s1 = rok ? v[r] : 0.0f, s2 = s1 * s1;
+          float s1 = rok ? v[r] - kv[r] : 0.0f, s2 = s1 * s1;
           s1 = row16_sum(s1);
           s2 = row16_sum(s2);
           if (lq == 0) {
@@ -226,6 +230,8 @@ __global__ __launch_bounds__(kRowThreads) void rowlin_fwd_kernel(RowLinArgs a, R
 #pragma unroll
         for (int w = 0; w < kRowWaves; ++w) s += red[w * 2 * tgw + i];
         a.stats[((int64_t)rg * 2 + which) * a.NO + o_base + ol] = s;
+        if (rg == 0 && which == 0)   // row G: the shift
+          a.stats[(int64_t)ge.G * 2 * a.NO + o_base + ol] = a.stats_shift != nullptr ? a.stats_shift[o_base + ol] : 0.0f;
       }
     }
   }
@@ -617,6 +623,7 @@ struct BnArgs {
   const float* mean_rstd_in;
   float* out;           // [M, D]
   float* mean_rstd;     // [2, D]
+  const float* shift;   // bn_stats: [D] shift of the partial sums (feta_rowops.h) or null
   float* running_mean;  // [D] or null
   float* running_var;   // [D] or null
   int64_t* nbt;         // num_batches_tracked or null
@@ -639,11 +646,12 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(BnArgs a) {
   const bool active = (int)threadIdx.x < slices * D;
   const int nrb = (a.M + kRowsPerBlock - 1) / kRowsPerBlock;
   float s1 = 0.0f, s2 = 0.0f;
+  const float kshift = (active && a.shift != nullptr) ? a.shift[col] : 0.0f;   // shifted sums (feta_rowops.h)
   if (active) {
     for (int rb = blockIdx.x; rb < nrb; rb += a.G) {
       const int r0 = rb * kRowsPerBlock;
       for (int r = r0 + slice; r < min(r0 + kRowsPerBlock, a.M); r += slices) {
-        const float v = a.y[(int64_t)r * D + col];
+        const float v = a.y[(int64_t)r * D + col] - kshift;
         s1 += v;
         s2 += v * v;
       }
@@ -660,6 +668,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(BnArgs a) {
     }
     a.stats_out[((int64_t)blockIdx.x * 2 + 0) * D + col] = t1;
     a.stats_out[((int64_t)blockIdx.x * 2 + 1) * D + col] = t2;
+    if (blockIdx.x == 0) a.stats_out[(int64_t)a.G * 2 * D + col] = kshift;   // row G: the shift
   }
 }
 
@@ -673,8 +682,8 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(BnArgs a) {
   float* red = feta_lds + 4 * D;   // [slices][2][D]
   reduce_partials(a.stats, a.Gs > 0 ? a.Gs : a.G, D, red, tot);
   for (int c = threadIdx.x; c < D; c += 256) {
-    const float mean = tot[c] / (float)a.M;
-    const float var = fmaxf(tot[D + c] / (float)a.M - mean * mean, 0.0f);
+    float mean, var;
+    bn_moments(a.stats, a.Gs > 0 ? a.Gs : a.G, D, a.M, tot, c, mean, var);
     const float rstd = rsqrtf(var + a.eps);
     const float scale = a.gamma[c] * rstd;
     sc[c] = scale;
@@ -946,9 +955,13 @@ extern "C" int feta_rowlin_bwd(const float* x, const float* w, const float* dy,
 }
 
 extern "C" int feta_bn_stats(const float* y, float* stats, int M, int D, feta_stream_t stream) {
+  return feta_bn_stats_shift(y, nullptr, stats, M, D, stream);
+}
+
+extern "C" int feta_bn_stats_shift(const float* y, const float* shift, float* stats, int M, int D, feta_stream_t stream) {
   FETA_REQUIRE(y && stats && M > 0 && D > 0 && D <= 256, "bn_stats: need 0 < D <= 256");
   BnArgs a{};
-  a.y = y; a.stats_out = stats; a.M = M; a.D = D; a.G = row_blocks(M);
+  a.y = y; a.shift = shift; a.stats_out = stats; a.M = M; a.D = D; a.G = row_blocks(M);
   const int slices = 256 / D > 0 ? 256 / D : 1;
   auto kern = bn_stats_kernel;
   hipLaunchKernelGGL(kern, dim3(a.G), dim3(256), sizeof(float) * slices * 2 * D, (hipStream_t)stream, a);

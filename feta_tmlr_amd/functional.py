@@ -36,7 +36,7 @@ class AttentionCoreFn(torch.autograd.Function):
     attn [B,H,N,N] or None).  C ABI: feta_attn_fwd / feta_attn_bwd."""
 
     @staticmethod
-    def forward(ctx, qkv, pe, n_real, num_heads, need_attn, tie_qk, batch_first, drop=None):
+    def forward(ctx, qkv, pe, n_real, num_heads, need_attn, tie_qk, batch_first, drop=None, clamp5=False):
         abi, stream = _lib.backend(qkv, pe, n_real)
         ctx.set_materialize_grads(False)   # no zero tensor for the non-differentiable attn output
         qkv = qkv.contiguous()
@@ -52,7 +52,8 @@ class AttentionCoreFn(torch.autograd.Function):
         stats = torch.empty((b, num_heads, n, 2), dtype=torch.float32, device=qkv.device)
         pe_c = None if pe is None else pe.to(qkv.dtype).contiguous()   # (bf16 storage: pe travels as bf16 too)
         scale = float(dh) ** -0.5
-        abi.attn_fwd(q, k, v, pe_c, n_real, out, attn, stats, scale, stream, drop=drop)
+        abi.attn_fwd(q, k, v, pe_c, n_real, out, attn, stats, scale, stream, drop=drop, clamp5=clamp5)
+        ctx.clamp5 = bool(clamp5)
         ctx.save_for_backward(qkv, pe_c, n_real, out, stats)
         ctx.cfg = (num_heads, tie_qk, batch_first, scale)
         ctx.drop = drop
@@ -65,7 +66,7 @@ class AttentionCoreFn(torch.autograd.Function):
     def backward(ctx, dconcat, _dattn):
         qkv, pe_c, n_real, out, stats = ctx.saved_tensors
         if dconcat is None:
-            return (None,) * 8
+            return (None,) * 9
         num_heads, tie_qk, batch_first, scale = ctx.cfg
         abi, stream = _lib.backend(qkv)
         l0, l1, d3 = qkv.shape
@@ -84,11 +85,11 @@ class AttentionCoreFn(torch.autograd.Function):
         dout = _token_view(dconcat.to(qkv.dtype).contiguous(), batch_first, num_heads)
         delta = torch.empty((b, num_heads, n), dtype=torch.float32, device=qkv.device)
         abi.attn_bwd(q, k, v, pe_c, n_real, out, dout, stats, delta, gsel(0), gsel(1), gsel(2),
-                     scale, stream, drop=ctx.drop)
+                     scale, stream, drop=ctx.drop, clamp5=ctx.clamp5)
         if tie_qk:
             dqkv[..., :d] += dqkv[..., d:2 * d]
             dqkv[..., d:2 * d] = 0
-        return dqkv, None, None, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None, None, None
 
 
 class FilterCoefficientsFn(torch.autograd.Function):
@@ -449,7 +450,7 @@ class RowLinearFn(torch.autograd.Function):
     per-block partial BatchNorm statistics of y.  C ABI: feta_rowlin_fwd / feta_rowlin_bwd."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, rowscale, residual, relu, want_stats):
+    def forward(ctx, x, w, bias, rowscale, residual, relu, want_stats, stats_shift=None):
         abi, stream = _lib.backend(x, w)
         ctx.set_materialize_grads(False)   # no zero tensor for the non-differentiable stats output
         assert not (relu and residual is not None), 'relu mask is taken from the saved output'
@@ -459,9 +460,15 @@ class RowLinearFn(torch.autograd.Function):
         y = torch.empty((m, no), dtype=torch.float32, device=x.device)
         stats = None
         if want_stats:
-            stats = torch.empty((abi.rowlin_blocks(m), 2, no), dtype=torch.float32, device=x.device)
+            # shifted partial sums + the shift row (csrc/feta_rowops.h): relative to the consumer BatchNorm's running mean
+            stats = torch.empty((abi.rowlin_blocks(m) + 1, 2, no), dtype=torch.float32, device=x.device)
         res = None if residual is None else residual.contiguous()
-        abi.rowlin_fwd(x, w, bias, rowscale, res, y, stats, relu, stream)
+        if want_stats and stats_shift is not None:
+            d = abi.rowlin_ex(m, x.shape[1], no, relu=relu, x=x, w=w, bias=bias, rowscale=rowscale, residual=res, y=y,
+                              stats=stats, stats_shift=stats_shift)
+            abi.rowlin_fwd_ex(d, stream)
+        else:
+            abi.rowlin_fwd(x, w, bias, rowscale, res, y, stats, relu, stream)
         ctx.save_for_backward(x, w, rowscale, y if relu else None)
         ctx.cfg = (bias is not None, residual is not None)
         if stats is not None:
@@ -472,7 +479,7 @@ class RowLinearFn(torch.autograd.Function):
     def backward(ctx, dy, _dstats):
         x, w, rowscale, ysaved = ctx.saved_tensors
         if dy is None:
-            return (None,) * 7
+            return (None,) * 8
         has_bias, has_res = ctx.cfg
         abi, stream = _lib.backend(x)
         m, ki = x.shape
@@ -484,7 +491,7 @@ class RowLinearFn(torch.autograd.Function):
         abi.rowlin_bwd(x, w, dy, rowscale, ysaved, dx, partial, dwdb, stream)
         dw = dwdb[:no * ki].view(no, ki)
         db = dwdb[no * ki:] if has_bias else None
-        return dx, dw, db, None, (dy if has_res else None), None, None
+        return dx, dw, db, None, (dy if has_res else None), None, None, None
 
 
 class RowLinearCatFn(torch.autograd.Function):
@@ -594,8 +601,8 @@ class BatchNormTrainFn(torch.autograd.Function):
         y = y.contiguous()
         m, d = y.shape
         if stats is None:
-            stats = torch.empty((abi.rowlin_blocks(m), 2, d), dtype=torch.float32, device=y.device)
-            abi.bn_stats(y, stats, stream)
+            stats = torch.empty((abi.rowlin_blocks(m) + 1, 2, d), dtype=torch.float32, device=y.device)
+            abi.bn_stats(y, stats, stream, shift=running_mean)
         out = torch.empty_like(y)
         mean_rstd = torch.empty((2, d), dtype=torch.float32, device=y.device)
         abi.bn_apply_fwd(y, stats, gamma, beta, out, mean_rstd, running_mean, running_var,
@@ -624,9 +631,10 @@ def row_linear_supported(ki, no, need_backward=True):
     return ki in ROWLIN_DIMS and (no in ROWLIN_DIMS if need_backward else no % 16 == 0)
 
 
-def row_linear(x, w, bias=None, rowscale=None, residual=None, relu=False, want_stats=False):
-    """x [M, KI] -> (y [M, NO], stats or None)."""
-    return RowLinearFn.apply(x, w, bias, rowscale, residual, relu, want_stats)
+def row_linear(x, w, bias=None, rowscale=None, residual=None, relu=False, want_stats=False, stats_shift=None):
+    """x [M, KI] -> (y [M, NO], stats [G + 1, 2, NO] or None).  stats_shift [NO]: the running mean of the BatchNorm that
+    will consume the statistics - they are sums of (y - shift) (csrc/feta_rowops.h)."""
+    return RowLinearFn.apply(x, w, bias, rowscale, residual, relu, want_stats, stats_shift)
 
 
 def row_linear_cat(x1, x2, w, bias=None, pending=None):
@@ -753,7 +761,8 @@ class DropoutState:
             cls._sync_device()
 
 
-def attention_core(qkv, pe, n_real, num_heads, need_attn=True, tie_qk=False, batch_first=False, dropout_p=0.0):
+def attention_core(qkv, pe, n_real, num_heads, need_attn=True, tie_qk=False, batch_first=False, dropout_p=0.0,
+                   stab='rowmax'):
     """dropout_p > 0: attention-probability dropout with a mask regenerated in backward (no mask tensor).  The key
     (seed, offset) is a pair of host values, or - DropoutState in device mode - a device tensor the kernels read when
     they run, which is what makes the op capturable."""
@@ -764,7 +773,11 @@ def attention_core(qkv, pe, n_real, num_heads, need_attn=True, tie_qk=False, bat
                                'the key on the device (functional.DropoutState.begin_device_mode; '
                                'train.GraphedTrainStep does)')
         drop = (float(dropout_p),) + DropoutState.next()
-    return AttentionCoreFn.apply(qkv, pe, n_real, num_heads, need_attn, tie_qk, batch_first, drop)
+    if stab not in ('rowmax', 'clamp5'):
+        raise ValueError("stab must be 'rowmax' or 'clamp5'")
+    if stab == 'clamp5' and drop is not None:
+        raise NotImplementedError('stab=clamp5 with attention dropout')
+    return AttentionCoreFn.apply(qkv, pe, n_real, num_heads, need_attn, tie_qk, batch_first, drop, stab == 'clamp5')
 
 
 def filter_coefficients(attn, n_real, gcn_weight, gcn_bias, pending=None):

@@ -96,6 +96,8 @@ def stack_supported(layers, d_model):
             return False
         if l.training and (l.dropout1.p > 0.0 or l.dropout.p > 0.0 or l.dropout2.p > 0.0 or l.self_attn.dropout > 0.0):
             return False
+        if getattr(l.self_attn, 'stab', 'rowmax') != 'rowmax':    # (the fused kernels implement exp(s - rowmax))
+            return False
         if bn:
             if not l.training or l.norm1.momentum is None or l.norm2.momentum is None:
                 return False
@@ -117,13 +119,18 @@ STACK_FLAT_GRAD = weakref.WeakKeyDictionary()
 MAX_STAT_ROWS = 256   # every consumer workgroup re-reduces the partial statistics: keep them few
 
 
-def _cap_partials(abi, stream, st, new):
-    """[G, 2, D] partial BatchNorm sums -> the same if G is small, else their total as [1, 2, D]
-    (one extra reduction launch, only at batch sizes where a step takes milliseconds anyway)."""
-    if st.shape[0] <= MAX_STAT_ROWS:
-        return st, st.shape[0]
-    tot = new(1, 2, st.shape[2])
-    abi.colsum(st.view(st.shape[0], -1), tot.view(-1), stream)
+def _cap_partials(abi, stream, st, new, shift_row=False):
+    """[G (+ 1), 2, D] partial sums -> the same if G is small, else their total as [1 (+ 1), 2, D] (one extra reduction
+    launch, only at batch sizes where a step takes milliseconds anyway).  shift_row: BatchNorm STATISTICS carry one more
+    row, the shift their sums are relative to (csrc/feta_rowops.h); it is not a partial and travels unchanged.
+    -> (buffer, number of partial rows)"""
+    g = st.shape[0] - (1 if shift_row else 0)
+    if g <= MAX_STAT_ROWS:
+        return st, g
+    tot = new(2 if shift_row else 1, 2, st.shape[2])
+    abi.colsum(st[:g].view(g, -1), tot[0].view(-1), stream)
+    if shift_row:
+        tot[1].copy_(st[g])
     return tot, 1
 
 
@@ -226,13 +233,13 @@ class FusedEncoderStackFn(torch.autograd.Function):
             if block:
                 # F1 + F2 + F3 in one launch, one workgroup per graph (csrc/block.hip)
                 G1 = b
-                st1 = new(G1, 2, d)
+                st1 = new(G1 + 1, 2, d)      # (+ the shift row: the sums are relative to norm1's running mean)
                 abi.attn_block_fwd(b, n, scale, stream, tie_qk=tie, x=y_prev, w_in=w_in, b_in=b_in, w_out=w_o,
                                    b_out=b_o, pe=pe_c, n_real=n_real, rowscale=degree_rows, qkv=qkv, out=out,
-                                   attn_stats=ast, attn=attn, y=y1, y_stats=st1,
+                                   attn_stats=ast, attn=attn, y=y1, y_stats=st1, y_shift=layer.norm1.running_mean,
                                    out_f32=(out32 if li == nl - 1 else None),
                                    sums=(pending.take_fwd() if (pending is not None and li == 0) else ()), **bn_prev)
-                st1, G1 = _cap_partials(abi, stream, st1, new)
+                st1, G1 = _cap_partials(abi, stream, st1, new, shift_row=True)
             else:
                 # F1
                 dsc = abi.rowlin_ex(m, d, 3 * d, x=y_prev if li else x_in, w=w_in, bias=b_in, y=qkv, **bn_prev)
@@ -244,9 +251,10 @@ class FusedEncoderStackFn(torch.autograd.Function):
                 abi.attn_fwd(q, k, v, pe_c, n_real, out.permute(1, 0, 2, 3), attn, ast, scale, stream)
                 # F3
                 G1 = G
-                st1 = new(G1, 2, d)
+                st1 = new(G1 + 1, 2, d)
                 dsc = abi.rowlin_ex(m, d, d, x=out.view(m, d), w=w_o, bias=b_o, rowscale=degree_rows,
-                                    residual=y_prev, res_bn=prm_prev, y=y1, stats=st1)
+                                    residual=y_prev, res_bn=prm_prev, y=y1, stats=st1,
+                                    stats_shift=layer.norm1.running_mean)
                 abi.rowlin_fwd_ex(dsc, stream)
             h, prm1 = newt(m, ff), new(4, d)
             n1 = layer.norm1
@@ -256,18 +264,20 @@ class FusedEncoderStackFn(torch.autograd.Function):
             if USE_FFN_FUSED and abi.ffn_supported(d, ff):
                 # F4 + F5 in one launch: the hidden activations stay in registers (csrc/ffn.hip)
                 G2 = abi.ffn_blocks(m)
-                st2 = new(G2, 2, d)
+                st2 = new(G2 + 1, 2, d)
                 abi.ffn_fwd(m, ff, stream, x=y1, w1=w1, b1=bb1, w2=w2, b2=bb2, h=h, y=y2, y_stats=st2,
+                            y_shift=layer.norm2.running_mean,
                             coeff=_coeff_fwd_role(pending, li, nl, attn, n_real), **bn1)
-                st2, G2 = _cap_partials(abi, stream, st2, new)
+                st2, G2 = _cap_partials(abi, stream, st2, new, shift_row=True)
             else:
                 # F4
                 dsc = abi.rowlin_ex(m, d, ff, relu=True, x=y1, w=w1, bias=bb1, y=h, **bn1)
                 abi.rowlin_fwd_ex(dsc, stream)
                 # F5
                 G2 = G
-                st2 = new(G2, 2, d)
-                dsc = abi.rowlin_ex(m, ff, d, x=h, w=w2, bias=bb2, residual=y1, res_bn=prm1, y=y2, stats=st2)
+                st2 = new(G2 + 1, 2, d)
+                dsc = abi.rowlin_ex(m, ff, d, x=h, w=w2, bias=bb2, residual=y1, res_bn=prm1, y=y2, stats=st2,
+                                    stats_shift=layer.norm2.running_mean)
                 abi.rowlin_fwd_ex(dsc, stream)
             saved.append(dict(x0=y_prev, prm0=prm_prev, qkv=qkv, out=out, ast=ast, y1=y1, prm1=prm1, h=h, y2=y2))
             y_prev, st_prev, G2_prev = y2, st2, G2
@@ -507,7 +517,7 @@ class FusedLayerNormStackFn(torch.autograd.Function):
             if block:
                 abi.attn_block_fwd(b, n, scale, stream, tie_qk=tie, x=x_in, w_in=w_in, b_in=b_in, w_out=w_o,
                                    b_out=b_o, pe=pe_c, n_real=n_real, rowscale=degree_rows, qkv=qkv, out=out,
-                                   attn_stats=ast, attn=attn, y=y1, y_stats=new(b, 2, d),   # (statistics unused)
+                                   attn_stats=ast, attn=attn, y=y1, y_stats=new(b + 1, 2, d),   # (statistics unused)
                                    out_f32=(out32 if li == nl - 1 else None),
                                    sums=(pending.take_fwd() if (pending is not None and li == 0) else ()))
             else:

@@ -13,7 +13,8 @@ dot-product scores, padded keys masked, exp(s - rowmax), multiplied by the posit
 ``pe`` (broadcast over heads), normalised by clamp(rowsum, 1e-6) - the same form as the in-tree
 DGL variants (LSPE/layers/graphit_gt_layer.py:39-43,120-131,164) - then out_proj, the optional
 ``degree`` scaling, residual + norm + FFN + residual + norm.  Choices the call sites do not pin are
-constructor flags (``tie_qk``, ``in_proj_bias``) rather than guesses.
+constructor flags (``tie_qk``, ``in_proj_bias``, ``stab`` = 'rowmax' | 'clamp5': the DGL variants clamp the score to
++-5 instead of subtracting the row maximum, LSPE/layers/graphit_gt_layer.py:39-43) rather than guesses.
 
 Kernels: the score/softmax/weighted-sum runs in feta_attn_fwd/bwd; every linear with its
 element-wise neighbours (bias, relu, degree scaling, residual) and the BatchNorm statistics runs in
@@ -35,11 +36,11 @@ def n_real_from_mask(key_padding_mask):
     return (~key_padding_mask).sum(dim=-1, dtype=torch.int32)
 
 
-def linear_rows(x2d, weight, bias, rowscale=None, residual=None, relu=False, want_stats=False):
+def linear_rows(x2d, weight, bias, rowscale=None, residual=None, relu=False, want_stats=False, stats_shift=None):
     """feta_rowlin on [M, KI] rows when the dims are instantiated, else the same arithmetic with
     rocBLAS + PyTorch ops (still on the GPU).  -> (y, stats or None)"""
     if FF.row_linear_supported(x2d.shape[1], weight.shape[0]):
-        return FF.row_linear(x2d, weight, bias, rowscale, residual, relu, want_stats)
+        return FF.row_linear(x2d, weight, bias, rowscale, residual, relu, want_stats, stats_shift)
     y = F.linear(x2d, weight, bias)
     if relu:
         y = F.relu(y)
@@ -54,9 +55,11 @@ class DiffMultiheadAttention(nn.Module):
     """Parameter names follow nn.MultiheadAttention (in_proj_weight [3d,d], out_proj.*) so that
     reference checkpoints (``encoder.layers.{i}.self_attn.*``) load."""
 
-    def __init__(self, embed_dim, num_heads, dropout=0.0, bias=False, tie_qk=False):
+    def __init__(self, embed_dim, num_heads, dropout=0.0, bias=False, tie_qk=False, stab='rowmax'):
         super().__init__()
         assert embed_dim % num_heads == 0
+        assert stab in ('rowmax', 'clamp5')
+        self.stab = stab     # exp(s - rowmax) (upstream GraphiT) | exp(clamp(s, -5, 5)) (the in-tree DGL witnesses)
         self.embed_dim = embed_dim
         self.num_heads = num_heads
         self.head_dim = embed_dim // num_heads
@@ -88,7 +91,7 @@ class DiffMultiheadAttention(nn.Module):
         qkv, _ = linear_rows(query.reshape(n * b, d), self.in_proj_weight, self.in_proj_bias)
         return FF.attention_core(qkv.view(n, b, 3 * d), pe, n_real, self.num_heads,
                                  need_attn=need_weights, tie_qk=self.tie_qk, batch_first=False,
-                                 dropout_p=self.dropout if self.training else 0.0)
+                                 dropout_p=self.dropout if self.training else 0.0, stab=self.stab)
 
     def forward(self, query, key, value, pe=None, key_padding_mask=None, need_weights=True,
                 attn_mask=None, need_heads=False, n_real=None):
@@ -108,12 +111,12 @@ class DiffMultiheadAttention(nn.Module):
 
 class DiffTransformerEncoderLayer(nn.Module):
     def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation='relu',
-                 batch_norm=False, tie_qk=False, in_proj_bias=False):
+                 batch_norm=False, tie_qk=False, in_proj_bias=False, stab='rowmax'):
         super().__init__()
         if activation != 'relu':
             raise NotImplementedError('relu only')
         self.self_attn = DiffMultiheadAttention(d_model, nhead, dropout=dropout, bias=in_proj_bias,
-                                                tie_qk=tie_qk)
+                                                tie_qk=tie_qk, stab=stab)
         self.linear1 = nn.Linear(d_model, dim_feedforward)
         self.dropout = nn.Dropout(dropout)
         self.linear2 = nn.Linear(dim_feedforward, d_model)
@@ -141,7 +144,7 @@ class DiffTransformerEncoderLayer(nn.Module):
         x0 = src.to(dt)
         qkv = F.linear(x0, cast(a.in_proj_weight), cast(a.in_proj_bias))
         concat, attn = FF.attention_core(qkv, pe, n_real, a.num_heads, need_attn=need_weights, tie_qk=a.tie_qk,
-                                         batch_first=False, dropout_p=a.dropout if self.training else 0.0)
+                                         batch_first=False, dropout_p=a.dropout if self.training else 0.0, stab=a.stab)
         src2 = F.linear(concat, cast(a.out_proj.weight), cast(a.out_proj.bias))
         if degree_rows is not None:
             src2 = src2 * degree_rows.view(n, b, 1).to(dt)
@@ -191,7 +194,8 @@ class DiffTransformerEncoderLayer(nn.Module):
         if fuse_drop:
             # y1 = x0 + degree * (concat W_o^T + b_o), BN statistics of y1 in the same launch
             y1, st1 = linear_rows(concat.reshape(m, d), op.weight, op.bias, rowscale=degree_rows,
-                                  residual=x0, want_stats=self.batch_norm)
+                                  residual=x0, want_stats=self.batch_norm,
+                                  stats_shift=self.norm1.running_mean if self.batch_norm else None)
         else:
             src2, _ = linear_rows(concat.reshape(m, d), op.weight, op.bias, rowscale=degree_rows)
             y1, st1 = x0 + self.dropout1(src2), None
@@ -199,7 +203,8 @@ class DiffTransformerEncoderLayer(nn.Module):
         if fuse_drop:
             h, _ = linear_rows(x1, self.linear1.weight, self.linear1.bias, relu=True)
             y2, st2 = linear_rows(h, self.linear2.weight, self.linear2.bias, residual=x1,
-                                  want_stats=self.batch_norm)
+                                  want_stats=self.batch_norm,
+                                  stats_shift=self.norm2.running_mean if self.batch_norm else None)
         else:
             h, _ = linear_rows(x1, self.linear1.weight, self.linear1.bias, relu=True)
             src2, _ = linear_rows(self.dropout(h), self.linear2.weight, self.linear2.bias)

@@ -263,13 +263,32 @@ int feta_attn_bwd_drop_dev(const void* q, const void* k, const void* v, int64_t 
                            void* dq, void* dk, void* dv, float scale, float p_drop, const uint64_t* state,
                            uint64_t offset_add, int dtype, int B, int N, int H, int dh, feta_stream_t stream);
 
+/* ---- A1 with a choice of exponent stabilisation (stab = {rowmax, clamp5}; ABI 7) --------------------
+ * FETA_STAB_ROWMAX: e = exp(s - rowmax) - feta_attn_fwd / feta_attn_bwd (upstream GraphiT, README.md:129);
+ * FETA_STAB_CLAMP5: e = exp(clamp(s, -5, 5)), the form of the in-tree DGL witnesses (LSPE/layers/graphit_gt_layer.py:
+ * 39-43, LPE/layers/graph_transformer_spectra_layer.py:239-243): no row maximum (stats holds 0 for it), a clamped
+ * score passes no gradient; everything else (key mask, * pe, / max(rowsum, 1e-6)) as feta_attn_fwd.  A1's source is
+ * absent from the reference, so the open semantic choices are flags.  dtype as feta_attn_fwd_drop. */
+#define FETA_STAB_ROWMAX 0
+#define FETA_STAB_CLAMP5 1
+int feta_attn_fwd_stab(const void* q, const void* k, const void* v, int64_t qkv_sb, int64_t qkv_sn,
+                       const void* pe, const int32_t* n_real, void* out, int64_t o_sb, int64_t o_sn,
+                       void* attn, float* stats, float scale, int stab, int dtype, int B, int N, int H, int dh,
+                       feta_stream_t stream);
+int feta_attn_bwd_stab(const void* q, const void* k, const void* v, int64_t qkv_sb, int64_t qkv_sn,
+                       const void* pe, const int32_t* n_real, const void* out, const void* dout,
+                       int64_t o_sb, int64_t o_sn, const float* stats, float* delta,
+                       void* dq, void* dk, void* dv, float scale, int stab, int dtype, int B, int N, int H, int dh,
+                       feta_stream_t stream);
+
 /* ---- A1/A4: row-wise linears of the encoder layer and BatchNorm1d --------------------------
  * Replaces the F.linear / relu / degree scaling / residual / BatchNorm1d sequence of
  * DiffTransformerEncoderLayer.forward (contract transformer/models.py:166-167; body per upstream
  * GraphiT, README.md:129) and linear_cat (transformer/models.py:223-224).  Activations are
  * [M, C] row-major, M = N*B rows.
  *   y = relu?(x W^T + bias) * rowscale[row]? + residual?        x [M,KI], W [NO,KI], y [M,NO]
- * stats (optional) receives per-block partial (sum, sumsq) of y: [feta_rowlin_blocks(M), 2, NO],
+ * stats (optional) receives per-block partial (sum, sumsq) of y: [feta_rowlin_blocks(M) + 1, 2, NO] (ABI 7: the last
+ * row records the shift of the sums, feta_rowlin_ex.stats_shift - zero through this entry point),
  * the BatchNorm statistics of the result without a separate pass.
  * KI in {16,32,64,128,192,256}; NO a multiple of 16 (backward: NO in the same set).
  */
@@ -300,9 +319,9 @@ typedef struct feta_rowlin_ex {
   const float* residual;  /* [M,NO] */
   const float* res_bn;    /* bn parameter block [4][NO] through which residual is seen */
   float* y;               /* [M,NO] */
-  float* stats;           /* [feta_rowlin_blocks(M),2,NO] partial (sum, sumsq) of y */
+  float* stats;           /* [feta_rowlin_blocks(M) + 1,2,NO] partial (shifted) (sum, sumsq) of y + the shift row */
   const float* x_bn;      /* finalized bn parameter block [4][KI] of the input, or */
-  const float* x_stats;   /* [Gx,2,KI] partial statistics to finalize here: needs x_gamma, x_beta, */
+  const float* x_stats;   /* [Gx + 1,2,KI] partial statistics (+ shift row) to finalize here: needs x_gamma, x_beta, */
   int Gx;                 /*   x_bn_out (written by block 0), optional running stats */
   const float* x_gamma;
   const float* x_beta;
@@ -339,6 +358,11 @@ typedef struct feta_rowlin_ex {
   const float* sum_y;     /* [M,KI] pre-norm values of the BatchNorm that produced x: emit */
   const float* sum_bn;    /*   sum_out [feta_rowlin_blocks(M),2,KI] = partial (sum dx, sum dx*xhat) */
   float* sum_out;
+  const float* stats_shift; /* nullable [NO] (ABI 7): `stats` are SHIFTED sums - sum (y - K), sum (y - K)^2 with K = this
+                               vector, the running mean of the BatchNorm that will consume them (0 if NULL) - and K is
+                               recorded in one extra row: stats / x_stats / y_stats buffers hold G + 1 rows, row G =
+                               [K | unused].  mean = K + S1 / M, var = S2 / M - (S1 / M)^2: the cancellation of
+                               E[y^2] - mean^2 moves from |mean| to |mean - running mean| (csrc/feta_rowops.h) */
 } feta_rowlin_ex;
 
 int feta_rowlin_fwd_ex(const feta_rowlin_ex* d, feta_stream_t stream);
@@ -362,6 +386,8 @@ int feta_bn_bwd_reduce(const float* y, const float* dout, const float* bn_prm, f
  * mean_rstd [2, D] is saved for backward; running_* (nullable) are updated with momentum and the
  * unbiased variance, num_batches_tracked (nullable, int64) is advanced by one, as nn.BatchNorm1d does. */
 int feta_bn_stats(const float* y, float* stats, int M, int D, feta_stream_t stream);
+/* ... with a shift (feta_rowlin_ex.stats_shift); either way stats has feta_rowlin_blocks(M) + 1 rows (ABI 7) */
+int feta_bn_stats_shift(const float* y, const float* shift, float* stats, int M, int D, feta_stream_t stream);
 int feta_bn_apply_fwd(const float* y, const float* stats, const float* gamma, const float* beta,
                       float* out, float* mean_rstd, float* running_mean, float* running_var,
                       int64_t* num_batches_tracked, float momentum, float eps, int M, int D, feta_stream_t stream);
@@ -415,6 +441,8 @@ typedef struct feta_attn_block {
   int64_t row_sb, row_sn;
   int tie_qk;
   int dtype;           /* FETA_F32 | FETA_BF16: storage type of x, pe, qkv, out, y [T] (ABI 7) */
+  const float* y_shift; /* nullable [64]: shift of the y statistics = running mean of the BatchNorm that will normalise y
+                           (feta_rowlin_ex.stats_shift); y_stats has B + 1 rows, row B receives the shift */
   float* out_f32;      /* nullable: `out` once more, as fp32 [M,64] - the fp32 filter stage behind a bf16 stack reads it
                           (out_each_head of the last layer, transformer/models.py:179) without a cast launch */
 } feta_attn_block;
@@ -505,6 +533,8 @@ typedef struct feta_ffn {
   float* y_stats;   /* or NULL */
   int M, FF;
   int dtype;        /* FETA_F32 | FETA_BF16: storage type of x, h, y [T] (ABI 7) */
+  const float* y_shift; /* nullable [64]: shift of the y statistics (feta_attn_block.y_shift); y_stats has
+                           feta_ffn_blocks(M) + 1 rows */
   int y_f32;        /* 1: y is written as fp32 whatever dtype says (last layer of a bf16 stack: its consumer, linear_cat
                        with the folded BatchNorm, transformer/models.py:223-224, is an fp32 kernel) */
 } feta_ffn;

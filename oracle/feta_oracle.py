@@ -304,7 +304,8 @@ def get_filter_coefficients_collapsed(attn, masks, gcn_w, gcn_b, lin_w, lin_b):
 # ---------------------------------------------------------------------------
 
 
-def attention_core(qkv, pe, key_padding_mask, num_heads, tie_qk=False, detach_max=False, drop_scale=None):
+def attention_core(qkv, pe, key_padding_mask, num_heads, tie_qk=False, detach_max=False, drop_scale=None,
+                   stab='rowmax'):
     """Scores -> masked exp -> (* pe) -> clamped normalisation -> (dropout) -> weighted sum, from the
     projected qkv [N,B,3d].  detach_max=True drops the (mathematically zero unless the
     1e-6 clamp is active) gradient through the row maximum, which is what the kernels do.
@@ -325,8 +326,15 @@ def attention_core(qkv, pe, key_padding_mask, num_heads, tie_qk=False, detach_ma
     s = torch.bmm(q, k.transpose(1, 2)).view(b, num_heads, n, n)
     if key_padding_mask is not None:
         s = s.masked_fill(key_padding_mask.unsqueeze(1).unsqueeze(2), float('-inf'))
-    mx = s.max(dim=-1, keepdim=True)[0]
-    s = torch.exp(s - (mx.detach() if detach_max else mx))
+    if stab == 'clamp5':
+        # the in-tree witnesses of the attention form: exp(score.clamp(-5, 5)), no row maximum
+        # (LSPE/layers/graphit_gt_layer.py:39-43, LPE/layers/graph_transformer_spectra_layer.py:239-243); masked keys
+        # (-inf) still give exp(-inf) = 0 under torch.where, not exp(-5)
+        masked = torch.isinf(s)
+        s = torch.where(masked, torch.zeros_like(s), torch.exp(s.clamp(-5.0, 5.0)))
+    else:
+        mx = s.max(dim=-1, keepdim=True)[0]
+        s = torch.exp(s - (mx.detach() if detach_max else mx))
     if pe is not None:
         s = s * pe.unsqueeze(1)
     a = s / s.sum(dim=-1, keepdim=True).clamp(min=1e-6)

@@ -87,15 +87,17 @@ def to_view(t64, seq_first, dev, dtype=torch.float32):
 
 
 def check_attn(abi, dev, stream, bsz, n, h, dh, use_pe, seq_first=True, seed=0, write_attn=True,
-               clamp_case=False, dtype=torch.float32, drop=None):
-    """drop = (p, seed, offset): attention-probability dropout - the oracle gets the mask the kernels derive."""
+               clamp_case=False, dtype=torch.float32, drop=None, clamp5=False):
+    """drop = (p, seed, offset): attention-probability dropout - the oracle gets the mask the kernels derive.
+    clamp5: stab = clamp5 (feta_attn_*_stab): exp(clamp(s, -5, 5)) instead of exp(s - rowmax); the scores are scaled up
+    so that a good share of them sits outside +-5 (their gradient is zero there)."""
     g = torch.Generator().manual_seed(seed)
     d = h * dh
     tol = TOL if dtype == torch.float32 else BF16_TOL
     nb = torch.randint(1, n + 1, (bsz,), generator=g, dtype=torch.int32)
     nb[0] = n
     mask = torch.arange(n)[None, :] >= nb[:, None]
-    qkv = round_to(torch.randn(n, bsz, 3 * d, generator=g, dtype=torch.float64), dtype)
+    qkv = round_to(torch.randn(n, bsz, 3 * d, generator=g, dtype=torch.float64) * (2.0 if clamp5 else 1.0), dtype)
     pe = None
     if use_pe:
         pe = torch.rand(bsz, n, n, generator=g, dtype=torch.float64)
@@ -111,7 +113,8 @@ def check_attn(abi, dev, stream, bsz, n, h, dh, use_pe, seq_first=True, seed=0, 
     if drop is not None:
         frac = float((ds_ == 0).double().mean())
         assert abs(frac - drop[0]) < 0.05, 'dropped fraction %.3f for p = %.2f' % (frac, drop[0])
-    _, a_ref, o_ref = O.attention_core(qkv_r, pe, mask, h, detach_max=clamp_case, drop_scale=ds_)
+    _, a_ref, o_ref = O.attention_core(qkv_r, pe, mask, h, detach_max=clamp_case, drop_scale=ds_,
+                                       stab='clamp5' if clamp5 else 'rowmax')
     z_ref = None
     (o_ref * dout).sum().backward()
 
@@ -131,8 +134,10 @@ def check_attn(abi, dev, stream, bsz, n, h, dh, use_pe, seq_first=True, seed=0, 
     stats = torch.zeros(bsz, h, n, 2, device=dev)
     pe32 = None if pe is None else pe.to(dtype).contiguous().to(dev)
     nbd = nb.to(dev)
-    abi.attn_fwd(qv, kv, vv, pe32, nbd, out, attn, stats, dh ** -0.5, stream, drop=drop)
+    abi.attn_fwd(qv, kv, vv, pe32, nbd, out, attn, stats, dh ** -0.5, stream, drop=drop, clamp5=clamp5)
     errs = {}
+    if clamp5:
+        assert float(stats[..., 0].abs().max()) == 0.0      # no row maximum in this form
     if write_attn:
         errs['attn'] = assert_close('attn', attn, a_ref, tol=tol)
     errs['out'] = assert_close('out_each_head', out, o_ref, tol=tol)
@@ -146,7 +151,7 @@ def check_attn(abi, dev, stream, bsz, n, h, dh, use_pe, seq_first=True, seed=0, 
         dq, dk, dv = (g5[:, :, i] for i in range(3))
     delta = torch.zeros(bsz, h, n, device=dev)
     do = to_view(dout, seq_first, dev, dtype)
-    abi.attn_bwd(qv, kv, vv, pe32, nbd, out, do, stats, delta, dq, dk, dv, dh ** -0.5, stream, drop=drop)
+    abi.attn_bwd(qv, kv, vv, pe32, nbd, out, do, stats, delta, dq, dk, dv, dh ** -0.5, stream, drop=drop, clamp5=clamp5)
     errs['dqkv'] = assert_close('dqkv', dqkv, qkv_r.grad, tol=tol)
     return errs
 
@@ -397,13 +402,29 @@ def check_rowlin(abi, dev, stream, m, ki, no, relu=False, rowscale=False, residu
     f = lambda t: None if t is None else t.detach().float().contiguous().to(dev)
     x32, w32, b32, rs32, res32 = f(x), f(w), f(b), f(rs), f(res)
     yo = torch.full((m, no), float('nan'), device=dev)
-    st = torch.full((abi.rowlin_blocks(m), 2, no), float('nan'), device=dev) if stats else None
+    # partial rows + the shift row (csrc/feta_rowops.h; zero through this entry point)
+    st = torch.full((abi.rowlin_blocks(m) + 1, 2, no), float('nan'), device=dev) if stats else None
     abi.rowlin_fwd(x32, w32, b32, rs32, res32, yo, st, relu, stream)
     errs = {'y': assert_close('y', yo, y)}
     if stats:
-        tot = st.double().sum(0).cpu()
+        assert float(st[-1, 0].abs().max()) == 0.0
+        tot = st[:-1].double().sum(0).cpu()
         assert_close('stats.sum', tot[0], y.detach().sum(0), tol=1e-5 * m ** 0.5)
         assert_close('stats.sumsq', tot[1], (y.detach() ** 2).sum(0), tol=1e-5 * m ** 0.5)
+        # ... and SHIFTED sums through the descriptor entry point: sum (y - K), sum (y - K)^2, K recorded in the last row
+        kk = torch.randn(no, generator=g, dtype=torch.float64)
+        st2 = torch.full_like(st, float('nan'))
+        yo2 = torch.empty_like(yo)
+        k_dev = f(kk)      # (kept alive: the descriptor holds raw pointers)
+        d = abi.rowlin_ex(m, ki, no, relu=relu, x=x32, w=w32, bias=b32, rowscale=rs32, residual=res32, y=yo2, stats=st2,
+                          stats_shift=k_dev)
+        abi.rowlin_fwd_ex(d, stream)
+        assert torch.equal(yo2, yo)
+        assert_close('stats shift row', st2[-1, 0], kk.float().double())
+        k32 = kk.float().double()
+        tot2 = st2[:-1].double().sum(0).cpu()
+        assert_close('shifted stats.sum', tot2[0], (y.detach() - k32).sum(0), tol=1e-5 * m ** 0.5)
+        assert_close('shifted stats.sumsq', tot2[1], ((y.detach() - k32) ** 2).sum(0), tol=1e-5 * m ** 0.5)
     dx = torch.full((m, ki), float('nan'), device=dev)
     partial = torch.zeros(abi.rowlin_chunks(m), no * ki + no, device=dev)
     dwdb = torch.full((no * ki + no,), float('nan'), device=dev)
@@ -425,7 +446,7 @@ def check_bn(abi, dev, stream, m, d, seed=0):
     (out * dout).sum().backward()
     f = lambda t: t.detach().float().contiguous().to(dev)
     y32 = f(y)
-    st = torch.full((abi.rowlin_blocks(m), 2, d), float('nan'), device=dev)
+    st = torch.full((abi.rowlin_blocks(m) + 1, 2, d), float('nan'), device=dev)
     abi.bn_stats(y32, st, stream)
     o = torch.full((m, d), float('nan'), device=dev)
     mr = torch.full((2, d), float('nan'), device=dev)
@@ -442,6 +463,49 @@ def check_bn(abi, dev, stream, m, d, seed=0):
     errs['dy'] = assert_close('bn dy', dyo, y.grad)
     errs['dgamma'] = assert_close('dgamma', dg, gamma.grad, tol=2e-5)
     errs['dbeta'] = assert_close('dbeta', dbt, beta.grad, tol=2e-5)
+    return errs
+
+
+def check_bn_far_from_zero(abi, dev, stream, m=4736, d=64, seed=0):
+    """Columns whose mean is ~10^3 standard deviations away from zero: E[y^2] - mean^2 in fp32
+    loses the variance there (eps 6e-8 x 10^6), nn.BatchNorm1d (Welford) does not.  The statistics are sums of (y - K)
+    with K = the BatchNorm's running mean as the producer saw it: once the running mean has locked on (here: one step with
+    momentum 1), output and running_var agree with F.batch_norm in fp64 to 1e-5 relative."""
+    g = torch.Generator().manual_seed(seed)
+    std = torch.rand(d, generator=g, dtype=torch.float64) + 0.5
+    mean = (torch.rand(d, generator=g, dtype=torch.float64) + 0.5) * 1e3 * std
+    gamma = torch.rand(d, generator=g, dtype=torch.float64) + 0.5
+    beta = torch.randn(d, generator=g, dtype=torch.float64)
+    f = lambda t: t.detach().float().contiguous().to(dev)
+    rm32, rv32 = torch.zeros(d, device=dev), torch.ones(d, device=dev)
+    errs = {}
+    for step, mom in enumerate((1.0, 0.1)):
+        y = (torch.randn(m, d, generator=g, dtype=torch.float64) * std + mean).float().double()   # fp32-representable
+        rm, rv = rm32.cpu().double().clone(), rv32.cpu().double().clone()
+        out = torch.nn.functional.batch_norm(y, rm, rv, gamma, beta, True, mom, 1e-5)
+        st = torch.full((abi.rowlin_blocks(m) + 1, 2, d), float('nan'), device=dev)
+        abi.bn_stats(f(y), st, stream, shift=rm32)
+        o = torch.full((m, d), float('nan'), device=dev)
+        mr = torch.full((2, d), float('nan'), device=dev)
+        abi.bn_apply_fwd(f(y), st, f(gamma), f(beta), o, mr, rm32, rv32, mom, 1e-5, stream)
+        rel_var = float(((rv32.cpu().double() - rv) / rv).abs().max())
+        err_out = maxdiff(o, out)
+        errs[step] = (err_out, rel_var)
+        if step == 1:      # the running mean of step 0 is the batch mean of similar data: the shift has locked on
+            # yardstick for the OUTPUT: nn.BatchNorm1d's own fp32 arithmetic on the same rows - at 10^3 sigma from zero
+            # one ulp of y (and of the mean) is 6e-5 sigma, which no fp32 normalisation can undo
+            out32 = torch.nn.functional.batch_norm(y.float(), rm.float(), rv.float(), gamma.float(), beta.float(), True,
+                                                   mom, 1e-5)
+            err_torch = maxdiff(out32, out)
+            errs['torch_fp32_out_err'] = err_torch
+            assert err_out <= max(4.0 * err_torch, 2e-5 * max(1.0, float(out.abs().max()))), errs
+            assert rel_var <= 1e-5, errs
+    # what the un-shifted sums give on the same data, for the record: the error this check is about
+    st0 = torch.full((abi.rowlin_blocks(m) + 1, 2, d), float('nan'), device=dev)
+    abi.bn_stats(f(y), st0, stream)
+    tot = st0[:-1].double().sum(0).cpu()
+    var0 = (tot[1] / m - (tot[0] / m) ** 2).clamp(min=0)
+    errs['naive_rel_var'] = float(((var0 - y.var(0, unbiased=False)) / y.var(0, unbiased=False)).abs().max())
     return errs
 
 
@@ -682,7 +746,7 @@ def check_attn_block_lp(abi, dev, stream, bsz=5, n_pad=21, n_min=3, seed=0, with
     qkv, out, y = new(m, 3 * d), new(m, d), new(m, d)
     ast = torch.full((bsz, heads, n_pad, 2), float('nan'), device=dev)
     attn = torch.full((bsz, heads, n_pad, n_pad), float('nan'), device=dev) if need_attn else None
-    st = torch.full((bsz, 2, d), float('nan'), device=dev)
+    st = torch.full((bsz + 1, 2, d), float('nan'), device=dev)     # (+ the shift row)
     rows = degree.t().reshape(m)
     abi.attn_block_fwd(bsz, n_pad, float(d // heads) ** -0.5, stream, x=b16(x).view(m, d), w_in=f32(p['w_in']),
                        b_in=f32(p['b_in']), w_out=f32(p['w_out']), b_out=f32(p['b_out']),
@@ -702,8 +766,8 @@ def check_attn_block_lp(abi, dev, stream, bsz=5, n_pad=21, n_min=3, seed=0, with
         assert_close('lp attn', attn, a_ref, tol=BF16_TOL)
     yf = y.view(m, d).float().cpu().double()
     # statistics are sums of the fp32 values BEFORE the bf16 store: compare with the stored values up to their rounding
-    assert_close('lp y_stats sum', st[:, 0].sum(0), yf.sum(0), tol=BF16_TOL)
-    assert_close('lp y_stats sumsq', st[:, 1].sum(0), (yf * yf).sum(0), tol=BF16_TOL)
+    assert_close('lp y_stats sum', st[:-1, 0].sum(0), yf.sum(0), tol=BF16_TOL)
+    assert_close('lp y_stats sumsq', st[:-1, 1].sum(0), (yf * yf).sum(0), tol=BF16_TOL)
     return dict(qkv=qkv, out=out, y=y, ast=ast, attn=attn)
 
 
@@ -721,7 +785,7 @@ def check_ffn_lp(abi, dev, stream, m=75, ff=128, seed=0, with_bn=True):
     prm[1] = torch.randn(d, generator=g) * 0.2
     h = torch.full((m, ff), float('nan'), dtype=BF16, device=dev)
     y = torch.full((m, d), float('nan'), dtype=BF16, device=dev)
-    st = torch.full((abi.ffn_blocks(m), 2, d), float('nan'), device=dev)
+    st = torch.full((abi.ffn_blocks(m) + 1, 2, d), float('nan'), device=dev)
     abi.ffn_fwd(m, ff, stream, x=y1.to(BF16).to(dev), x_bn=prm.to(dev) if with_bn else None, w1=w1.to(dev), b1=b1.to(dev),
                 w2=w2.to(dev), b2=b2.to(dev), h=h, y=y, y_stats=st)
     x = y1 * prm[0].double() + prm[1].double() if with_bn else y1
@@ -730,8 +794,8 @@ def check_ffn_lp(abi, dev, stream, m=75, ff=128, seed=0, with_bn=True):
     assert_close('lp h', h, h_ref, tol=BF16_TOL)
     assert_close('lp y2', y, y_ref, tol=BF16_TOL)
     yf = y.float().cpu().double()
-    assert_close('lp y2 stats sum', st[:, 0].sum(0), yf.sum(0), tol=BF16_TOL)
-    assert_close('lp y2 stats sumsq', st[:, 1].sum(0), (yf * yf).sum(0), tol=BF16_TOL)
+    assert_close('lp y2 stats sum', st[:-1, 0].sum(0), yf.sum(0), tol=BF16_TOL)
+    assert_close('lp y2 stats sumsq', st[:-1, 1].sum(0), (yf * yf).sum(0), tol=BF16_TOL)
 
 
 def check_ffn_bwd_lp(abi, dev, stream, m=150, ff=128, seed=0, with_bn=True):
@@ -814,7 +878,7 @@ def check_attn_block_bwd_lp(abi, dev, stream, bsz=5, n_pad=21, n_min=3, seed=0, 
     new = lambda *s: torch.full(s, float('nan'), dtype=BF16, device=dev)
     qkv, out, y = new(m, 3 * d), new(m, d), new(m, d)
     ast = torch.full((bsz, heads, n_pad, 2), float('nan'), device=dev)
-    st = torch.empty((bsz, 2, d), device=dev)
+    st = torch.empty((bsz + 1, 2, d), device=dev)
     rows = degree.t().reshape(m)
     scale = float(d // heads) ** -0.5
     pe_d = None if pe is None else b16(pe)

@@ -126,6 +126,11 @@ def test_batchnorm(emu, m, d):
     KC.check_bn(emu, CPU, None, m, d)
 
 
+def test_batchnorm_statistics_far_from_zero(emu):
+    errs = KC.check_bn_far_from_zero(emu, CPU, None, m=600, d=64)
+    print(errs)
+
+
 @pytest.mark.parametrize('r,c', [(19, 4096 + 64), (3, 8192), (64, 4100), (74, 4096), (300, 4096), (200, 48), (1, 16)])
 def test_colsum_shapes(emu, r, c):
     KC.check_colsum(emu, CPU, None, r, c)
@@ -247,3 +252,11 @@ def test_lin_gemm_tiled(emu, monkeypatch, r, k, n, with_dx, bf16):
     shapes: forward, dX and dW roles interleaved in one launch, fp32 row sums for db, pending column sums"""
     monkeypatch.setenv('FETA_LIN_TILED', '2')
     KC.check_lin(emu, CPU, None, r, k, n, with_dx=with_dx, bf16=bf16)
+
+
+@pytest.mark.parametrize('bsz,n,h,dh,use_pe,dtype', [(3, 20, 2, 16, True, torch.float32), (2, 37, 4, 16, False, torch.float32),
+                                                     (2, 70, 1, 64, True, torch.float32), (2, 33, 2, 32, True, torch.bfloat16)])
+def test_attn_stab_clamp5(emu, bsz, n, h, dh, use_pe, dtype):
+    """stab = clamp5 (witnesses LSPE/layers/graphit_gt_layer.py:39-43): exp(clamp(s, -5, 5)), forward and
+    backward with zero gradient through clamped scores, fp32 and bf16 storage"""
+    KC.check_attn(emu, CPU, None, bsz, n, h, dh, use_pe, dtype=dtype, clamp5=True)

@@ -129,6 +129,14 @@ def test_batchnorm(hip, m, d):
     KC.check_bn(abi, dev, stream, m, d)
 
 
+def test_batchnorm_statistics_far_from_zero(hip):
+    """column mean ~ 10^3 standard deviations: output and running_var against F.batch_norm in fp64, 1e-5 relative"""
+    abi, dev, stream = hip
+    errs = KC.check_bn_far_from_zero(abi, dev, stream)
+    print(errs)
+    assert errs['naive_rel_var'] > 1e-3      # (what E[y^2] - mean^2 alone would have given on this data)
+
+
 @pytest.mark.parametrize('r,c', [(19, 4096 + 64), (3, 8192), (64, 4100), (74, 4096), (300, 4096), (200, 48), (1, 16)])
 def test_colsum_shapes(hip, r, c):
     KC.check_colsum(*hip, r, c)
@@ -269,3 +277,11 @@ def test_lin_gemm_tiled(hip, monkeypatch, r, k, n, with_dx, bf16):
     monkeypatch.setenv('FETA_LIN_TILED', '2')
     abi, dev, stream = hip
     KC.check_lin(abi, dev, stream, r, k, n, with_dx=with_dx, bf16=bf16)
+
+
+@pytest.mark.parametrize('bsz,n,h,dh,use_pe,dtype', [(3, 20, 2, 16, True, torch.float32), (2, 37, 4, 16, False, torch.float32),
+                                                     (2, 70, 1, 64, True, torch.float32), (2, 33, 2, 32, True, torch.bfloat16)])
+def test_attn_stab_clamp5(hip, bsz, n, h, dh, use_pe, dtype):
+    """stab = clamp5 (witnesses LSPE/layers/graphit_gt_layer.py:39-43): exp(clamp(s, -5, 5)), forward and
+    backward with zero gradient through clamped scores, fp32 and bf16 storage"""
+    KC.check_attn(*hip, bsz, n, h, dh, use_pe, dtype=dtype, clamp5=True)

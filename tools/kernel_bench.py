@@ -127,7 +127,7 @@ def main():
         w = rnd(no, ki) / ki ** 0.5
         bb = rnd(no)
         yo = torch.empty(m, no, device=dev)
-        sto = torch.empty(abi.rowlin_blocks(m), 2, no, device=dev)
+        sto = torch.empty(abi.rowlin_blocks(m) + 1, 2, no, device=dev)
         add('rowlin_fwd %s %dx%d' % (nm, ki, no), lambda: abi.rowlin_fwd(xi, w, bb, None, None, yo, sto, False, st),
             f4 * (m * ki + no * ki + m * no))
         dyo = rnd(m, no)
@@ -137,7 +137,7 @@ def main():
         add('rowlin_bwd %s (+colsum)' % nm, lambda: abi.rowlin_bwd(xi, w, dyo, None, None, dxi, part, dwdb, st),
             f4 * (2 * m * ki + m * no + 2 * no * ki))
     yb = rnd(m, d)
-    stb = torch.empty(abi.rowlin_blocks(m), 2, d, device=dev)
+    stb = torch.empty(abi.rowlin_blocks(m) + 1, 2, d, device=dev)
     abi.bn_stats(yb, stb, st)
     ob = torch.empty(m, d, device=dev)
     mr = torch.empty(2, d, device=dev)

@@ -20,14 +20,22 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=128)
 ap.add_argument('--steps', type=int, default=200)
 ap.add_argument('--layer-norm', action='store_true')
+ap.add_argument('--dropout', type=float, default=0.0,
+                help='--dropout of the reference scripts (experiments/run_transformer_gengcn.py:47): attention-probability and '
+                     'activation dropout; the layers then run op by op (the fused stack has no dropout), the attention masks '
+                     'are keyed on the device so that the step stays ONE hipGraph')
+ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'])
 args = ap.parse_args()
 dev = torch.device('cuda:0')
 torch.manual_seed(0)
 ds = D.SyntheticGraphDataset('zinc', args.batch, in_dim=28, seed=0)
 batch9, cache = D.collate(ds.samples, k_eig=16, n_pad=37, device=dev)
-model = DiffGraphTransformerGenGCN(28, 1, 64, 4, dim_feedforward=128, dropout=0.0, nb_layers=3,
+model = DiffGraphTransformerGenGCN(28, 1, 64, 4, dim_feedforward=128, dropout=args.dropout, nb_layers=3,
                                    batch_norm=not args.layer_norm, filter_order=4, heads_share_graph=True,
                                    filter_mode='spectral').to(dev)
+if args.dtype == 'bf16':
+    from feta_tmlr_amd.transformer.layers import set_storage_dtype
+    set_storage_dtype(model, torch.bfloat16)
 model.train()
 crit = T.make_criterion('zinc')
 
@@ -84,6 +92,6 @@ t_coll, t_stage = timed_host(host_collate), timed_host(staged)
 print('collate of one ZINC batch (B=%d, pe + U/lambda included): per-graph host collate %.1f us/graph | pinned stager + '
       'device spectrum %.2f us/graph (%.0fx); step time per graph %.2f us'
       % (args.batch, t_coll / args.batch * 1e6, t_stage / args.batch * 1e6, t_coll / t_stage, cap / args.batch * 1e6))
-print('ZINC task, B=%d, %s: eager %.3f ms/step (%.0f graphs/s) | one hipGraph per step %.3f ms/step (%.0f graphs/s)'
-      % (args.batch, 'LayerNorm' if args.layer_norm else 'BatchNorm', eager * 1e3, args.batch / eager,
+print('ZINC task, B=%d, %s, dropout %.2f, %s: eager %.3f ms/step (%.0f graphs/s) | one hipGraph per step %.3f ms/step (%.0f graphs/s)'
+      % (args.batch, 'LayerNorm' if args.layer_norm else 'BatchNorm', args.dropout, args.dtype, eager * 1e3, args.batch / eager,
          cap * 1e3, args.batch / cap))
