@@ -56,7 +56,8 @@ __device__ unsigned int feta_block_launch;
 // function of the parameters alone - would otherwise be a launch of its own (~7 us).
 // T: storage type of x, pe, qkv, out, y and of the LDS tiles (feta_lp.h); weights, biases, statistics, attn: fp32.
 template <class T, int NT>
-__global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a, ColsumPlan sums, int main_grid) {
+__global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a, ColsumPlan sums, int main_grid,
+                                                                    int weights_last) {
   typedef Lp<T> L;
   typedef typename L::Op Op;
   typedef typename L::Vec Vec;
@@ -143,12 +144,19 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
     xg = a.x_gamma[tid];
     xb = a.x_beta[tid];
   }
-  // (the weights were requested last: when they are here, so is everything requested before them)
+  // Loads return in request order: the partial statistics and the first graph's rows are here long before the 64 KB of
+  // weights.  Round 3 experiment (FETA_BLOCK_WEIGHTS_LAST=1): they are CONSUMED in that order too - statistics finalized
+  // and the first graph staged while the weights are still travelling, the weights stored to LDS last; the barriers in
+  // between order LDS traffic only (lds_barrier: a __syncthreads() behind the published-parameter stores of workgroup 0
+  // waits for vmcnt(0), i.e. for the weights).  It bought nothing (see the launcher): the default stays weights first.
+  auto store_weights = [&]() {
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int idx = tid + kRowThreads * i;
-    L::st4(Wi + (idx >> 4) * P + 4 * (idx & 15), wv[i].x, wv[i].y, wv[i].z, wv[i].w);   // (rounded once, here, for bf16)
-  }
+    for (int i = 0; i < 16; ++i) {
+      const int idx = tid + kRowThreads * i;
+      L::st4(Wi + (idx >> 4) * P + 4 * (idx & 15), wv[i].x, wv[i].y, wv[i].z, wv[i].w);   // (rounded once, here, for bf16)
+    }
+  };
+  if (!weights_last) store_weights();
   FETA_STAMP(6);
   if (a.x_stats != nullptr) {
     // first consumer of fresh statistics: every workgroup finalizes them (redundantly and
@@ -185,8 +193,10 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
     __syncthreads();   // the tiles of the previous graph have been consumed
     request_graph(b);
   }
+  const bool late_weights = first && weights_last;
   first = false;
-  __syncthreads();
+  if (late_weights) lds_barrier();   // (xss is LDS data; the weights stay in flight)
+  else __syncthreads();
 #pragma unroll
   for (int i = 0; i < XI; ++i) {
     const int idx = tid + kRowThreads * i, node = idx / RV, q = idx % RV;
@@ -211,6 +221,7 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
       if (idx < nn) Pe[qq * PEP + kk] = pel[i];
     }
   }
+  if (late_weights) store_weights();
   __syncthreads();
   FETA_STAMP(1);
 
@@ -449,7 +460,12 @@ int launch_block_fwd(const BlockArgs& a, const feta_colsum_seg* segs, int nseg, 
   const int grid = a.B < cap ? a.B : cap;
   ColsumPlan plan{};
   const int tiles = plan_colsum(segs, nseg, plan);
-  hipLaunchKernelGGL(kern, dim3(grid + tiles), dim3(kRowThreads), lds, stream, a, plan, grid);
+  // Measured (round 3, B = 128): 0.2812 vs 0.2803 ms/step fp32, 0.2385 vs 0.2399 bf16, the phase stamps sum to the same
+  // 4.7 us either way - the prologue is a chain of LDS work and barriers, not a wait for the weight stream.  Off by
+  // default (and the fp32 four-tile instantiation would spill 92 B per lane holding the weights that long).
+  int weights_last = 0;
+  if (const char* e = getenv("FETA_BLOCK_WEIGHTS_LAST")) weights_last = atoi(e) != 0 && !(NT == 4 && sizeof(T) == sizeof(float));
+  hipLaunchKernelGGL(kern, dim3(grid + tiles), dim3(kRowThreads), lds, stream, a, plan, grid, weights_last);
   return check_launch("feta_attn_block_fwd");
 }
 

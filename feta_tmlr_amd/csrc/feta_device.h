@@ -105,6 +105,16 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Workgroup barrier that orders LDS traffic only: global loads (and stores) in flight stay in flight.  __syncthreads()
+// is a release / acquire on ALL address spaces, and on gfx9 one counter (vmcnt) covers loads and stores alike - once a
+// global store has been issued, every later __syncthreads() also waits for every prefetch that is still travelling.
+// Use it only where the data handed between the waves lives in LDS.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 // tanh(x) = 1 - 2 / (1 + e^{2x}): saturates correctly at +-1, absolute error ~1e-7
 __device__ __forceinline__ float fast_tanh(float x) {

@@ -38,6 +38,8 @@ struct FfnBwdGeom {
   int per;  // 16-row blocks per chunk
   int NS;   // hidden-unit slices per chunk
   int xcd;  // 1: XCD-aware order of the workgroups (see ffn_bwd_kernel)
+  int wxcd; // 1: XCD-aware order of the W-role workgroups of a capped grid
+  int cxw;  // > 0: capped grid with the X role walking chunk-wise, cxw X walkers per chunk (wxcd is then not used)
   int main_grid;   // workgroups of the two roles above; beyond: the coefficient generator's backward (feta_coeff.h)
 };
 
@@ -110,6 +112,35 @@ __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, Ffn
   } else {
     xblk = (int)blockIdx.x < ge.XB ? (int)blockIdx.x : -1;
     wbi = (int)blockIdx.x - ge.XB;
+    if (wbi >= 0 && ge.wxcd) {
+      // capped grids (large batches): the NS hidden-unit slices of a row chunk read the same rows of dy, y2, x - in
+      // launch order they sat on NS different XCDs and every one fetched the chunk from HBM (3.3x the algorithmic
+      // bytes at B = 16384, profiles/r03_traffic_b16384.json).  Read as (chunk group, slice, XCD): the slices of chunk
+      // 8 * group + XCD run on that XCD, 8 workgroup ids apart, and meet in its L2 (1.9x).
+      const int xcd = wbi & 7, v = wbi >> 3;
+      const int si_ = v % ge.NS, rc_ = (v / ge.NS) * 8 + xcd;
+      if (rc_ >= ge.RC) return;
+      wbi = rc_ * ge.NS + si_;
+    }
+  }
+  // ge.cxw > 0 (capped grid, whole chunks per XCD): the X role walks ITS chunk too.  The grid is read as (chunk group,
+  // item, XCD) with cxw X walkers and NS W slices per chunk; walker i of chunk rc takes the chunk's 32-row blocks
+  // i, i + cxw, ... - at the pace of the W slices, which pass over the same rows 64 at a time on the same XCD.
+  int x_lo = xblk, x_hi = (a.M + kFbRows - 1) / kFbRows, x_step = ge.XB;
+  if (ge.cxw > 0) {
+    const int xcd = (int)blockIdx.x & 7, v = (int)blockIdx.x >> 3, items = ge.cxw + ge.NS;
+    const int item = v % items, rc = (v / items) * 8 + xcd;
+    if (rc >= ge.RC) return;
+    if (item < ge.cxw) {
+      xblk = rc * ge.cxw + item;                 // (its row of sum_out)
+      wbi = -1;
+      x_lo = rc * (ge.per / 2) + item;
+      x_hi = min((rc + 1) * (ge.per / 2), x_hi);
+      x_step = ge.cxw;
+    } else {
+      xblk = -1;
+      wbi = rc * ge.NS + (item - ge.cxw);
+    }
   }
   float* gv = feta_lds;   // [5][64]
   float* after = gv;
@@ -204,9 +235,9 @@ __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, Ffn
     const int nblk = (a.M + kFbRows - 1) / kFbRows;
     const int row_last = a.M - 1;
     constexpr int NU = kFbRows * RV / kRowThreads;   // vectors of the gradient tile per thread
-    for (int blk = xblk; blk < nblk; blk += ge.XB) {
+    for (int blk = x_lo; blk < x_hi; blk += x_step) {
       const int r0 = blk * kFbRows;
-      if (blk != xblk) __syncthreads();   // the tiles of the previous block have been consumed
+      if (blk != x_lo) __syncthreads();   // the tiles of the previous block have been consumed
       // requests of the block: gradient tile, relu operands, residual rows of the sums
       float dv[NU][VEC], yv[NU][VEC];
 #pragma unroll
@@ -467,7 +498,20 @@ int launch_ffn_bwd(const FfnGradArgs& a, const CoeffBwdRole& cb, hipStream_t str
   const int nblk = (a.M + kFbRows - 1) / kFbRows;
   ge.xcd = (ge.XB == nblk && ge.per == 4) ? 1 : 0;
   if (const char* e = getenv("FETA_FFN_BWD_XCD")) ge.xcd = ge.xcd && atoi(e) != 0;
-  const int grid = ge.xcd ? 8 * ((ge.RC + 7) / 8) * (2 + ge.NS) : ge.XB + ge.RC * ge.NS;
+  ge.wxcd = ge.xcd ? 0 : 1;
+  if (const char* e = getenv("FETA_FFN_BWD_WXCD")) ge.wxcd = ge.wxcd && atoi(e) != 0;
+  // chunk-wise X role (FETA_FFN_BWD_CXW=1; needs whole 32-row blocks per chunk and a whole number of walkers per chunk).
+  // Measured at B = 16384 (round 3): the W-role order alone 684 us / 1.74 GB (launch order: 725 us / 3.12 GB; algorithmic
+  // 0.94 GB), with the X role chunk-wise as well 829 us / 1.88 GB - walkers and slices do not stay in step, and the
+  // strided X blocks had spread the tail better.  Off by default.
+  ge.cxw = 0;
+  if (const char* e = getenv("FETA_FFN_BWD_CXW")) {
+    if (atoi(e) != 0 && !ge.xcd && ge.wxcd && ge.per % 2 == 0 && ge.XB >= ge.RC && ge.XB % ge.RC == 0) ge.cxw = ge.XB / ge.RC;
+  }
+  if (ge.cxw > 0) ge.wxcd = 0;
+  const int grid = ge.xcd ? 8 * ((ge.RC + 7) / 8) * (2 + ge.NS)
+                 : ge.cxw > 0 ? 8 * ((ge.RC + 7) / 8) * (ge.cxw + ge.NS)
+                              : ge.XB + (ge.wxcd ? 8 * ((ge.RC + 7) / 8) * ge.NS : ge.RC * ge.NS);
   ge.main_grid = grid;
   hipLaunchKernelGGL(kern, dim3(grid + role), dim3(kRowThreads), lds, stream, a, ge, cb);
   return check_launch("feta_ffn_bwd");

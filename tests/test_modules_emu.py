@@ -446,6 +446,11 @@ def test_attn_block_walks_several_graphs_per_workgroup(emu, monkeypatch):
     monkeypatch.setenv('FETA_FFN_MAX_GRID', '3')
     check_attn_block_equals_three_launches(CPU, lambda: _lib.override_for_tests(emu), monkeypatch, 'zinc',
                                            9, 30, False, True, bsz=5)
+    # ... and the experimental orders of the capped FFN backward grid (chunk-wise X role) and of the block prologue
+    monkeypatch.setenv('FETA_FFN_BWD_CXW', '1')
+    monkeypatch.setenv('FETA_BLOCK_WEIGHTS_LAST', '1')
+    check_attn_block_equals_three_launches(CPU, lambda: _lib.override_for_tests(emu), monkeypatch, 'zinc',
+                                           9, 30, False, True, bsz=5)
 
 
 @pytest.mark.parametrize('n_min,n_max,bsz', [(2, 3, 1), (1, 2, 2), (16, 16, 2), (17, 17, 1), (48, 48, 1)])

@@ -150,6 +150,8 @@ inline float row16_sum(float v) {
 // orders this wave's LDS writes before its later LDS reads (other lanes' data)
 inline void wave_lds_sync() { simt::wave_barrier(); }
 
+inline void lds_barrier() { simt::block_barrier(); }
+
 inline float fast_exp(float x) { return expf(x); }
 inline float fast_tanh(float x) { return 1.0f - 2.0f / (1.0f + expf(2.0f * x)); }
 inline float fast_rcp(float x) { return 1.0f / x; }
