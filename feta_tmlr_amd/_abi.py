@@ -146,6 +146,7 @@ class AttnBlock(C.Structure):
 
 SIGNATURES.update({
     'feta_attn_block_supported': ([C.c_int, C.c_int, C.c_int], C.c_int),
+    'feta_attn_block_stat_rows': ([C.c_int, C.c_int], C.c_int),
     'feta_attn_block_fwd': ([C.POINTER(AttnBlock), _S], C.c_int),
     'feta_attn_block_fwd_sums': ([C.POINTER(AttnBlock), C.POINTER(ColsumSeg), C.c_int, _S], C.c_int),
 })
@@ -216,7 +217,7 @@ SIGNATURES.update({
     'feta_ffn_bwd_coeff': ([C.POINTER(FfnGrad), C.POINTER(CoeffBwdRole), _S], C.c_int),
 })
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class FetaError(RuntimeError):
@@ -531,6 +532,10 @@ class Abi:
 
     def attn_block_supported(self, n, d_model, heads):
         return bool(self.lib.feta_attn_block_supported(n, d_model, heads))
+
+    def attn_block_stat_rows(self, b, n):
+        """partial rows a forward launch writes into y_stats (+ 1 shift row behind them)"""
+        return int(self.lib.feta_attn_block_stat_rows(b, n))
 
     def attn_block_fwd(self, b, n, scale, stream, seq_first=True, momentum=0.1, eps=1e-5, Gx=0, tie_qk=False,
                        sums=(), **ptrs):

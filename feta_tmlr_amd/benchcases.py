@@ -32,7 +32,7 @@ def stack_layer_cases(abi, st, dev, b, n, d, heads, ff, pe, n_real, last_layer_a
     if abi.attn_block_supported(n, d, heads):
         x, w_in, b_in = rndt(m, d), rnd(3 * d, d) / d ** 0.5, rnd(3 * d)
         w_o, b_o, deg = rnd(d, d) / d ** 0.5, rnd(d), torch.rand(m, generator=g).to(dev)
-        qkv, out, y1, st1 = newt(m, 3 * d), newt(m, d), newt(m, d), new(b + 1, 2, d)
+        qkv, out, y1, st1 = newt(m, 3 * d), newt(m, d), newt(m, d), new(abi.attn_block_stat_rows(b, n) + 1, 2, d)
         ast, attn = new(b, heads, n, 2), new(b, heads, n, n)
         stats_prev = rnd(G + 1, 2, d).abs()      # (partial rows + the shift row)
         common = dict(x=x, w_in=w_in, b_in=b_in, w_out=w_o, b_out=b_o, pe=pe, n_real=n_real, rowscale=deg,

@@ -139,10 +139,11 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
     const float* src = r < 3 * D ? a.w_in + (int64_t)r * D : a.w_out + (int64_t)(r - 3 * D) * D;
     wv[i] = *reinterpret_cast<const float4*>(src + 4 * q);
   }
-  float xg = 1.0f, xb = 0.0f;
+  float xg = 1.0f, xb = 0.0f, xk = 0.0f;
   if (a.x_stats != nullptr && tid < D) {
     xg = a.x_gamma[tid];
     xb = a.x_beta[tid];
+    xk = partials_shift(a.x_stats, a.Gx, D, tid);
   }
   // Loads return in request order: the partial statistics and the first graph's rows are here long before the 64 KB of
   // weights.  Round 3 experiment (FETA_BLOCK_WEIGHTS_LAST=1): they are CONSUMED in that order too - statistics finalized
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
     reduce_partials_finish(a.x_stats, a.Gx, D, pb, scr + 2 * D, scr);
     for (int c = tid; c < D; c += kRowThreads) {
       float mean, var;
-      bn_moments(a.x_stats, a.Gx, D, a.M, scr, c, mean, var);
+      bn_moments_k(xk, D, a.M, scr, c, mean, var);   // (c == tid: the loop runs once for the first D threads)
       const float rstd = rsqrtf(var + a.eps);
       const float scale = xg * rstd;
       const float shift = xb - mean * scale;
@@ -449,6 +450,500 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
   FETA_RT_LAUNCH_DONE(feta_block_launch);
 }
 
+// ---- round 3: eight waves per workgroup, optionally two workgroups per graph ------------------------------------
+// The four-wave kernel above puts ONE wave on each SIMD of ONE CU per graph: nothing issues under that wave's 32-cycle
+// fp32 MFMAs, the VALU work of a phase waits for them, and at the BASELINE batch (128 graphs) half of the 256 CUs have no
+// graph at all.  Here a graph has S = 2 * WGS "query slots" - (workgroup w of the graph, wave
+// parity p), slot = 2 w + p - and wave (head h, parity p) of workgroup w
+//   * projects K (p = 0) or V (p = 1) of its head for ALL key tiles and hands it to its sibling through LDS (the tiles
+//     leave the MFMA in the operand layout of the score / P.V products, so a lane writes and reads back 16 bytes per
+//     tile: no conflicts, no shuffles); with two workgroups per graph both project every K and V tile (a 16-row tile
+//     costs 2 x 16 MFMAs) and each writes its share of them to HBM;
+//   * projects Q, runs the attention core and out_proj for the query tiles qb = slot (mod S) only;
+//   * y's BatchNorm partial sums: the two parities of a head own the same 16 output columns over different rows and meet in
+//     LDS; a workgroup emits ONE partial row (row b * WGS + w of y_stats: rows are complete per workgroup, nothing is
+//     exchanged between workgroups).
+// Every loop over query tiles stays a compile-time loop over all NT tiles with a wave-uniform ownership branch, so that
+// register arrays are indexed statically (a runtime index would put them in scratch).
+constexpr int kBlk8Threads = 512;
+
+template <class T>
+__host__ __device__ inline int block8_region_floats(int nt) {   // exchange region of one (head, tensor) = one wave's staging
+  const int stg = 16 * (16 * nt + 1), xch = nt * 64 * (int)sizeof(typename Lp<T>::Op) / 4;
+  return stg > xch ? stg : xch;
+}
+
+template <class T>
+__host__ __device__ inline int block8_lds_bytes(int nt) {
+  const int nr = 16 * nt, P = kBlkD + Lp<T>::PAD;
+  int b = (int)sizeof(T) * (4 * kBlkD * P + 2 * nr * P);   // W_in, W_out, X tile, OUT tile
+  int f = 2 * kBlkD + 128;                                 // scale / shift of the input BatchNorm; statistics hand-over
+  const int fin = reduce_scratch_floats(kBlkD), reg = 8 * block8_region_floats<T>(nt);
+  f += fin > reg ? fin : reg;
+  f += nr * (nr + 4);                                      // pe tile
+  const int role = 4 * colsum_role_lds_floats(kBlk8Threads);
+  const int tot = b + 4 * f;
+  return tot > role ? tot : role;
+}
+
+template <class T, int NT, int WGS>
+__global__ __launch_bounds__(kBlk8Threads) void attn_block_fwd8_kernel(BlockArgs a, ColsumPlan sums, int main_grid) {
+  typedef Lp<T> L;
+  typedef typename L::Op Op;
+  typedef typename L::Vec Vec;
+  constexpr int TH = kBlk8Threads;
+  constexpr int D = kBlkD, DH = kBlkDH, P = kBlkD + L::PAD, NR = 16 * NT, KP = NR + 1;
+  constexpr int S = 2 * WGS;                 // query slots of a graph
+  constexpr int NQ = (NT + S - 1) / S;       // query tiles of a wave
+  constexpr int KVU = NT >= 4 ? 2 : NT;      // K / V tiles in flight (their results go to LDS: the loop need not be unrolled, and at
+                                             // four tiles the fully unrolled form spills)
+  constexpr int RV = D / L::VEC;
+  constexpr int XI = (NR * RV + TH - 1) / TH;
+  constexpr int QR = WGS == 1 ? NR : (NR < 32 ? NR : 32);   // query rows of a workgroup (their pe rows are staged)
+  constexpr int PEI = (QR * NR + TH - 1) / TH;
+  if ((int)blockIdx.x >= main_grid) {
+    colsum_role<TH>(sums, (int)blockIdx.x - main_grid);
+    return;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, h = wv & 3, p = wv >> 2, lq = lane & 15, g = lane >> 4;
+  const int gp = main_grid / WGS;            // graphs in flight; the workgroups of graph b are b, b + gp (one XCD when gp % 8 == 0)
+  const int w = (int)blockIdx.x / gp, b0 = (int)blockIdx.x % gp;
+  const int slot = 2 * w + p;
+  T* Wi = reinterpret_cast<T*>(lds_bytes());   // [192][P]
+  T* Wo = Wi + 3 * D * P;                      // [64][P]
+  T* Xs = Wo + D * P;                          // [NR][P]
+  T* Os = Xs + NR * P;                         // [NR][P]
+  float* xss = reinterpret_cast<float*>(Os + NR * P);   // [2][64]
+  float* sx = xss + 2 * D;                     // [4 heads][4 g][8]: statistics of the odd-parity waves
+  float* scr = sx + 128;                       // finalize scratch, then the K / V hand-over, then the probability staging
+  const int PER = block8_region_floats<T>(NT);
+  Op* XK = reinterpret_cast<Op*>(scr + (2 * h) * PER);       // K^T tiles of head h (operand layout)
+  Op* XV = reinterpret_cast<Op*>(scr + (2 * h + 1) * PER);   // V tiles of head h
+  float* stg = scr + (2 * h + p) * PER;                      // this wave's probability staging (attn write)
+  constexpr int PEP = NR + 4;
+  float* Pe = reinterpret_cast<float*>(lds_bytes() + block8_lds_bytes<T>(NT)) - NR * PEP;
+  const T* gx = reinterpret_cast<const T*>(a.x);
+  const T* gpe = reinterpret_cast<const T*>(a.pe);
+  T* gqkv = reinterpret_cast<T*>(a.qkv);
+  T* gout = reinterpret_cast<T*>(a.out);
+  T* gy = reinterpret_cast<T*>(a.y);
+  const bool x_norm = a.x_stats != nullptr || a.x_bn != nullptr;
+  FETA_STAMP(0);
+
+  PartialBatch pb;
+  partials_request(a.x_stats != nullptr ? a.x_stats : a.w_in, a.x_stats != nullptr ? a.Gx : 0, D, pb);
+  const bool has_pe = a.pe != nullptr;
+  Vec xv[XI];
+  float pel[PEI];
+  float rsv[NQ];
+  int n = 0;
+  const int nn = a.N * a.N;
+  // this workgroup's query rows [q0, q1) and their pe elements [q0 N, q1 N) - one contiguous stream
+  const int q0 = WGS == 1 ? 0 : 32 * w, q1 = WGS == 1 ? a.N : min(a.N, 32 * w + 32);
+  const int pe0 = q0 * a.N, pecnt = max(q1 - q0, 0) * a.N;
+  auto request_graph = [&](int b) {
+    n = a.n_real[b];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int idx = min(tid + TH * i, NR * RV - 1), node = idx / RV, q = idx % RV;
+      const int64_t row = (int64_t)b * a.row_sb + (int64_t)min(node, a.N - 1) * a.row_sn;
+      xv[i] = L::ldv(gx + row * D + L::VEC * q);
+    }
+#pragma unroll
+    for (int i = 0; i < PEI; ++i)
+      pel[i] = has_pe ? L::ld1(gpe + (int64_t)b * nn + pe0 + max(min(tid + TH * i, pecnt - 1), 0)) : 1.0f;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int qc = min(16 * (slot + S * i) + lq, a.N - 1);
+      rsv[i] = a.rowscale != nullptr ? a.rowscale[(int64_t)b * a.row_sb + (int64_t)qc * a.row_sn] : 1.0f;
+    }
+  };
+  request_graph(b0);
+  float4 binq = make_float4(0.0f, 0.0f, 0.0f, 0.0f), bink = binq, bo = binq;
+  float bin1 = 0.0f;
+  if (a.b_in != nullptr) {
+    binq = *reinterpret_cast<const float4*>(a.b_in + DH * h + 4 * g);
+    bink = *reinterpret_cast<const float4*>(a.b_in + (a.tie_qk ? 0 : D) + DH * h + 4 * g);
+    bin1 = a.b_in[2 * D + DH * h + lq];
+  }
+  if (a.b_out != nullptr) bo = *reinterpret_cast<const float4*>(a.b_out + DH * h + 4 * g);
+  float4 wvv[8];   // 256 rows of 16 float4 (W_in then W_out: fp32 masters), 8 per thread
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = tid + TH * i, r = idx >> 4, q = idx & 15;
+    const float* src = r < 3 * D ? a.w_in + (int64_t)r * D : a.w_out + (int64_t)(r - 3 * D) * D;
+    wvv[i] = *reinterpret_cast<const float4*>(src + 4 * q);
+  }
+  float xg = 1.0f, xb = 0.0f, xk = 0.0f;
+  if (a.x_stats != nullptr && tid < D) {
+    xg = a.x_gamma[tid];
+    xb = a.x_beta[tid];
+    xk = partials_shift(a.x_stats, a.Gx, D, tid);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = tid + TH * i;
+    L::st4(Wi + (idx >> 4) * P + 4 * (idx & 15), wvv[i].x, wvv[i].y, wvv[i].z, wvv[i].w);
+  }
+  FETA_STAMP(6);
+  if (a.x_stats != nullptr) {
+    reduce_partials_finish(a.x_stats, a.Gx, D, pb, scr + 2 * D, scr);
+    for (int c = tid; c < D; c += TH) {
+      float mean, var;
+      bn_moments_k(xk, D, a.M, scr, c, mean, var);   // (c == tid: the loop runs once for the first D threads)
+      const float rstd = rsqrtf(var + a.eps);
+      const float scale = xg * rstd;
+      const float shift = xb - mean * scale;
+      xss[c] = scale;
+      xss[D + c] = shift;
+      if (blockIdx.x == 0) {
+        a.x_bn_out[c] = scale;
+        a.x_bn_out[D + c] = shift;
+        a.x_bn_out[2 * D + c] = mean;
+        a.x_bn_out[3 * D + c] = rstd;
+        if (a.x_rmean != nullptr) {
+          const float unbiased = a.M > 1 ? var * (float)a.M / (float)(a.M - 1) : var;
+          a.x_rmean[c] = (1.0f - a.momentum) * a.x_rmean[c] + a.momentum * mean;
+          a.x_rvar[c] = (1.0f - a.momentum) * a.x_rvar[c] + a.momentum * unbiased;
+        }
+        if (c == 0 && a.x_nbt != nullptr) *a.x_nbt += 1;
+      }
+    }
+  } else if (a.x_bn != nullptr) {
+    for (int c = tid; c < 2 * D; c += TH) xss[c] = a.x_bn[c];
+  }
+  FETA_STAMP(7);
+  bool first = true;
+  for (int b = b0; b < a.B; b += gp) {
+  if (!first) {
+    __syncthreads();   // the tiles of the previous graph have been consumed
+    request_graph(b);
+  }
+  first = false;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int idx = tid + TH * i, node = idx / RV, q = idx % RV;
+    if (XI * TH != NR * RV && idx >= NR * RV) continue;
+    Vec v = xv[i];
+    if (x_norm) {
+      float f[L::VEC];
+      L::unpack(v, f);
+#pragma unroll
+      for (int e = 0; e < L::VEC; ++e) f[e] = f[e] * xss[L::VEC * q + e] + xss[D + L::VEC * q + e];
+      v = L::pack(f);
+    }
+    L::stv(Xs + node * P + L::VEC * q, v);  // rows >= N: a copy of row N-1, never stored
+  }
+  {
+    const float rn = 1.0f / (float)a.N;
+#pragma unroll
+    for (int i = 0; i < PEI; ++i) {
+      const int idx = tid + TH * i, e = pe0 + idx;
+      const int qq = (int)(((float)e + 0.5f) * rn), kk = e - qq * a.N;
+      if (idx < pecnt) Pe[qq * PEP + kk] = pel[i];
+    }
+  }
+  __syncthreads();
+  FETA_STAMP(1);
+
+  // ---- in_proj: Q^T (scaled) of this wave's query tiles; K^T (p = 0) or V (p = 1) of every key tile -> LDS ----------
+  Op qs[NQ], kf[NT], vbo[NT];
+  {
+    // (the row operand of a tile is read from LDS where it is used: holding all NT of them costs 16 NT registers, and two
+    // waves share a SIMD's register file here)
+    {
+      RowOp<T, D> wf;
+      load_row_op<T, D>(wf, Wi + (DH * h + lq) * P, g);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        if ((nt & (S - 1)) != slot) continue;
+        const int node = 16 * nt + lq;
+        RowOp<T, D> xf;
+        load_row_op<T, D>(xf, Xs + node * P, g);
+        f32x4 t = dot_row_ops<T, D>(wf, xf, zero4());   // (c = 4g + r, node = lq)
+        t[0] += binq.x; t[1] += binq.y; t[2] += binq.z; t[3] += binq.w;
+        if (node < a.N) {
+          const int64_t row = (int64_t)b * a.row_sb + (int64_t)node * a.row_sn;
+          L::st4(gqkv + row * 3 * D + DH * h + 4 * g, t[0], t[1], t[2], t[3]);
+        }
+        qs[nt / S] = L::mk(t[0] * a.scale, t[1] * a.scale, t[2] * a.scale, t[3] * a.scale);
+      }
+    }
+    if (p == 0) {
+      RowOp<T, D> wf;
+      load_row_op<T, D>(wf, Wi + ((a.tie_qk ? 0 : D) + DH * h + lq) * P, g);
+#pragma unroll KVU
+      for (int nt = 0; nt < NT; ++nt) {
+        Op kk = L::zero();
+        if (16 * nt < n) {   // a key tile without a real node: no K (wave-uniform)
+          const int node = 16 * nt + lq;
+          RowOp<T, D> xf;
+          load_row_op<T, D>(xf, Xs + node * P, g);
+          f32x4 t = dot_row_ops<T, D>(wf, xf, zero4());
+          t[0] += bink.x; t[1] += bink.y; t[2] += bink.z; t[3] += bink.w;
+          if (!a.tie_qk && node < a.N && (nt % WGS) == w) {
+            const int64_t row = (int64_t)b * a.row_sb + (int64_t)node * a.row_sn;
+            L::st4(gqkv + row * 3 * D + D + DH * h + 4 * g, t[0], t[1], t[2], t[3]);
+          }
+          kk = L::mk(t);
+        }
+        L::sto(XK + nt * 64 + lane, kk);
+      }
+    } else {
+      RowOp<T, D> wf;
+      load_row_op<T, D>(wf, Wi + (2 * D + DH * h + lq) * P, g);
+#pragma unroll KVU
+      for (int nt = 0; nt < NT; ++nt) {
+        Op vv = L::zero();
+        if (16 * nt < n) {
+          RowOp<T, D> xf;
+          load_row_op<T, D>(xf, Xs + (16 * nt + lq) * P, g);
+          f32x4 t = dot_row_ops<T, D>(xf, wf, zero4());   // (node = 4g + r, c' = lq)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            t[r] += bin1;
+            const int nd = 16 * nt + 4 * g + r;
+            if (nd < a.N && (nt % WGS) == w) {
+              const int64_t row = (int64_t)b * a.row_sb + (int64_t)nd * a.row_sn;
+              L::st1(gqkv + row * 3 * D + 2 * D + DH * h + lq, t[r]);
+            }
+            if (nd >= n) t[r] = 0.0f;  // padded keys carry no value
+          }
+          vv = L::mk(t);
+        }
+        L::sto(XV + nt * 64 + lane, vv);
+      }
+    }
+  }
+  lds_barrier();
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    kf[nt] = L::ldo(XK + nt * 64 + lane);
+    vbo[nt] = L::ldo(XV + nt * 64 + lane);
+  }
+  FETA_STAMP(2);
+
+  // ---- attention core of this wave's query tiles (the arithmetic of the four-wave kernel) -----------------------
+  const int bh = b * kBlkH + h;
+  f32x4 acc[NQ][NT];
+#pragma unroll
+  for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) acc[i][kt] = zero4();
+    if (16 * kt < n) {
+#pragma unroll
+      for (int i = 0; i < NQ; ++i)
+        if (slot + S * i < NT) acc[i][kt] = L::mma(kf[kt], qs[i], zero4());  // (key 4g+r, query lq)
+    }
+  }
+  float mx[NQ], zs[NQ], rinv[NQ];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (16 * kt + 4 * g + r < n) m = fmaxf(m, acc[i][kt][r]);
+    mx[i] = m;
+  }
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) mx[i] = fmaxf(mx[i], shfl_xor(mx[i], 16));
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) mx[i] = fmaxf(mx[i], shfl_xor(mx[i], 32));
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) zs[i] = 0.0f;
+  float pv[NQ][NT][4];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int qc = min(min(16 * (slot + S * i), NR - 16) + lq, a.N - 1);
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      const float4 t = *reinterpret_cast<const float4*>(Pe + qc * PEP + 16 * kt + 4 * g);
+      pv[i][kt][0] = t.x; pv[i][kt][1] = t.y; pv[i][kt][2] = t.z; pv[i][kt][3] = t.w;
+    }
+  }
+#pragma unroll
+  for (int kt = 0; kt < NT; ++kt) {
+    if (16 * kt >= n) continue;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      if (slot + S * i >= NT) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool kok = 16 * kt + 4 * g + r < n;
+        const float e = kok ? fast_exp(acc[i][kt][r] - mx[i]) * pv[i][kt][r] : 0.0f;
+        acc[i][kt][r] = e;
+        zs[i] += e;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) zs[i] += shfl_xor(zs[i], 16);
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) zs[i] += shfl_xor(zs[i], 32);
+  f32x4 o[NQ];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    rinv[i] = 1.0f / fmaxf(zs[i], 1e-6f);
+    o[i] = zero4();
+    const int qb = slot + S * i, q = 16 * qb + lq;
+    if (g == 0 && qb < NT && q < a.N) {
+      float* st = a.attn_stats + ((int64_t)bh * a.N + q) * 2;
+      st[0] = mx[i];
+      st[1] = zs[i];
+    }
+  }
+#pragma unroll
+  for (int kt = 0; kt < NT; ++kt) {
+    if (16 * kt >= n) continue;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      if (slot + S * i >= NT) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][kt][r] *= rinv[i];
+      o[i] = L::mma(L::mk(acc[i][kt]), vbo[kt], o[i]);  // (query 4g+r, c' lq)
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int qb = slot + S * i;
+    if (qb < NT) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) L::st1(Os + (16 * qb + 4 * g + r) * P + DH * h + lq, o[i][r]);
+    }
+  }
+  if (a.attn != nullptr) {
+    lds_barrier();   // the staging area of this wave is the K / V hand-over its sibling may still be reading
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int qb = slot + S * i;
+      if (qb >= NT) continue;
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stg[lq * KP + 16 * kt + 4 * g + r] = acc[i][kt][r];
+      wave_lds_sync();
+      const int rows = min(16, a.N - 16 * qb);
+      float* dst = a.attn + ((int64_t)bh * a.N + 16 * qb) * a.N;
+      for (int j = lane; j < rows * a.N; j += 64) {
+        const int qq = j / a.N, kk = j - qq * a.N;
+        dst[j] = stg[qq * KP + kk];
+      }
+      wave_lds_sync();
+    }
+  }
+  FETA_STAMP(3);
+  lds_barrier();
+  FETA_STAMP(4);
+
+  // ---- concat rows of this workgroup's tiles to HBM; out_proj: wave (h, p) owns output columns 16h .. 16h+15 of its
+  // own query tiles
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int idx = tid + TH * i, node = idx / RV, q = idx % RV;
+    if (node < a.N && (((node >> 4) & (S - 1)) >> 1) == w) {
+      const int64_t row = (int64_t)b * a.row_sb + (int64_t)node * a.row_sn;
+      const Vec ov = L::ldv(Os + node * P + L::VEC * q);
+      L::stv(gout + row * D + L::VEC * q, ov);
+      if (a.out_f32 != nullptr) {
+        float f[L::VEC];
+        L::unpack(ov, f);
+#pragma unroll
+        for (int e = 0; e < L::VEC; e += 4)
+          *reinterpret_cast<float4*>(a.out_f32 + row * D + L::VEC * q + e) = make_float4(f[e], f[e + 1], f[e + 2], f[e + 3]);
+      }
+    }
+  }
+  {
+    RowOp<T, D> wf;
+    load_row_op<T, D>(wf, Wo + (DH * h + lq) * P, g);
+    const int o0 = DH * h + 4 * g;
+    float s1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float4 ks = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (a.y_shift != nullptr) ks = *reinterpret_cast<const float4*>(a.y_shift + o0);
+    const float kv[4] = {ks.x, ks.y, ks.z, ks.w};
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int qb = slot + S * i;
+      if (qb >= NT) continue;
+      const int node = 16 * qb + lq;
+      const bool rok = node < a.N;
+      const int64_t row = (int64_t)b * a.row_sb + (int64_t)min(node, a.N - 1) * a.row_sn;
+      const float rs = rsv[i];
+      RowOp<T, D> of;
+      load_row_op<T, D>(of, Os + node * P, g);
+      const f32x4 t = dot_row_ops<T, D>(wf, of, zero4());  // (o = 16h + 4g + r, node lq)
+      float res[4];
+      L::ld4(Xs + node * P + o0, res);
+      float v[4] = {(t[0] + bo.x) * rs + res[0], (t[1] + bo.y) * rs + res[1], (t[2] + bo.z) * rs + res[2],
+                    (t[3] + bo.w) * rs + res[3]};
+      if (rok) L::st4(gy + row * D + o0, v[0], v[1], v[2], v[3]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float x1 = rok ? v[r] - kv[r] : 0.0f;
+        s1[r] += row16_sum(x1);
+        s2[r] += row16_sum(x1 * x1);
+      }
+    }
+    // the two parities of a head hold sums over different rows of the same columns: odd hands over, even adds and stores
+    if (p == 1 && lq == 0) {
+      float* e = sx + (4 * h + g) * 8;
+      *reinterpret_cast<float4*>(e) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+      *reinterpret_cast<float4*>(e + 4) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+    }
+    lds_barrier();
+    if (p == 0 && lq == 0) {
+      const float* e = sx + (4 * h + g) * 8;
+      const float4 t1 = *reinterpret_cast<const float4*>(e), t2 = *reinterpret_cast<const float4*>(e + 4);
+      float* st = a.y_stats + ((int64_t)b * WGS + w) * 2 * D;
+      *reinterpret_cast<float4*>(st + o0) = make_float4(s1[0] + t1.x, s1[1] + t1.y, s1[2] + t1.z, s1[3] + t1.w);
+      *reinterpret_cast<float4*>(st + D + o0) = make_float4(s2[0] + t2.x, s2[1] + t2.y, s2[2] + t2.z, s2[3] + t2.w);
+      if (b == 0 && w == 0) *reinterpret_cast<float4*>(a.y_stats + (int64_t)a.B * WGS * 2 * D + o0) = ks;   // the shift row
+    }
+  }
+  }  // graphs of this workgroup
+  FETA_STAMP(5);
+  FETA_RT_LAUNCH_DONE(feta_block_launch);
+}
+
+// Form of a forward launch: waves per workgroup and workgroups per graph.  Two workgroups per graph where a graph has
+// three or four query tiles and the launch still fits the chip (one resident workgroup per CU); FETA_BLOCK_FWD_WAVES=4
+// selects the four-wave kernel of rounds 1-2, FETA_BLOCK_FWD_WGS=1|2 overrides the split (A/B timing, tests).
+struct BlockFwdForm {
+  int waves, wgs, cap;
+};
+static BlockFwdForm block_fwd_form(int B, int N) {
+  BlockFwdForm f{8, 1, kBlkMaxGrid};
+  if (const char* e = getenv("FETA_BLOCK_MAX_GRID")) f.cap = atoi(e) > 0 ? atoi(e) : f.cap;
+  if (const char* e = getenv("FETA_BLOCK_FWD_WAVES")) f.waves = atoi(e) == 4 ? 4 : 8;
+  if (f.waves == 4) return f;
+  const int nt = (N + 15) / 16;
+  f.wgs = (nt >= 3 && 2 * B <= f.cap) ? 2 : 1;
+  if (const char* e = getenv("FETA_BLOCK_FWD_WGS")) {
+    const int v = atoi(e);
+    if (v == 1 || (v == 2 && nt >= 3)) f.wgs = v;   // (two workgroups need query tiles for both)
+  }
+  return f;
+}
+
+template <class T, int NT, int WGS>
+int launch_block_fwd8(const BlockArgs& a, const feta_colsum_seg* segs, int nseg, int cap, hipStream_t stream) {
+  const size_t lds = block8_lds_bytes<T>(NT);
+  auto kern = attn_block_fwd8_kernel<T, NT, WGS>;
+  static LdsSeen lds_seen;
+  allow_dynamic_lds(kern, lds, lds_seen);
+  int gp = cap / WGS;   // graphs in flight
+  if (gp < 1) gp = 1;
+  if (a.B < gp) gp = a.B;
+  const int grid = gp * WGS;
+  ColsumPlan plan{};
+  const int tiles = plan_colsum(segs, nseg, plan);
+  hipLaunchKernelGGL(kern, dim3(grid + tiles), dim3(kBlk8Threads), lds, stream, a, plan, grid);
+  return check_launch("feta_attn_block_fwd");
+}
+
 template <class T, int NT>
 int launch_block_fwd(const BlockArgs& a, const feta_colsum_seg* segs, int nseg, hipStream_t stream) {
   const size_t lds = block_lds_bytes<T>(NT, a.attn != nullptr);
@@ -471,6 +966,19 @@ int launch_block_fwd(const BlockArgs& a, const feta_colsum_seg* segs, int nseg, 
 
 template <class T>
 int dispatch_block_fwd(const BlockArgs& a, const feta_colsum_seg* segs, int nseg, hipStream_t stream) {
+  const BlockFwdForm f = block_fwd_form(a.B, a.N);
+  if (f.waves == 8) {
+    if (f.wgs == 2) {
+      if ((a.N + 15) / 16 == 3) return launch_block_fwd8<T, 3, 2>(a, segs, nseg, f.cap, stream);
+      return launch_block_fwd8<T, 4, 2>(a, segs, nseg, f.cap, stream);
+    }
+    switch ((a.N + 15) / 16) {
+      case 1: return launch_block_fwd8<T, 1, 1>(a, segs, nseg, f.cap, stream);
+      case 2: return launch_block_fwd8<T, 2, 1>(a, segs, nseg, f.cap, stream);
+      case 3: return launch_block_fwd8<T, 3, 1>(a, segs, nseg, f.cap, stream);
+      default: return launch_block_fwd8<T, 4, 1>(a, segs, nseg, f.cap, stream);
+    }
+  }
   switch ((a.N + 15) / 16) {
     case 1: return launch_block_fwd<T, 1>(a, segs, nseg, stream);
     case 2: return launch_block_fwd<T, 2>(a, segs, nseg, stream);
@@ -491,6 +999,11 @@ extern "C" int feta_debug_block_stamps(unsigned long long* out256) {
 
 extern "C" int feta_attn_block_supported(int N, int d_model, int heads) {
   return (d_model == kBlkD && heads == kBlkH && N >= 1 && N <= 64) ? 1 : 0;
+}
+
+extern "C" int feta_attn_block_stat_rows(int B, int N) {
+  if (B < 1 || N < 1 || N > 64) return 0;
+  return B * block_fwd_form(B, N).wgs;
 }
 
 extern "C" int feta_attn_block_fwd(const feta_attn_block* d, feta_stream_t stream) {

@@ -41,6 +41,11 @@ struct Lp<float> {
     const float4 x = *reinterpret_cast<const float4*>(p);
     return Op{{x.x, x.y, x.z, x.w}};
   }
+  // an operand parked in LDS in its register layout (16 bytes per lane)
+  static __device__ __forceinline__ Op ldo(const Op* p) { return ld(reinterpret_cast<const float*>(p)); }
+  static __device__ __forceinline__ void sto(Op* p, const Op& o) {
+    *reinterpret_cast<float4*>(p) = make_float4(o.v[0], o.v[1], o.v[2], o.v[3]);
+  }
   static __device__ __forceinline__ Op ld_scaled(const float* p, float s) {
     const float4 x = *reinterpret_cast<const float4*>(p);
     return Op{{x.x * s, x.y * s, x.z * s, x.w * s}};
@@ -87,6 +92,8 @@ struct Lp<bf16_t> {
   static __device__ __forceinline__ Op mk(float a, float b, float c, float d) { return pack_bf16x4(a, b, c, d); }
   static __device__ __forceinline__ Op mk(const f32x4& a) { return pack_bf16x4(a[0], a[1], a[2], a[3]); }
   static __device__ __forceinline__ Op ld(const bf16_t* p) { return *reinterpret_cast<const bf16x4_pk*>(p); }
+  static __device__ __forceinline__ Op ldo(const Op* p) { return *p; }
+  static __device__ __forceinline__ void sto(Op* p, const Op& o) { *p = o; }
   static __device__ __forceinline__ Op ld_scaled(const bf16_t* p, float s) {
     const Op x = ld(p);
     return pack_bf16x4(bf16x4_get(x, 0) * s, bf16x4_get(x, 1) * s, bf16x4_get(x, 2) * s, bf16x4_get(x, 3) * s);

@@ -169,6 +169,14 @@ __device__ __forceinline__ void bn_moments(const float* part, int G, int D, int 
   var = fmaxf(tot[D + c] / (float)M - m1 * m1, 0.0f);
 }
 
+// the same with the shift already in a register: the consumers request it (and gamma / beta) with their first loads - read
+// after the reduction it is one more dependent round trip to the memory side in the middle of the prologue
+__device__ __forceinline__ void bn_moments_k(float shift, int D, int M, const float* tot, int c, float& mean, float& var) {
+  const float m1 = tot[c] / (float)M;
+  mean = shift + m1;
+  var = fmaxf(tot[D + c] / (float)M - m1 * m1, 0.0f);
+}
+
 __host__ __device__ inline int reduce_red_floats(int D) {
   const int nq = 2 * D / 4;
   const int slices = kRowThreads / nq > 0 ? kRowThreads / nq : 1;

@@ -100,6 +100,14 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a, CoeffFw
                  ? *reinterpret_cast<const float4*>(a.y_shift + 16 * (2 * hh + t) + 4 * g)
                  : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
+  // gamma, beta and the shift of the input BatchNorm travel with the first requests (three floats for each of the first D
+  // threads): read after the reduction they were one more dependent round trip in the middle of the prologue
+  float xg = 1.0f, xb = 0.0f, xk = 0.0f;
+  if (a.x_stats != nullptr && tid < D) {
+    xg = a.x_gamma[tid];
+    xb = a.x_beta[tid];
+    xk = partials_shift(a.x_stats, a.Gx, D, tid);
+  }
   {
     constexpr int NV = 2 * FF * D / 4 / kRowThreads;  // float4 per thread: W1 then W2 (fp32 masters)
     float4 wv4[NV];
@@ -128,10 +136,10 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a, CoeffFw
     reduce_partials(a.x_stats, a.Gx, D, scr + 2 * D, scr);
     for (int c = tid; c < D; c += kRowThreads) {
       float mean, var;
-      bn_moments(a.x_stats, a.Gx, D, a.M, scr, c, mean, var);
+      bn_moments_k(xk, D, a.M, scr, c, mean, var);   // (c == tid: the loop runs once for the first D threads)
       const float rstd = rsqrtf(var + a.eps);
-      const float scale = a.x_gamma[c] * rstd;
-      const float shift = a.x_beta[c] - mean * scale;
+      const float scale = xg * rstd;
+      const float shift = xb - mean * scale;
       xss[c] = scale;
       xss[D + c] = shift;
       if (blockIdx.x == 0) {

@@ -231,8 +231,8 @@ class FusedEncoderStackFn(torch.autograd.Function):
                                momentum=float(pl.momentum), eps=float(pl.eps))
                 saved[li - 1]['prm2'] = prm_prev
             if block:
-                # F1 + F2 + F3 in one launch, one workgroup per graph (csrc/block.hip)
-                G1 = b
+                # F1 + F2 + F3 in one launch, one or two workgroups per graph (csrc/block.hip)
+                G1 = abi.attn_block_stat_rows(b, n)
                 st1 = new(G1 + 1, 2, d)      # (+ the shift row: the sums are relative to norm1's running mean)
                 abi.attn_block_fwd(b, n, scale, stream, tie_qk=tie, x=y_prev, w_in=w_in, b_in=b_in, w_out=w_o,
                                    b_out=b_o, pe=pe_c, n_real=n_real, rowscale=degree_rows, qkv=qkv, out=out,
@@ -517,7 +517,7 @@ class FusedLayerNormStackFn(torch.autograd.Function):
             if block:
                 abi.attn_block_fwd(b, n, scale, stream, tie_qk=tie, x=x_in, w_in=w_in, b_in=b_in, w_out=w_o,
                                    b_out=b_o, pe=pe_c, n_real=n_real, rowscale=degree_rows, qkv=qkv, out=out,
-                                   attn_stats=ast, attn=attn, y=y1, y_stats=new(b + 1, 2, d),   # (statistics unused)
+                                   attn_stats=ast, attn=attn, y=y1, y_stats=new(abi.attn_block_stat_rows(b, n) + 1, 2, d),   # (statistics unused)
                                    out_f32=(out32 if li == nl - 1 else None),
                                    sums=(pending.take_fwd() if (pending is not None and li == 0) else ()))
             else:

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FETA_ABI_VERSION 7
+#define FETA_ABI_VERSION 8
 
 #define FETA_OK 0
 #define FETA_E_ARG (-1)     /* bad shape / stride / alignment / unsupported size */
@@ -408,9 +408,12 @@ int feta_bn_bwd(const float* y, const float* dout, const float* mean_rstd, const
  * (publishing x_bn_out and updating x_rmean / x_rvar), or neither (first layer).
  * Outputs: qkv [M,192] (in_proj result, for backward), out [M,64] (per-head attention outputs,
  * concatenated: out_each_head), attn_stats [B,4,N,2] (row max, un-clamped row sum), attn
- * [B,4,N,N] or NULL, y [M,64] = x_norm + rowscale * (out W_out^T + b_out), y_stats [B][2][64]
- * per-graph (sum, sum of squares) over the N rows of the graph - padded rows included, as
- * nn.BatchNorm1d over the [N*B, d] view counts them. */
+ * [B,4,N,N] or NULL, y [M,64] = x_norm + rowscale * (out W_out^T + b_out), y_stats [G][2][64]
+ * partial (sum, sum of squares) over the rows of y - padded rows included, as nn.BatchNorm1d over the
+ * [N*B, d] view counts them.  G = feta_attn_block_stat_rows(B, N) (ABI 8): one row per WORKGROUP - a graph is one
+ * workgroup of eight waves (head x query-tile parity), or two such workgroups (query tiles split between them, K and V
+ * projected by both) where a graph has more than two 16-row tiles and 2 B workgroups still fit the chip; the shift row
+ * (y_shift) is row G. */
 typedef struct feta_attn_block {
   const float* x;
   const float* x_bn;
@@ -442,12 +445,14 @@ typedef struct feta_attn_block {
   int tie_qk;
   int dtype;           /* FETA_F32 | FETA_BF16: storage type of x, pe, qkv, out, y [T] (ABI 7) */
   const float* y_shift; /* nullable [64]: shift of the y statistics = running mean of the BatchNorm that will normalise y
-                           (feta_rowlin_ex.stats_shift); y_stats has B + 1 rows, row B receives the shift */
+                           (feta_rowlin_ex.stats_shift); y_stats has G + 1 rows (G = feta_attn_block_stat_rows), row G
+                           receives the shift */
   float* out_f32;      /* nullable: `out` once more, as fp32 [M,64] - the fp32 filter stage behind a bf16 stack reads it
                           (out_each_head of the last layer, transformer/models.py:179) without a cast launch */
 } feta_attn_block;
 
 int feta_attn_block_supported(int N, int d_model, int heads);
+int feta_attn_block_stat_rows(int B, int N);   /* partial rows a forward launch writes into y_stats (0: unsupported shape) */
 int feta_attn_block_fwd(const feta_attn_block* d, feta_stream_t stream);
 /* the same launch with up to FETA_COLSUM_MAX_SEGS independent column sums in trailing workgroups (ABI 6): at the
  * BASELINE batch the first launch of a forward pass leaves half the chip idle, and s = colsum(gcn.weight) of the

@@ -746,7 +746,7 @@ def check_attn_block_lp(abi, dev, stream, bsz=5, n_pad=21, n_min=3, seed=0, with
     qkv, out, y = new(m, 3 * d), new(m, d), new(m, d)
     ast = torch.full((bsz, heads, n_pad, 2), float('nan'), device=dev)
     attn = torch.full((bsz, heads, n_pad, n_pad), float('nan'), device=dev) if need_attn else None
-    st = torch.full((bsz + 1, 2, d), float('nan'), device=dev)     # (+ the shift row)
+    st = torch.full((abi.attn_block_stat_rows(bsz, n_pad) + 1, 2, d), float('nan'), device=dev)     # (+ the shift row)
     rows = degree.t().reshape(m)
     abi.attn_block_fwd(bsz, n_pad, float(d // heads) ** -0.5, stream, x=b16(x).view(m, d), w_in=f32(p['w_in']),
                        b_in=f32(p['b_in']), w_out=f32(p['w_out']), b_out=f32(p['b_out']),
@@ -878,7 +878,7 @@ def check_attn_block_bwd_lp(abi, dev, stream, bsz=5, n_pad=21, n_min=3, seed=0, 
     new = lambda *s: torch.full(s, float('nan'), dtype=BF16, device=dev)
     qkv, out, y = new(m, 3 * d), new(m, d), new(m, d)
     ast = torch.full((bsz, heads, n_pad, 2), float('nan'), device=dev)
-    st = torch.empty((bsz + 1, 2, d), device=dev)
+    st = torch.empty((abi.attn_block_stat_rows(bsz, n_pad) + 1, 2, d), device=dev)
     rows = degree.t().reshape(m)
     scale = float(d // heads) ** -0.5
     pe_d = None if pe is None else b16(pe)

@@ -247,6 +247,16 @@ def test_attn_block_fwd_bf16(hip, kw):
     KC.check_attn_block_lp(abi, dev, stream, **kw)
 
 
+@pytest.mark.parametrize('env', [dict(FETA_BLOCK_FWD_WAVES='4'), dict(FETA_BLOCK_FWD_WGS='1'),
+                                 dict(FETA_BLOCK_FWD_WGS='2', FETA_BLOCK_MAX_GRID='2')])
+@pytest.mark.parametrize('kw', [dict(bsz=40, n_pad=37, n_min=9), dict(bsz=7, n_pad=64, n_min=40, with_pe=False)])
+def test_attn_block_fwd_bf16_forms(hip, monkeypatch, env, kw):
+    abi, dev, stream = hip
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    KC.check_attn_block_lp(abi, dev, stream, **kw)
+
+
 @pytest.mark.parametrize('kw', [dict(), dict(split=True), dict(bsz=3, n_pad=37, n_min=9, with_pe=False, with_bn=True),
                                 dict(bsz=2, n_pad=16, n_min=1, split=True, with_bn=True), dict(bsz=2, n_pad=64, n_min=40),
                                 dict(bsz=128, n_pad=37, n_min=9, split=True, with_bn=True),

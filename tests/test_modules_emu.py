@@ -424,6 +424,26 @@ def test_attn_block_equals_three_launches(emu, monkeypatch, shape, n_min, n_max,
                                            n_min, n_max, tie_qk, pe_on, split=split)
 
 
+# forms of the forward launch (csrc/block.hip, block_fwd_form): FETA_BLOCK_FWD_WAVES / FETA_BLOCK_FWD_WGS / FETA_BLOCK_MAX_GRID
+FWD_FORMS = {
+    'four waves': dict(FETA_BLOCK_FWD_WAVES='4'),
+    'eight waves, one workgroup per graph': dict(FETA_BLOCK_FWD_WGS='1'),
+    'eight waves, two workgroups per graph': dict(FETA_BLOCK_FWD_WGS='2'),
+    'two workgroups per graph walking the batch': dict(FETA_BLOCK_FWD_WGS='2', FETA_BLOCK_MAX_GRID='4'),
+    'one workgroup walking the batch': dict(FETA_BLOCK_FWD_WGS='1', FETA_BLOCK_MAX_GRID='2'),
+}
+
+
+@pytest.mark.parametrize('form', sorted(FWD_FORMS))
+@pytest.mark.parametrize('shape,n_min,n_max,pe_on', [('zinc', 20, 37, True), ('pattern', 44, 64, False)])
+def test_attn_block_forward_forms(emu, monkeypatch, form, shape, n_min, n_max, pe_on):
+    """every form of the attention-block forward launch == the three-launch sequence (3 and 4 row tiles; 5 graphs)"""
+    for k, v in FWD_FORMS[form].items():
+        monkeypatch.setenv(k, v)
+    check_attn_block_equals_three_launches(CPU, lambda: _lib.override_for_tests(emu), monkeypatch, shape,
+                                           n_min, n_max, False, pe_on, bsz=5)
+
+
 def test_capped_statistics_partials_give_the_same_result(emu, monkeypatch):
     """large batches: the per-workgroup BatchNorm partial sums are reduced once before their consumers
     (fused_stack.MAX_STAT_ROWS); forced here with a cap of 2 rows"""

@@ -70,6 +70,19 @@ def test_attn_block_equals_three_launches(monkeypatch, shape, n_min, n_max, tie_
                                            n_min, n_max, tie_qk, pe_on, bsz=bsz, split=split)
 
 
+@pytest.mark.parametrize('form', ['four waves', 'eight waves, one workgroup per graph', 'eight waves, two workgroups per graph',
+                                  'two workgroups per graph walking the batch', 'one workgroup walking the batch'])
+@pytest.mark.parametrize('shape,n_min,n_max,pe_on,bsz', [('zinc', 9, 37, True, 128), ('pattern', 44, 64, False, 9),
+                                                         ('zinc', 9, 37, True, 300)])
+def test_attn_block_forward_forms(monkeypatch, form, shape, n_min, n_max, pe_on, bsz):
+    import contextlib
+    from test_modules_emu import FWD_FORMS, check_attn_block_equals_three_launches
+    for k, v in FWD_FORMS[form].items():
+        monkeypatch.setenv(k, v)
+    check_attn_block_equals_three_launches(torch.device('cuda:0'), contextlib.nullcontext, monkeypatch, shape,
+                                           n_min, n_max, False, pe_on, bsz=bsz)
+
+
 @pytest.mark.parametrize('n_min,n_max,bsz', [(2, 3, 1), (1, 2, 2), (16, 16, 2), (17, 17, 1), (48, 48, 1), (9, 37, 300)])
 def test_fused_kernels_edge_shapes(monkeypatch, n_min, n_max, bsz):
     """tiny graphs, one graph, tile-boundary node counts, and a batch above the per-graph attention
