@@ -71,15 +71,20 @@ __global__ __launch_bounds__(64 * kWaves) void attn_fwd_kernel(AttnArgs a) {
   load_row_sel<DH>(qf, tok_row(a.q, a.qsb, a.qsn, b, qc, h, DH), q < a.N, g, a.scale);
 
   // S^T tiles: acc[kt][r] <-> key 16kt + 4g + r, query q
-  f32x4 acc[KT_MAX];
+  // (scalars, not f32x4 acc[KT_MAX]: the optimizer promotes such an array to ONE 4 KT_MAX-wide vector value and every
+  // conditional tile update then copies the whole tuple - 256 + 127 registers at KT_MAX = 8; see csrc/attnout.hip)
+  float acc[KT_MAX][4];
 #pragma unroll
   for (int kt = 0; kt < KT_MAX; ++kt) {
+    f32x4 t = zero4();
     if (kt < KT) {
       const int key = 16 * kt + lq;
       Feat<DH> kf;
       load_row_sel<DH>(kf, tok_row(a.k, a.qsb, a.qsn, b, min(key, nm1), h, DH), key < n, g);
-      acc[kt] = dot_rows<DH>(kf, qf, zero4());
+      t = dot_rows<DH>(kf, qf, zero4());
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[kt][r] = t[r];
   }
 
   float m = -INFINITY;

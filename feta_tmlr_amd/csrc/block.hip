@@ -726,15 +726,17 @@ __global__ __launch_bounds__(kBlk8Threads) void attn_block_fwd8_kernel(BlockArgs
 
   // ---- attention core of this wave's query tiles (the arithmetic of the four-wave kernel) -----------------------
   const int bh = b * kBlkH + h;
-  f32x4 acc[NQ][NT];
+  // (scalars, not f32x4 acc[NQ][NT]: at 32 floats the optimizer promotes such an array to ONE vector value and every
+  // conditional tile update copies the whole tuple - see csrc/attnout.hip)
+  float acc[NQ][NT][4];
 #pragma unroll
   for (int kt = 0; kt < NT; ++kt) {
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) acc[i][kt] = zero4();
-    if (16 * kt < n) {
+    for (int i = 0; i < NQ; ++i) {
+      f32x4 t = zero4();
+      if (16 * kt < n && slot + S * i < NT) t = L::mma(kf[kt], qs[i], zero4());  // (key 4g+r, query lq)
 #pragma unroll
-      for (int i = 0; i < NQ; ++i)
-        if (slot + S * i < NT) acc[i][kt] = L::mma(kf[kt], qs[i], zero4());  // (key 4g+r, query lq)
+      for (int r = 0; r < 4; ++r) acc[i][kt][r] = t[r];
     }
   }
   float mx[NQ], zs[NQ], rinv[NQ];
@@ -754,26 +756,20 @@ __global__ __launch_bounds__(kBlk8Threads) void attn_block_fwd8_kernel(BlockArgs
   for (int i = 0; i < NQ; ++i) mx[i] = fmaxf(mx[i], shfl_xor(mx[i], 32));
 #pragma unroll
   for (int i = 0; i < NQ; ++i) zs[i] = 0.0f;
-  float pv[NQ][NT][4];
-#pragma unroll
-  for (int i = 0; i < NQ; ++i) {
-    const int qc = min(min(16 * (slot + S * i), NR - 16) + lq, a.N - 1);
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt) {
-      const float4 t = *reinterpret_cast<const float4*>(Pe + qc * PEP + 16 * kt + 4 * g);
-      pv[i][kt][0] = t.x; pv[i][kt][1] = t.y; pv[i][kt][2] = t.z; pv[i][kt][3] = t.w;
-    }
-  }
+  // pe of this lane's (query lq, keys 4g .. 4g+3) pairs: one 16-byte LDS read per tile pair, where it is used
 #pragma unroll
   for (int kt = 0; kt < NT; ++kt) {
     if (16 * kt >= n) continue;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
       if (slot + S * i >= NT) continue;
+      const int qc = min(16 * (slot + S * i) + lq, a.N - 1);
+      const float4 t = *reinterpret_cast<const float4*>(Pe + qc * PEP + 16 * kt + 4 * g);
+      const float pv[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const bool kok = 16 * kt + 4 * g + r < n;
-        const float e = kok ? fast_exp(acc[i][kt][r] - mx[i]) * pv[i][kt][r] : 0.0f;
+        const float e = kok ? fast_exp(acc[i][kt][r] - mx[i]) * pv[r] : 0.0f;
         acc[i][kt][r] = e;
         zs[i] += e;
       }
@@ -803,7 +799,7 @@ __global__ __launch_bounds__(kBlk8Threads) void attn_block_fwd8_kernel(BlockArgs
       if (slot + S * i >= NT) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[i][kt][r] *= rinv[i];
-      o[i] = L::mma(L::mk(acc[i][kt]), vbo[kt], o[i]);  // (query 4g+r, c' lq)
+      o[i] = L::mma(L::mk(acc[i][kt][0], acc[i][kt][1], acc[i][kt][2], acc[i][kt][3]), vbo[kt], o[i]);  // (query 4g+r, c' lq)
     }
   }
 #pragma unroll

@@ -21,7 +21,8 @@ __global__ __launch_bounds__(kCoeffThreads) void coeff_fwd_kernel(
     const float* __restrict__ attn, const int32_t* __restrict__ n_real, const float* __restrict__ s,
     const float* __restrict__ gbias, float* __restrict__ cj_out, float* __restrict__ pooled, int B,
     int N, int H, int C, int stage) {
-  coeff_fwd_body(attn, n_real, s, gbias, cj_out, pooled, B, N, H, C, stage, (int)blockIdx.x);
+  coeff_fwd_body(attn, n_real, s, gbias, cj_out, pooled, B, N, H, C, stage, (int)blockIdx.x, (int)blockIdx.y,
+                 (int)gridDim.y);
 }
 
 __global__ __launch_bounds__(kCoeffThreads) void coeff_bwd_kernel(
@@ -213,10 +214,17 @@ extern "C" int feta_coeff_fwd(const float* attn, const int32_t* n_real, const fl
   FETA_REQUIRE(attn && n_real && s && gcn_bias && cj && pooled, "coeff_fwd: null pointer");
   FETA_REQUIRE(B > 0 && H > 0 && C > 0 && N > 0 && N <= kCoeffThreads,
                "coeff_fwd: need 0 < N <= %d (got %d)", kCoeffThreads, N);
-  const int stage = coeff_fwd_stage(N);
-  const size_t lds = sizeof(float) * coeff_fwd_lds_floats(N);
-  const dim3 grid(B * H), block(kCoeffThreads);
+  // stand-alone launch: the block's attention rows are staged whenever they fit a CU's LDS (N <= 192: the unstaged
+  // column sweeps are 2 N dependent trips to L2 - 57 us at N = 128), and graphs beyond 64 nodes split the channels of a
+  // block over 4 workgroups (config 4, PATTERN)
+  const int want = N > 64 ? 2 : 1;
+  const int stage = sizeof(float) * (size_t)coeff_fwd_lds_floats_mode(N, want) <= 150 * 1024 ? want : 0;
+  const size_t lds = sizeof(float) * (size_t)coeff_fwd_lds_floats_mode(N, stage);
+  const int cs = (N > 64 && C >= 4 * kCoeffThreads) ? 4 : 1;
+  const dim3 grid(B * H, cs), block(kCoeffThreads);
   auto kern = coeff_fwd_kernel;
+  static LdsSeen lds_seen;
+  allow_dynamic_lds(kern, lds, lds_seen);
   hipLaunchKernelGGL(kern, grid, block, lds, (hipStream_t)stream, attn, n_real, s, gcn_bias, cj,
                      pooled, B, N, H, C, stage);
   return check_launch("feta_coeff_fwd");

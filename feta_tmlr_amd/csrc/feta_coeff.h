@@ -19,7 +19,9 @@ constexpr int kCoeffLdsTileMax = 12 * 1024;  // floats of attention staged per b
 __device__ __forceinline__ void coeff_fwd_body(
     const float* __restrict__ attn, const int32_t* __restrict__ n_real, const float* __restrict__ s,
     const float* __restrict__ gbias, float* __restrict__ cj_out, float* __restrict__ pooled, int B,
-    int N, int H, int C, int stage, int blk) {
+    int N, int H, int C, int stage, int blk, int cs = 0, int CS = 1) {
+  // (cs, CS): this workgroup pools channel slice cs of CS - large graphs (N > 64: 128 tanh per channel and block, C = 1024
+  // channels) run CS workgroups per block, each recomputing the cheap c_j part; slice 0 writes cj_out
   float* dis = feta_lds;            // [N]
   float* cjs = feta_lds + N;        // [N]
   float* ps = feta_lds + 2 * N;     // [4][64] column partial sums (staged path)
@@ -74,7 +76,88 @@ __device__ __forceinline__ void coeff_fwd_body(
       float c = 0.0f;
       if (col < n) c = ((ps[col] + ps[64 + col]) + (ps[128 + col] + ps[192 + col])) * dis[col];
       cjs[col] = c;
-      cj_out[(int64_t)blk * N + col] = c;
+      if (cs == 0) cj_out[(int64_t)blk * N + col] = c;
+    }
+    __syncthreads();
+  } else if (stage == 2) {
+    // graphs beyond 64 nodes (stand-alone launch; config 4): the two column sweeps as float4 column groups x row slices
+    // on all 256 threads over the staged rows (pitch NP = N rounded up to 4).  The diagonal rule (a zero self loop
+    // counts 1: models.py:276,281 + add_remaining_self_loops) is a correction of the plain column sums:
+    //   deg_j = sum_i a_ij + [a_jj == 0],   c_j = dis_j (sum_i dis_i a_ij + [a_jj == 0] dis_j)
+    const int NP = (N + 3) & ~3, NC4 = NP >> 2, SL = kCoeffThreads / NC4;
+    float* ps2 = feta_lds + 2 * N;     // [SL][NP] (<= 1024 floats)
+    float* tl = ps2 + 1024;            // [n][NP]
+    if ((N & 3) == 0) {
+      const int cnt4 = n * NC4;
+      const float4* a4 = reinterpret_cast<const float4*>(a);
+      for (int base = threadIdx.x; base < cnt4; base += 8 * kCoeffThreads) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int idx = base + u * kCoeffThreads;
+          v[u] = a4[idx < cnt4 ? idx : cnt4 - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int idx = base + u * kCoeffThreads;
+          if (idx < cnt4) reinterpret_cast<float4*>(tl)[idx] = v[u];   // (NP == N: same linear index)
+        }
+      }
+    } else {
+      const int cnt = n * N;
+      for (int base = threadIdx.x; base < cnt; base += 8 * kCoeffThreads) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int idx = base + u * kCoeffThreads;
+          v[u] = a[idx < cnt ? idx : cnt - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int idx = base + u * kCoeffThreads;
+          if (idx < cnt) tl[(idx / N) * NP + idx % N] = v[u];
+        }
+      }
+      for (int i = threadIdx.x; i < n * (NP - N); i += kCoeffThreads) tl[(i / (NP - N)) * NP + N + i % (NP - N)] = 0.0f;
+    }
+    __syncthreads();
+    const int cg = threadIdx.x % NC4, sl = threadIdx.x / NC4;
+    const bool act = sl < SL;
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (act)
+      for (int i = sl; i < n; i += SL) {
+        const float4 v = *reinterpret_cast<const float4*>(tl + i * NP + 4 * cg);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    if (act) *reinterpret_cast<float4*>(ps2 + sl * NP + 4 * cg) = acc;
+    __syncthreads();
+    float dj = 0.0f, diag0 = 0.0f;
+    if (j < n) {
+      float deg = 0.0f;
+      for (int q = 0; q < SL; ++q) deg += ps2[q * NP + j];
+      diag0 = tl[j * NP + j] == 0.0f ? 1.0f : 0.0f;
+      deg += diag0;
+      dj = deg > 0.0f ? rsqrtf(deg) : 0.0f;
+      dis[j] = dj;
+    }
+    __syncthreads();
+    acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (act)
+      for (int i = sl; i < n; i += SL) {
+        const float4 v = *reinterpret_cast<const float4*>(tl + i * NP + 4 * cg);
+        const float di = dis[i];
+        acc.x += di * v.x; acc.y += di * v.y; acc.z += di * v.z; acc.w += di * v.w;
+      }
+    if (act) *reinterpret_cast<float4*>(ps2 + sl * NP + 4 * cg) = acc;
+    __syncthreads();
+    if (j < N) {
+      float c = 0.0f;
+      if (j < n) {
+        for (int q = 0; q < SL; ++q) c += ps2[q * NP + j];
+        c = (c + diag0 * dj) * dj;
+      }
+      cjs[j] = c;
+      if (cs == 0) cj_out[(int64_t)blk * N + j] = c;
     }
     __syncthreads();
   } else {
@@ -113,12 +196,14 @@ __device__ __forceinline__ void coeff_fwd_body(
         c *= dis[j];
       }
       cjs[j] = c;
-      cj_out[(int64_t)blk * N + j] = c;
+      if (cs == 0) cj_out[(int64_t)blk * N + j] = c;
     }
     __syncthreads();
   }
   const float inv_n = 1.0f / (float)n;
-  for (int c = threadIdx.x; c < C; c += kCoeffThreads) {
+  const int cw = ((C + CS - 1) / CS + kCoeffThreads - 1) / kCoeffThreads * kCoeffThreads;   // channels per slice
+  const int cend = min(C, (cs + 1) * cw);
+  for (int c = cs * cw + threadIdx.x; c < cend; c += kCoeffThreads) {
     const float sc = s[c], bc = gbias[c];
     float acc = 0.0f;
     for (int i = 0; i < n; ++i) acc += fast_tanh(cjs[i] * sc + bc);
@@ -179,8 +264,17 @@ __device__ __forceinline__ void coeff_bwd_body(
 }
 
 
-__host__ __device__ inline int coeff_fwd_stage(int N) { return N * N <= kCoeffLdsTileMax ? 1 : 0; }
-__host__ __device__ inline int coeff_fwd_lds_floats(int N) { return 2 * N + 4 * 64 + (coeff_fwd_stage(N) ? N * N : 0); }
+// staging mode of a block's attention rows as a ROLE (48 KB tile budget): 1 = N <= 64 (64 x 4 thread layout), 2 = larger
+// graphs (float4 column groups x row slices, pitch N rounded up to 4), 0 = not staged.  The stand-alone launch
+// (feta_coeff_fwd) stages up to a CU's LDS with the same arithmetic per mode.
+__host__ __device__ inline int coeff_fwd_stage(int N) {
+  if (N <= 64) return 1;
+  return N * ((N + 3) & ~3) <= kCoeffLdsTileMax ? 2 : 0;
+}
+__host__ __device__ inline int coeff_fwd_lds_floats_mode(int N, int stage) {
+  return 2 * N + (stage == 2 ? 1024 + N * ((N + 3) & ~3) : 4 * 64 + (stage == 1 ? N * N : 0));
+}
+__host__ __device__ inline int coeff_fwd_lds_floats(int N) { return coeff_fwd_lds_floats_mode(N, coeff_fwd_stage(N)); }
 
 // plain argument blocks of the two roles (device pointers)
 struct CoeffFwdRole {

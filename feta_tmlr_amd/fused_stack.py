@@ -37,6 +37,9 @@ PER_LAYER = 12  # tensors per layer in the flat parameter list
 # FETA_ATTN_BLOCK=0 keeps the three-launch sequence (A/B timing, fallback for other shapes)
 USE_ATTN_BLOCK = os.environ.get('FETA_ATTN_BLOCK', '1') != '0'
 USE_FFN_FUSED = os.environ.get('FETA_FFN_FUSED', '1') != '0'
+# graphs beyond the one-launch block (64 < N <= 256, config 4): attention core + out_proj + degree + residual + statistics
+# as one launch behind the in_proj launch (csrc/attnout.hip); 0: feta_attn_fwd -> feta_rowlin_fwd_ex
+USE_ATTN_OUT = os.environ.get('FETA_ATTN_OUT', '1') != '0'
 # backward of the FFN half (linear2 + linear1) in one launch (csrc/ffn_bwd.hip); 0: two feta_rowlin_bwd_ex launches
 USE_FFN_BWD = os.environ.get('FETA_FFN_BWD', '1') != '0'
 # backward of the attention sub-block (out_proj + attention + in_proj) in one launch per layer (csrc/block_bwd.hip,
@@ -244,18 +247,27 @@ class FusedEncoderStackFn(torch.autograd.Function):
                 # F1
                 dsc = abi.rowlin_ex(m, d, 3 * d, x=y_prev if li else x_in, w=w_in, bias=b_in, y=qkv, **bn_prev)
                 abi.rowlin_fwd_ex(dsc, stream)
-                # F2
-                q, k, v = _views(qkv, n, b, heads, dh)
-                if tie:
-                    k = q
-                abi.attn_fwd(q, k, v, pe_c, n_real, out.permute(1, 0, 2, 3), attn, ast, scale, stream)
-                # F3
-                G1 = G
-                st1 = new(G1 + 1, 2, d)
-                dsc = abi.rowlin_ex(m, d, d, x=out.view(m, d), w=w_o, bias=b_o, rowscale=degree_rows,
-                                    residual=y_prev, res_bn=prm_prev, y=y1, stats=st1,
-                                    stats_shift=layer.norm1.running_mean)
-                abi.rowlin_fwd_ex(dsc, stream)
+                if USE_ATTN_OUT and not lowp and abi.attn_out_supported(n, d, heads):
+                    # F2 + F3 in one launch, one workgroup per (graph, 32 query rows) (csrc/attnout.hip)
+                    G1 = abi.attn_out_stat_rows(b, n)
+                    st1 = new(G1 + 1, 2, d)
+                    abi.attn_out_fwd(b, n, scale, stream, tie_qk=tie, x=y_prev if li else x_in, x_bn=prm_prev, w_out=w_o,
+                                     b_out=b_o, pe=pe_c, n_real=n_real, rowscale=degree_rows, qkv=qkv, out=out,
+                                     attn_stats=ast, attn=attn, y=y1, y_stats=st1, y_shift=layer.norm1.running_mean)
+                    st1, G1 = _cap_partials(abi, stream, st1, new, shift_row=True)
+                else:
+                    # F2
+                    q, k, v = _views(qkv, n, b, heads, dh)
+                    if tie:
+                        k = q
+                    abi.attn_fwd(q, k, v, pe_c, n_real, out.permute(1, 0, 2, 3), attn, ast, scale, stream)
+                    # F3
+                    G1 = G
+                    st1 = new(G1 + 1, 2, d)
+                    dsc = abi.rowlin_ex(m, d, d, x=out.view(m, d), w=w_o, bias=b_o, rowscale=degree_rows,
+                                        residual=y_prev, res_bn=prm_prev, y=y1, stats=st1,
+                                        stats_shift=layer.norm1.running_mean)
+                    abi.rowlin_fwd_ex(dsc, stream)
             h, prm1 = newt(m, ff), new(4, d)
             n1 = layer.norm1
             bn1 = dict(x_stats=st1, Gx=G1, x_gamma=g1, x_beta=be1, x_bn_out=prm1, x_rmean=n1.running_mean,
@@ -523,13 +535,17 @@ class FusedLayerNormStackFn(torch.autograd.Function):
             else:
                 dsc = abi.rowlin_ex(m, d, 3 * d, x=x_in, w=w_in, bias=b_in, y=qkv)
                 abi.rowlin_fwd_ex(dsc, stream)
-                q, k, v = _views(qkv, n, b, heads, dh)
-                if tie:
-                    k = q
-                abi.attn_fwd(q, k, v, pe_c, n_real, out.permute(1, 0, 2, 3), attn, ast, scale, stream)
-                dsc = abi.rowlin_ex(m, d, d, x=out.view(m, d), w=w_o, bias=b_o, rowscale=degree_rows,
-                                    residual=x_in, y=y1)
-                abi.rowlin_fwd_ex(dsc, stream)
+                if USE_ATTN_OUT and not lowp and abi.attn_out_supported(n, d, heads):
+                    abi.attn_out_fwd(b, n, scale, stream, tie_qk=tie, x=x_in, w_out=w_o, b_out=b_o, pe=pe_c, n_real=n_real,
+                                     rowscale=degree_rows, qkv=qkv, out=out, attn_stats=ast, attn=attn, y=y1)
+                else:
+                    q, k, v = _views(qkv, n, b, heads, dh)
+                    if tie:
+                        k = q
+                    abi.attn_fwd(q, k, v, pe_c, n_real, out.permute(1, 0, 2, 3), attn, ast, scale, stream)
+                    dsc = abi.rowlin_ex(m, d, d, x=out.view(m, d), w=w_o, bias=b_o, rowscale=degree_rows,
+                                        residual=x_in, y=y1)
+                    abi.rowlin_fwd_ex(dsc, stream)
             x1, lst1 = newt(m, d), new(m, 2)
             abi.layernorm_fwd(y1, g1, be1, float(layer.norm1.eps), x1, lst1, stream)
             h, y2 = newt(m, ff), newt(m, d)

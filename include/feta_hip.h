@@ -460,6 +460,19 @@ int feta_attn_block_fwd(const feta_attn_block* d, feta_stream_t stream);
  * parameters alone. */
 int feta_attn_block_fwd_sums(const feta_attn_block* d, const feta_colsum_seg* segs, int nseg, feta_stream_t stream);
 
+/* ---- attention core + out_proj behind the in_proj launch, for graphs beyond feta_attn_block (ABI 8) -------------
+ * (feta_attn_out_supported: d_model = 64, 4 heads, N <= 256.)  Replaces feta_attn_fwd -> feta_rowlin_fwd_ex
+ * (out_proj + degree + residual + BatchNorm statistics) of DiffTransformerEncoderLayer.forward for config 4 (PATTERN,
+ * experiments/run_transformer_gengcn_SBM_cv.py; contract transformer/models.py:166-167,179,244): one workgroup per
+ * (graph, 32 query rows), the per-head outputs meet in LDS and are the out_proj operand.  Same descriptor as
+ * feta_attn_block, read as follows: qkv [M,192] is an INPUT (the in_proj result), x is the residual (seen through the
+ * published parameter block x_bn when given; x_stats must be NULL - the in_proj launch finalized them), w_in / b_in are
+ * ignored; outputs out, out_f32, attn_stats, attn, y as there; y_stats (nullable) [G + 1][2][64] with
+ * G = feta_attn_out_stat_rows(B, N) = B * ceil(N / 32) partial rows and the shift row behind them. */
+int feta_attn_out_supported(int N, int d_model, int heads);
+int feta_attn_out_stat_rows(int B, int N);
+int feta_attn_out_fwd(const feta_attn_block* d, feta_stream_t stream);
+
 /* ---- backward of the attention sub-block in ONE launch ------------------------------------------------------
  * (feta_attn_block_bwd_supported: d_model = 64, 4 heads, N <= 64; K not tied to Q.)  Replaces
  * feta_rowlin_bwd_ex (out_proj) -> feta_attn_bwd -> feta_rowlin_bwd_ex (in_proj) of the layer's backward:

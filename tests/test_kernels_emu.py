@@ -58,7 +58,7 @@ def test_attn_clamped_rows(emu):
     KC.check_attn(emu, CPU, None, 2, 19, 4, 16, True, clamp_case=True)
 
 
-@pytest.mark.parametrize('bsz,n,h,c', [(3, 12, 2, 64), (2, 37, 4, 256), (1, 5, 1, 16), (2, 100, 2, 64), (1, 64, 4, 32)])
+@pytest.mark.parametrize('bsz,n,h,c', [(3, 12, 2, 64), (2, 37, 4, 256), (1, 5, 1, 16), (2, 100, 2, 64), (1, 64, 4, 32), (2, 128, 4, 1024), (1, 190, 2, 1100)])
 def test_coeff(emu, bsz, n, h, c):
     KC.check_coeff(emu, CPU, None, bsz, n, h, c)
 

@@ -41,7 +41,8 @@ def test_attn_clamped_rows(hip):
 
 @pytest.mark.parametrize('bsz,n,h,c,faithful', [(3, 12, 2, 64, True), (2, 37, 4, 256, True),
                                                 (1, 5, 1, 16, True), (16, 37, 4, 1024, False),
-                                                (2, 200, 4, 1024, False)])
+                                                (2, 200, 4, 1024, False), (64, 128, 4, 1024, False),
+                                                (3, 190, 2, 1100, False)])
 def test_coeff(hip, bsz, n, h, c, faithful):
     abi, dev, stream = hip
     KC.check_coeff(abi, dev, stream, bsz, n, h, c, faithful=faithful)

@@ -424,6 +424,45 @@ def test_attn_block_equals_three_launches(emu, monkeypatch, shape, n_min, n_max,
                                            n_min, n_max, tie_qk, pe_on, split=split)
 
 
+def check_attn_out_equals_two_launches(dev, hook, monkeypatch, shape, n_min, n_max, batch_norm, tie_qk=False, pe_on=True,
+                                       bsz=2, layers=2, use_block=True):
+    """attention core + out_proj + degree + residual + statistics as one launch behind in_proj (csrc/attnout.hip,
+    N <= 256) == feta_attn_fwd -> feta_rowlin_fwd_ex, through the whole model (BatchNorm and LayerNorm stacks)"""
+    from feta_tmlr_amd import fused_stack
+    torch.manual_seed(11)
+    model = DiffGraphTransformerGenGCN(9, 1, 64, 4, dim_feedforward=128, dropout=0.0, nb_layers=layers,
+                                       batch_norm=batch_norm, filter_order=2, heads_share_graph=True,
+                                       filter_mode='spectral', tie_qk=tie_qk)
+    with torch.no_grad():
+        for l in model.encoder.layers:
+            l.self_attn.out_proj.bias.normal_(0, 0.1)
+    ds = D.SyntheticGraphDataset(shape, bsz, in_dim=9, seed=4, pos_enc=pe_on, n_min=n_min, n_max=n_max)
+    n_pad = max(g.num_nodes for g in ds.samples)
+    batch9, cache = D.collate(ds.samples, k_eig=min(n_pad, 32), device=dev)
+    model = model.to(dev)
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(fused_stack, 'USE_ATTN_OUT', on)
+        res.append(_stack_run(model, batch9, cache, use_block, monkeypatch, hook))
+    a, b = res
+    KC.assert_close('output', a[0], b[0].double(), tol=2e-6)
+    KC.assert_close('coefficients', a[1], b[1].double(), tol=2e-6)
+    KC.assert_close('dx', a[2], b[2].double(), tol=1e-5)
+    assert a[3].keys() == b[3].keys()
+    for k in a[3]:
+        KC.assert_close('grad ' + k, a[3][k], b[3][k].double(), tol=1e-5)
+
+
+@pytest.mark.parametrize('shape,n_min,n_max,batch_norm,tie_qk,pe_on', [
+    ('pattern', 70, 120, True, False, True),      # 8 key tiles, BatchNorm stack (statistics rows per chunk)
+    ('pattern', 65, 117, False, False, True),     # odd N_pad, LayerNorm stack
+    ('pattern', 100, 188, True, True, False),     # 12 key tiles, K tied to Q, no positional kernel
+])
+def test_attn_out_equals_two_launches(emu, monkeypatch, shape, n_min, n_max, batch_norm, tie_qk, pe_on):
+    check_attn_out_equals_two_launches(CPU, lambda: _lib.override_for_tests(emu), monkeypatch, shape, n_min, n_max,
+                                       batch_norm, tie_qk, pe_on)
+
+
 # forms of the forward launch (csrc/block.hip, block_fwd_form): FETA_BLOCK_FWD_WAVES / FETA_BLOCK_FWD_WGS / FETA_BLOCK_MAX_GRID
 FWD_FORMS = {
     'four waves': dict(FETA_BLOCK_FWD_WAVES='4'),

@@ -70,6 +70,20 @@ def test_attn_block_equals_three_launches(monkeypatch, shape, n_min, n_max, tie_
                                            n_min, n_max, tie_qk, pe_on, bsz=bsz, split=split)
 
 
+@pytest.mark.parametrize('shape,n_min,n_max,batch_norm,tie_qk,pe_on,bsz', [
+    ('pattern', 70, 120, True, False, True, 64),
+    ('pattern', 65, 117, False, False, True, 9),
+    ('pattern', 100, 188, True, True, False, 16),
+    ('pattern', 200, 256, True, False, True, 3),
+    ('zinc', 9, 37, True, False, True, 5),         # (N <= 64 is the block kernel's shape; this one takes any N)
+])
+def test_attn_out_equals_two_launches(monkeypatch, shape, n_min, n_max, batch_norm, tie_qk, pe_on, bsz):
+    import contextlib
+    from test_modules_emu import check_attn_out_equals_two_launches
+    check_attn_out_equals_two_launches(torch.device('cuda:0'), contextlib.nullcontext, monkeypatch, shape, n_min, n_max,
+                                       batch_norm, tie_qk, pe_on, bsz=bsz, use_block=shape != 'zinc')
+
+
 @pytest.mark.parametrize('form', ['four waves', 'eight waves, one workgroup per graph', 'eight waves, two workgroups per graph',
                                   'two workgroups per graph walking the batch', 'one workgroup walking the batch'])
 @pytest.mark.parametrize('shape,n_min,n_max,pe_on,bsz', [('zinc', 9, 37, True, 128), ('pattern', 44, 64, False, 9),
