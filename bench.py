@@ -429,6 +429,16 @@ def roofline(args, gpu, dev, lowp=False):
         cand.append(('attn_bwd (dq + dkdv)', 'attn_bwd', L,
                      lambda: abi.attn_bwd(q, k, v, gpu['pe'], nr, out, dout, stats, delta, dq, dk, dv, sc, st),
                      4 * b * (3 * n * d + 2 * n * d + n * n + 2 * h * n + 3 * n * d + h * n)))
+    if not abi.attn_block_supported(n, d, h) and abi.attn_out_supported(n, d, h) and not lowp:
+        # graphs beyond the one-launch block (config 4): attention core + out_proj + residual + statistics behind in_proj
+        xo, wo_, bo_ = rnd(n * b, d), rnd(d, d) / d ** 0.5, rnd(d)
+        oo, yo = torch.empty(n * b, d, device=dev), torch.empty(n * b, d, device=dev)
+        sto = torch.empty(abi.attn_out_stat_rows(b, n) + 1, 2, d, device=dev)
+        deg_o = torch.rand(n * b, device=dev)
+        cand.append(('attn_out_fwd', 'attn_out_fwd', L,
+                     lambda: abi.attn_out_fwd(b, n, sc, st, x=xo, w_out=wo_, b_out=bo_, pe=gpu['pe'], n_real=nr,
+                                              rowscale=deg_o, qkv=qkv, out=oo, attn_stats=stats, attn=None, y=yo, y_stats=sto),
+                     4 * b * (3 * n * d + n * n + n * d + 2 * n * d + 2 * h * n) + 4 * d * d))
     if args.filter_mode == 'spectral' and not args.no_share_graph:
         xs, dys = rnd(n, b, h, dh).permute(1, 0, 2, 3), rnd(n, b, h, dh).permute(1, 0, 2, 3)
         ys, dxs = tok(), tok()
@@ -653,6 +663,34 @@ def main(argv=None):
                                      'ms_per_step': round(dt2 / args.steps * 1e3, 4),
                                      'what': 'python bench.py --two-phase: the backward --gpus N > 1 runs (head '
                                              'gradients first, their all-reduce under the stack backward), on one GPU'}
+
+    # BASELINE configs 4 and 5 as further objects of the same line (parity-test shapes, not the metric): PATTERN
+    # (B = 64, N_pad = 128, K = 32; experiments/run_transformer_gengcn_SBM_cv.py) and the molhiv bucket (B = 1024,
+    # N_pad = 64, bf16 storage), each timed like the headline leg and with the roofline object of its own dominant kernel
+    if (world == 1 and not args.dry_cpu and args.dtype == 'f32' and not args.no_literal and args.shape == 'zinc'
+            and args.batch == 128):
+        import copy
+        extra['extra_configs'] = []
+        for name, kw in (('config 4: PATTERN-shaped, B=64, N_pad=128, K=32, fp32',
+                          dict(shape='pattern', batch=64, n_pad=128, k_eig=32, dtype='f32')),
+                         ('config 5: molhiv-shaped, B=1024, N_pad=64 bucket, K=16, bf16 storage',
+                          dict(shape='molhiv', batch=1024, n_pad=64, k_eig=16, dtype='bf16'))):
+            ax = copy.copy(args)
+            for k_, v_ in kw.items():
+                setattr(ax, k_, v_)
+            ax.steps, ax.warmup, ax.kernel_iters = min(args.steps, 30), min(args.warmup, 5), min(args.kernel_iters, 50)
+            _, gpux = make_batch(ax, rank, dev)
+            encx = build_encoder(ax).to(dev)
+            encx.train()
+            stepx, _, _ = make_step(ax, encx, gpux, world, dev)
+            dtx = time_steps(stepx, ax, world, dev)
+            log('%s: %.3f ms/step' % (name, dtx / ax.steps * 1e3))
+            extra['extra_configs'].append({
+                'config': name, 'value': round(ax.batch * ax.steps / dtx, 2), 'unit': 'graphs/s',
+                'ms_per_step': round(dtx / ax.steps * 1e3, 4), 'steps': ax.steps, 'dtype': ax.dtype,
+                'flags': '--shape %s --batch %d --n-pad %d --k-eig %d --dtype %s' % (ax.shape, ax.batch, ax.n_pad, ax.k_eig, ax.dtype),
+                'roofline': roofline(ax, gpux, dev, lowp=ax.dtype == 'bf16')})
+            del gpux, encx, stepx
 
     literal = None
     if (not args.no_literal and not args.dry_cpu and args.dtype == 'f32'

@@ -54,7 +54,10 @@ def stack_layer_cases(abi, st, dev, b, n, d, heads, ff, pe, n_real, last_layer_a
     if abi.ffn_supported(d, ff):
         x, w1, b1, w2, b2 = rndt(m, d), rnd(ff, d) / d ** 0.5, rnd(ff), rnd(d, ff) / ff ** 0.5, rnd(d)
         hbuf, y2, st2 = newt(m, ff), newt(m, d), new(abi.ffn_blocks(m) + 1, 2, d)
-        g1 = min(b, 256)      # the stack caps the partial rows a consumer re-reduces (fused_stack.MAX_STAT_ROWS)
+        # partial rows of the statistics this launch finalizes = workgroups of the forward block in front of it (two per
+        # graph at the BASELINE batch); the stack caps them (fused_stack.MAX_STAT_ROWS)
+        g1 = abi.attn_block_stat_rows(b, n) if abi.attn_block_supported(n, d, heads) else b
+        g1 = g1 if g1 <= 384 else 1
         stats1 = rnd(g1 + 1, 2, d).abs()
         fkw = dict(x=x, w1=w1, b1=b1, w2=w2, b2=b2, h=hbuf, y=y2, y_stats=st2, x_stats=stats1,
                    x_gamma=prm_of(d)[0], x_beta=prm_of(d)[1], x_bn_out=new(4, d))
@@ -118,8 +121,11 @@ def stack_layer_cases(abi, st, dev, b, n, d, heads, ff, pe, n_real, last_layer_a
                       ['ffn_bwd']))
         if fused_a:
             # ... below a layer whose attention backward ran as two workgroups per graph: the gradient in two parts
-            kw2 = dict(kw, dy_b=rndt(m, d))
-            fdsc2 = abi.ffn_bwd_desc(m, ff, Gs=G, partial_ld=cols, partial_ptr=part.data_ptr(), **kw2)
+            # (its BatchNorm sums come from that launch: two partial rows per graph)
+            gs2 = 2 * abi.attn_block_bwd_blocks(b)
+            gs2 = gs2 if gs2 <= 384 else 1
+            kw2 = dict(kw, dy_b=rndt(m, d), g_sum=rnd(gs2, 2, d))
+            fdsc2 = abi.ffn_bwd_desc(m, ff, Gs=gs2, partial_ld=cols, partial_ptr=part.data_ptr(), **kw2)
             keep_f2 = (kw2, part)
             cases.append(('ffn_bwd (gradient in two parts)', 1.0, lambda: (abi.ffn_bwd_launch(fdsc2, st), keep_f2)[0],
                           ft * (5 * m * d + m * ff) + f4 * (2 * d * ff + RC * cols), ['ffn_bwd']))

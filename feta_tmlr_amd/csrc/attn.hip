@@ -962,6 +962,193 @@ void launch_bwd_graph_t(const AttnArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3(a.B), dim3(512), lds, stream, a);
 }
 
+// ---- backward, one workgroup per (graph, head): 4 heads x dh 16, 64 < N <= 128 (config 4, PATTERN) -----------------
+// The per-(head, tile) kernels above issue 10 (dq) / 26 (dk, dv) gather instructions per tile pair and lane, every one
+// of them 64 scattered 4-byte accesses: at N = 128 they are bound by the address unit (16 + 18 us per layer; prefetching
+// further ahead or batching all loads changed nothing).  Here the head's q, k, v, dout (+ dout2), out slices (64-byte
+// rows, pitch 20 floats), the graph's pe block and the statistics are staged ONCE with 16-byte requests; waves 0-3 take the
+// query tiles (dq), waves 4-7 the key tiles (dk, dv), every operand - row layout or column gather - comes from LDS
+// (conflict-free pitches), and the tile loops are plain runtime loops (nothing is held across tiles but the accumulators).
+constexpr int kHbP = 16 + 4;   // pitch of a staged 16-float head row
+
+__host__ __device__ inline int attn_bwd_head_lds_floats(int nt) {
+  const int nr = 16 * nt;
+  return 5 * nr * kHbP + nr * (nr + 4) + 3 * nr;
+}
+
+template <int NT>
+__global__ __launch_bounds__(512) void attn_bwd_head_kernel(AttnArgs a) {
+  constexpr int DH = 16, H = 4, P = kHbP, NR = 16 * NT, PEP = NR + 4;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lq = lane & 15, g = lane >> 4;
+  const int w4 = wv & 3, role = wv >> 2;
+  const int b = (int)blockIdx.x / H, h = (int)blockIdx.x % H, bh = blockIdx.x;
+  const int n = a.n_real[b];
+  const int KT = (n + 15) >> 4, NB = a.NB;
+  float* Qs = feta_lds;        // [NR][P]
+  float* Ks = Qs + NR * P;
+  float* Vs = Ks + NR * P;
+  float* Ds = Vs + NR * P;     // dout (+ dout2)
+  float* Os = Ds + NR * P;     // out
+  float* PE = Os + NR * P;     // [NR][PEP]
+  float* ST = PE + NR * PEP;   // [NR][2]
+  float* DL = ST + 2 * NR;     // [NR] delta
+  const bool has_pe = a.pe != nullptr;
+  const int nm1 = a.N - 1;
+
+  constexpr int RI = (NR * 4 + 511) / 512;
+  float4 qv[RI], kv[RI], vv[RI], dv_[RI], ov[RI];
+#pragma unroll
+  for (int i = 0; i < RI; ++i) {
+    const int idx = min(tid + 512 * i, NR * 4 - 1), node = min(idx >> 2, nm1), c4 = 4 * (idx & 3);
+    qv[i] = *reinterpret_cast<const float4*>(tok_row(a.q, a.qsb, a.qsn, b, node, h, DH) + c4);
+    kv[i] = *reinterpret_cast<const float4*>(tok_row(a.k, a.qsb, a.qsn, b, node, h, DH) + c4);
+    vv[i] = *reinterpret_cast<const float4*>(tok_row(a.v, a.qsb, a.qsn, b, node, h, DH) + c4);
+    ov[i] = *reinterpret_cast<const float4*>(tok_row(a.out, a.osb, a.osn, b, node, h, DH) + c4);
+    float4 d1 = *reinterpret_cast<const float4*>(tok_row(a.dout, a.osb, a.osn, b, node, h, DH) + c4);
+    if (a.dout2 != nullptr) {
+      const float4 d2 = *reinterpret_cast<const float4*>(tok_row(a.dout2, a.osb, a.osn, b, node, h, DH) + c4);
+      d1 = make_float4(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z, d1.w + d2.w);
+    }
+    dv_[i] = d1;
+  }
+  float sv = 0.0f;
+  if (tid < 2 * NR) sv = a.stats_in[((int64_t)bh * a.N + min(tid >> 1, nm1)) * 2 + (tid & 1)];
+  // the graph's pe block: N x N contiguous elements, 16 requests in flight per thread
+  const int nn = a.N * a.N;
+  const float rn = 1.0f / (float)a.N;
+  for (int base = tid; base < nn; base += 16 * 512) {
+    float pv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) pv[u] = has_pe ? a.pe[(int64_t)b * nn + min(base + 512 * u, nn - 1)] : 1.0f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = base + 512 * u;
+      const int qq = (int)(((float)idx + 0.5f) * rn), kk = idx - qq * a.N;   // (idx + 1/2) / N: never near an integer
+      if (idx < nn) PE[qq * PEP + kk] = pv[u];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < RI; ++i) {
+    const int idx = tid + 512 * i;
+    if (idx < NR * 4) {
+      const int off = (idx >> 2) * P + 4 * (idx & 3);   // rows >= N: copies of row N-1 (finite; masked below)
+      *reinterpret_cast<float4*>(Qs + off) = qv[i];
+      *reinterpret_cast<float4*>(Ks + off) = kv[i];
+      *reinterpret_cast<float4*>(Vs + off) = vv[i];
+      *reinterpret_cast<float4*>(Ds + off) = dv_[i];
+      *reinterpret_cast<float4*>(Os + off) = ov[i];
+    }
+  }
+  if (tid < 2 * NR) ST[tid] = sv;
+  lds_barrier();
+  if (tid < NR) {   // delta[q] = dout[q] . out[q]
+    float d = 0.0f;
+#pragma unroll
+    for (int c4 = 0; c4 < DH; c4 += 4) {
+      const float4 x = *reinterpret_cast<const float4*>(Ds + tid * P + c4), y = *reinterpret_cast<const float4*>(Os + tid * P + c4);
+      d += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    }
+    DL[tid] = d;
+    if (tid < a.N) a.delta[(int64_t)bh * a.N + tid] = d;
+  }
+  lds_barrier();
+
+  if (role == 0) {
+    // dq of query tiles w4, w4 + 4: S^T orientation (key 4g+r, query lq)
+    for (int qb = w4; qb < NB; qb += 4) {
+      const int q = 16 * qb + lq;
+      const bool qok = q < a.N;
+      Feat<DH> qf, dof;
+      load_row<DH>(qf, Qs + q * P, g, a.scale);
+      load_row<DH>(dof, Ds + q * P, g);
+      const float m = ST[2 * q], z = ST[2 * q + 1];
+      const float rinv = 1.0f / fmaxf(z, 1e-6f);
+      const float delta = z < 1e-6f ? 0.0f : DL[q];   // clamp active: the normaliser is a constant
+      f32x4 dq = zero4();
+      for (int kt = 0; kt < KT; ++kt) {
+        Feat<DH> kf, vf;
+        load_row<DH>(kf, Ks + (16 * kt + lq) * P, g);
+        load_row<DH>(vf, Vs + (16 * kt + lq) * P, g);
+        const f32x4 s = dot_rows<DH>(kf, qf, zero4());
+        const f32x4 da = dot_rows<DH>(vf, dof, zero4());
+        const float4 pe4 = *reinterpret_cast<const float4*>(PE + min(q, nm1) * PEP + 16 * kt + 4 * g);
+        const float pv[4] = {pe4.x, pe4.y, pe4.z, pe4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = 16 * kt + 4 * g + r;
+          const float p = (key < n && qok) ? fast_exp(s[r] - m) * pv[r] * rinv : 0.0f;
+          dq = mfma16(p * (da[r] - delta), Ks[key * P + lq], dq);   // (query 4g+r, c lq)
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qq = 16 * qb + 4 * g + r;
+        if (qq < a.N) tok_row(a.dq, a.qsb, a.qsn, b, qq, h, DH)[lq] = dq[r] * a.scale;
+      }
+    }
+  } else {
+    // dk, dv of key tiles w4, w4 + 4: S orientation (query 4g+r, key lq)
+    for (int kb = w4; kb < NB; kb += 4) {
+      const int key = 16 * kb + lq;
+      const bool kok = key < n;
+      f32x4 dk = zero4(), dv = zero4();
+      if (16 * kb < n) {
+        Feat<DH> kf, vf;
+        load_row<DH>(kf, Ks + key * P, g);
+        load_row<DH>(vf, Vs + key * P, g);
+        for (int qb = 0; qb < NB; ++qb) {
+          Feat<DH> qf, dof;
+          load_row<DH>(qf, Qs + (16 * qb + lq) * P, g, a.scale);
+          load_row<DH>(dof, Ds + (16 * qb + lq) * P, g);
+          const f32x4 s = dot_rows<DH>(qf, kf, zero4());
+          const f32x4 da = dot_rows<DH>(dof, vf, zero4());
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int qq = 16 * qb + 4 * g + r;
+            const float m = ST[2 * qq], z = ST[2 * qq + 1];
+            const bool ok = qq < a.N && kok;
+            const float p = ok ? fast_exp(s[r] - m) * PE[min(qq, nm1) * PEP + min(key, nm1)] * (1.0f / fmaxf(z, 1e-6f)) : 0.0f;
+            const float ds = p * (da[r] - (z < 1e-6f ? 0.0f : DL[qq]));
+            dv = mfma16(p, Ds[qq * P + lq], dv);              // (key 4g+r, c lq)
+            dk = mfma16(ds, Qs[qq * P + lq] * a.scale, dk);
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kk = 16 * kb + 4 * g + r;
+        if (kk < a.N) {
+          tok_row(a.dk, a.qsb, a.qsn, b, kk, h, DH)[lq] = dk[r];
+          tok_row(a.dv, a.qsb, a.qsn, b, kk, h, DH)[lq] = dv[r];
+        }
+      }
+    }
+  }
+}
+
+template <int NT>
+void launch_bwd_head_t(const AttnArgs& a, hipStream_t stream) {
+  const size_t lds = sizeof(float) * attn_bwd_head_lds_floats(NT);
+  auto kern = attn_bwd_head_kernel<NT>;
+  static LdsSeen lds_seen;
+  allow_dynamic_lds(kern, lds, lds_seen);
+  hipLaunchKernelGGL(kern, dim3(a.B * a.H), dim3(512), lds, stream, a);
+}
+
+// -> true if the one-workgroup-per-(graph, head) backward was launched (4 heads x dh 16, 64 < N <= 128)
+bool try_bwd_head(const AttnArgs& a, int dh, hipStream_t stream) {
+  if (a.H != 4 || dh != 16 || a.N <= 64 || a.N > 128) return false;
+  if (const char* e = getenv("FETA_ATTN_BWD_HEAD"))
+    if (e[0] == '0') return false;
+  switch (a.NB) {
+    case 5: launch_bwd_head_t<5>(a, stream); break;
+    case 6: launch_bwd_head_t<6>(a, stream); break;
+    case 7: launch_bwd_head_t<7>(a, stream); break;
+    default: launch_bwd_head_t<8>(a, stream); break;
+  }
+  return true;
+}
+
 // -> true if the one-workgroup-per-graph backward was launched (4 heads x dh 16, N <= 64)
 bool try_bwd_graph(const AttnArgs& a, int dh, hipStream_t stream) {
   if (a.H != 4 || dh != 16 || a.N > 64) return false;
@@ -982,9 +1169,13 @@ bool try_bwd_graph(const AttnArgs& a, int dh, hipStream_t stream) {
 template <int DH>
 int launch_bwd(const AttnArgs& a, hipStream_t stream) {
   if (try_bwd_graph(a, DH, stream)) return check_launch("feta_attn_bwd");
+  if (try_bwd_head(a, DH, stream)) return check_launch("feta_attn_bwd");
   if constexpr (DH <= 16) {
     if (a.NB <= 3) { launch_bwd_dense_t<DH, 3>(a, stream); return check_launch("feta_attn_bwd"); }
     if (a.NB <= 4) { launch_bwd_dense_t<DH, 4>(a, stream); return check_launch("feta_attn_bwd"); }
+    // (measured, PATTERN B = 64, N = 128: the batched-load form with 8 key tiles - 256 + 78 registers, one wave per SIMD -
+    // 0.514 ms per step against 0.481 for the two pipelined kernels below; prefetching two tiles ahead in those: 0.489.
+    // Their 10 / 26 gather instructions per tile are bound by the address unit, not by one memory latency)
   }
   FETA_REQUIRE(a.dout2 == nullptr, "attn_bwd: dout2 is only supported for N <= 64, dh <= 16");
   const dim3 grid((a.total + kWaves - 1) / kWaves), block(64 * kWaves);

@@ -478,7 +478,7 @@ __host__ __device__ inline int block8_lds_bytes(int nt) {
   const int nr = 16 * nt, P = kBlkD + Lp<T>::PAD;
   int b = (int)sizeof(T) * (4 * kBlkD * P + 2 * nr * P);   // W_in, W_out, X tile, OUT tile
   int f = 2 * kBlkD + 128;                                 // scale / shift of the input BatchNorm; statistics hand-over
-  const int fin = reduce_scratch_floats(kBlkD), reg = 8 * block8_region_floats<T>(nt);
+  const int fin = reduce_scratch_floats(kBlkD, kBlk8Threads), reg = 8 * block8_region_floats<T>(nt);
   f += fin > reg ? fin : reg;
   f += nr * (nr + 4);                                      // pe tile
   const int role = 4 * colsum_role_lds_floats(kBlk8Threads);
@@ -530,8 +530,8 @@ __global__ __launch_bounds__(kBlk8Threads) void attn_block_fwd8_kernel(BlockArgs
   const bool x_norm = a.x_stats != nullptr || a.x_bn != nullptr;
   FETA_STAMP(0);
 
-  PartialBatch pb;
-  partials_request(a.x_stats != nullptr ? a.x_stats : a.w_in, a.x_stats != nullptr ? a.Gx : 0, D, pb);
+  PartialBatchT<16> pb;   // (all 512 threads: 16 slices x 16 rows = every partial row of the BASELINE batch in one batch)
+  partials_request_t<TH, 16>(a.x_stats != nullptr ? a.x_stats : a.w_in, a.x_stats != nullptr ? a.Gx : 0, D, pb);
   const bool has_pe = a.pe != nullptr;
   Vec xv[XI];
   float pel[PEI];
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(kBlk8Threads) void attn_block_fwd8_kernel(BlockArgs
   }
   FETA_STAMP(6);
   if (a.x_stats != nullptr) {
-    reduce_partials_finish(a.x_stats, a.Gx, D, pb, scr + 2 * D, scr);
+    reduce_partials_finish_t<TH, 16>(a.x_stats, a.Gx, D, pb, scr + 2 * D, scr);
     for (int c = tid; c < D; c += TH) {
       float mean, var;
       bn_moments_k(xk, D, a.M, scr, c, mean, var);   // (c == tid: the loop runs once for the first D threads)

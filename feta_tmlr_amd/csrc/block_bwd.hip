@@ -45,7 +45,7 @@ __host__ __device__ inline int block_bwd_lds_bytes(int nt, bool gbn) {
          + 4 * (nr * (nr + 1)           // pe
                 + kBbH * nr * 2 + nr    // softmax statistics, row scale
                 + 8 * kBbD + 8 * 2 * 16 // fp32 column sums of the bias gradients: db_out per wave, dq | dk | dv per wave
-                + (gbn ? 5 * kBbD + reduce_scratch_floats(kBbD) : 0));
+                + (gbn ? 5 * kBbD + reduce_scratch_floats(kBbD, 512) : 0));
 }
 
 #ifdef FETA_TIMING
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
     const int cpre = min(tid, D - 1);
     const float bn_scale = a.bn1[cpre], bn_mean = a.bn1[2 * D + cpre], bn_rstd = a.bn1[3 * D + cpre];
     if (a.g_sum != nullptr) {
-      reduce_partials(a.g_sum, a.Gs, D, scr + 2 * D, scr);
+      reduce_partials_t<kBbThreads, 16>(a.g_sum, a.Gs, D, scr + 2 * D, scr);   // (all 512 threads: 256 rows in ONE batch)
       for (int c = tid; c < D; c += kBbThreads) {
         gv[3 * D + c] = scr[c] / (float)a.M;
         gv[4 * D + c] = scr[D + c] / (float)a.M;

@@ -74,27 +74,37 @@ __device__ __forceinline__ void stage_float4(int count, Src src, Dst dst) {
 constexpr int kPartialUnroll = FETA_PARTIAL_UNROLL;   // 16-byte loads in flight per thread beyond the first batch
 constexpr int kPartialFirst = 16;
 
-struct PartialBatch {
-  float4 v[kPartialFirst];
+// THREADS: threads of the workgroup that take part (all of them call; the first slices * nq do the work); NF: rows per slice
+// requested in the FIRST batch.  Every partial row of the BASELINE batch must be in that batch - a row beyond it costs a
+// second (and third) dependent round trip in the middle of a prologue: round 3 measured + 1.7 us on ffn_fwd when its
+// producer began to emit 256 rows instead of 128 (two workgroups per graph), and the 148 rows of the feed-forward kernels
+// had always cost their 512-thread consumers a second trip for the last 20.  256 threads x NF = 32 and 512 threads x
+// NF = 16 both cover 256 rows.
+template <int NF>
+struct PartialBatchT {
+  float4 v[NF];
 };
+typedef PartialBatchT<kPartialFirst> PartialBatch;
 
-__device__ __forceinline__ void partials_request(const float* part, int G, int D, PartialBatch& pb) {
+template <int THREADS, int NF>
+__device__ __forceinline__ void partials_request_t(const float* part, int G, int D, PartialBatchT<NF>& pb) {
   const int nq = 2 * D / 4;
-  const int slices = kRowThreads / nq > 0 ? kRowThreads / nq : 1;
+  const int slices = THREADS / nq > 0 ? THREADS / nq : 1;
   const int q = threadIdx.x % nq, slice = threadIdx.x / nq;
   const float4* p4 = reinterpret_cast<const float4*>(part);
   const bool mine = (int)threadIdx.x < slices * nq;
 #pragma unroll
-  for (int u = 0; u < kPartialFirst; ++u) {
+  for (int u = 0; u < NF; ++u) {
     const int gr = slice + u * slices;
     pb.v[u] = p4[(int64_t)((mine && gr < G) ? gr : 0) * nq + (mine ? q : 0)];
   }
 }
 
-__device__ __forceinline__ void reduce_partials_finish(const float* part, int G, int D, const PartialBatch& pb,
-                                                       float* red, float* tot) {
+template <int THREADS, int NF>
+__device__ __forceinline__ void reduce_partials_finish_t(const float* part, int G, int D, const PartialBatchT<NF>& pb,
+                                                         float* red, float* tot) {
   const int nq = 2 * D / 4;
-  const int slices = kRowThreads / nq > 0 ? kRowThreads / nq : 1;
+  const int slices = THREADS / nq > 0 ? THREADS / nq : 1;
   const int q = threadIdx.x % nq, slice = threadIdx.x / nq;
   if ((int)threadIdx.x < slices * nq) {
     const float4* p4 = reinterpret_cast<const float4*>(part);
@@ -103,11 +113,11 @@ __device__ __forceinline__ void reduce_partials_finish(const float* part, int G,
 #pragma unroll
     for (int u = 0; u < 4; ++u) s[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
-    for (int u = 0; u < kPartialFirst; ++u) {
+    for (int u = 0; u < NF; ++u) {
       const float m = slice + u * slices < G ? 1.0f : 0.0f;
       s[u & 3].x += m * pb.v[u].x; s[u & 3].y += m * pb.v[u].y; s[u & 3].z += m * pb.v[u].z; s[u & 3].w += m * pb.v[u].w;
     }
-    int gi = slice + kPartialFirst * slices;
+    int gi = slice + NF * slices;
     for (; gi + (U - 1) * slices < G; gi += U * slices) {
       float4 v[U];
 #pragma unroll
@@ -137,7 +147,7 @@ __device__ __forceinline__ void reduce_partials_finish(const float* part, int G,
     r[3] = (s[0].w + s[1].w) + (s[2].w + s[3].w);
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < 2 * D; c += kRowThreads) {
+  for (int c = threadIdx.x; c < 2 * D; c += THREADS) {
     float t = 0.0f;
     for (int sl = 0; sl < slices; ++sl) t += red[sl * 2 * D + c];
     tot[c] = t;
@@ -145,10 +155,22 @@ __device__ __forceinline__ void reduce_partials_finish(const float* part, int G,
   __syncthreads();
 }
 
+template <int THREADS, int NF>
+__device__ __forceinline__ void reduce_partials_t(const float* part, int G, int D, float* red, float* tot) {
+  PartialBatchT<NF> pb;
+  partials_request_t<THREADS, NF>(part, G, D, pb);
+  reduce_partials_finish_t<THREADS, NF>(part, G, D, pb, red, tot);
+}
+
+__device__ __forceinline__ void partials_request(const float* part, int G, int D, PartialBatch& pb) {
+  partials_request_t<kRowThreads, kPartialFirst>(part, G, D, pb);
+}
+__device__ __forceinline__ void reduce_partials_finish(const float* part, int G, int D, const PartialBatch& pb,
+                                                       float* red, float* tot) {
+  reduce_partials_finish_t<kRowThreads, kPartialFirst>(part, G, D, pb, red, tot);
+}
 __device__ __forceinline__ void reduce_partials(const float* part, int G, int D, float* red, float* tot) {
-  PartialBatch pb;
-  partials_request(part, G, D, pb);
-  reduce_partials_finish(part, G, D, pb, red, tot);
+  reduce_partials_t<kRowThreads, kPartialFirst>(part, G, D, red, tot);
 }
 
 // BatchNorm partial statistics are SHIFTED sums (round 3): a producer accumulates sum (y - K) and sum (y - K)^2 per
@@ -177,13 +199,13 @@ __device__ __forceinline__ void bn_moments_k(float shift, int D, int M, const fl
   var = fmaxf(tot[D + c] / (float)M - m1 * m1, 0.0f);
 }
 
-__host__ __device__ inline int reduce_red_floats(int D) {
+__host__ __device__ inline int reduce_red_floats(int D, int threads = kRowThreads) {
   const int nq = 2 * D / 4;
-  const int slices = kRowThreads / nq > 0 ? kRowThreads / nq : 1;
+  const int slices = threads / nq > 0 ? threads / nq : 1;
   return slices * 2 * D;  // red[slices][2D]
 }
-__host__ __device__ inline int reduce_scratch_floats(int D) {
-  return 2 * D + reduce_red_floats(D);  // tot[2][D] + red
+__host__ __device__ inline int reduce_scratch_floats(int D, int threads = kRowThreads) {
+  return 2 * D + reduce_red_floats(D, threads);  // tot[2][D] + red
 }
 
 }  // namespace feta

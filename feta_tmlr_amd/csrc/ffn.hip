@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a, CoeffFw
     // (requesting the partial sums together with the weights was measured SLOWER, 18.0 k vs 15.0 k cycles:
     // every workgroup asks for the same rows at the same moment, and the in-order return of loads parks the
     // weights behind that hot spot)
-    reduce_partials(a.x_stats, a.Gx, D, scr + 2 * D, scr);
+    reduce_partials_t<kRowThreads, 32>(a.x_stats, a.Gx, D, scr + 2 * D, scr);   // (256 rows in ONE batch: feta_rowops.h)
     for (int c = tid; c < D; c += kRowThreads) {
       float mean, var;
       bn_moments_k(xk, D, a.M, scr, c, mean, var);   // (c == tid: the loop runs once for the first D threads)

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, Ffn
     const int cpre = min(tid, D - 1);
     const float bn_scale = a.g_bn[cpre], bn_mean = a.g_bn[2 * D + cpre], bn_rstd = a.g_bn[3 * D + cpre];
     if (a.g_sum != nullptr) {
-      reduce_partials(a.g_sum, a.Gs, D, scr + 2 * D, scr);
+      reduce_partials_t<kRowThreads, 32>(a.g_sum, a.Gs, D, scr + 2 * D, scr);   // (256 rows in ONE batch: feta_rowops.h)
       for (int c = tid; c < D; c += kRowThreads) {
         gv[3 * D + c] = scr[c] / (float)a.M;
         gv[4 * D + c] = scr[D + c] / (float)a.M;

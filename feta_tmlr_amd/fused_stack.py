@@ -119,7 +119,8 @@ def stack_supported(layers, d_model):
 # state_dict / deepcopy / pickle of a model must not see it)
 STACK_FLAT_GRAD = weakref.WeakKeyDictionary()
 
-MAX_STAT_ROWS = 256   # every consumer workgroup re-reduces the partial statistics: keep them few
+MAX_STAT_ROWS = 384   # every consumer workgroup re-reduces the partial statistics: keep them few (beyond this, one
+                      # reduction launch in front of the consumers: ~5 us against ~G x G x 512 bytes of L2 reads)
 
 
 def _cap_partials(abi, stream, st, new, shift_row=False):
@@ -131,9 +132,11 @@ def _cap_partials(abi, stream, st, new, shift_row=False):
     if g <= MAX_STAT_ROWS:
         return st, g
     tot = new(2 if shift_row else 1, 2, st.shape[2])
-    abi.colsum(st[:g].view(g, -1), tot[0].view(-1), stream)
     if shift_row:
-        tot[1].copy_(st[g])
+        # (the shift row travels as a one-row "sum" of the same launch: no copy launch)
+        abi.colsum_multi([(st[:g].view(g, -1), tot[0].view(-1)), (st[g].view(1, -1), tot[1].view(-1))], stream)
+    else:
+        abi.colsum(st[:g].view(g, -1), tot[0].view(-1), stream)
     return tot, 1
 
 
@@ -432,7 +435,7 @@ class FusedEncoderStackFn(torch.autograd.Function):
             abi.rowlin_bwd_ex(dsc, None, stream)
             dout2 = None
             if d2 is not None:
-                if abi.attn_bwd_takes_dout2(n, dh):   # added inside the kernel's loads
+                if abi.attn_bwd_takes_dout2(n, dh, heads=heads):   # added inside the kernel's loads
                     dout2 = d2.contiguous().view(n, b, heads, dh).permute(1, 0, 2, 3)
                 else:
                     dconcat = dconcat + d2.contiguous().view(m, d)
@@ -654,7 +657,7 @@ class FusedLayerNormStackFn(torch.autograd.Function):
             abi.rowlin_bwd_ex(dsc, None, stream)
             dout2 = None
             if d2 is not None:
-                if abi.attn_bwd_takes_dout2(n, dh):
+                if abi.attn_bwd_takes_dout2(n, dh, heads=heads):
                     dout2 = d2.contiguous().view(n, b, heads, dh).permute(1, 0, 2, 3)
                 else:
                     dconcat = dconcat + d2.contiguous().view(m, d)

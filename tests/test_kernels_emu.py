@@ -21,6 +21,8 @@ CPU = torch.device('cpu')
     (2, 33, 1, 32, True, False),
     (1, 70, 1, 64, True, True),
     (2, 9, 2, 4, False, True),
+    (2, 100, 4, 16, True, True),       # 64 < N <= 128, 4 heads x 16: one workgroup per (graph, head) in backward
+    (1, 65, 4, 16, False, False),
 ])
 def test_attn(emu, bsz, n, h, dh, use_pe, seq_first):
     KC.check_attn(emu, CPU, None, bsz, n, h, dh, use_pe, seq_first)

@@ -21,6 +21,9 @@ pytestmark = pytest.mark.gpu
     (128, 37, 4, 16, True, True),      # BASELINE config 2 (ZINC shape)
     (32, 28, 4, 16, True, True),       # config 1 (MUTAG shape)
     (8, 188, 4, 16, True, True),       # config 4 (PATTERN shape, N_pad 188)
+    (64, 128, 4, 16, True, True),      # config 4 at N_pad 128: one workgroup per (graph, head) in backward
+    (5, 117, 4, 16, True, False),      # ... odd N_pad, batch-first
+    (3, 65, 4, 16, False, True),       # ... five row tiles, no positional kernel
     (16, 222, 4, 16, False, True),     # config 5 (molhiv, largest bucket)
     (4, 256, 2, 32, True, True),       # FETA_MAX_NODES
 ])

@@ -112,15 +112,16 @@ def test_shard_indices_partition():
         assert got == list(range(37))
 
 
-def _build_bn(seed=0, batch_norm=True):
+def _build_bn(seed=0, batch_norm=True, filter_mode='cheb'):
     """d_model 64 / 4 heads: takes the fused stack, BatchNorm or LayerNorm (flat stack-gradient buffer)"""
     from feta_tmlr_amd.transformer.models import DiffGraphTransformerGenGCN
     torch.manual_seed(seed)
     return DiffGraphTransformerGenGCN(8, 1, 64, 4, dim_feedforward=128, dropout=0.0, nb_layers=2,
-                                      batch_norm=batch_norm, filter_order=2, heads_share_graph=True)
+                                      batch_norm=batch_norm, filter_order=2, heads_share_graph=True,
+                                      filter_mode=filter_mode)
 
 
-def _worker_inplace(rank, world, port, ret, batch_norm):
+def _worker_inplace(rank, world, port, ret, batch_norm, lowp=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import ctypes
@@ -133,14 +134,19 @@ def _worker_inplace(rank, world, port, ret, batch_norm):
     emu = _abi.bind(ctypes.CDLL(os.path.join(ROOT, 'tools', 'simt', 'libfeta_emu.so')))
     ds = D.SyntheticGraphDataset('mutag', 4, in_dim=64, seed=5, n_min=4, n_max=12)
     mine = [ds[i] for i in shard_indices(len(ds), rank, world)]
-    batch9, cache = D.collate(mine)
+    batch9, cache = D.collate(mine, k_eig=12) if lowp else D.collate(mine)
     x, mask, pe, _, degree, _, edge_index, batch, fi = batch9
     src = x.permute(1, 0, 2).contiguous()
     g = torch.Generator().manual_seed(100 + rank)
     dout = torch.randn(src.shape, generator=g)
+    if lowp:       # bf16 storage (BASELINE config 3): token rows and pe of the resident batch in the storage type
+        src, pe = src.to(torch.bfloat16), pe.to(torch.bfloat16)
     out = {}
     for mode in ('packed', 'inplace'):
-        enc = _build_bn(batch_norm=batch_norm).encoder
+        enc = _build_bn(batch_norm=batch_norm, filter_mode='spectral' if lowp else 'cheb').encoder
+        if lowp:
+            from feta_tmlr_amd.transformer.layers import set_storage_dtype
+            set_storage_dtype(enc, torch.bfloat16)
         enc.train()
         kw = dict(degree=degree, src_key_padding_mask=mask, graph_cache=cache)
         with _lib.override_for_tests(emu):
@@ -184,4 +190,17 @@ def test_inplace_reducers_equal_packed_bucket_world2(emu, batch_norm):
     for rank in (0, 1):
         packed, inplace = ret[rank]
         assert torch.allclose(packed, inplace, rtol=1e-6, atol=1e-7), float((packed - inplace).abs().max())
+    assert torch.allclose(ret[0][1], ret[1][1])
+
+
+def test_bf16_stack_split_backward_world2(emu):
+    """the bf16 storage stack (fused bf16 kernels, fp32 gradients) under the split backward of bench.py --gpus N:
+    in-place reducers == the packed bucket, identical on both ranks"""
+    port = 29500 + (os.getpid() % 400) + 23
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_inplace, args=(2, port, ret, True, True), nprocs=2, join=True)
+    for rank in (0, 1):
+        packed, inplace = ret[rank]
+        assert torch.allclose(packed, inplace, rtol=1e-5, atol=1e-6), float((packed - inplace).abs().max())
     assert torch.allclose(ret[0][1], ret[1][1])
