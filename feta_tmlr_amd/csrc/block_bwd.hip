@@ -159,7 +159,14 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
   // thread that wrote it: the row stays in the XCD's L2), the partial sums for the previous BatchNorm stay in registers
   const int nwg = (int)gridDim.x;
   int b = (int)blockIdx.x - hp * a.B;
+  const int lane0 = lane;
   do {
+    // LOOP form: everything a lane derives from its id (tile addresses, predicates, offsets) is invariant in the graph
+    // loop, and the compiler hoists all of it - hundreds of registers held across the attention phase (up to 676 B of
+    // scratch per lane).  The lane id is laundered once per graph, so those values are recomputed where they are used.
+    int lane_l = lane0;
+    if (LOOP) asm volatile("" : "+v"(lane_l));
+    const int lane = lane_l, tid = (wv << 6) | lane, lq = lane & 15, g = lane >> 4;
     const bool first = !LOOP || b < nwg;
     if (LOOP && !first) __syncthreads();   // the tiles of the previous graph have been consumed
     // The weight column slices below are loop-invariant loads: hoisted out of the graph loop they would be held across

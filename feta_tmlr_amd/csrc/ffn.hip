@@ -162,7 +162,13 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a, CoeffFw
   FFN_STAMP(2);
   const bool want_stats = a.y_stats != nullptr;
   float tot1[1] = {0.0f};   // thread tid < 128: one entry of the workgroup's [2][64] (sum, sum of squares)
+  const int lane0 = lane;
   for (int blk = blockIdx.x; blk < nblk; blk += main_grid) {
+  // (what a lane derives from its id is invariant in this loop and would be hoisted and held across the body; the id is
+  // laundered once per row block - csrc/block_bwd.hip)
+  int lane_l = lane0;
+  asm volatile("" : "+v"(lane_l));
+  const int lane = lane_l, tid = (wv << 6) | lane, lq = lane & 15, g = lane >> 4;
   if (blk != (int)blockIdx.x) {
     __syncthreads();   // exchange / reduction scratch of the previous row block consumed
     row = blk * kFfnRows + 16 * rt + lq;

@@ -235,7 +235,12 @@ __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, Ffn
     const int nblk = (a.M + kFbRows - 1) / kFbRows;
     const int row_last = a.M - 1;
     constexpr int NU = kFbRows * RV / kRowThreads;   // vectors of the gradient tile per thread
+    const int lane0 = lane;
     for (int blk = x_lo; blk < x_hi; blk += x_step) {
+      // (the lane id is laundered once per row block: csrc/block_bwd.hip)
+      int lane_l = lane0;
+      asm volatile("" : "+v"(lane_l));
+      const int lane = lane_l, tid = (w << 6) | lane, lq = lane & 15, g = lane >> 4;
       const int r0 = blk * kFbRows;
       if (blk != x_lo) __syncthreads();   // the tiles of the previous block have been consumed
       // requests of the block: gradient tile, relu operands, residual rows of the sums

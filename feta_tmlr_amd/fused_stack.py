@@ -48,11 +48,12 @@ USE_ATTN_BLOCK_BWD = os.environ.get('FETA_ATTN_BLOCK_BWD', '1') != '0'
 # two workgroups per graph (one per pair of heads) where the consumer of dx is the fused FFN backward, which adds the
 # two parts on load (feta_attn_block_grad.dx_b); 0: one workgroup per graph everywhere (A/B timing)
 USE_ATTN_BLOCK_SPLIT = os.environ.get('FETA_ATTN_BLOCK_SPLIT', '1') != '0'
-# more graphs than workgroups (B > 256): the fused attention-block backward walks several graphs per workgroup.  That
-# instantiation spills (the graph loop costs registers, csrc/block_bwd.hip) and measured SLOWER than the three-launch
-# form on fp32 (molhiv B = 1024, N_pad = 64: 533 k vs 649 k graphs/s), so fp32 stacks take it only on request; bf16
-# stacks always do (the three-launch kernels have no bf16 form)
-USE_ATTN_BLOCK_BWD_LOOP = os.environ.get('FETA_BLOCK_BWD_LOOP', '0') != '0'
+# more graphs than workgroups (B > 256): the fused attention-block backward walks several graphs per workgroup.  Until the
+# lane id was laundered once per graph (csrc/block_bwd.hip: everything a lane derives from its id is invariant in the
+# graph loop and was hoisted - up to 676 B of scratch per lane) that instantiation was slower than the three-launch form
+# on fp32 (molhiv B = 1024, N_pad = 64: 533 k vs 649 k graphs/s); spill-free it wins: 734 k vs 663 k fp32, 901 k (777 k)
+# bf16, ZINC B = 512 736 k vs 699 k.  0: three launches for fp32 stacks beyond 256 graphs (A/B timing)
+USE_ATTN_BLOCK_BWD_LOOP = os.environ.get('FETA_BLOCK_BWD_LOOP', '1') != '0'
 
 
 def _fused_attn_bwd(abi, b, n, d, heads, tie, dt):

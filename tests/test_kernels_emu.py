@@ -222,9 +222,10 @@ def test_attn_block_fwd_bf16(emu, kw):
     KC.check_attn_block_lp(emu, CPU, None, **kw)
 
 
-@pytest.mark.parametrize('env', [dict(FETA_BLOCK_FWD_WAVES='4'), dict(FETA_BLOCK_FWD_WGS='1'),
-                                 dict(FETA_BLOCK_FWD_WGS='2', FETA_BLOCK_MAX_GRID='2')])
-@pytest.mark.parametrize('kw', [dict(bsz=3, n_pad=37, n_min=9), dict(bsz=2, n_pad=64, n_min=40, with_pe=False)])
+@pytest.mark.parametrize('env,kw', [
+    (dict(FETA_BLOCK_FWD_WAVES='4'), dict(bsz=3, n_pad=37, n_min=9)),
+    (dict(FETA_BLOCK_FWD_WGS='1'), dict(bsz=2, n_pad=64, n_min=40, with_pe=False)),
+    (dict(FETA_BLOCK_FWD_WGS='2', FETA_BLOCK_MAX_GRID='2'), dict(bsz=3, n_pad=37, n_min=9))])
 def test_attn_block_fwd_bf16_forms(emu, monkeypatch, env, kw):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
