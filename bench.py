@@ -66,8 +66,8 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=200)     # (a step is 0.28 ms: 200 steps read the steady state, the first
+    ap.add_argument('--warmup', type=int, default=20)     # replays after a capture are ~1.5 % slower)
     ap.add_argument('--batch', type=int, default=128, help='graphs per GPU per step')
     ap.add_argument('--layers', type=int, default=3)
     ap.add_argument('--heads', type=int, default=4)
@@ -466,8 +466,12 @@ def roofline(args, gpu, dev, lowp=False):
                      4 * (3 * r_ * c + 2 * c * c + cat_part.numel())))
     # NOT measured in this run: committed products of separate rocprofv3 --pmc passes (tools/profile_round.sh), named in
     # the object so that nobody takes them for same-run counters
-    tfiles = ('r03_traffic_b128_bf16.json',) if lowp else ('r03_traffic_b128.json', 'r02_traffic_b128.json')
-    mfiles = ('r03_pmc_mfma_b128_bf16.json',) if lowp else ('r03_pmc_mfma_b128.json', 'r02_pmc_mfma_b128.json')
+    tfiles = (('r03_end_traffic_b128_bf16.json', 'r03_traffic_b128_bf16.json') if lowp else
+              ('r03_end_traffic_b128.json', 'r03_traffic_b128.json', 'r02_traffic_b128.json'))
+    mfiles = (('r03_end_pmc_mfma_b128_bf16.json', 'r03_pmc_mfma_b128_bf16.json') if lowp else
+              ('r03_end_pmc_mfma_b128.json', 'r03_pmc_mfma_b128.json', 'r02_pmc_mfma_b128.json'))
+    if b != 128 or n != 37:      # (the committed PMC passes are of the BASELINE batch: other shapes carry no counters)
+        tfiles = mfiles = ()
     traffic, traffic_src = _load_json(*tfiles)
     mfma, mfma_src = _load_json(*mfiles)
     groups = {}
@@ -678,7 +682,7 @@ def main(argv=None):
             ax = copy.copy(args)
             for k_, v_ in kw.items():
                 setattr(ax, k_, v_)
-            ax.steps, ax.warmup, ax.kernel_iters = min(args.steps, 30), min(args.warmup, 5), min(args.kernel_iters, 50)
+            ax.steps, ax.warmup, ax.kernel_iters = min(args.steps, 100), min(args.warmup, 10), min(args.kernel_iters, 50)
             _, gpux = make_batch(ax, rank, dev)
             encx = build_encoder(ax).to(dev)
             encx.train()

@@ -331,11 +331,11 @@ class Abi:
     @staticmethod
     def attn_bwd_takes_dout2(n, dh, dtype=torch.float32, heads=None):
         """a second gradient into out_each_head added inside the kernel's loads: the batched-load kernels (N <= 64,
-        dh <= 16) and the per-(graph, head) kernel (4 heads x 16, N <= 128)"""
+        dh <= 16) and the per-(graph, head) kernel (4 heads x 16, N <= 256)"""
         if dtype != torch.float32:
             return False
         head_kernel = os.environ.get('FETA_ATTN_BWD_HEAD', '1') != '0'     # (csrc/attn.hip: try_bwd_head)
-        return (n <= 64 and dh <= 16) or (head_kernel and n <= 128 and dh == 16 and heads == 4)
+        return (n <= 64 and dh <= 16) or (head_kernel and n <= 256 and dh == 16 and heads == 4)
 
     def attn_bwd(self, q, k, v, pe, n_real, out, dout, stats, delta, dq, dk, dv, scale, stream, dout2=None,
                  drop=None, clamp5=False):

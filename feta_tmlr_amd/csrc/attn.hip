@@ -962,7 +962,7 @@ void launch_bwd_graph_t(const AttnArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3(a.B), dim3(512), lds, stream, a);
 }
 
-// ---- backward, one workgroup per (graph, head): 4 heads x dh 16, 64 < N <= 128 (config 4, PATTERN) -----------------
+// ---- backward, one workgroup per (graph, head): 4 heads x dh 16, 64 < N <= 256 (config 4, PATTERN) -----------------
 // The per-(head, tile) kernels above issue 10 (dq) / 26 (dk, dv) gather instructions per tile pair and lane, every one
 // of them 64 scattered 4-byte accesses: at N = 128 they are bound by the address unit (16 + 18 us per layer; prefetching
 // further ahead or batching all loads changed nothing).  Here the head's q, k, v, dout (+ dout2), out slices (64-byte
@@ -971,12 +971,15 @@ void launch_bwd_graph_t(const AttnArgs& a, hipStream_t stream) {
 // (conflict-free pitches), and the tile loops are plain runtime loops (nothing is held across tiles but the accumulators).
 constexpr int kHbP = 16 + 4;   // pitch of a staged 16-float head row
 
-__host__ __device__ inline int attn_bwd_head_lds_floats(int nt) {
+__host__ __device__ inline int attn_bwd_head_lds_floats(int nt, bool pe_lds) {
   const int nr = 16 * nt;
-  return 5 * nr * kHbP + nr * (nr + 4) + 3 * nr;
+  return 5 * nr * kHbP + (pe_lds ? nr * (nr + 4) : 0) + 3 * nr;
 }
 
-template <int NT>
+// PE_LDS: the graph's pe block staged in LDS (N <= 128: 66 KB); beyond that it no longer fits beside the operand tiles and
+// is read from global memory where it is used - one 16-byte (or four 4-byte) request per tile pair in the dq role, four
+// gathers in the dk / dv role, requested one tile ahead - everything else still comes from LDS (N <= 256).
+template <int NT, bool PE_LDS>
 __global__ __launch_bounds__(512) void attn_bwd_head_kernel(AttnArgs a) {
   constexpr int DH = 16, H = 4, P = kHbP, NR = 16 * NT, PEP = NR + 4;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lq = lane & 15, g = lane >> 4;
@@ -989,11 +992,13 @@ __global__ __launch_bounds__(512) void attn_bwd_head_kernel(AttnArgs a) {
   float* Vs = Ks + NR * P;
   float* Ds = Vs + NR * P;     // dout (+ dout2)
   float* Os = Ds + NR * P;     // out
-  float* PE = Os + NR * P;     // [NR][PEP]
-  float* ST = PE + NR * PEP;   // [NR][2]
+  float* PE = Os + NR * P;     // [NR][PEP] (PE_LDS)
+  float* ST = PE + (PE_LDS ? NR * PEP : 0);   // [NR][2]
   float* DL = ST + 2 * NR;     // [NR] delta
   const bool has_pe = a.pe != nullptr;
   const int nm1 = a.N - 1;
+  const float* peg = has_pe ? a.pe + (int64_t)b * a.N * a.N : nullptr;   // this graph's block
+  const bool pe_vec = (a.N & 3) == 0;
 
   constexpr int RI = (NR * 4 + 511) / 512;
   float4 qv[RI], kv[RI], vv[RI], dv_[RI], ov[RI];
@@ -1016,7 +1021,7 @@ __global__ __launch_bounds__(512) void attn_bwd_head_kernel(AttnArgs a) {
   // the graph's pe block: N x N contiguous elements, 16 requests in flight per thread
   const int nn = a.N * a.N;
   const float rn = 1.0f / (float)a.N;
-  for (int base = tid; base < nn; base += 16 * 512) {
+  for (int base = tid; PE_LDS && base < nn; base += 16 * 512) {
     float pv[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) pv[u] = has_pe ? a.pe[(int64_t)b * nn + min(base + 512 * u, nn - 1)] : 1.0f;
@@ -1065,14 +1070,35 @@ __global__ __launch_bounds__(512) void attn_bwd_head_kernel(AttnArgs a) {
       const float rinv = 1.0f / fmaxf(z, 1e-6f);
       const float delta = z < 1e-6f ? 0.0f : DL[q];   // clamp active: the normaliser is a constant
       f32x4 dq = zero4();
+      float pnx[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+      const float* perow = has_pe ? peg + (int64_t)min(q, nm1) * a.N : nullptr;
+      auto load_pe = [&](int kt_) {   // pe[q][16 kt_ + 4g .. + 3] (columns clamped: masked keys are selected away)
+        if (!has_pe) return;
+        const int c0 = 16 * kt_ + 4 * g;
+        if (pe_vec && c0 + 3 <= nm1) {
+          const float4 t = *reinterpret_cast<const float4*>(perow + c0);
+          pnx[0] = t.x; pnx[1] = t.y; pnx[2] = t.z; pnx[3] = t.w;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pnx[r] = perow[min(c0 + r, nm1)];
+        }
+      };
+      if (!PE_LDS && KT > 0) load_pe(0);
       for (int kt = 0; kt < KT; ++kt) {
         Feat<DH> kf, vf;
         load_row<DH>(kf, Ks + (16 * kt + lq) * P, g);
         load_row<DH>(vf, Vs + (16 * kt + lq) * P, g);
         const f32x4 s = dot_rows<DH>(kf, qf, zero4());
         const f32x4 da = dot_rows<DH>(vf, dof, zero4());
-        const float4 pe4 = *reinterpret_cast<const float4*>(PE + min(q, nm1) * PEP + 16 * kt + 4 * g);
-        const float pv[4] = {pe4.x, pe4.y, pe4.z, pe4.w};
+        float pv[4];
+        if (PE_LDS) {
+          const float4 pe4 = *reinterpret_cast<const float4*>(PE + min(q, nm1) * PEP + 16 * kt + 4 * g);
+          pv[0] = pe4.x; pv[1] = pe4.y; pv[2] = pe4.z; pv[3] = pe4.w;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pv[r] = pnx[r];
+          load_pe(min(kt + 1, KT - 1));   // the next tile's values travel under this tile's products
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = 16 * kt + 4 * g + r;
@@ -1096,18 +1122,33 @@ __global__ __launch_bounds__(512) void attn_bwd_head_kernel(AttnArgs a) {
         Feat<DH> kf, vf;
         load_row<DH>(kf, Ks + key * P, g);
         load_row<DH>(vf, Vs + key * P, g);
+        float pnx[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+        const float* pecol = has_pe ? peg + min(key, nm1) : nullptr;
+        auto load_pe = [&](int qb_) {   // pe[16 qb_ + 4g + r][key]
+          if (!has_pe) return;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pnx[r] = pecol[(int64_t)min(16 * qb_ + 4 * g + r, nm1) * a.N];
+        };
+        if (!PE_LDS) load_pe(0);
         for (int qb = 0; qb < NB; ++qb) {
           Feat<DH> qf, dof;
           load_row<DH>(qf, Qs + (16 * qb + lq) * P, g, a.scale);
           load_row<DH>(dof, Ds + (16 * qb + lq) * P, g);
           const f32x4 s = dot_rows<DH>(qf, kf, zero4());
           const f32x4 da = dot_rows<DH>(dof, vf, zero4());
+          float pv[4];
+          if (!PE_LDS) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pv[r] = pnx[r];
+            load_pe(min(qb + 1, NB - 1));
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int qq = 16 * qb + 4 * g + r;
             const float m = ST[2 * qq], z = ST[2 * qq + 1];
             const bool ok = qq < a.N && kok;
-            const float p = ok ? fast_exp(s[r] - m) * PE[min(qq, nm1) * PEP + min(key, nm1)] * (1.0f / fmaxf(z, 1e-6f)) : 0.0f;
+            if (PE_LDS) pv[r] = PE[min(qq, nm1) * PEP + min(key, nm1)];
+            const float p = ok ? fast_exp(s[r] - m) * pv[r] * (1.0f / fmaxf(z, 1e-6f)) : 0.0f;
             const float ds = p * (da[r] - (z < 1e-6f ? 0.0f : DL[qq]));
             dv = mfma16(p, Ds[qq * P + lq], dv);              // (key 4g+r, c lq)
             dk = mfma16(ds, Qs[qq * P + lq] * a.scale, dk);
@@ -1126,25 +1167,28 @@ __global__ __launch_bounds__(512) void attn_bwd_head_kernel(AttnArgs a) {
   }
 }
 
-template <int NT>
+template <int NT, bool PE_LDS>
 void launch_bwd_head_t(const AttnArgs& a, hipStream_t stream) {
-  const size_t lds = sizeof(float) * attn_bwd_head_lds_floats(NT);
-  auto kern = attn_bwd_head_kernel<NT>;
+  const size_t lds = sizeof(float) * attn_bwd_head_lds_floats(NT, PE_LDS);
+  auto kern = attn_bwd_head_kernel<NT, PE_LDS>;
   static LdsSeen lds_seen;
   allow_dynamic_lds(kern, lds, lds_seen);
   hipLaunchKernelGGL(kern, dim3(a.B * a.H), dim3(512), lds, stream, a);
 }
 
-// -> true if the one-workgroup-per-(graph, head) backward was launched (4 heads x dh 16, 64 < N <= 128)
+// -> true if the one-workgroup-per-(graph, head) backward was launched (4 heads x dh 16, 64 < N <= 256)
 bool try_bwd_head(const AttnArgs& a, int dh, hipStream_t stream) {
-  if (a.H != 4 || dh != 16 || a.N <= 64 || a.N > 128) return false;
+  if (a.H != 4 || dh != 16 || a.N <= 64 || a.N > 256) return false;
   if (const char* e = getenv("FETA_ATTN_BWD_HEAD"))
     if (e[0] == '0') return false;
   switch (a.NB) {
-    case 5: launch_bwd_head_t<5>(a, stream); break;
-    case 6: launch_bwd_head_t<6>(a, stream); break;
-    case 7: launch_bwd_head_t<7>(a, stream); break;
-    default: launch_bwd_head_t<8>(a, stream); break;
+    case 5: launch_bwd_head_t<5, true>(a, stream); break;
+    case 6: launch_bwd_head_t<6, true>(a, stream); break;
+    case 7: launch_bwd_head_t<7, true>(a, stream); break;
+    case 8: launch_bwd_head_t<8, true>(a, stream); break;
+    default:
+      if (a.NB <= 12) launch_bwd_head_t<12, false>(a, stream);
+      else launch_bwd_head_t<16, false>(a, stream);
   }
   return true;
 }

@@ -624,7 +624,7 @@ __global__ __launch_bounds__(kBlk8Threads) void attn_block_fwd8_kernel(BlockArgs
   // (everything a lane derives from its id is invariant in the graph loop and would be hoisted and held across the whole
   // body - csrc/block_bwd.hip: the lane id is laundered once per graph)
   int lane_l = lane0;
-  asm volatile("" : "+v"(lane_l));
+  FETA_OPAQUE_LANE(lane_l);
   const int lane = lane_l, tid = (wv << 6) | lane, lq = lane & 15, g = lane >> 4;
   __syncthreads();
 #pragma unroll

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
     // loop, and the compiler hoists all of it - hundreds of registers held across the attention phase (up to 676 B of
     // scratch per lane).  The lane id is laundered once per graph, so those values are recomputed where they are used.
     int lane_l = lane0;
-    if (LOOP) asm volatile("" : "+v"(lane_l));
+    if (LOOP) FETA_OPAQUE_LANE(lane_l);
     const int lane = lane_l, tid = (wv << 6) | lane, lq = lane & 15, g = lane >> 4;
     const bool first = !LOOP || b < nwg;
     if (LOOP && !first) __syncthreads();   // the tiles of the previous graph have been consumed

@@ -15,6 +15,10 @@ extern __shared__ __attribute__((aligned(16))) float feta_lds[];
 // (the laundered value comes back as a generic pointer: FETA_GLOBAL restores the global address space, without which
 // every access through it becomes a flat_load / flat_store and waits on both memory counters)
 #define FETA_OPAQUE_PTR(p) asm volatile("" : "+s"(p))
+// Makes a per-lane value opaque at this point.  Used on the LANE ID at the top of a graph / row-block loop: everything a
+// lane derives from its id is invariant in such a loop, the compiler hoists all of it and holds hundreds of registers
+// across the body (csrc/block_bwd.hip: up to 676 B of scratch per lane); laundered, the values are recomputed where used.
+#define FETA_OPAQUE_LANE(x) asm volatile("" : "+v"(x))
 typedef const float __attribute__((address_space(1)))* feta_gcf;   // keep accesses through a laundered pointer global_*
 
 namespace feta {

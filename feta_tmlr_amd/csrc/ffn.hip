@@ -167,7 +167,7 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a, CoeffFw
   // (what a lane derives from its id is invariant in this loop and would be hoisted and held across the body; the id is
   // laundered once per row block - csrc/block_bwd.hip)
   int lane_l = lane0;
-  asm volatile("" : "+v"(lane_l));
+  FETA_OPAQUE_LANE(lane_l);
   const int lane = lane_l, tid = (wv << 6) | lane, lq = lane & 15, g = lane >> 4;
   if (blk != (int)blockIdx.x) {
     __syncthreads();   // exchange / reduction scratch of the previous row block consumed

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, Ffn
     for (int blk = x_lo; blk < x_hi; blk += x_step) {
       // (the lane id is laundered once per row block: csrc/block_bwd.hip)
       int lane_l = lane0;
-      asm volatile("" : "+v"(lane_l));
+      FETA_OPAQUE_LANE(lane_l);
       const int lane = lane_l, tid = (w << 6) | lane, lq = lane & 15, g = lane >> 4;
       const int r0 = blk * kFbRows;
       if (blk != x_lo) __syncthreads();   // the tiles of the previous block have been consumed

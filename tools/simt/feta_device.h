@@ -13,6 +13,7 @@ struct f32x4 {
 extern float* feta_lds;  // sized per launch, NaN-poisoned guard behind it (simt_runtime.cpp)
 
 #define FETA_OPAQUE_PTR(p) ((void)(p))
+#define FETA_OPAQUE_LANE(x) ((void)(x))
 typedef const float* feta_gcf;
 
 namespace feta {
