@@ -23,6 +23,7 @@ CPU = torch.device('cpu')
     (2, 9, 2, 4, False, True),
     (2, 100, 4, 16, True, True),       # 64 < N <= 128, 4 heads x 16: one workgroup per (graph, head) in backward
     (1, 65, 4, 16, False, False),
+    (1, 150, 4, 16, True, True),       # 128 < N <= 256: the same kernel with pe read from global memory
 ])
 def test_attn(emu, bsz, n, h, dh, use_pe, seq_first):
     KC.check_attn(emu, CPU, None, bsz, n, h, dh, use_pe, seq_first)
