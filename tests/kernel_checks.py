@@ -2,6 +2,10 @@
 on the host SIMT emulation of the kernel sources (``-m "not gpu"``) and on the MI355X through
 libfeta_hip.so (``-m gpu``).  ``abi`` is a feta_tmlr_amd._abi.Abi; ``dev`` the torch device the
 buffers live on; ``stream`` the hipStream_t handle (None for the emulation)."""
+import atexit
+import json
+import os
+
 import numpy as np
 import torch
 
@@ -26,11 +30,59 @@ def maxdiff(a, b):
     return (a.detach().double().cpu() - b.detach().double().cpu()).abs().max().item()
 
 
+# Regression guard on the MEASURED errors: the tolerances above are bars, the errors the
+# MI355X actually produces are 10 - 100x below them, so a 10x regression could hide inside a bar.  tests/golden/
+# gpu_measured_errors.json holds, per (test id, check name, occurrence), the relative error err / max(1, max|ref|) one GPU
+# run produced (FETA_RECORD_ERRORS=<path> python -m pytest tests -m gpu writes it); every later GPU run must stay within
+# GUARD_FACTOR of it (kernels and inputs are deterministic; the floor absorbs last-bit noise).  Only fp32 checks on CUDA
+# tensors are guarded; a kernel change that moves rounding (another summation order) is re-recorded, knowingly.
+GUARD_FACTOR, GUARD_FLOOR = 4.0, 3e-7
+_GUARD_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'gpu_measured_errors.json')
+_RECORD = os.environ.get('FETA_RECORD_ERRORS')
+_guard_table, _guard_seen, _guard_new = {}, {}, {}
+if os.path.exists(_GUARD_PATH) and not _RECORD and os.environ.get('FETA_ERROR_GUARD', '1') != '0':
+    with open(_GUARD_PATH) as _f:
+        _guard_table = json.load(_f).get('errors', {})
+
+
+def _guard_key(name):
+    node = os.environ.get('PYTEST_CURRENT_TEST', '').split(' ')[0]
+    k = node + '::' + name
+    i = _guard_seen.get(k, 0)
+    _guard_seen[k] = i + 1
+    return '%s#%d' % (k, i)
+
+
+def _guard_flush():
+    if _RECORD and _guard_new:
+        old = {}
+        if os.path.exists(_RECORD):
+            with open(_RECORD) as f:
+                old = json.load(f).get('errors', {})
+        for k, v in _guard_new.items():
+            old[k] = max(v, old.get(k, 0.0))
+        with open(_RECORD, 'w') as f:
+            json.dump({'what': 'relative errors err / max(1, max|ref|) of the fp32 checks of one `pytest -m gpu` run on an '
+                               'MI355X (tests/kernel_checks.py: regression guard)', 'errors': dict(sorted(old.items()))},
+                      f, indent=0)
+
+
+atexit.register(_guard_flush)
+
+
 def assert_close(name, got, ref, tol=TOL):
-    """max-abs error <= tol * max(1, max|ref|)."""
+    """max-abs error <= tol * max(1, max|ref|); on the GPU also <= GUARD_FACTOR x the error this check is known to have."""
     err = maxdiff(got, ref)
     scale = max(1.0, ref.detach().abs().max().item())
     assert np.isfinite(err) and err <= tol * scale, '%s: max|err| %.3e (ref scale %.2f)' % (name, err, scale)
+    if torch.is_tensor(got) and got.is_cuda and got.dtype == torch.float32 and tol <= 1e-3:
+        key, rel = _guard_key(name), err / scale
+        if _RECORD:
+            _guard_new[key] = max(rel, _guard_new.get(key, 0.0))
+        elif key in _guard_table:
+            bar = max(GUARD_FACTOR * _guard_table[key], GUARD_FLOOR)
+            assert rel <= bar, ('%s: relative error %.3e, %.1fx the recorded %.3e (tests/golden/gpu_measured_errors.json)'
+                                % (name, rel, rel / max(_guard_table[key], 1e-30), _guard_table[key]))
     return err
 
 
