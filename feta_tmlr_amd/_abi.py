@@ -202,6 +202,7 @@ SIGNATURES.update({
     'feta_attn_block_bwd_supported': ([C.c_int, C.c_int, C.c_int], C.c_int),
     'feta_attn_block_bwd_blocks': ([C.c_int], C.c_int),
     'feta_attn_block_bwd': ([C.POINTER(AttnBlockGrad), _S], C.c_int),
+    'feta_attn_block_bwd_sums': ([C.POINTER(AttnBlockGrad), C.POINTER(ColsumSeg), C.c_int, _S], C.c_int),
 })
 
 
@@ -589,8 +590,9 @@ class Abi:
     def attn_block_bwd_blocks(self, b):
         return int(self.lib.feta_attn_block_bwd_blocks(b))
 
-    def attn_block_bwd(self, b, n, scale, stream, seq_first=True, Gs=0, partial_ld=0, partial_ptr=None, **ptrs):
-        """feta_attn_block_bwd; tensor-valued keyword arguments become the descriptor's pointers."""
+    def attn_block_bwd(self, b, n, scale, stream, seq_first=True, Gs=0, partial_ld=0, partial_ptr=None, sums=(), **ptrs):
+        """feta_attn_block_bwd; tensor-valued keyword arguments become the descriptor's pointers.  sums: [(in [R, C],
+        out [C])] column sums that ride in trailing workgroups of the launch (feta_attn_block_bwd_sums)"""
         d = AttnBlockGrad()
         d.B, d.N, d.M, d.scale, d.Gs, d.partial_ld = b, n, b * n, scale, Gs, partial_ld
         d.row_sb, d.row_sn = (1, b) if seq_first else (n, 1)
@@ -601,7 +603,11 @@ class Abi:
         for k, t in ptrs.items():
             if t is not None:
                 setattr(d, k, t.data_ptr())
-        self._check(self.lib.feta_attn_block_bwd(C.byref(d), stream), 'feta_attn_block_bwd')
+        if sums:
+            self._check(self.lib.feta_attn_block_bwd_sums(C.byref(d), self._colsum_segs(sums), len(sums), stream),
+                        'feta_attn_block_bwd_sums')
+        else:
+            self._check(self.lib.feta_attn_block_bwd(C.byref(d), stream), 'feta_attn_block_bwd')
 
     def ffn_supported(self, d_model, ff):
         return bool(self.lib.feta_ffn_supported(d_model, ff))

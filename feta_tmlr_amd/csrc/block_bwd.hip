@@ -25,6 +25,7 @@
 #include <cstdlib>
 
 #include "feta_abi_common.h"
+#include "feta_colsum.h"
 #include "feta_lp.h"
 #include "feta_rowops.h"
 
@@ -68,7 +69,15 @@ __device__ __forceinline__ void acc_to(float* p, float v, bool first) {
 // LOOP: more graphs than workgroups - a separate instantiation, because the graph loop costs registers (the single-graph
 // forms are spill-free; the compiler treats everything invariant in the loop as hoistable).
 template <class T, int NT, bool SPLIT, bool LOOP>
-__global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
+__global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a, ColsumPlan sums, int main_grid) {
+  // Workgroups beyond main_grid reduce column sums (feta_colsum.h): the LAST launch of a stack's backward runs one workgroup
+  // per graph - half the chip at the BASELINE batch - while every split-K partial of the layers behind it, and of this
+  // layer's feed-forward half, is already complete; reduced here, the stack's final reduction launch is left with this
+  // launch's own columns (40 MB -> 8.5 MB at the BASELINE batch)
+  if ((int)blockIdx.x >= main_grid) {
+    colsum_role<kBbThreads>(sums, (int)blockIdx.x - main_grid);
+    return;
+  }
   typedef Lp<T> L;
   typedef typename L::Op Op;
   typedef typename L::Vec Vec;
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
   // one graph per workgroup (SPLIT: per two) up to kBbMaxGrid graphs; beyond that the workgroups walk the graphs
   // b, b + gridDim.x, ... and ADD each graph's weight-gradient tiles to their own partial row (read-modify-write by the
   // thread that wrote it: the row stays in the XCD's L2), the partial sums for the previous BatchNorm stay in registers
-  const int nwg = (int)gridDim.x;
+  const int nwg = main_grid;
   int b = (int)blockIdx.x - hp * a.B;
   const int lane0 = lane;
   do {
@@ -637,35 +646,38 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a) {
 }
 
 template <class T, int NT>
-int launch_block_bwd(const BwdArgs& a, hipStream_t stream) {
-  const size_t lds = block_bwd_lds_bytes<T>(NT, a.y1 != nullptr);
+int launch_block_bwd(const BwdArgs& a, const feta_colsum_seg* segs, int nseg, hipStream_t stream) {
+  size_t lds = block_bwd_lds_bytes<T>(NT, a.y1 != nullptr);
   const int grid = feta_attn_block_bwd_blocks(a.B);
+  ColsumPlan plan{};
+  const int tiles = plan_colsum(segs, nseg, plan);
+  if (tiles > 0 && lds < sizeof(float) * colsum_role_lds_floats(kBbThreads)) lds = sizeof(float) * colsum_role_lds_floats(kBbThreads);
   if (a.dx_b != nullptr) {   // two workgroups per graph
     auto kern = attn_block_bwd_kernel<T, NT, true, false>;
     static LdsSeen lds_seen;
     allow_dynamic_lds(kern, lds, lds_seen);
-    hipLaunchKernelGGL(kern, dim3(2 * a.B), dim3(kBbThreads), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(2 * a.B + tiles), dim3(kBbThreads), lds, stream, a, plan, 2 * a.B);
   } else if (grid == a.B) {
     auto kern = attn_block_bwd_kernel<T, NT, false, false>;
     static LdsSeen lds_seen;
     allow_dynamic_lds(kern, lds, lds_seen);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBbThreads), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid + tiles), dim3(kBbThreads), lds, stream, a, plan, grid);
   } else {
     auto kern = attn_block_bwd_kernel<T, NT, false, true>;
     static LdsSeen lds_seen;
     allow_dynamic_lds(kern, lds, lds_seen);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBbThreads), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid + tiles), dim3(kBbThreads), lds, stream, a, plan, grid);
   }
   return check_launch("feta_attn_block_bwd");
 }
 
 template <class T>
-int dispatch_block_bwd(const BwdArgs& a, hipStream_t stream) {
+int dispatch_block_bwd(const BwdArgs& a, const feta_colsum_seg* segs, int nseg, hipStream_t stream) {
   switch ((a.N + 15) / 16) {
-    case 1: return launch_block_bwd<T, 1>(a, stream);
-    case 2: return launch_block_bwd<T, 2>(a, stream);
-    case 3: return launch_block_bwd<T, 3>(a, stream);
-    default: return launch_block_bwd<T, 4>(a, stream);
+    case 1: return launch_block_bwd<T, 1>(a, segs, nseg, stream);
+    case 2: return launch_block_bwd<T, 2>(a, segs, nseg, stream);
+    case 3: return launch_block_bwd<T, 3>(a, segs, nseg, stream);
+    default: return launch_block_bwd<T, 4>(a, segs, nseg, stream);
   }
 }
 
@@ -692,7 +704,15 @@ extern "C" int feta_attn_block_bwd_blocks(int B) {
 }
 
 extern "C" int feta_attn_block_bwd(const feta_attn_block_grad* d, feta_stream_t stream) {
+  return feta_attn_block_bwd_sums(d, nullptr, 0, stream);
+}
+
+extern "C" int feta_attn_block_bwd_sums(const feta_attn_block_grad* d, const feta_colsum_seg* segs, int nseg,
+                                        feta_stream_t stream) {
   FETA_REQUIRE(d != nullptr, "attn_block_bwd: null descriptor");
+  FETA_REQUIRE(nseg >= 0 && nseg <= FETA_COLSUM_MAX_SEGS && (nseg == 0 || segs != nullptr),
+               "attn_block_bwd: 0..%d column-sum segments", FETA_COLSUM_MAX_SEGS);
+  for (int i = 0; i < nseg; ++i) FETA_REQUIRE(colsum_seg_ok(segs[i]), "attn_block_bwd: bad segment %d", i);
   const BwdArgs& a = *d;
   FETA_REQUIRE(a.dy && a.w_out && a.w_in && a.qkv && a.out && a.n_real && a.attn_stats && a.x0 && a.dx && a.partial,
                "attn_block_bwd: null pointer");
@@ -707,6 +727,6 @@ extern "C" int feta_attn_block_bwd(const feta_attn_block_grad* d, feta_stream_t 
                aligned16(a.y1) && aligned16(a.dout2) && aligned16(a.g_sum) && aligned16(a.dx_b),
                "attn_block_bwd: tensors must be 16-byte aligned");
   FETA_REQUIRE(a.dtype == FETA_F32 || a.dtype == FETA_BF16, "attn_block_bwd: dtype %d", a.dtype);
-  if (a.dtype == FETA_BF16) return dispatch_block_bwd<bf16_t>(a, (hipStream_t)stream);
-  return dispatch_block_bwd<float>(a, (hipStream_t)stream);
+  if (a.dtype == FETA_BF16) return dispatch_block_bwd<bf16_t>(a, segs, nseg, (hipStream_t)stream);
+  return dispatch_block_bwd<float>(a, segs, nseg, (hipStream_t)stream);
 }

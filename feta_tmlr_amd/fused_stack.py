@@ -69,6 +69,12 @@ def layer_params(layer):
             layer.linear2.weight, layer.linear2.bias, layer.norm2.weight, layer.norm2.bias]
 
 
+# the split-K partials that are complete when the LAST launch of a stack's backward starts (every layer but the first, and
+# the first layer's feed-forward half) are reduced in trailing workgroups of that launch (feta_attn_block_bwd_sums): the
+# final reduction launch is left with that launch's own columns (colsum 10.5 -> 8.4 us, the launch itself 24.1 -> 25.6 us:
+# 0.2749 -> 0.2735 ms per step at B = 128; at B >= 512, where that launch fills the chip, it costs 0.7 % - not taken there);
+# 0: everything in the final launch (A/B timing)
+USE_EARLY_COLSUM = os.environ.get('FETA_EARLY_COLSUM', '1') != '0'
 USE_LN_STACK = os.environ.get('FETA_LN_STACK', '1') != '0'   # 0: LayerNorm layers run op by op (A/B timing)
 
 
@@ -350,6 +356,7 @@ class FusedEncoderStackFn(torch.autograd.Function):
         bn_tail = dwdb_all[total:].view(nl, 4, d)
 
         slots = {}
+        early_done = None     # 'a' columns already reduced by the last launch (USE_EARLY_COLSUM)
         if d_final is None:   # only the per-head output of the last layer was used
             d_final = torch.zeros(n, b, d, dtype=torch.float32, device=dev)
         if dt != torch.float32 and d_final.dtype != torch.float32:
@@ -402,6 +409,7 @@ class FusedEncoderStackFn(torch.autograd.Function):
             grads[base + 10], grads[base + 11] = dg2, db2
             fin1, dg1, db1 = new(2, d), bn_tail[li, 0], bn_tail[li, 1]
             grads[base + 4], grads[base + 5] = dg1, db1
+            a_done = wslot.cur['a']      # 'a' columns of the layers behind this one: complete
             ppo, offo = wslot('a', d, d)
             slots[base + 2] = (offo, d, d)
             ppi, offi = wslot('a', 3 * d, d)
@@ -410,6 +418,13 @@ class FusedEncoderStackFn(torch.autograd.Function):
             if fused_attn:
                 # B3 + B4 + B5 in one launch, one workgroup per graph (csrc/block_bwd.hip): dconcat and dqkv stay on chip
                 dx0 = newt(m, d)
+                early = ()
+                if li == 0 and USE_EARLY_COLSUM and b <= 160:   # (measured: a gain only while this launch leaves CUs idle)
+                    # the last launch of this backward: everything but its own partial columns is reduced beside it
+                    early = [(part_f, dwdb_all[:tf])]
+                    if a_done > 0:
+                        early.append((part_a[:, :a_done], dwdb_all[tf:tf + a_done]))
+                    early_done = a_done
                 # the layer below takes the gradient in two parts iff its FFN backward is the fused kernel
                 split = (USE_ATTN_BLOCK_SPLIT and li > 0 and USE_FFN_BWD and abi.attn_block_bwd_blocks(b) == b
                          and abi.ffn_bwd_supported(d, params[(li - 1) * PER_LAYER + 6].shape[0]))
@@ -422,7 +437,7 @@ class FusedEncoderStackFn(torch.autograd.Function):
                                    w_out=w_o, w_in=w_in, qkv=s['qkv'], out=s['out'],
                                    dout2=None if d2 is None else d2.contiguous().view(m, d), pe=pe_c, n_real=n_real,
                                    attn_stats=s['ast'], x0=s['x0'], bn0=s['prm0'] if li > 0 else None, dx=dx0,
-                                   sum_out=gs_prev)
+                                   sum_out=gs_prev, sums=early)
                 Gs_next = 2 * GB
                 if gs_prev is not None:
                     gs_prev, Gs_next = _cap_partials(abi, stream, gs_prev, new)
@@ -466,7 +481,11 @@ class FusedEncoderStackFn(torch.autograd.Function):
         assert dcur_b is None
         assert wslot.cur == {'f': tf, 'a': ta}
         # ... and whatever column sums the filter stage left for this launch (functional.PendingSums)
-        abi.colsum_multi([(part_f, dwdb_all[:tf]), (part_a, dwdb_all[tf:total])] + _take_pending(ctx), stream)
+        if early_done is not None:
+            last = [(part_a[:, early_done:], dwdb_all[tf + early_done:total])]
+        else:
+            last = [(part_f, dwdb_all[:tf]), (part_a, dwdb_all[tf:total])]
+        abi.colsum_multi(last + _take_pending(ctx), stream)
         if ctx.owner is not None:
             STACK_FLAT_GRAD[ctx.owner] = dwdb_all
         for idx, (off, no, ki) in slots.items():

@@ -524,6 +524,10 @@ typedef struct feta_attn_block_grad {
 int feta_attn_block_bwd_supported(int N, int d_model, int heads);
 int feta_attn_block_bwd_blocks(int B);
 int feta_attn_block_bwd(const feta_attn_block_grad* d, feta_stream_t stream);
+/* the same launch with up to FETA_COLSUM_MAX_SEGS independent column sums in trailing workgroups (ABI 8): the last launch
+ * of a stack's backward leaves half the chip idle at the BASELINE batch while the split-K partials of everything behind it
+ * are complete - reduced here, the final reduction launch is left with this launch's own partial columns. */
+int feta_attn_block_bwd_sums(const feta_attn_block_grad* d, const feta_colsum_seg* segs, int nseg, feta_stream_t stream);
 
 /* ---- feed-forward half of one encoder layer in ONE launch -----------------------------------
  * x = BN1(y1) (x_bn | x_stats as in feta_rowlin_ex / feta_attn_block);  h = relu(x W1^T + b1);
