@@ -26,7 +26,27 @@ def abi() -> Abi:
             raise FetaError('%s is missing: build it with `python -m feta_tmlr_amd.build` '
                             '(hipcc, gfx950). There is no CPU fallback.' % _PATH)
         _ABI = bind(ctypes.CDLL(_PATH))
+        _load_gemm_tuning()
     return _ABI
+
+
+_GEMM_TUNING = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'gemm_tuning_gfx950.csv')
+
+
+def _load_gemm_tuning():
+    """The fp32 path keeps LIBRARY GEMMs for the C x C linear of the coefficient generator; the
+    rocBLAS / hipBLASLt solutions PyTorch's TunableOp selected for those shapes on an MI355X (tools/tune_gemm.py) ship
+    with the package and are handed to TunableOp with tuning disabled - shapes that are not in the file run the default
+    heuristic as before.  FETA_TUNED_GEMM=0 leaves TunableOp alone."""
+    if os.environ.get('FETA_TUNED_GEMM', '1') == '0' or not os.path.exists(_GEMM_TUNING):
+        return
+    try:
+        if torch.cuda.is_available() and not torch.cuda.tunable.is_enabled():
+            torch.cuda.tunable.enable(True)
+            torch.cuda.tunable.tuning_enable(False)
+            torch.cuda.tunable.read_file(_GEMM_TUNING)
+    except Exception:      # (a library tuning file is never a reason to fail)
+        pass
 
 
 _TEST_ABI = None

@@ -300,7 +300,8 @@ extern "C" int feta_attn_out_fwd(const feta_attn_block* d, feta_stream_t stream)
                aligned16(a.y_stats) && aligned16(a.b_out) && aligned16(a.out_f32) && aligned16(a.y_shift) &&
                aligned16(a.x_bn),
                "attn_out_fwd: tensors must be 16-byte aligned");
-  FETA_REQUIRE(a.dtype == FETA_F32 || a.dtype == FETA_BF16, "attn_out_fwd: dtype %d", a.dtype);
-  if (a.dtype == FETA_BF16) return dispatch_attn_out<bf16_t>(a, (hipStream_t)stream);
+  // (the kernel is written against the storage policy of feta_lp.h, but the bf16 layer stack stops at N <= 64 - shapes
+  // beyond run its op-by-op path - so only the fp32 instantiation is built and tested)
+  FETA_REQUIRE(a.dtype == FETA_F32, "attn_out_fwd: fp32 token tensors only (dtype %d)", a.dtype);
   return dispatch_attn_out<float>(a, (hipStream_t)stream);
 }

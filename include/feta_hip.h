@@ -468,7 +468,8 @@ int feta_attn_block_fwd_sums(const feta_attn_block* d, const feta_colsum_seg* se
  * feta_attn_block, read as follows: qkv [M,192] is an INPUT (the in_proj result), x is the residual (seen through the
  * published parameter block x_bn when given; x_stats must be NULL - the in_proj launch finalized them), w_in / b_in are
  * ignored; outputs out, out_f32, attn_stats, attn, y as there; y_stats (nullable) [G + 1][2][64] with
- * G = feta_attn_out_stat_rows(B, N) = B * ceil(N / 32) partial rows and the shift row behind them. */
+ * G = feta_attn_out_stat_rows(B, N) = B * ceil(N / 32) partial rows and the shift row behind them.  fp32 token tensors
+ * (dtype = FETA_F32) only. */
 int feta_attn_out_supported(int N, int d_model, int heads);
 int feta_attn_out_stat_rows(int B, int N);
 int feta_attn_out_fwd(const feta_attn_block* d, feta_stream_t stream);
