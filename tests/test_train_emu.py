@@ -31,6 +31,12 @@ def test_lap_pos_enc_step_matches_oracle(emu, task, batch_norm, mode):
     TC.check_task_step(task, torch.device('cpu'), _ctx(emu), batch_norm=batch_norm, mode=mode, lap_dim=8)
 
 
+def test_config5_bf16_lappe_bucket_step(emu):
+    """BASELINE config 5 in one piece (molhiv shell + lappe lap-dim 8 + bf16 storage + an N_pad <= 64 bucket), emulated at
+    5 graphs; the MI355X suite runs 320"""
+    TC.check_config5_step(CPU, lambda: _lib.override_for_tests(emu), bsz=5, n_min=20, n_max=36)
+
+
 def test_oracle_lap_encoding_matches_product():
     """LapEncoding (transformer/position_encoding.py:127-161): product and oracle agree up to the sign of
     each column on graphs with simple low eigenvalues; zero-padded columns for graphs smaller than dim."""

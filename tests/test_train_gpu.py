@@ -32,6 +32,12 @@ def test_lap_pos_enc_step_matches_oracle(hip, task, batch_norm, mode):
     TC.check_task_step(task, hip[1], contextlib.nullcontext, batch_norm=batch_norm, mode=mode, lap_dim=8)
 
 
+def test_config5_bf16_lappe_bucket_step(hip):
+    """BASELINE config 5 in one piece: molhiv shell + lappe lap-dim 8 + bf16 storage + an N_pad <= 64 bucket of 320 graphs"""
+    errs = TC.check_config5_step(hip[1], contextlib.nullcontext)
+    print({k: round(v, 4) for k, v in errs.items()})
+
+
 def test_molhiv_shell_outputs(hip):
     TC.check_molhiv_outputs(hip[1], contextlib.nullcontext)
 

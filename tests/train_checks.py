@@ -156,3 +156,60 @@ def check_sbm_padded_equals_gather(dev, run_ctx):
         lw = model.loss(out, batch9[5])
     KC.assert_close('weighted SBM loss', lw.cpu(), O.sbm_weighted_loss(out.detach().cpu().double(),
                                                                       batch9[5].cpu(), 3))
+
+
+def check_config5_step(dev, run_ctx, bsz=320, n_min=20, n_max=64, layers=2):
+    """BASELINE config 5 all at once (exercised piecewise until round 3): the molhiv shell
+    (transformer/models.py:598-742) with ``--lappe --lap-dim 8``, d_model = 64 / 4 heads (the fused stack's shape), one
+    N_pad <= 64 bucket of `bsz` graphs (320: more graphs than workgroups, the kernels walk - the fp64 oracle's cost grows
+    quadratically with the batch, 1024 graphs take it minutes; bench.py times the 1024-graph bucket), on bf16 STORAGE (layers.set_storage_dtype: fused bf16 stack, fp32 statistics,
+    parameter gradients and filter stage) - logits, loss and every parameter gradient of one step against the fp64 oracle
+    on the same fp32 inputs and master weights.  Bars: those of the bf16 leg of the bench (tests/bench_checks.py)."""
+    import bench_checks as BC
+    from feta_tmlr_amd.transformer.layers import set_storage_dtype
+    from feta_tmlr_amd.transformer.position_encoding import LapEncoding
+    torch.manual_seed(0)
+    d, heads, lap_dim = 64, 4, 8
+    model = M.DiffGraphTransformerGenGCNMolHiv(9, 1, d, heads, dim_feedforward=2 * d, dropout=0.0, nb_layers=layers,
+                                               batch_norm=False, filter_order=4, heads_share_graph=True,
+                                               filter_mode='spectral', lap_pos_enc=True, lap_pos_enc_dim=lap_dim)
+    ds = D.SyntheticGraphDataset('mutag', bsz, seed=0, n_min=n_min, n_max=n_max, features='atom', labels='binary',
+                                 nan_label_frac=0.3)
+    ds.samples[0].y, ds.samples[1].y, ds.samples[2].y = float('nan'), 1.0, 0.0
+    with torch.no_grad():
+        model.encoder.spectral_gnns.bias.normal_(0, 0.1)
+        model.encoder.gcn.bias.normal_(0, 0.1)
+        model.embedding_lap_pos_enc.bias.normal_(0, 0.1)
+    LapEncoding(lap_dim, normalization='sym').apply_to(ds)
+    n_pad = max(g.num_nodes for g in ds.samples)
+    assert n_pad <= 64
+    batch9, cache = D.collate(ds.samples, k_eig=16, device=dev)
+    model = model.to(dev)
+    p64 = params64(model)
+    set_storage_dtype(model, torch.bfloat16)
+    crit = T.make_criterion('molhiv', nb_class=1)
+    with run_ctx():
+        loss, out = T.task_loss('molhiv', model, crit, batch9, cache)
+        loss.backward()
+    # the K = 16 eigenbasis operator is the bench's operator, not a reference operator (SURVEY F3): its oracle is the
+    # eigenbasis formulation on the very U, lambda the kernels read
+    x, mask, pe, lap, degree, labels, edge_index, batch, fi = (None if t is None else t.cpu() for t in batch9)
+    c = cache.to(torch.device('cpu'))
+    logit, prob, coeff = O.graph_transformer_gengcn_molhiv(
+        x, edge_index, batch, fi, mask, pe.double(), degree.double(), p64, num_layers=layers, num_heads=heads, order=4,
+        batch_norm=False, heads_share_graph=True, x_lap_pos_enc=lap.double(), eig=(c.u.double(), c.lam.double()),
+        collapsed=True)
+    loss_ref = O.molhiv_loss(logit, labels.double())
+    loss_ref.backward()
+    errs = {'out': KC.assert_close('config 5 logits', out.float().cpu(), logit, tol=BC.BF16_MODEL_TOL),
+            'loss': KC.assert_close('config 5 loss', loss.float().cpu(), loss_ref, tol=BC.BF16_MODEL_TOL)}
+    for k, p in model.named_parameters():
+        g_ref = p64[k].grad
+        if p.grad is None:
+            assert g_ref is None or float(g_ref.abs().max()) == 0.0, k
+            continue
+        if float(g_ref.norm()) < 1e-9:
+            continue
+        errs[k] = BC.rel_fro(p.grad, g_ref)
+        assert errs[k] <= BC.bf16_grad_tol(k), 'config 5 gradient %s: relative Frobenius error %.3f' % (k, errs[k])
+    return errs
