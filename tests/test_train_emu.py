@@ -34,7 +34,7 @@ def test_lap_pos_enc_step_matches_oracle(emu, task, batch_norm, mode):
 def test_config5_bf16_lappe_bucket_step(emu):
     """BASELINE config 5 in one piece (molhiv shell + lappe lap-dim 8 + bf16 storage + an N_pad <= 64 bucket), emulated at
     5 graphs; the MI355X suite runs 320"""
-    TC.check_config5_step(CPU, lambda: _lib.override_for_tests(emu), bsz=5, n_min=20, n_max=36)
+    TC.check_config5_step(torch.device('cpu'), _ctx(emu), bsz=5, n_min=20, n_max=36)
 
 
 def test_oracle_lap_encoding_matches_product():
