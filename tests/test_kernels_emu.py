@@ -178,6 +178,27 @@ def test_eigh_sym_truncated_equals_full(emu):
     KC.check_eigh_truncated_equals_full(emu, CPU, None)
 
 
+def test_attn_out_rejects_what_it_does_not_take(emu):
+    """feta_attn_out_fwd: N <= 256, the residual seen through a PUBLISHED parameter block only (fresh statistics are the
+    in_proj launch's to finalize), fp32 token tensors; feta_attn_block_stat_rows / feta_attn_out_stat_rows report 0 for
+    shapes their kernels do not take"""
+    assert emu.attn_out_supported(256, 64, 4) and not emu.attn_out_supported(257, 64, 4)
+    assert not emu.attn_out_supported(100, 32, 4) and not emu.attn_out_supported(100, 64, 2)
+    assert emu.attn_out_stat_rows(64, 128) == 256 and emu.attn_out_stat_rows(3, 33) == 6 and emu.attn_out_stat_rows(3, 300) == 0
+    assert emu.attn_block_stat_rows(3, 65) == 0 and emu.attn_block_stat_rows(5, 20) == 5
+    b, n, d, h = 2, 70, 64, 4
+    m = b * n
+    z = lambda *s: torch.zeros(*s)
+    kw = dict(x=z(m, d), w_out=z(d, d), b_out=z(d), pe=None, n_real=torch.full((b,), n, dtype=torch.int32),
+              qkv=z(m, 3 * d), out=z(m, d), attn_stats=z(b, h, n, 2), attn=None, y=z(m, d))
+    emu.attn_out_fwd(b, n, 0.25, None, **kw)          # (the plain call is fine)
+    with pytest.raises(ValueError, match='x_bn'):
+        emu.attn_out_fwd(b, n, 0.25, None, x_stats=z(3, 2, d), **kw)
+    with pytest.raises(ValueError, match='fp32'):
+        emu.attn_out_fwd(b, n, 0.25, None, **dict(kw, x=z(m, d).bfloat16(), qkv=z(m, 3 * d).bfloat16(),
+                                                  out=z(m, d).bfloat16(), y=z(m, d).bfloat16()))
+
+
 def test_eigh_sym_rejects_large_n(emu):
     assert emu.eigh_sym_supported(256) and not emu.eigh_sym_supported(257)
     assert emu.eigh_sym_workspace_bytes(3, 192) == 0 and emu.eigh_sym_workspace_bytes(3, 222) == 4 * 3 * 222 * 260
