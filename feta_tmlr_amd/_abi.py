@@ -151,6 +151,7 @@ SIGNATURES.update({
     'feta_attn_out_supported': ([C.c_int, C.c_int, C.c_int], C.c_int),
     'feta_attn_out_stat_rows': ([C.c_int, C.c_int], C.c_int),
     'feta_attn_out_fwd': ([C.POINTER(AttnBlock), _S], C.c_int),
+    'feta_attn_out_fwd_sums': ([C.POINTER(AttnBlock), C.POINTER(ColsumSeg), C.c_int, _S], C.c_int),
     'feta_attn_block_fwd': ([C.POINTER(AttnBlock), _S], C.c_int),
     'feta_attn_block_fwd_sums': ([C.POINTER(AttnBlock), C.POINTER(ColsumSeg), C.c_int, _S], C.c_int),
 })
@@ -578,11 +579,15 @@ class Abi:
     def attn_out_stat_rows(self, b, n):
         return int(self.lib.feta_attn_out_stat_rows(b, n))
 
-    def attn_out_fwd(self, b, n, scale, stream, seq_first=True, tie_qk=False, **ptrs):
+    def attn_out_fwd(self, b, n, scale, stream, seq_first=True, tie_qk=False, sums=(), **ptrs):
         """feta_attn_out_fwd (attention core + out_proj behind the in_proj launch, N <= 256): the feta_attn_block
-        descriptor with qkv as input and x as the residual"""
+        descriptor with qkv as input and x as the residual; sums: [(in [R, C], out [C])] column sums in trailing workgroups"""
         d = self.attn_block_desc(b, n, scale, seq_first, tie_qk=tie_qk, **ptrs)
-        self._check(self.lib.feta_attn_out_fwd(C.byref(d), stream), 'feta_attn_out_fwd')
+        if sums:
+            self._check(self.lib.feta_attn_out_fwd_sums(C.byref(d), self._colsum_segs(sums), len(sums), stream),
+                        'feta_attn_out_fwd_sums')
+        else:
+            self._check(self.lib.feta_attn_out_fwd(C.byref(d), stream), 'feta_attn_out_fwd')
 
     def attn_block_bwd_supported(self, n, d_model, heads):
         return bool(self.lib.feta_attn_block_bwd_supported(n, d_model, heads))

@@ -16,6 +16,7 @@
 #include <cstdlib>
 
 #include "feta_abi_common.h"
+#include "feta_colsum.h"
 #include "feta_lp.h"
 #include "feta_rowops.h"
 
@@ -46,7 +47,13 @@ __device__ __forceinline__ void load_w_row_op(RowOp<T, kAoD>& t, const float* ro
 }
 
 template <class T, int KTM>
-__global__ __launch_bounds__(kAoThreads) void attn_out_fwd_kernel(AoArgs a) {
+__global__ __launch_bounds__(kAoThreads) void attn_out_fwd_kernel(AoArgs a, ColsumPlan sums, int main_grid) {
+  // workgroups beyond main_grid reduce column sums (feta_colsum.h): s = colsum(gcn.weight) of the coefficient generator - a
+  // function of the parameters alone - rides in the first launch of a forward pass instead of a launch of its own
+  if ((int)blockIdx.x >= main_grid) {
+    colsum_role<kAoThreads>(sums, (int)blockIdx.x - main_grid);
+    return;
+  }
   typedef Lp<T> L;
   typedef typename L::Op Op;
   typedef typename L::Vec Vec;
@@ -251,29 +258,32 @@ __global__ __launch_bounds__(kAoThreads) void attn_out_fwd_kernel(AoArgs a) {
       float* st = a.y_stats + (int64_t)blockIdx.x * 2 * D;
       *reinterpret_cast<float4*>(st + o0) = make_float4(s1[0] + t1.x, s1[1] + t1.y, s1[2] + t1.z, s1[3] + t1.w);
       *reinterpret_cast<float4*>(st + D + o0) = make_float4(s2[0] + t2.x, s2[1] + t2.y, s2[2] + t2.z, s2[3] + t2.w);
-      if (blockIdx.x == 0) *reinterpret_cast<float4*>(a.y_stats + (int64_t)gridDim.x * 2 * D + o0) = ks;   // the shift row
+      if (blockIdx.x == 0) *reinterpret_cast<float4*>(a.y_stats + (int64_t)main_grid * 2 * D + o0) = ks;   // the shift row
     }
   }
 }
 
 template <class T, int KTM>
-int launch_attn_out(const AoArgs& a, hipStream_t stream) {
-  const size_t lds = attn_out_lds_bytes<T>(KTM, a.attn != nullptr);
+int launch_attn_out(const AoArgs& a, const feta_colsum_seg* segs, int nseg, hipStream_t stream) {
+  size_t lds = attn_out_lds_bytes<T>(KTM, a.attn != nullptr);
+  ColsumPlan plan{};
+  const int tiles = plan_colsum(segs, nseg, plan);
+  if (tiles > 0 && lds < sizeof(float) * colsum_role_lds_floats(kAoThreads)) lds = sizeof(float) * colsum_role_lds_floats(kAoThreads);
   auto kern = attn_out_fwd_kernel<T, KTM>;
   static LdsSeen lds_seen;
   allow_dynamic_lds(kern, lds, lds_seen);
   const int chunks = (a.N + kAoChunk - 1) / kAoChunk;
-  hipLaunchKernelGGL(kern, dim3(a.B * chunks), dim3(kAoThreads), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3(a.B * chunks + tiles), dim3(kAoThreads), lds, stream, a, plan, a.B * chunks);
   return check_launch("feta_attn_out_fwd");
 }
 
 template <class T>
-int dispatch_attn_out(const AoArgs& a, hipStream_t stream) {
+int dispatch_attn_out(const AoArgs& a, const feta_colsum_seg* segs, int nseg, hipStream_t stream) {
   const int kt = (a.N + 15) / 16;
-  if (kt <= 4) return launch_attn_out<T, 4>(a, stream);
-  if (kt <= 8) return launch_attn_out<T, 8>(a, stream);
-  if (kt <= 12) return launch_attn_out<T, 12>(a, stream);
-  return launch_attn_out<T, 16>(a, stream);
+  if (kt <= 4) return launch_attn_out<T, 4>(a, segs, nseg, stream);
+  if (kt <= 8) return launch_attn_out<T, 8>(a, segs, nseg, stream);
+  if (kt <= 12) return launch_attn_out<T, 12>(a, segs, nseg, stream);
+  return launch_attn_out<T, 16>(a, segs, nseg, stream);
 }
 
 }  // namespace feta
@@ -290,7 +300,14 @@ extern "C" int feta_attn_out_stat_rows(int B, int N) {
 }
 
 extern "C" int feta_attn_out_fwd(const feta_attn_block* d, feta_stream_t stream) {
+  return feta_attn_out_fwd_sums(d, nullptr, 0, stream);
+}
+
+extern "C" int feta_attn_out_fwd_sums(const feta_attn_block* d, const feta_colsum_seg* segs, int nseg, feta_stream_t stream) {
   FETA_REQUIRE(d != nullptr, "attn_out_fwd: null descriptor");
+  FETA_REQUIRE(nseg >= 0 && nseg <= FETA_COLSUM_MAX_SEGS && (nseg == 0 || segs != nullptr),
+               "attn_out_fwd: 0..%d column-sum segments", FETA_COLSUM_MAX_SEGS);
+  for (int i = 0; i < nseg; ++i) FETA_REQUIRE(colsum_seg_ok(segs[i]), "attn_out_fwd: bad segment %d", i);
   const AoArgs& a = *d;
   FETA_REQUIRE(a.x && a.w_out && a.n_real && a.qkv && a.out && a.attn_stats && a.y, "attn_out_fwd: null pointer");
   FETA_REQUIRE(a.B > 0 && a.N >= 1 && a.N <= 256, "attn_out_fwd: N=%d outside [1,256]", a.N);
@@ -303,5 +320,5 @@ extern "C" int feta_attn_out_fwd(const feta_attn_block* d, feta_stream_t stream)
   // (the kernel is written against the storage policy of feta_lp.h, but the bf16 layer stack stops at N <= 64 - shapes
   // beyond run its op-by-op path - so only the fp32 instantiation is built and tested)
   FETA_REQUIRE(a.dtype == FETA_F32, "attn_out_fwd: fp32 token tensors only (dtype %d)", a.dtype);
-  return dispatch_attn_out<float>(a, (hipStream_t)stream);
+  return dispatch_attn_out<float>(a, segs, nseg, (hipStream_t)stream);
 }

@@ -309,6 +309,8 @@ class PendingSums:
         coefficient generator's forward (outputs allocated here), or None if nobody asked / s is not ready."""
         if self.coeff_fwd_req is None or self.s is None or self.fwd_sums or attn is None:
             return None
+        if attn.shape[-1] > 64:      # (beyond the role's LDS tile budget the stand-alone launch is the faster form:
+            return None              # csrc/feta_coeff.h - channel slices over 4 workgroups, staged rows)
         gcn_bias, self.coeff_fwd_req = self.coeff_fwd_req, None
         b, h, n, _ = attn.shape
         cj = torch.empty((h * b, n), dtype=torch.float32, device=attn.device)

@@ -263,7 +263,8 @@ class FusedEncoderStackFn(torch.autograd.Function):
                     st1 = new(G1 + 1, 2, d)
                     abi.attn_out_fwd(b, n, scale, stream, tie_qk=tie, x=y_prev if li else x_in, x_bn=prm_prev, w_out=w_o,
                                      b_out=b_o, pe=pe_c, n_real=n_real, rowscale=degree_rows, qkv=qkv, out=out,
-                                     attn_stats=ast, attn=attn, y=y1, y_stats=st1, y_shift=layer.norm1.running_mean)
+                                     attn_stats=ast, attn=attn, y=y1, y_stats=st1, y_shift=layer.norm1.running_mean,
+                                     sums=(pending.take_fwd() if (pending is not None and li == 0) else ()))
                     st1, G1 = _cap_partials(abi, stream, st1, new, shift_row=True)
                 else:
                     # F2
@@ -560,7 +561,8 @@ class FusedLayerNormStackFn(torch.autograd.Function):
                 abi.rowlin_fwd_ex(dsc, stream)
                 if USE_ATTN_OUT and not lowp and abi.attn_out_supported(n, d, heads):
                     abi.attn_out_fwd(b, n, scale, stream, tie_qk=tie, x=x_in, w_out=w_o, b_out=b_o, pe=pe_c, n_real=n_real,
-                                     rowscale=degree_rows, qkv=qkv, out=out, attn_stats=ast, attn=attn, y=y1)
+                                     rowscale=degree_rows, qkv=qkv, out=out, attn_stats=ast, attn=attn, y=y1,
+                                     sums=(pending.take_fwd() if (pending is not None and li == 0) else ()))
                 else:
                     q, k, v = _views(qkv, n, b, heads, dh)
                     if tie:

@@ -473,6 +473,8 @@ int feta_attn_block_fwd_sums(const feta_attn_block* d, const feta_colsum_seg* se
 int feta_attn_out_supported(int N, int d_model, int heads);
 int feta_attn_out_stat_rows(int B, int N);
 int feta_attn_out_fwd(const feta_attn_block* d, feta_stream_t stream);
+/* ... with column sums in trailing workgroups, as feta_attn_block_fwd_sums (s = colsum(gcn.weight) in the first launch) */
+int feta_attn_out_fwd_sums(const feta_attn_block* d, const feta_colsum_seg* segs, int nseg, feta_stream_t stream);
 
 /* ---- backward of the attention sub-block in ONE launch ------------------------------------------------------
  * (feta_attn_block_bwd_supported: d_model = 64, 4 heads, N <= 64; K not tied to Q.)  Replaces
