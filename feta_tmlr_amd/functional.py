@@ -234,6 +234,14 @@ import os as _os
 # the floor is 10.2 / 20.4 us and the library sits at 80 % of it; FETA_LIN_OWN_MAX_MACS=2147483648 selects ours (A/B).
 # bf16 compute (bf16 storage legs) always takes the tiled kernels: 9.3 / 16.5 us, no cast launches.
 LIN_OWN_GEMM_MAX_MACS = int(_os.environ.get('FETA_LIN_OWN_MAX_MACS', str(1 << 27)))
+# bf16 compute (the bf16 storage legs): from this many rows H*B the three products run as LIBRARY bf16 GEMMs with fp32 output
+# (torch.mm(..., out_dtype=float32) on bf16 copies of the operands - the same arithmetic as the tiled kernels of
+# csrc/lin.hip: operands rounded to bf16, fp32 accumulation and result).  The tiled kernels read fp32 operands and win
+# while the products are small (rows 512: 9.7 / 16.9 us against 33 / 52 us with the cast launches); at config 5's 4096
+# rows they sit at 200 / 143 TFLOP/s (42.9 / 120.3 us) and the library, casts included, takes 35.5 / 60.3 us
+# (tools/scratch/bf16_gemm_probe.py, eager).  Inside the captured step: 1024 rows 0.3683 vs 0.3651 ms (tiled kernels stay), 2048
+# rows 0.547 vs 0.570 ms, 4096 rows (config 5) 1.08 vs 1.145 ms.
+LIN_LIB_BF16_MIN_ROWS = int(_os.environ.get('FETA_LIN_LIB_BF16_MIN_ROWS', '2048'))
 
 
 class PendingSums:
@@ -361,10 +369,19 @@ class FilterFromPooledFn(torch.autograd.Function):
         # csrc/lin.hip (one 16 x 16 tile per wave straight from L2, gradient products and column sums in one launch)
         # where the products are launch-bound; the library GEMM where they are compute-bound (C = 1024 at the
         # BASELINE shape: 1 GFLOP each, ~12 us at half the fp32 matrix peak; lin.hip is L2-bound there, 31 us)
-        ctx.own_gemm = abi.lin_supported(r_, k_, n_) and (r_ * k_ * n_ <= LIN_OWN_GEMM_MAX_MACS or ctx.gemm_bf16)
+        ctx.lib_bf16 = bool(ctx.gemm_bf16 and r_ >= LIN_LIB_BF16_MIN_ROWS and pooled.is_cuda)
+        ctx.own_gemm = (not ctx.lib_bf16 and abi.lin_supported(r_, k_, n_)
+                        and (r_ * k_ * n_ <= LIN_OWN_GEMM_MAX_MACS or ctx.gemm_bf16))
+        ctx.lp = None
         if ctx.own_gemm:
             coeff = torch.empty((pooled.shape[0], lin_w.shape[0]), dtype=torch.float32, device=pooled.device)
             abi.lin_fwd(pooled, lin_w, lin_b, coeff, stream, bf16=ctx.gemm_bf16)
+        elif ctx.lib_bf16:
+            p16, w16 = pooled.to(torch.bfloat16), lin_w.to(torch.bfloat16)
+            coeff = torch.mm(p16, w16.t(), out_dtype=torch.float32)
+            if lin_b is not None:
+                coeff += lin_b
+            ctx.lp = (p16, w16)       # (the backward's operands: no second pair of cast launches)
         else:
             coeff = torch.addmm(lin_b, pooled, lin_w.t())
         ctx.pending = pending
@@ -428,7 +445,13 @@ class FilterFromPooledFn(torch.autograd.Function):
                                        if p_ is not None]
             else:
                 abi.colsum_multi(sums, stream)
-            dpooled, dw_lin = dcoeff.mm(lin_w), dcoeff.t().mm(pooled)
+            if ctx.lib_bf16:
+                p16, w16 = ctx.lp
+                d16 = dcoeff.to(torch.bfloat16)
+                dpooled = torch.mm(d16, w16, out_dtype=torch.float32)
+                dw_lin = torch.mm(d16.t(), p16, out_dtype=torch.float32)
+            else:
+                dpooled, dw_lin = dcoeff.mm(lin_w), dcoeff.t().mm(pooled)
         if not has_bias:
             dbias = None
         return (dx, dpooled, dw_lin, db_lin, dbias) + (None,) * 9

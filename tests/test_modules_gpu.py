@@ -157,3 +157,35 @@ def test_fused_stack_updates_running_statistics():
     import contextlib
     from test_modules_emu import check_fused_stack_updates_running_statistics
     check_fused_stack_updates_running_statistics(torch.device('cuda:0'), contextlib.nullcontext)
+
+
+def test_linear_bf16_library_path_equals_tiled_kernels(monkeypatch):
+    """bf16 compute of the C x C linear at config 5's row count (H * B = 4096): library bf16 GEMMs with fp32 output on
+    bf16 copies of the operands (functional.LIN_LIB_BF16_MIN_ROWS) == the tiled kernels that round the fp32 operands when
+    they stage them (csrc/lin.hip) - coefficients, filter output and every gradient of the node"""
+    from feta_tmlr_amd import functional as FF
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(3)
+    b, n, h, dh, k, order = 1024, 6, 4, 16, 4, 4
+    c = order * dh * dh
+    rnd = lambda *s_: torch.randn(*s_, generator=g).to(dev)
+    x = rnd(n, b, h, dh).permute(1, 0, 2, 3)
+    n_real = torch.randint(2, n + 1, (b,), generator=g, dtype=torch.int32).to(dev)
+    u, lam = rnd(b, n, k) / 2, (torch.rand(b, k, generator=g) * 2 - 1).to(dev)
+    res = []
+    for min_rows in (1 << 30, 4096):
+        monkeypatch.setattr(FF, 'LIN_LIB_BF16_MIN_ROWS', min_rows)
+        g.manual_seed(7)          # the same operands for both runs
+        pooled = (rnd(h * b, c) / 4).requires_grad_(True)
+        lin_w, lin_b = (rnd(c, c) / 32).requires_grad_(True), (rnd(c) / 8).requires_grad_(True)
+        bias = (rnd(dh) / 8).requires_grad_(True)
+        y, coeff = FF.filter_from_pooled(x, pooled, lin_w, lin_b, bias, n_real, (u, lam), 'spec', order,
+                                         heads_share_graph=True, gemm_bf16=True)
+        w_out = torch.linspace(0.5, 1.5, y.numel(), device=dev).view_as(y)
+        ((y * w_out).sum() + 0.01 * coeff.pow(2).sum()).backward()
+        res.append((y.detach(), coeff.detach(), pooled.grad, lin_w.grad, lin_b.grad, bias.grad, pooled.detach()))
+    a, bb = res
+    assert torch.equal(a[6], bb[6])
+    for name, t0, t1 in zip(('y', 'coeff', 'dpooled', 'dW', 'db', 'dbias'), a[:6], bb[:6]):
+        scale = float(t0.abs().max())
+        assert float((t0 - t1).abs().max()) <= 2e-5 * max(1.0, scale), name
