@@ -126,8 +126,11 @@ def stack_supported(layers, d_model):
 # state_dict / deepcopy / pickle of a model must not see it)
 STACK_FLAT_GRAD = weakref.WeakKeyDictionary()
 
-MAX_STAT_ROWS = 384   # every consumer workgroup re-reduces the partial statistics: keep them few (beyond this, one
-                      # reduction launch in front of the consumers: ~5 us against ~G x G x 512 bytes of L2 reads)
+# every consumer workgroup re-reduces the partial statistics of its producer: beyond this many rows ONE reduction launch
+# runs in front of the consumers (~5 us against ~G x G x 512 bytes of L2 reads).  Measured (round 3): 512 beats 384 and
+# 1024 at the batches where it matters - molhiv B = 1024 bf16 948 k / 960 k / 955 k graphs/s, ZINC B = 512 fp32
+# 745 k / 773 k / 770 k (the feed-forward kernels emit 512 rows there: not capped any more)
+MAX_STAT_ROWS = int(os.environ.get('FETA_MAX_STAT_ROWS', '512'))
 
 
 def _cap_partials(abi, stream, st, new, shift_row=False):
