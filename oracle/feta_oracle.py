@@ -595,3 +595,48 @@ def warmup_lr(step, lr, warmup):
     if step < warmup:
         return 1e-6 + step * (lr - 1e-6) / warmup
     return lr * warmup ** 0.5 * step ** -0.5
+
+
+# ---- N3: the collate / wire format (transformer/data.py:161-225) -------------------------------------------------
+def collate_reference(batch, n_tags=None):
+    """Restatement of ``GraphDataset.collate_fn().collate`` (transformer/data.py:161-225), loop for loop: `batch` is a
+    list of objects with the fields the reference reads off a PyG ``Data`` - x [n, f] (or x_onehot when n_tags is given),
+    y, edge_index [2, E], and optionally pe [n, n], lap_pe [n, k], degree [n].
+    -> (padded_x, mask, pos_enc, lap_pos_enc, degree, labels, edge_index, batch_indices, feature_indices_to_gather),
+    the 9-tuple of :224 (device placement of the last three, :224, is the caller's business).
+    Deviation, stated: labels are returned as the list the reference hands to ``default_collate`` (:224) - stacking
+    python scalars / tensors into a tensor is torch's code, not the reference's."""
+    batch = list(batch)                                                        # :163
+    max_len = max(len(g.x) for g in batch)                                     # :164
+    width = batch[0].x.shape[1] if n_tags is None else n_tags                  # :166-170 (n_features | n_tags)
+    padded_x = torch.zeros((len(batch), max_len, width))
+    mask = torch.zeros((len(batch), max_len), dtype=torch.bool)                # :171
+    labels = []
+    use_pe = getattr(batch[0], 'pe', None) is not None                         # :178
+    pos_enc = torch.zeros((len(batch), max_len, max_len)) if use_pe else None  # :181 (dense branch)
+    use_lap_pe = getattr(batch[0], 'lap_pe', None) is not None                 # :187
+    lap_pos_enc = None
+    if use_lap_pe:
+        lap_pos_enc = torch.zeros((len(batch), max_len, batch[0].lap_pe.shape[-1]))   # :189-190
+    use_degree = getattr(batch[0], 'degree', None) is not None                 # :193
+    degree = torch.zeros((len(batch), max_len)) if use_degree else None        # :195
+    feature_indices_to_gather, edge_indices, batch_indices = [], [], []
+    node_offset = 0
+    for i, g in enumerate(batch):                                              # :201
+        labels.append(g.y)
+        g_len = len(g.x)
+        padded_x[i, :g_len, :] = torch.as_tensor(g.x if n_tags is None else g.x_onehot, dtype=torch.float32)  # :205-208
+        mask[i, g_len:] = True                                                 # :209
+        if use_pe:
+            pos_enc[i, :g_len, :g_len] = torch.as_tensor(g.pe, dtype=torch.float32)          # :211
+        if use_lap_pe:
+            lap_pos_enc[i, :g_len, :g.lap_pe.shape[-1]] = torch.as_tensor(g.lap_pe, dtype=torch.float32)   # :213
+        if use_degree:
+            degree[i, :g_len] = torch.as_tensor(g.degree, dtype=torch.float32)               # :215
+        feature_indices_to_gather.extend([[i, node_idx] for node_idx in range(g_len)])        # :217
+        edge_indices.append(torch.as_tensor(g.edge_index) + node_offset)                      # :218
+        batch_indices.extend([i] * g_len)                                                     # :219
+        node_offset += g_len                                                                   # :220
+    edge_indices = torch.cat(edge_indices, dim=1)                                             # :222
+    return (padded_x, mask, pos_enc, lap_pos_enc, degree, labels, edge_indices,
+            torch.tensor(batch_indices), torch.tensor(feature_indices_to_gather))             # :224
