@@ -89,6 +89,9 @@ def parse(argv=None):
                          'fp32 statistics and master weights, bf16 gradient bucket')
     ap.add_argument('--no-literal', action='store_true', help='skip the reference_literal leg')
     ap.add_argument('--layer-norm', action='store_true', help='LayerNorm instead of the ZINC default BatchNorm')
+    ap.add_argument('--no-pe', action='store_true',
+                    help='pe=None: no relative positional kernel (what the README commands of the TU / molhiv / SBM '
+                         'scripts run: they pass no --pos-enc, README.md:49,65,71)')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of one hipGraph per step')
     ap.add_argument('--two-phase', action='store_true',
                     help='force the split backward (default for --gpus > 1: overlaps the all-reduce of the '
@@ -140,6 +143,8 @@ def make_batch(args, rank, dev):
     ds = D.SyntheticGraphDataset(args.shape, args.batch, in_dim=args.dim, seed=rank, n_min=n_min, n_max=n_max)
     batch9, cache = D.collate(ds.samples, k_eig=args.k_eig, n_pad=args.n_pad)
     x, mask, pe, _, degree, _, edge_index, batch, fi = batch9
+    if getattr(args, 'no_pe', False):
+        pe = None
     src = x.permute(1, 0, 2).contiguous()          # [N,B,d] seq-first, embedding skipped
     g = torch.Generator().manual_seed(1000 + rank)
     dout = torch.randn(src.shape, generator=g)
@@ -565,7 +570,7 @@ def cpu_baseline(args, cpu, enc, spectral, share, primary=True):
     def step(collapsed=False):
         leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
         src = cpu['src'][:, :sub].clone().requires_grad_(True)
-        out, _, _ = O.encoder_gengcn(src, cpu['pe'][:sub], ei, cpu['fi'][:n_tot], cpu['batch'][:n_tot],
+        out, _, _ = O.encoder_gengcn(src, None if cpu['pe'] is None else cpu['pe'][:sub], ei, cpu['fi'][:n_tot], cpu['batch'][:n_tot],
                                      cpu['degree'][:sub], m, leaves, args.layers, args.heads, args.order,
                                      batch_norm=not args.layer_norm, heads_share_graph=share,
                                      collapsed=collapsed, eig=eig)
@@ -675,10 +680,20 @@ def main(argv=None):
             and args.batch == 128):
         import copy
         extra['extra_configs'] = []
-        for name, kw in (('config 4: PATTERN-shaped, B=64, N_pad=128, K=32, fp32',
-                          dict(shape='pattern', batch=64, n_pad=128, k_eig=32, dtype='f32')),
-                         ('config 5: molhiv-shaped, B=1024, N_pad=64 bucket, K=16, bf16 storage',
-                          dict(shape='molhiv', batch=1024, n_pad=64, k_eig=16, dtype='bf16'))):
+        ref_default = dict(layer_norm=True, no_pe=True)    # what README.md:49,65,71 run: no --batch-norm, no --pos-enc
+        for name, kw, with_roofline in (
+                ('config 4: PATTERN-shaped, B=64, N_pad=128, K=32, fp32',
+                 dict(shape='pattern', batch=64, n_pad=128, k_eig=32, dtype='f32'), True),
+                ('config 4 (reference defaults: LayerNorm, pe=None): PATTERN-shaped, B=64, N_pad=128, K=32, fp32',
+                 dict(shape='pattern', batch=64, n_pad=128, k_eig=32, dtype='f32', **ref_default), False),
+                ('config 5: molhiv-shaped, B=1024, N_pad=64 bucket, K=16, bf16 storage',
+                 dict(shape='molhiv', batch=1024, n_pad=64, k_eig=16, dtype='bf16'), True),
+                ('config 5 (reference defaults: LayerNorm, pe=None): molhiv-shaped, B=1024, N_pad=64 bucket, K=16, bf16 storage',
+                 dict(shape='molhiv', batch=1024, n_pad=64, k_eig=16, dtype='bf16', **ref_default), False),
+                ('config 5 (reference defaults: LayerNorm, pe=None), fp32',
+                 dict(shape='molhiv', batch=1024, n_pad=64, k_eig=16, dtype='f32', **ref_default), False),
+                ('config 1 (reference defaults: LayerNorm, pe=None): MUTAG-shaped, B=32, N_pad=28, K=8, fp32',
+                 dict(shape='mutag', batch=32, n_pad=28, k_eig=8, dtype='f32', **ref_default), False)):
             ax = copy.copy(args)
             for k_, v_ in kw.items():
                 setattr(ax, k_, v_)
@@ -689,11 +704,16 @@ def main(argv=None):
             stepx, _, _ = make_step(ax, encx, gpux, world, dev)
             dtx = time_steps(stepx, ax, world, dev)
             log('%s: %.3f ms/step' % (name, dtx / ax.steps * 1e3))
-            extra['extra_configs'].append({
+            row = {
                 'config': name, 'value': round(ax.batch * ax.steps / dtx, 2), 'unit': 'graphs/s',
                 'ms_per_step': round(dtx / ax.steps * 1e3, 4), 'steps': ax.steps, 'dtype': ax.dtype,
-                'flags': '--shape %s --batch %d --n-pad %d --k-eig %d --dtype %s' % (ax.shape, ax.batch, ax.n_pad, ax.k_eig, ax.dtype),
-                'roofline': roofline(ax, gpux, dev, lowp=ax.dtype == 'bf16')})
+                'norm': 'layer' if ax.layer_norm else 'batch', 'pe': not ax.no_pe,
+                'flags': '--shape %s --batch %d --n-pad %d --k-eig %d --dtype %s%s%s' % (
+                    ax.shape, ax.batch, ax.n_pad, ax.k_eig, ax.dtype, ' --layer-norm' if ax.layer_norm else '',
+                    ' --no-pe' if ax.no_pe else '')}
+            if with_roofline:
+                row['roofline'] = roofline(ax, gpux, dev, lowp=ax.dtype == 'bf16')
+            extra['extra_configs'].append(row)
             del gpux, encx, stepx
 
     literal = None

@@ -57,7 +57,7 @@ def check_bench_step(dev, run_ctx, argv, filter_mode=None, share=None, replays=2
     out = step.held['out'].detach().cpu()
     mode = enc.filter_mode
     eig = (cpu['cache'].u.double(), cpu['cache'].lam.double()) if mode == 'spectral' else None
-    ref, _, _ = O.encoder_gengcn(cpu['src'].double(), cpu['pe'].double(), cpu['edge_index'], cpu['fi'],
+    ref, _, _ = O.encoder_gengcn(cpu['src'].double(), None if cpu['pe'] is None else cpu['pe'].double(), cpu['edge_index'], cpu['fi'],
                                  cpu['batch'], cpu['degree'].double(), cpu['mask'], p64, args.layers, args.heads,
                                  args.order, batch_norm=not args.layer_norm, heads_share_graph=enc.heads_share_graph,
                                  collapsed=True, eig=eig)

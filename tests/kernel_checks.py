@@ -208,6 +208,72 @@ def check_attn(abi, dev, stream, bsz, n, h, dh, use_pe, seq_first=True, seed=0, 
     return errs
 
 
+def check_attn_out(abi, dev, stream, bsz, n, use_pe=True, tie_qk=False, seed=0, write_attn=True, with_bn=False,
+                   n_min=1, with_stats=True):
+    """feta_attn_out_fwd (csrc/attnout.hip: attention core + out_proj + degree + residual + BatchNorm statistics as one
+    launch behind in_proj, 4 heads x 16, N <= 256) DIRECTLY against the oracle: oracle.attention_core on the same qkv,
+    then out_proj, degree scale and residual as oracle.encoder_layer states them; the residual
+    optionally seen through a BatchNorm parameter block (with_bn: the previous layer's norm2 applied on load)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(seed)
+    h, dh = 4, 16
+    d = h * dh
+    m = n * bsz
+    nb = torch.randint(n_min, n + 1, (bsz,), generator=g, dtype=torch.int32)
+    nb[0] = n
+    mask = torch.arange(n)[None, :] >= nb[:, None]
+    real = (~mask).t().unsqueeze(-1)                                     # [N,B,1]
+    qkv = torch.randn(n, bsz, 3 * d, generator=g, dtype=torch.float64)
+    x = torch.randn(n, bsz, d, generator=g, dtype=torch.float64) * real
+    pe = None
+    if use_pe:
+        pe = torch.rand(bsz, n, n, generator=g, dtype=torch.float64)
+        pe = pe * (~mask)[:, None, :] * (~mask)[:, :, None]
+    degree = (torch.rand(bsz, n, generator=g, dtype=torch.float64) * 0.5 + 0.5) * (~mask)
+    w_o = torch.randn(d, d, generator=g, dtype=torch.float64) / 8
+    b_o = torch.randn(d, generator=g, dtype=torch.float64) * 0.1
+    prm = None
+    if with_bn:
+        prm = torch.zeros(4, d, dtype=torch.float64)
+        prm[0] = torch.rand(d, generator=g, dtype=torch.float64) + 0.5
+        prm[1] = torch.randn(d, generator=g, dtype=torch.float64) * 0.2
+    concat, a_ref, _ = O.attention_core(qkv, pe, mask, h, tie_qk=tie_qk)
+    res = x if prm is None else x * prm[0] + prm[1]
+    y_ref = res + degree.t().unsqueeze(-1) * F.linear(concat, w_o, b_o)
+
+    f32 = lambda t: t.float().contiguous().to(dev)
+    nan = lambda *s: torch.full(s, float('nan'), device=dev)
+    out, y = nan(m, d), nan(m, d)
+    ast = nan(bsz, h, n, 2)
+    attn = nan(bsz, h, n, n) if write_attn else None
+    g_rows = abi.attn_out_stat_rows(bsz, n)
+    st = nan(g_rows + 1, 2, d) if with_stats else None
+    shift = f32(torch.randn(d, generator=g, dtype=torch.float64) * 0.1) if with_stats else None
+    abi.attn_out_fwd(bsz, n, dh ** -0.5, stream, tie_qk=tie_qk, x=f32(x).view(m, d), x_bn=None if prm is None else f32(prm),
+                     w_out=f32(w_o), b_out=f32(b_o), pe=None if pe is None else f32(pe), n_real=nb.to(dev),
+                     rowscale=f32(degree.t().reshape(m)), qkv=f32(qkv).view(m, 3 * d), out=out, attn_stats=ast, attn=attn,
+                     y=y, y_stats=st, y_shift=shift)
+    errs = {'out': assert_close('attn_out concat', out.view(n, bsz, d), concat, tol=TOL)}
+    # rows of padded nodes: the residual row (zero here, or the BatchNorm shift of a zero row) - the oracle's masked
+    # softmax gives those query rows a uniform attention over the real keys, which the reference never reads either
+    # (transformer/models.py:347 gathers real nodes only); compare real rows, and require finite padded rows
+    zero = torch.zeros((), dtype=torch.float64)
+    errs['y'] = assert_close('attn_out y', torch.where(real, y.view(n, bsz, d).cpu().double(), zero),
+                             torch.where(real, y_ref, zero), tol=TOL)
+    assert bool(torch.isfinite(y).all())
+    if write_attn:
+        rq = (~mask)[:, None, :, None]
+        errs['attn'] = assert_close('attn_out attn', torch.where(rq, attn.cpu().double(), zero), torch.where(rq, a_ref, zero),
+                                    tol=TOL)
+    if with_stats:
+        yf = y.double().cpu()
+        k = st[-1, 0].double().cpu()
+        assert_close('attn_out shift row', st[-1, 0], shift, tol=0.0)
+        errs['sum'] = assert_close('attn_out stats sum', st[:-1, 0].sum(0), (yf - k).sum(0), tol=TOL)
+        errs['sumsq'] = assert_close('attn_out stats sumsq', st[:-1, 1].sum(0), ((yf - k) ** 2).sum(0), tol=TOL)
+    return errs
+
+
 def random_attention(bsz, h, n, nb, g, zero_diag=False):
     """Row-stochastic attention with exact zeros outside the real block."""
     mask = torch.arange(n)[None, :] >= nb[:, None]

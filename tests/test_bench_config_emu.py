@@ -24,6 +24,18 @@ def test_bench_step_matches_oracle(emu, mode, share, two_phase):
                         replays=1, two_phase=two_phase)
 
 
+@pytest.mark.parametrize('argv', [
+    ['--shape', 'pattern', '--batch', '3', '--n-pad', '70', '--k-eig', '8', '--layers', '2', '--no-graph'],
+    ['--shape', 'pattern', '--batch', '2', '--n-pad', '66', '--k-eig', '8', '--layers', '2', '--no-graph', '--layer-norm', '--no-pe'],
+    SMALL + ['--layer-norm', '--no-pe'],
+    SMALL + ['--shape', 'mutag', '--layer-norm'],
+])
+def test_bench_extra_configurations_match_oracle(emu, argv):
+    """the further legs of the bench line (extra_configs) at small shapes: graphs beyond 64 nodes (in_proj ->
+    feta_attn_out_fwd -> ... -> attn_bwd_head_kernel), LayerNorm stacks, pe=None"""
+    BC.check_bench_step(CPU, lambda: _lib.override_for_tests(emu), argv, replays=1)
+
+
 @pytest.mark.parametrize('share,extra', [(True, []), (False, []), (True, ['--layer-norm']), (True, ['--two-phase'])])
 def test_bench_step_bf16_matches_oracle(emu, share, extra):
     """--dtype bf16 (BASELINE configs 3 / 5): bf16 storage, bf16 MFMA, fp32 statistics and master weights - the fused

@@ -24,6 +24,27 @@ def test_timed_configuration_matches_oracle(hip, mode, share, two_phase):
     print('max abs errors:', {k: '%.2e' % v for k, v in errs.items()})
 
 
+PATTERN = ['--shape', 'pattern', '--batch', '64', '--k-eig', '32']
+
+
+@pytest.mark.parametrize('argv', [
+    PATTERN + ['--n-pad', '128'],                               # BASELINE config 4 as bench.py's extra_configs time it
+    PATTERN + ['--n-pad', '120', '--layer-norm'],               # ... with the norm the reference defaults to
+    PATTERN + ['--n-pad', '120', '--layer-norm', '--no-pe'],    # ... and pe=None (README.md:71 passes no --pos-enc)
+    PATTERN + ['--n-pad', '188', '--batch', '16'],              # beyond 128 nodes: pe read from global memory in backward
+    ['--shape', 'mutag', '--batch', '32', '--n-pad', '28', '--k-eig', '8', '--layer-norm', '--no-pe'],   # config 1 (README.md:49)
+    ['--shape', 'molhiv', '--batch', '320', '--n-pad', '64', '--layer-norm', '--no-pe'],                # config 5's norm, fp32
+    ['--shape', 'molhiv', '--batch', '320', '--n-pad', '64'],
+])
+def test_timed_extra_configurations_match_oracle(hip, argv):
+    """Every further leg bench.py prints (extra_configs): the N > 64 encoder (in_proj -> feta_attn_out_fwd -> ffn -> ...
+    -> attn_bwd_head_kernel -> large-graph coefficient generator) and the reference-default LayerNorm / pe=None legs of
+    configs 1, 4 and 5, through the captured hipGraph against oracle.encoder_gengcn: output 1e-5, gradients 3e-5 relative."""
+    errs, used_graph = BC.check_bench_step(hip[1], contextlib.nullcontext, argv, replays=2)
+    assert used_graph
+    print('max abs errors:', {k: '%.2e' % v for k, v in errs.items()})
+
+
 @pytest.mark.parametrize('argv', [[], ['--two-phase'],
                                   ['--shape', 'molhiv', '--batch', '96', '--n-pad', '64', '--k-eig', '32', '--layer-norm'],
                                   ['--shape', 'molhiv', '--batch', '300', '--n-pad', '64', '--k-eig', '32']])

@@ -178,6 +178,15 @@ def test_eigh_sym_truncated_equals_full(emu):
     KC.check_eigh_truncated_equals_full(emu, CPU, None)
 
 
+@pytest.mark.parametrize('bsz,n,use_pe,tie_qk,with_bn,write_attn', [
+    (2, 65, True, False, False, True),
+    (2, 100, False, True, True, True),
+    (1, 130, True, False, True, False),
+])
+def test_attn_out_against_oracle(emu, bsz, n, use_pe, tie_qk, with_bn, write_attn):
+    KC.check_attn_out(emu, CPU, None, bsz, n, use_pe=use_pe, tie_qk=tie_qk, with_bn=with_bn, write_attn=write_attn)
+
+
 def test_attn_out_rejects_what_it_does_not_take(emu):
     """feta_attn_out_fwd: N <= 256, the residual seen through a PUBLISHED parameter block only (fresh statistics are the
     in_proj launch's to finalize), fp32 token tensors; feta_attn_block_stat_rows / feta_attn_out_stat_rows report 0 for
