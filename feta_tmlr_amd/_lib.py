@@ -26,27 +26,62 @@ def abi() -> Abi:
             raise FetaError('%s is missing: build it with `python -m feta_tmlr_amd.build` '
                             '(hipcc, gfx950). There is no CPU fallback.' % _PATH)
         _ABI = bind(ctypes.CDLL(_PATH))
-        _load_gemm_tuning()
     return _ABI
 
 
 _GEMM_TUNING = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'gemm_tuning_gfx950.csv')
+_TUNING_STATE = None     # None: not tried; True: solutions loaded; False: unavailable (off, no file, rejected, user-owned)
 
 
-def _load_gemm_tuning():
-    """The fp32 path keeps LIBRARY GEMMs for the C x C linear of the coefficient generator; the
-    rocBLAS / hipBLASLt solutions PyTorch's TunableOp selected for those shapes on an MI355X (tools/tune_gemm.py) ship
-    with the package and are handed to TunableOp with tuning disabled - shapes that are not in the file run the default
-    heuristic as before.  FETA_TUNED_GEMM=0 leaves TunableOp alone."""
-    if os.environ.get('FETA_TUNED_GEMM', '1') == '0' or not os.path.exists(_GEMM_TUNING):
-        return
-    try:
-        if torch.cuda.is_available() and not torch.cuda.tunable.is_enabled():
-            torch.cuda.tunable.enable(True)
-            torch.cuda.tunable.tuning_enable(False)
-            torch.cuda.tunable.read_file(_GEMM_TUNING)
-    except Exception:      # (a library tuning file is never a reason to fail)
-        pass
+def _tuning_ready():
+    """Loads the recorded solutions once.  Nothing is left switched on: TunableOp's enable / tuning flags are process
+    state of the HOST program and are only touched inside `tuned_gemm` blocks (ADVICE / VERDICT round 3)."""
+    global _TUNING_STATE
+    if _TUNING_STATE is None:
+        _TUNING_STATE = False
+        try:
+            tn = torch.cuda.tunable
+            if (os.environ.get('FETA_TUNED_GEMM', '1') != '0' and os.path.exists(_GEMM_TUNING)
+                    and torch.cuda.is_available() and not tn.is_enabled()):     # (enabled already: the user's own tuning)
+                was_tuning = tn.tuning_is_enabled()
+                tn.enable(True)
+                try:
+                    tn.tuning_enable(False)
+                    _TUNING_STATE = bool(tn.read_file(_GEMM_TUNING))     # False: validators (ROCm / torch build) differ
+                finally:
+                    tn.tuning_enable(was_tuning)
+                    tn.enable(False)
+                if not _TUNING_STATE:
+                    import warnings
+                    warnings.warn('feta_tmlr_amd: %s was recorded for another rocBLAS / PyTorch build and is ignored '
+                                  '(the C x C linear runs the library default heuristic)' % os.path.basename(_GEMM_TUNING))
+        except Exception:      # (a library tuning file is never a reason to fail)
+            _TUNING_STATE = False
+    return _TUNING_STATE
+
+
+class tuned_gemm:
+    """``with tuned_gemm():`` around THIS package's library GEMM calls (the C x C linear of the coefficient generator on
+    the fp32 path): inside the block TunableOp looks the shapes up in the rocBLAS / hipBLASLt
+    solutions it selected on an MI355X (tools/tune_gemm.py -> gemm_tuning_gfx950.csv, tuning disabled); on exit the
+    host program's TunableOp state is what it was.  Inside a hipGraph capture the choice is made once, at capture.
+    FETA_TUNED_GEMM=0, a rejected file, or a host program that has TunableOp on for itself: the block is a no-op."""
+
+    def __enter__(self):
+        self.on = False
+        if _TEST_ABI is None and _tuning_ready() and not torch.cuda.tunable.is_enabled():
+            tn = torch.cuda.tunable
+            self.was_tuning = tn.tuning_is_enabled()
+            tn.enable(True)
+            tn.tuning_enable(False)
+            self.on = True
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            torch.cuda.tunable.tuning_enable(self.was_tuning)
+            torch.cuda.tunable.enable(False)
+        return False
 
 
 _TEST_ABI = None

@@ -171,7 +171,8 @@ class DenseLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias):
         ctx.save_for_backward(x, w)
-        return torch.addmm(bias, x, w.t())
+        with _lib.tuned_gemm():
+            return torch.addmm(bias, x, w.t())
 
     @staticmethod
     def backward(ctx, dy):
@@ -180,7 +181,8 @@ class DenseLinearFn(torch.autograd.Function):
         dy = dy.contiguous()
         db = torch.empty(dy.shape[1], dtype=dy.dtype, device=dy.device)
         abi.colsum(dy, db, stream)
-        return dy.mm(w), dy.t().mm(x), db
+        with _lib.tuned_gemm():
+            return dy.mm(w), dy.t().mm(x), db
 
 
 def dense_linear(x, w, bias):
@@ -383,7 +385,8 @@ class FilterFromPooledFn(torch.autograd.Function):
                 coeff += lin_b
             ctx.lp = (p16, w16)       # (the backward's operands: no second pair of cast launches)
         else:
-            coeff = torch.addmm(lin_b, pooled, lin_w.t())
+            with _lib.tuned_gemm():
+                coeff = torch.addmm(lin_b, pooled, lin_w.t())
         ctx.pending = pending
         # pooled's gradient flows into FilterCoefficientsFn: if that node flushes, it runs after this one
         ctx.defer = pending is not None and pending.coeff_armed and ctx.needs_input_grad[1] and not ctx.own_gemm
@@ -441,8 +444,9 @@ class FilterFromPooledFn(torch.autograd.Function):
             if ctx.defer and PendingSums.untouched(*ctx.params):
                 for pr in sums:
                     ctx.pending.add(*pr)
+                # (dbias is None when only the coefficients were used downstream - a regulariser on them, dy is None)
                 ctx.pending.owners += [(p_, g_.detach()) for p_, g_ in ((ctx.params[0], db_lin), (ctx.params[1], dbias))
-                                       if p_ is not None]
+                                       if p_ is not None and g_ is not None]
             else:
                 abi.colsum_multi(sums, stream)
             if ctx.lib_bf16:
@@ -451,7 +455,8 @@ class FilterFromPooledFn(torch.autograd.Function):
                 dpooled = torch.mm(d16, w16, out_dtype=torch.float32)
                 dw_lin = torch.mm(d16.t(), p16, out_dtype=torch.float32)
             else:
-                dpooled, dw_lin = dcoeff.mm(lin_w), dcoeff.t().mm(pooled)
+                with _lib.tuned_gemm():
+                    dpooled, dw_lin = dcoeff.mm(lin_w), dcoeff.t().mm(pooled)
         if not has_bias:
             dbias = None
         return (dx, dpooled, dw_lin, db_lin, dbias) + (None,) * 9
@@ -719,7 +724,11 @@ class DropoutState:
     therefore draws the masks the eager loop would have drawn at that step."""
     seed = None
     offset = 0
-    _dev = None      # int64 [seed, offset] on the device of the captured step
+    _dev = None      # int64 [seed, offset] on the device of the captured steps (device mode), else None
+    _keys = {}       # device -> THE key tensor of that device.  Captured graphs hold its raw address (the kernels read
+    #                  it at run time, the captured end_step add writes it), so it is created once per device and never
+    #                  replaced or freed: a second GraphedTrainStep (one per padded-size bucket) shares it - and with it
+    #                  ONE offset stream, so buckets never replay each other's (seed, offset) pairs
     _calls = 0       # masked calls so far in the current step (device mode)
 
     @classmethod
@@ -729,9 +738,10 @@ class DropoutState:
 
     @classmethod
     def _sync_device(cls):
-        if cls._dev is not None:
-            cls._dev.copy_(torch.tensor([cls.seed, cls.offset], dtype=torch.int64))
-            cls._calls = 0
+        """host (seed, offset) -> every key tensor that exists (graphs captured on any device follow a re-seed)"""
+        for key in cls._keys.values():
+            key.copy_(torch.tensor([cls.seed, cls.offset], dtype=torch.int64))
+        cls._calls = 0
 
     @classmethod
     def device_mode(cls):
@@ -741,11 +751,20 @@ class DropoutState:
     def begin_device_mode(cls, device):
         if cls.seed is None:
             cls.manual_seed(torch.initial_seed())
-        cls._dev = torch.tensor([cls.seed, cls.offset], dtype=torch.int64).to(device)
+        device = torch.device(device)
+        if device.type == 'cuda' and device.index is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        key = cls._keys.get(device)
+        if key is None:
+            key = cls._keys[device] = torch.zeros(2, dtype=torch.int64, device=device)
+        key.copy_(torch.tensor([cls.seed, cls.offset], dtype=torch.int64))
+        cls._dev = key
         cls._calls = 0
 
     @classmethod
     def end_device_mode(cls):
+        """Back to host-held keys.  The key tensors stay alive (graphs captured in device mode may still be replayed:
+        they keep reading and advancing their device's key)."""
         cls._dev = None
         cls._calls = 0
 

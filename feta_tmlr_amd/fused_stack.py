@@ -337,6 +337,10 @@ class FusedEncoderStackFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_final, d_concat_last, _d_attn):
         saved, params = ctx.saved_state, ctx.params
+        if d_final is None and d_concat_last is None:
+            # nothing downstream used the stack (e.g. a loss on the filter coefficients alone: they derive from the
+            # DETACHED attention matrix, transformer/models.py:282) - autograd still visits the node, with no gradient
+            return (None,) * (8 + len(params))
         n, b, d, heads, dh, tie, scale, G, nl = ctx.meta
         pe_c, degree_rows, n_real = ctx.aux
         abi, stream = _lib.backend(saved[0]['qkv'])
@@ -603,6 +607,8 @@ class FusedLayerNormStackFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_final, d_concat_last, _d_attn):
         saved, params = ctx.saved_state, ctx.params
+        if d_final is None and d_concat_last is None:
+            return (None,) * (8 + len(params))      # (see FusedEncoderStackFn.backward)
         n, b, d, heads, dh, tie, scale, nl = ctx.meta
         pe_c, degree_rows, n_real = ctx.aux
         abi, stream = _lib.backend(saved[0]['qkv'])

@@ -110,6 +110,9 @@ def train_step(task, model, criterion, optimizer, batch9, graph_cache=None, lr=N
     loss, _ = task_loss(task, model, criterion, batch9, graph_cache)
     loss.backward()
     optimizer.step()
+    from .functional import DropoutState
+    if DropoutState.device_mode():
+        DropoutState.end_step()      # (an eager step between graph replays: the shared device offset moves past its masks)
     return loss.detach()
 
 

@@ -371,8 +371,9 @@ int feta_rowlin_fwd_ex(const feta_rowlin_ex* d, feta_stream_t stream);
 int feta_rowlin_bwd_ex(const feta_rowlin_ex* d, float* dwdb, feta_stream_t stream);
 
 /* out = BN(y) written explicitly (end of the stack), publishing the bn parameter block [4][D].
- * stats holds G_stats partial rows [G_stats][2][D] (0: feta_rowlin_blocks(M), the producer was a
- * feta_rowlin_fwd*; feta_ffn_blocks(M) after feta_ffn_fwd; B after feta_attn_block_fwd). */
+ * stats holds G_stats partial rows and, behind them, the shift row: [G_stats + 1][2][D] (G_stats = 0 means
+ * feta_rowlin_blocks(M), the producer was a feta_rowlin_fwd*; feta_ffn_blocks(M) after feta_ffn_fwd;
+ * feta_attn_block_stat_rows(B, N) after feta_attn_block_fwd). */
 int feta_bn_apply_fwd_prm(const float* y, const float* stats, const float* gamma, const float* beta,
                           float* out, float* bn_prm, float* running_mean, float* running_var,
                           int64_t* num_batches_tracked, float momentum, float eps, int M, int D, int G_stats,
@@ -382,7 +383,9 @@ int feta_bn_bwd_reduce(const float* y, const float* dout, const float* bn_prm, f
                        int M, int D, feta_stream_t stream);
 
 /* Training-mode BatchNorm1d over the M rows (padded rows included, as nn.BatchNorm1d on the
- * [N*B, d] view does).  stats [feta_rowlin_blocks(M), 2, D] from feta_rowlin_fwd or feta_bn_stats.
+ * [N*B, d] view does).  stats [feta_rowlin_blocks(M) + 1, 2, D] from feta_rowlin_fwd or feta_bn_stats:
+ * G = feta_rowlin_blocks(M) partial rows PLUS ONE shift row (ABI 7: the sums are relative to the shift recorded in
+ * row G; feta_bn_stats writes zeros there) - a caller that sizes the buffer with G rows gets a D-float overrun.
  * mean_rstd [2, D] is saved for backward; running_* (nullable) are updated with momentum and the
  * unbiased variance, num_batches_tracked (nullable, int64) is advanced by one, as nn.BatchNorm1d does. */
 int feta_bn_stats(const float* y, float* stats, int M, int D, feta_stream_t stream);

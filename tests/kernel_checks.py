@@ -40,9 +40,35 @@ GUARD_FACTOR, GUARD_FLOOR = 4.0, 3e-7
 _GUARD_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'gpu_measured_errors.json')
 _RECORD = os.environ.get('FETA_RECORD_ERRORS')
 _guard_table, _guard_seen, _guard_new = {}, {}, {}
+_guard_validators = None     # what the table was recorded on: the guard only holds there
 if os.path.exists(_GUARD_PATH) and not _RECORD and os.environ.get('FETA_ERROR_GUARD', '1') != '0':
     with open(_GUARD_PATH) as _f:
-        _guard_table = json.load(_f).get('errors', {})
+        _j = json.load(_f)
+        _guard_table, _guard_validators = _j.get('errors', {}), _j.get('validators')
+
+
+def _validators():
+    """Device and library builds a recorded rounding belongs to: library GEMMs (rocBLAS / hipBLASLt solutions) and the
+    compiler's instruction selection change with them, the tolerance bars of the checks do not."""
+    return {'device': torch.cuda.get_device_name(0) if torch.cuda.is_available() else None,
+            'torch': torch.__version__, 'hip': getattr(torch.version, 'hip', None)}
+
+
+_guard_checked = False
+
+
+def _guard_active():
+    """The recorded errors are one sample from one (device, ROCm, torch) build: on any other the guard is off (the
+    tolerance bars still hold) and says so once."""
+    global _guard_checked, _guard_table
+    if not _guard_checked:
+        _guard_checked = True
+        if _guard_table and _guard_validators is not None and _guard_validators != _validators():
+            import warnings
+            warnings.warn('tests/golden/gpu_measured_errors.json was recorded on %s; this is %s: regression guard off'
+                          % (_guard_validators, _validators()))
+            _guard_table = {}
+    return bool(_guard_table)
 
 
 def _guard_key(name):
@@ -63,7 +89,8 @@ def _guard_flush():
             old[k] = max(v, old.get(k, 0.0))
         with open(_RECORD, 'w') as f:
             json.dump({'what': 'relative errors err / max(1, max|ref|) of the fp32 checks of one `pytest -m gpu` run on an '
-                               'MI355X (tests/kernel_checks.py: regression guard)', 'errors': dict(sorted(old.items()))},
+                               'MI355X (tests/kernel_checks.py: regression guard)', 'validators': _validators(),
+                       'errors': dict(sorted(old.items()))},
                       f, indent=0)
 
 
@@ -79,7 +106,7 @@ def assert_close(name, got, ref, tol=TOL):
         key, rel = _guard_key(name), err / scale
         if _RECORD:
             _guard_new[key] = max(rel, _guard_new.get(key, 0.0))
-        elif key in _guard_table:
+        elif _guard_active() and key in _guard_table:
             bar = max(GUARD_FACTOR * _guard_table[key], GUARD_FLOOR)
             assert rel <= bar, ('%s: relative error %.3e, %.1fx the recorded %.3e (tests/golden/gpu_measured_errors.json)'
                                 % (name, rel, rel / max(_guard_table[key], 1e-30), _guard_table[key]))

@@ -355,6 +355,20 @@ def test_deferred_column_sums_and_gradient_accumulation(emu, monkeypatch, own_ge
             for n, p in model.named_parameters():
                 if p.grad is not None:
                     KC.assert_close('create_graph ' + n, p.grad.detach(), once[n].double(), tol=1e-6)
+            # only the coefficients carry a loss (a regulariser on them alone): the filter's own gradient is None, its
+            # bias gets no gradient, and the deferred path must not trip over that
+            model.zero_grad(set_to_none=True)
+            out, _, coeff = model(x, edge_index, batch, fi, mask, pe, degree=degree, return_filter_coeff=True,
+                                  graph_cache=cache)
+            (0.01 * coeff.pow(2).sum()).backward()
+            assert model.encoder.spectral_gnns.bias.grad is None
+            c_only = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+            model.zero_grad(set_to_none=True)
+            out, _, coeff = model(x, edge_index, batch, fi, mask, pe, degree=degree, return_filter_coeff=True,
+                                  graph_cache=cache)
+            ref_c = torch.autograd.grad(0.01 * coeff.pow(2).sum(), [model.encoder.linear.bias, model.encoder.linear.weight])
+            KC.assert_close('coefficients only: linear.bias', c_only['encoder.linear.bias'], ref_c[0].double(), tol=1e-6)
+            KC.assert_close('coefficients only: linear.weight', c_only['encoder.linear.weight'], ref_c[1].double(), tol=1e-6)
             model.zero_grad(set_to_none=True)
             h = model.encoder.linear.bias.register_hook(lambda g: seen.append(g.clone()))
             run()

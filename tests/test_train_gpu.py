@@ -123,3 +123,51 @@ def test_graphed_train_step_with_attention_dropout(hip):
         assert FF.DropoutState._dev.tolist() == [77, 3 * graphed.drop_calls]
     finally:
         FF.DropoutState.end_device_mode()
+
+
+def test_two_graphed_steps_share_one_dropout_key(hip):
+    """One GraphedTrainStep per padded-size bucket (the class docstring's use): both graphs hold the address of the SAME
+    persistent device key, so building the second does not orphan the first one's key (the key tensor
+    was replaced, graph 1 then read freed memory), interleaved replays draw the offsets the eager loop draws on the same
+    batch sequence, a re-seed reaches both graphs, and an eager step between replays advances the shared offset."""
+    from feta_tmlr_amd import functional as FF
+    dev = hip[1]
+    task = 'tu'
+    model_a, batch_x, cache_x = TC.build_case(task, dev, batch_norm=False, seed=0, bsz=4)
+    _, batch_y, cache_y = TC.build_case(task, dev, batch_norm=False, seed=5, bsz=6)       # another bucket: other [B, N_pad]
+    model_b, _, _ = TC.build_case(task, dev, batch_norm=False, seed=0, bsz=4)
+    model_b.load_state_dict(model_a.state_dict())
+    for m in (model_a, model_b):
+        for layer in m.encoder.layers:
+            layer.self_attn.dropout = 0.2
+        m.train()
+    crit = T.make_criterion(task, nb_class=3)
+    opt_a = T.make_optimizer(task, model_a.parameters(), lr=0.0)
+    opt_b = T.make_optimizer(task, model_b.parameters(), lr=0.0, capturable=True)
+    seq = [(batch_x, cache_x), (batch_y, cache_y), (batch_x, cache_x), (batch_y, cache_y), (batch_x, cache_x)]
+    try:
+        FF.DropoutState.manual_seed(123)
+        eager = [float(T.train_step(task, model_a, crit, opt_a, b9, T.prepare_cache(model_a, b9, c))) for b9, c in seq]
+        assert len(set(eager)) == len(eager)            # lr = 0: only masks / batches differ - and they all do
+        FF.DropoutState.manual_seed(999)                # (the graphs are built under another seed and re-seeded below)
+        gx = T.GraphedTrainStep(task, model_b, crit, opt_b, batch_x, cache_x)
+        key_x = FF.DropoutState._dev
+        gy = T.GraphedTrainStep(task, model_b, crit, opt_b, batch_y, cache_y)
+        assert FF.DropoutState._dev is key_x and FF.DropoutState._dev.data_ptr() == key_x.data_ptr()
+        # churn the caching allocator: a key that had been freed would be overwritten here
+        junk = [torch.full((2,), 7, dtype=torch.int64, device=dev) for _ in range(64)]
+        del junk
+        FF.DropoutState.manual_seed(123)
+        got = []
+        for i, (b9, c) in enumerate(seq):
+            if i == 2:      # an eager step in the middle of the replays (device mode stays on)
+                got.append(float(T.train_step(task, model_b, crit, opt_b, b9, T.prepare_cache(model_b, b9, c))))
+            else:
+                got.append(float((gx if b9 is batch_x else gy)(b9, c)))
+        for i, (a, b) in enumerate(zip(eager, got)):
+            assert abs(a - b) <= 3e-5 * max(1.0, abs(a)), (i, eager, got)
+        torch.cuda.synchronize()
+        calls = gx.drop_calls
+        assert FF.DropoutState._dev.tolist() == [123, len(seq) * calls] and FF.DropoutState.snapshot() == (123, len(seq) * calls)
+    finally:
+        FF.DropoutState.end_device_mode()
