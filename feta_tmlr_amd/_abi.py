@@ -141,7 +141,7 @@ class AttnBlock(C.Structure):
         ('rowscale', _F), ('qkv', _F), ('out', _F), ('attn_stats', _F), ('attn', _F), ('y', _F),
         ('y_stats', _F), ('scale', C.c_float), ('B', C.c_int), ('N', C.c_int), ('M', C.c_int),
         ('row_sb', C.c_int64), ('row_sn', C.c_int64), ('tie_qk', C.c_int), ('dtype', C.c_int), ('y_shift', _F),
-        ('out_f32', _F),
+        ('out_f32', _F), ('x_ln_gamma', _F), ('x_ln_beta', _F),
     ]
 
 
@@ -178,6 +178,7 @@ class Ffn(C.Structure):
         ('momentum', C.c_float), ('eps', C.c_float),
         ('w1', _F), ('b1', _F), ('w2', _F), ('b2', _F), ('h', _F), ('y', _F), ('y_stats', _F),
         ('M', C.c_int), ('FF', C.c_int), ('dtype', C.c_int), ('y_shift', _F), ('y_f32', C.c_int),
+        ('x_ln_gamma', _F), ('x_ln_beta', _F),
     ]
 
 
@@ -196,6 +197,7 @@ class AttnBlockGrad(C.Structure):
         ('pe', _F), ('n_real', _I), ('attn_stats', _F), ('x0', _F), ('bn0', _F), ('dx', _F), ('dx_b', _F), ('sum_out', _F),
         ('partial', _F), ('partial_ld', C.c_int), ('scale', C.c_float), ('B', C.c_int), ('N', C.c_int), ('M', C.c_int),
         ('row_sb', C.c_int64), ('row_sn', C.c_int64), ('dtype', C.c_int), ('dout2_f32', C.c_int),
+        ('ln1_gamma', _F), ('x0_ln_gamma', _F), ('x0_ln_beta', _F), ('ln_eps', C.c_float),
     ]
 
 
@@ -213,6 +215,7 @@ class FfnGrad(C.Structure):
         ('dy', _F), ('dy_b', _F), ('g_y', _F), ('g_bn', _F), ('g_sum', _F), ('Gs', C.c_int), ('g_fin', _F), ('g_fin_out', _F),
         ('dgamma', _F), ('dbeta', _F), ('h', _F), ('w2', _F), ('w1', _F), ('x', _F), ('x_bn', _F), ('dx', _F),
         ('sum_out', _F), ('partial', _F), ('partial_ld', C.c_int), ('M', C.c_int), ('FF', C.c_int), ('dtype', C.c_int), ('g_f32', C.c_int),
+        ('g_ln_gamma', _F), ('x_ln_gamma', _F), ('x_ln_beta', _F), ('ln_eps', C.c_float),
     ]
 
 
@@ -223,7 +226,7 @@ SIGNATURES.update({
     'feta_ffn_bwd_coeff': ([C.POINTER(FfnGrad), C.POINTER(CoeffBwdRole), _S], C.c_int),
 })
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class FetaError(RuntimeError):
@@ -595,11 +598,12 @@ class Abi:
     def attn_block_bwd_blocks(self, b):
         return int(self.lib.feta_attn_block_bwd_blocks(b))
 
-    def attn_block_bwd(self, b, n, scale, stream, seq_first=True, Gs=0, partial_ld=0, partial_ptr=None, sums=(), **ptrs):
+    def attn_block_bwd(self, b, n, scale, stream, seq_first=True, Gs=0, partial_ld=0, partial_ptr=None, sums=(), ln_eps=1e-5,
+                       **ptrs):
         """feta_attn_block_bwd; tensor-valued keyword arguments become the descriptor's pointers.  sums: [(in [R, C],
         out [C])] column sums that ride in trailing workgroups of the launch (feta_attn_block_bwd_sums)"""
         d = AttnBlockGrad()
-        d.B, d.N, d.M, d.scale, d.Gs, d.partial_ld = b, n, b * n, scale, Gs, partial_ld
+        d.B, d.N, d.M, d.scale, d.Gs, d.partial_ld, d.ln_eps = b, n, b * n, scale, Gs, partial_ld, ln_eps
         d.row_sb, d.row_sn = (1, b) if seq_first else (n, 1)
         if partial_ptr is not None:
             d.partial = partial_ptr
@@ -652,9 +656,9 @@ class Abi:
     def ffn_bwd_blocks(self, m):
         return int(self.lib.feta_ffn_bwd_blocks(m))
 
-    def ffn_bwd_desc(self, m, ff, Gs=0, partial_ld=0, partial_ptr=None, **ptrs):
+    def ffn_bwd_desc(self, m, ff, Gs=0, partial_ld=0, partial_ptr=None, ln_eps=1e-5, **ptrs):
         d = FfnGrad()
-        d.M, d.FF, d.Gs, d.partial_ld = m, ff, Gs, partial_ld
+        d.M, d.FF, d.Gs, d.partial_ld, d.ln_eps = m, ff, Gs, partial_ld, ln_eps
         if partial_ptr is not None:
             d.partial = partial_ptr
         d.dtype = _stack_dtype(ptrs, ('dy', 'dy_b', 'g_y', 'h', 'x', 'dx'), f32_ok=('dy', 'g_y'))

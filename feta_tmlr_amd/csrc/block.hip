@@ -20,6 +20,7 @@
 
 #include "feta_abi_common.h"
 #include "feta_colsum.h"
+#include "feta_ln.h"
 #include "feta_lp.h"
 #include "feta_rowops.h"
 
@@ -186,7 +187,10 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
     }
   } else if (a.x_bn != nullptr) {
     for (int c = tid; c < 2 * D; c += kRowThreads) xss[c] = a.x_bn[c];
+  } else if (a.x_ln_gamma != nullptr) {   // LayerNorm on load (feta_ln.h): xss = gamma | beta
+    for (int c = tid; c < 2 * D; c += kRowThreads) xss[c] = c < D ? a.x_ln_gamma[c] : a.x_ln_beta[c - D];
   }
+  const bool x_ln = a.x_ln_gamma != nullptr;
   FETA_STAMP(7);
   bool first = true;
   for (int b = blockIdx.x; b < a.B; b += main_grid) {
@@ -208,6 +212,13 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
       L::unpack(v, f);
 #pragma unroll
       for (int e = 0; e < L::VEC; ++e) f[e] = f[e] * xss[L::VEC * q + e] + xss[D + L::VEC * q + e];
+      v = L::pack(f);
+    } else if (x_ln) {
+      // the row is held by RV consecutive lanes: mean / rstd by DPP sums over them, then gamma / beta (a wave-uniform
+      // branch: a wave stages whole rows)
+      float f[L::VEC];
+      L::unpack(v, f);
+      ln_apply<L::VEC>(f, xss + L::VEC * q, xss + D + L::VEC * q, a.eps);
       v = L::pack(f);
     }
     L::stv(Xs + node * P + L::VEC * q, v);  // rows >= N: a copy of row N-1, never stored
@@ -431,14 +442,16 @@ __global__ __launch_bounds__(kRowThreads) void attn_block_fwd_kernel(BlockArgs a
       float v[4] = {(t[0] + bo.x) * rs + res[0], (t[1] + bo.y) * rs + res[1], (t[2] + bo.z) * rs + res[2],
                     (t[3] + bo.w) * rs + res[3]};
       if (rok) L::st4(gy + row * D + o0, v[0], v[1], v[2], v[3]);
+      if (a.y_stats != nullptr) {   // (NULL: LayerNorm stack - nobody needs column statistics)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float x1 = rok ? v[r] - kv[r] : 0.0f;
-        s1[r] += row16_sum(x1);
-        s2[r] += row16_sum(x1 * x1);
+        for (int r = 0; r < 4; ++r) {
+          const float x1 = rok ? v[r] - kv[r] : 0.0f;
+          s1[r] += row16_sum(x1);
+          s2[r] += row16_sum(x1 * x1);
+        }
       }
     }
-    if (lq == 0) {
+    if (lq == 0 && a.y_stats != nullptr) {
       float* st = a.y_stats + (int64_t)b * 2 * D;
       *reinterpret_cast<float4*>(st + o0) = make_float4(s1[0], s1[1], s1[2], s1[3]);
       *reinterpret_cast<float4*>(st + D + o0) = make_float4(s2[0], s2[1], s2[2], s2[3]);
@@ -611,7 +624,10 @@ __global__ __launch_bounds__(kBlk8Threads) void attn_block_fwd8_kernel(BlockArgs
     }
   } else if (a.x_bn != nullptr) {
     for (int c = tid; c < 2 * D; c += TH) xss[c] = a.x_bn[c];
+  } else if (a.x_ln_gamma != nullptr) {   // LayerNorm on load (feta_ln.h): xss = gamma | beta
+    for (int c = tid; c < 2 * D; c += TH) xss[c] = c < D ? a.x_ln_gamma[c] : a.x_ln_beta[c - D];
   }
+  const bool x_ln = a.x_ln_gamma != nullptr;
   FETA_STAMP(7);
   bool first = true;
   const int lane0 = lane;
@@ -637,6 +653,13 @@ __global__ __launch_bounds__(kBlk8Threads) void attn_block_fwd8_kernel(BlockArgs
       L::unpack(v, f);
 #pragma unroll
       for (int e = 0; e < L::VEC; ++e) f[e] = f[e] * xss[L::VEC * q + e] + xss[D + L::VEC * q + e];
+      v = L::pack(f);
+    } else if (x_ln) {
+      // the row is held by RV consecutive lanes: mean / rstd by DPP sums over them, then gamma / beta (a wave-uniform
+      // branch: a wave stages whole rows)
+      float f[L::VEC];
+      L::unpack(v, f);
+      ln_apply<L::VEC>(f, xss + L::VEC * q, xss + D + L::VEC * q, a.eps);
       v = L::pack(f);
     }
     L::stv(Xs + node * P + L::VEC * q, v);  // rows >= N: a copy of row N-1, never stored
@@ -882,13 +905,16 @@ __global__ __launch_bounds__(kBlk8Threads) void attn_block_fwd8_kernel(BlockArgs
       float v[4] = {(t[0] + bo.x) * rs + res[0], (t[1] + bo.y) * rs + res[1], (t[2] + bo.z) * rs + res[2],
                     (t[3] + bo.w) * rs + res[3]};
       if (rok) L::st4(gy + row * D + o0, v[0], v[1], v[2], v[3]);
+      if (a.y_stats != nullptr) {   // (NULL: LayerNorm stack - nobody needs column statistics)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float x1 = rok ? v[r] - kv[r] : 0.0f;
-        s1[r] += row16_sum(x1);
-        s2[r] += row16_sum(x1 * x1);
+        for (int r = 0; r < 4; ++r) {
+          const float x1 = rok ? v[r] - kv[r] : 0.0f;
+          s1[r] += row16_sum(x1);
+          s2[r] += row16_sum(x1 * x1);
+        }
       }
     }
+    if (a.y_stats == nullptr) continue;
     // the two parities of a head hold sums over different rows of the same columns: odd hands over, even adds and stores
     if (p == 1 && lq == 0) {
       float* e = sx + (4 * h + g) * 8;
@@ -1019,7 +1045,7 @@ extern "C" int feta_attn_block_fwd_sums(const feta_attn_block* d, const feta_col
                "attn_block_fwd: 0..%d column-sum segments", FETA_COLSUM_MAX_SEGS);
   for (int i = 0; i < nseg; ++i) FETA_REQUIRE(colsum_seg_ok(segs[i]), "attn_block_fwd: bad segment %d", i);
   const BlockArgs& a = *d;
-  FETA_REQUIRE(a.x && a.w_in && a.w_out && a.n_real && a.qkv && a.out && a.attn_stats && a.y && a.y_stats,
+  FETA_REQUIRE(a.x && a.w_in && a.w_out && a.n_real && a.qkv && a.out && a.attn_stats && a.y,
                "attn_block_fwd: null pointer");
   FETA_REQUIRE(a.B > 0 && a.N >= 1 && a.N <= 64, "attn_block_fwd: N=%d outside [1,64]", a.N);
   FETA_REQUIRE(a.M == a.B * a.N, "attn_block_fwd: M=%d is not B*N", a.M);
@@ -1029,6 +1055,8 @@ extern "C" int feta_attn_block_fwd_sums(const feta_attn_block* d, const feta_col
                aligned16(a.y) && aligned16(a.y_stats) && aligned16(a.x_stats) && aligned16(a.b_in) && aligned16(a.b_out) &&
                aligned16(a.out_f32) && aligned16(a.y_shift),
                "attn_block_fwd: tensors must be 16-byte aligned");
+  FETA_REQUIRE(a.x_ln_gamma == nullptr || (a.x_ln_beta != nullptr && a.x_stats == nullptr && a.x_bn == nullptr),
+               "attn_block_fwd: x_ln_gamma needs x_ln_beta and excludes x_bn / x_stats");
   FETA_REQUIRE(a.dtype == FETA_F32 || a.dtype == FETA_BF16, "attn_block_fwd: dtype %d", a.dtype);
   if (a.dtype == FETA_BF16) return dispatch_block_fwd<bf16_t>(a, segs, nseg, (hipStream_t)stream);
   return dispatch_block_fwd<float>(a, segs, nseg, (hipStream_t)stream);

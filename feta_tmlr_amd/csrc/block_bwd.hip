@@ -26,6 +26,7 @@
 
 #include "feta_abi_common.h"
 #include "feta_colsum.h"
+#include "feta_ln.h"
 #include "feta_lp.h"
 #include "feta_rowops.h"
 
@@ -40,13 +41,14 @@ constexpr int kBbMaxGrid = 256;
 
 // LDS bytes of a workgroup: seven [NR][64 + pad] tiles of T, fp32 for everything else
 template <class T>
-__host__ __device__ inline int block_bwd_lds_bytes(int nt, bool gbn) {
+__host__ __device__ inline int block_bwd_lds_bytes(int nt, bool gbn, bool gln = false) {
   const int nr = 16 * nt, P = kBbD + Lp<T>::PAD;
   return (int)sizeof(T) * 7 * nr * P    // q, k, v (later dq, dk, dv), dconcat, out, g1, x0
          + 4 * (nr * (nr + 1)           // pe
                 + kBbH * nr * 2 + nr    // softmax statistics, row scale
                 + 8 * kBbD + 8 * 2 * 16 // fp32 column sums of the bias gradients: db_out per wave, dq | dk | dv per wave
-                + (gbn ? 5 * kBbD + reduce_scratch_floats(kBbD, 512) : 0));
+                + (gbn ? 5 * kBbD + reduce_scratch_floats(kBbD, 512) : 0)
+                + (gln ? 8 * 2 * kBbD : 0));   // LayerNorm stack: column sums of (dy xhat1, dy) per wave
 }
 
 #ifdef FETA_TIMING
@@ -117,7 +119,12 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a, C
   const T* gd2 = reinterpret_cast<const T*>(a.dout2);
   const T* gpe = reinterpret_cast<const T*>(a.pe);
   const T* gx0 = reinterpret_cast<const T*>(a.x0);
-  const bool gbn = a.y1 != nullptr;
+  const bool gbn = a.bn1 != nullptr;
+  // LayerNorm stack (feta_ln.h): dy is the gradient w.r.t. LN1(y1) and its LayerNorm backward is taken per row where the
+  // gradient rows are staged; x0 holds pre-norm rows and is normalised where IT is staged
+  const bool gln = a.ln1_gamma != nullptr, x0ln = a.x0_ln_gamma != nullptr;
+  const bool has_y1 = a.y1 != nullptr;
+  float* DGL = gv;                // [8 waves][2][64] column sums of (dy xhat1, dy) (gv itself is BatchNorm's)
   const bool has_pe = a.pe != nullptr;
   const bool want_sums = a.sum_out != nullptr;
   const bool xbn = a.bn0 != nullptr;
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a, C
       dyv[i] = L::ldv(gdy + row * D + c4);
       // (no ternary on a whole vector: it is lowered to a private-memory select - the operands are read through a
       // pointer that falls back to a tensor which is always there)
-      y1v[i] = L::ldv((gbn ? gy1 : gdy) + row * D + c4);
+      y1v[i] = L::ldv((has_y1 ? gy1 : gdy) + row * D + c4);
       x0v[i] = L::ldv(gx0 + row * D + c4);
       if (d2_f32) {   // the filter branch's gradient arrives as fp32 behind a bf16 stack: rounded here
         float f[VEC];
@@ -241,6 +248,29 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a, C
     float dbo[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) dbo[e] = 0.0f;
+    // a thread stages the same VEC columns of every row it touches: its slices of gamma1 / gamma0 / beta0 and its column
+    // sums of (dy xhat1, dy) are registers (requested here, through laundered pointers: they live through the staging
+    // loop only, not across the graph loop)
+    float gl1[VEC], gl0[VEC], bl0[VEC], dgam[VEC], dbet[VEC];
+    {
+      const float* p1 = gln ? a.ln1_gamma : a.w_out;
+      const float* p0 = x0ln ? a.x0_ln_gamma : a.w_out;
+      const float* q0 = x0ln ? a.x0_ln_beta : a.w_out;
+      if (LOOP) {
+        FETA_OPAQUE_PTR(p1);
+        FETA_OPAQUE_PTR(p0);
+        FETA_OPAQUE_PTR(q0);
+      }
+      const feta_gcf p1g = (feta_gcf)p1, p0g = (feta_gcf)p0, q0g = (feta_gcf)q0;
+      const int c0v = VEC * (tid % RV);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        gl1[e] = p1g[c0v + e];
+        gl0[e] = p0g[c0v + e];
+        bl0[e] = q0g[c0v + e];
+        dgam[e] = dbet[e] = 0.0f;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < RI; ++i) {
       const int idx = tid + kBbThreads * i;
@@ -260,10 +290,24 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a, C
         put(Ks, kv[i], rkv);
         put(Vs, vv[i], rkv);
         put(Os, ov[i], rk);
-        put(X0, x0v[i], rk);
+        if (x0ln) {   // x0 = LayerNorm(pre-norm row) * gamma0 + beta0 (a wave stages whole rows: wave-uniform)
+          float f[VEC];
+          L::unpack(x0v[i], f);
+          ln_apply<VEC>(f, gl0, bl0, a.ln_eps);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) f[e] = rk ? f[e] : 0.0f;
+          L::stv(X0 + off, L::pack(f));
+        } else {
+          put(X0, x0v[i], rk);
+        }
         put(Ds, d2v[i], dk2);     // dout2; the product is added below
         float v[VEC];
         L::unpack(dyv[i], v);
+        if (gln) {
+          float yy[VEC];
+          L::unpack(y1v[i], yy);
+          ln_backward<VEC>(v, yy, gl1, a.ln_eps, rk, dgam, dbet);
+        }
         if (gbn) {
           float yy[VEC];
           L::unpack(y1v[i], yy);
@@ -291,6 +335,24 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a, C
       sv += shfl_xor(sv, 32);
       if (lane < RV) DBO[wv * D + VEC * lane + e] = sv;
     }
+    if (gln) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float sg = dgam[e], sb = dbet[e];
+        if (RV <= 8) {
+          sg += shfl_xor(sg, 8);
+          sb += shfl_xor(sb, 8);
+        }
+        sg += shfl_xor(sg, 16);
+        sb += shfl_xor(sb, 16);
+        sg += shfl_xor(sg, 32);
+        sb += shfl_xor(sb, 32);
+        if (lane < RV) {
+          DGL[(wv * 2 + 0) * D + VEC * lane + e] = sg;
+          DGL[(wv * 2 + 1) * D + VEC * lane + e] = sb;
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < PEI; ++i) {
       const int idx = tid + kBbThreads * i;
@@ -299,12 +361,20 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a, C
     __syncthreads();
     BB_STAMP(2);
     float* prow = a.partial + (int64_t)(SPLIT ? b : (int)blockIdx.x) *
-                                  (a.partial_ld > 0 ? (int64_t)a.partial_ld : (int64_t)(4 * D * D + 4 * D));
+                                  (a.partial_ld > 0 ? (int64_t)a.partial_ld
+                                                    : (int64_t)(4 * D * D + 4 * D + (gln ? 2 * D : 0)));
     if (hp == 0 && tid < D) {
       float sv = 0.0f;
 #pragma unroll
       for (int w8 = 0; w8 < 8; ++w8) sv += DBO[w8 * D + tid];
       acc_to(prow + D * D + tid, sv, first);
+    }
+    if (gln && hp == 0 && tid >= D && tid < 3 * D) {   // [dgamma1 | dbeta1] behind db_in
+      const int which = (tid - D) / D, c = (tid - D) % D;
+      float sv = 0.0f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) sv += DGL[(w8 * 2 + which) * D + c];
+      acc_to(prow + 4 * D * D + 4 * D + which * D + c, sv, first);
     }
 
     // ---- dconcat^T tiles (c = 16h + 4g + r, row = 16 rt + lq) = sum_o W_out[o][c] (degree g1)[row][o] (+ dout2) ----
@@ -647,7 +717,7 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a, C
 
 template <class T, int NT>
 int launch_block_bwd(const BwdArgs& a, const feta_colsum_seg* segs, int nseg, hipStream_t stream) {
-  size_t lds = block_bwd_lds_bytes<T>(NT, a.y1 != nullptr);
+  size_t lds = block_bwd_lds_bytes<T>(NT, a.bn1 != nullptr, a.ln1_gamma != nullptr);
   const int grid = feta_attn_block_bwd_blocks(a.B);
   ColsumPlan plan{};
   const int tiles = plan_colsum(segs, nseg, plan);
@@ -721,7 +791,10 @@ extern "C" int feta_attn_block_bwd_sums(const feta_attn_block_grad* d, const fet
                "attn_block_bwd: the two-workgroup form (dx_b) needs one workgroup per graph (B=%d > %d)", a.B,
                feta_attn_block_bwd_blocks(a.B));
   FETA_REQUIRE(a.N >= 1 && a.N <= 64 && a.M == a.B * a.N, "attn_block_bwd: N=%d outside [1,64] or M != B*N", a.N);
-  FETA_REQUIRE(!a.y1 || (a.bn1 && a.g_sum && a.Gs > 0), "attn_block_bwd: y1 needs bn1, g_sum, Gs");
+  FETA_REQUIRE(!a.y1 || a.ln1_gamma || (a.bn1 && a.g_sum && a.Gs > 0), "attn_block_bwd: y1 needs bn1, g_sum, Gs - or ln1_gamma");
+  FETA_REQUIRE(!a.bn1 || a.y1, "attn_block_bwd: bn1 needs y1");
+  FETA_REQUIRE(!a.ln1_gamma || (a.y1 && !a.bn1 && !a.g_sum), "attn_block_bwd: ln1_gamma needs y1 and excludes bn1 / g_sum");
+  FETA_REQUIRE(!a.x0_ln_gamma || (a.x0_ln_beta && !a.bn0 && !a.sum_out), "attn_block_bwd: x0_ln_gamma needs x0_ln_beta and excludes bn0 / sum_out");
   FETA_REQUIRE(!a.sum_out || a.bn0, "attn_block_bwd: sum_out needs bn0");
   FETA_REQUIRE(aligned16(a.dy) && aligned16(a.qkv) && aligned16(a.out) && aligned16(a.x0) && aligned16(a.dx) &&
                aligned16(a.y1) && aligned16(a.dout2) && aligned16(a.g_sum) && aligned16(a.dx_b),

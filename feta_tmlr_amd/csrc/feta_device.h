@@ -101,6 +101,17 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+// Sum over the 8 lanes of HALF a DPP row (lanes with equal lane >> 3): an xor butterfly on the VALU - quad_perm [1,0,3,2],
+// quad_perm [2,3,0,1], row_half_mirror (lane i <-> 7 - i of the half row: after the two quad steps every lane of a quad
+// holds the quad's sum).  Every lane of the group gets bit for bit the same total.  (A 64-element bf16 row is 8 lanes of
+// 16 bytes: feta_ln.h.)
+__device__ __forceinline__ float row8_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
+  return v;
+}
+
 // A wave's DS operations execute in order; this only stops the compiler from
 // moving a wave-private LDS read above the write that another lane made.
 __device__ __forceinline__ void wave_lds_sync() {

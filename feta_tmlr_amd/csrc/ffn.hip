@@ -15,6 +15,7 @@
 
 #include "feta_abi_common.h"
 #include "feta_coeff.h"
+#include "feta_ln.h"
 #include "feta_lp.h"
 #include "feta_rowops.h"
 
@@ -155,9 +156,14 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a, CoeffFw
         if (c == 0 && a.x_nbt != nullptr) *a.x_nbt += 1;
       }
     }
+  } else if (a.x_ln_gamma != nullptr) {
+    // LayerNorm on load (feta_ln.h): xss = gamma | beta, mean / rstd per row where the rows are loaded
+    for (int c = tid; c < 2 * D; c += kRowThreads) xss[c] = c < D ? a.x_ln_gamma[c] : a.x_ln_beta[c - D];
   } else {
     for (int c = tid; c < 2 * D; c += kRowThreads) xss[c] = a.x_bn != nullptr ? a.x_bn[c] : (c < D ? 1.0f : 0.0f);
   }
+  const bool x_ln = a.x_ln_gamma != nullptr;
+  const float ln_eps = a.eps;
   __syncthreads();
   FFN_STAMP(2);
   const bool want_stats = a.y_stats != nullptr;
@@ -177,6 +183,31 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a, CoeffFw
     load_x();
   }
   RowOp<T, D> xf;
+  if (x_ln) {
+    // the row lq of this wave's tile is spread over the four lanes lq + 16 g (16 features each): mean and biased variance
+    // in two passes over the registers, as F.layer_norm; the scale / shift below then are gamma / beta
+    float s0 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s0 += (xr[j][0] + xr[j][1]) + (xr[j][2] + xr[j][3]);
+    s0 += shfl_xor(s0, 16);
+    s0 += shfl_xor(s0, 32);
+    const float mean = s0 * (1.0f / D);
+    float q0 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xr[j][e] -= mean;
+        q0 += xr[j][e] * xr[j][e];
+      }
+    q0 += shfl_xor(q0, 16);
+    q0 += shfl_xor(q0, 32);
+    const float rstd = 1.0f / sqrtf(q0 * (1.0f / D) + ln_eps);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xr[j][e] *= rstd;
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const float4 sc = *reinterpret_cast<const float4*>(xss + 16 * j + 4 * g);
@@ -324,6 +355,8 @@ extern "C" int feta_ffn_fwd_coeff(const feta_ffn* d, const feta_coeff_fwd_role* 
   FETA_REQUIRE(feta_ffn_supported(kFfnD, a.FF), "ffn_fwd: dim_feedforward %d not in {64,128,256}", a.FF);
   FETA_REQUIRE(a.x_stats == nullptr || (a.x_gamma && a.x_beta && a.x_bn_out && a.Gx > 0),
                "ffn_fwd: x_stats needs x_gamma, x_beta, x_bn_out, Gx");
+  FETA_REQUIRE(a.x_ln_gamma == nullptr || (a.x_ln_beta != nullptr && a.x_stats == nullptr && a.x_bn == nullptr),
+               "ffn_fwd: x_ln_gamma needs x_ln_beta and excludes x_bn / x_stats");
   FETA_REQUIRE(aligned16(a.x) && aligned16(a.w1) && aligned16(a.w2) && aligned16(a.h) && aligned16(a.y) &&
                    aligned16(a.b1) && aligned16(a.b2) && aligned16(a.x_stats) && aligned16(a.y_stats),
                "ffn_fwd: tensors must be 16-byte aligned");

@@ -21,6 +21,7 @@
 
 #include "feta_abi_common.h"
 #include "feta_coeff.h"
+#include "feta_ln.h"
 #include "feta_lp.h"
 #include "feta_rowops.h"
 
@@ -144,7 +145,22 @@ __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, Ffn
   }
   float* gv = feta_lds;   // [5][64]
   float* after = gv;
-  const bool gbn = a.g_y != nullptr;
+  const bool gbn = a.g_bn != nullptr;
+  // LayerNorm stack (feta_ln.h): dy is the gradient w.r.t. LN2(y2) - its LayerNorm backward is taken per row where the
+  // gradient rows are staged (both roles), x = LN1(y1) per row where the x rows are staged (W role).  A thread of a
+  // staging loop holds the same VEC columns of every row it touches: its gamma / beta slices live in registers.
+  const bool gln = a.g_ln_gamma != nullptr, xln = a.x_ln_gamma != nullptr;
+  const float ln_eps = a.ln_eps;
+  float gl2[L::VEC], gl1[L::VEC], bl1[L::VEC];
+  {
+    const int c0v = L::VEC * (tid % (kFbD / L::VEC));
+#pragma unroll
+    for (int e = 0; e < L::VEC; ++e) {
+      gl2[e] = gln ? a.g_ln_gamma[c0v + e] : 1.0f;
+      gl1[e] = xln ? a.x_ln_gamma[c0v + e] : 1.0f;
+      bl1[e] = xln ? a.x_ln_beta[c0v + e] : 0.0f;
+    }
+  }
   if (gbn) {
     float* scr = gv + 5 * D;
     after = scr;
@@ -178,10 +194,12 @@ __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, Ffn
   // (captures local pointers only: a lambda that captures the argument struct `a` by reference here made the compiler
   // keep a copy of the whole struct in private memory)
   const bool two_parts = a.dy_b != nullptr;
+  const bool has_gy = a.g_y != nullptr;
   const bool g_f32 = a.g_f32 != 0 && sizeof(T) != sizeof(float);   // dy, g_y fp32 behind a bf16 stack (its last layer)
   const float* fdy = a.dy;
   const float* fgy = a.g_y;
-  auto load_g = [gdy, gdyb, ggy, gbn, two_parts, g_f32, fdy, fgy](int64_t off, float (&dv)[VEC], float (&yv)[VEC]) {
+  auto load_g = [gdy, gdyb, ggy, has_gy, two_parts, g_f32, fdy, fgy](int64_t off, float (&dv)[VEC], float (&yv)[VEC]) {
+    const bool gbn = has_gy;   // (the pre-norm rows are read for the BatchNorm and for the LayerNorm backward alike)
     if (g_f32) {
 #pragma unroll
       for (int e = 0; e < VEC; e += 4) {
@@ -263,6 +281,12 @@ __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, Ffn
         const int idx = tid + u * kRowThreads, rr = idx / RV, c4 = idx % RV;
         g2_of<VEC>(dv[u], yv[u], gv, VEC * c4, gbn);
         const bool ok = r0 + rr < a.M;
+        if (gln) {
+          float dg_[VEC], db_[VEC];   // (the W role emits dgamma2 / dbeta2)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) dg_[e] = db_[e] = 0.0f;
+          ln_backward<VEC>(dv[u], yv[u], gl2, ln_eps, ok, dg_, db_);
+        }
 #pragma unroll
         for (int e = 0; e < VEC; ++e) dv[u][e] = ok ? dv[u][e] : 0.0f;
         L::stv(gt + rr * GP + VEC * c4, L::pack(dv[u]));
@@ -352,6 +376,9 @@ __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, Ffn
 #pragma unroll
     for (int r = 0; r < 4; ++r) cs1[t][r] = 0.0f;
   const bool xbn = a.x_bn != nullptr;
+  float dgam[VEC], dbet[VEC];   // LayerNorm stack: sums of (dy xhat2, dy) over the chunk's rows, this thread's columns
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) dgam[e] = dbet[e] = 0.0f;
   constexpr int NG = 64 * RV / kRowThreads, NH = 64 * HV / kRowThreads;   // vectors per thread: g2 / x1 tiles, h slice
   for (int r0 = row_lo; r0 < row_hi; r0 += 64) {
     if (r0 > row_lo) __syncthreads();
@@ -376,8 +403,10 @@ __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, Ffn
       const int idx = tid + u * kRowThreads, rr = idx / RV, c4 = idx % RV;
       const bool ok = r0 + rr < row_hi;
       g2_of<VEC>(dv[u], yv[u], gv, VEC * c4, gbn);
+      if (gln) ln_backward<VEC>(dv[u], yv[u], gl2, ln_eps, ok, dgam, dbet);
       float x[VEC];
       L::unpack(xv[u], x);
+      if (xln) ln_apply<VEC>(x, gl1, bl1, ln_eps);
       if (xbn) {
 #pragma unroll
         for (int e4 = 0; e4 < VEC; e4 += 4) {
@@ -444,7 +473,8 @@ __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, Ffn
       }
     }
   }
-  float* p = a.partial + (int64_t)rc * (a.partial_ld > 0 ? (int64_t)a.partial_ld : (int64_t)(2 * D * FF + D + FF));
+  float* p = a.partial + (int64_t)rc * (a.partial_ld > 0 ? (int64_t)a.partial_ld
+                                                         : (int64_t)(2 * D * FF + D + FF + (gln ? 2 * D : 0)));
   float* pW2 = p;
   float* pb2 = p + D * FF;
   float* pW1 = pb2 + D;
@@ -460,6 +490,15 @@ __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, Ffn
   __syncthreads();
   float* red2 = after;                        // [256][VEC]: thread tid holds columns VEC (tid % RV) ..
   float* red1 = after + kRowThreads * VEC;    // [4 waves][2 tiles][16]
+  float* red3 = red1 + 4 * 2 * 16;            // [256][VEC] dgamma2, [256][VEC] dbeta2 (LayerNorm stack)
+  float* red4 = red3 + kRowThreads * VEC;
+  if (gln && si == 0) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      red3[tid * VEC + e] = dgam[e];
+      red4[tid * VEC + e] = dbet[e];
+    }
+  }
 #pragma unroll
   for (int e = 0; e < VEC; ++e) red2[tid * VEC + e] = cs2[e];
 #pragma unroll
@@ -475,6 +514,15 @@ __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, Ffn
     float sv = 0.0f;
     for (int k = 0; k < kRowThreads / RV; ++k) sv += red2[(c4 + RV * k) * VEC + e];
     pb2[tid] = sv;
+    if (gln) {   // [dgamma2 | dbeta2] behind db1
+      float sg = 0.0f, sb = 0.0f;
+      for (int k = 0; k < kRowThreads / RV; ++k) {
+        sg += red3[(c4 + RV * k) * VEC + e];
+        sb += red4[(c4 + RV * k) * VEC + e];
+      }
+      pb1[FF + tid] = sg;
+      pb1[FF + D + tid] = sb;
+    }
   }
   if (tid < kFbSlice) {
     const int t = tid >> 4, cc = tid & 15;
@@ -493,7 +541,7 @@ int launch_ffn_bwd(const FfnGradArgs& a, const CoeffBwdRole& cb, hipStream_t str
   const int nrb16 = (a.M + 15) / 16;
   ge.per = (nrb16 + ge.RC - 1) / ge.RC;
   ge.NS = FF / kFbSlice;
-  size_t lds = ffn_bwd_lds_bytes<T>(FF, a.g_y != nullptr);
+  size_t lds = ffn_bwd_lds_bytes<T>(FF, a.g_bn != nullptr);
   const int role = cb.cj != nullptr ? ((cb.C + kCoeffThreads - 1) / kCoeffThreads) * cb.G : 0;
   if (role > 0 && sizeof(float) * (size_t)(kCoeffPass * cb.N) > lds) lds = sizeof(float) * (size_t)(kCoeffPass * cb.N);
   auto kern = ffn_bwd_kernel<T, FF>;
@@ -544,7 +592,10 @@ extern "C" int feta_ffn_bwd_coeff(const feta_ffn_grad* d, const feta_coeff_bwd_r
   const FfnGradArgs& a = *d;
   FETA_REQUIRE(a.dy && a.h && a.w2 && a.w1 && a.x && a.dx && a.partial && a.M > 0, "ffn_bwd: null pointer / empty");
   FETA_REQUIRE(feta_ffn_bwd_supported(kFbD, a.FF), "ffn_bwd: dim_feedforward %d not in {64,128}", a.FF);
-  FETA_REQUIRE(!a.g_y || (a.g_bn && (a.g_sum || a.g_fin)), "ffn_bwd: g_y needs g_bn and g_sum | g_fin");
+  FETA_REQUIRE(!a.g_y || a.g_ln_gamma || (a.g_bn && (a.g_sum || a.g_fin)), "ffn_bwd: g_y needs g_bn and g_sum | g_fin, or g_ln_gamma");
+  FETA_REQUIRE(!a.g_ln_gamma || (a.g_y && !a.g_bn && !a.g_sum && !a.g_fin), "ffn_bwd: g_ln_gamma needs g_y and excludes g_bn / g_sum / g_fin");
+  FETA_REQUIRE(!a.x_ln_gamma || (a.x_ln_beta && !a.x_bn), "ffn_bwd: x_ln_gamma needs x_ln_beta and excludes x_bn");
+  FETA_REQUIRE(!a.g_bn || a.g_y, "ffn_bwd: g_bn needs g_y");
   FETA_REQUIRE(!a.g_sum || a.Gs > 0, "ffn_bwd: g_sum needs Gs");
   FETA_REQUIRE(!a.sum_out || a.x_bn, "ffn_bwd: sum_out needs x_bn (the BatchNorm that produced x)");
   FETA_REQUIRE(aligned16(a.dy_b) && aligned16(a.dy) && aligned16(a.h) && aligned16(a.x) && aligned16(a.dx) && aligned16(a.g_y) &&

@@ -76,6 +76,23 @@ def layer_params(layer):
 # 0: everything in the final launch (A/B timing)
 USE_EARLY_COLSUM = os.environ.get('FETA_EARLY_COLSUM', '1') != '0'
 USE_LN_STACK = os.environ.get('FETA_LN_STACK', '1') != '0'   # 0: LayerNorm layers run op by op (A/B timing)
+# LayerNorm stacks: the CONSUMER of a pre-norm tensor applies the LayerNorm when it stages the rows (ABI 9, csrc/feta_ln.h:
+# norm2 inside the next layer's attention block, norm1 inside the feed-forward kernel, their backward inside the gradient
+# loads of feta_ffn_bwd / feta_attn_block_bwd) - two launches per layer and direction like the BatchNorm stack, no
+# normalised tensor in HBM; 0: feta_layernorm_fwd / _bwd launches between the fused kernels (round-3 form, A/B timing)
+USE_LN_ON_LOAD = os.environ.get('FETA_LN_ON_LOAD', '1') != '0'
+
+
+def ln_on_load_supported(abi, layers, n, b, d_model, tie):
+    """every launch of the stack is one of the four fused kernels (they carry the LayerNorm on load)"""
+    if not (USE_LN_ON_LOAD and USE_ATTN_BLOCK and USE_FFN_FUSED and USE_FFN_BWD and USE_ATTN_BLOCK_BWD) or tie:
+        return False
+    heads = layers[0].self_attn.num_heads
+    if not (abi.attn_block_supported(n, d_model, heads) and abi.attn_block_bwd_supported(n, d_model, heads)
+            and abi.attn_block_bwd_blocks(b) > 0):
+        return False
+    return all(abi.ffn_supported(d_model, l.linear1.out_features) and abi.ffn_bwd_supported(d_model, l.linear1.out_features)
+               for l in layers)
 
 
 def lowp_stack_supported(abi, layers, n, b, d_model):
@@ -150,7 +167,7 @@ def _cap_partials(abi, stream, st, new, shift_row=False):
     return tot, 1
 
 
-def _partial_buffers(abi, new, m, b, n, d, heads, ff0, nl, fused_attn):
+def _partial_buffers(abi, new, m, b, n, d, heads, ff0, nl, fused_attn, ln_cols=False):
     """Split-K partial buffers of a stack backward and the slot allocator.  Two buffers, because their row counts
     differ: 'f' (linear2 / linear1 of every layer) has one row per feta_rowlin_chunks(M) row chunk, 'a' (out_proj /
     in_proj) the same or - with the fused attention-block backward - one row per graph.  dwdb_all = [f columns |
@@ -158,8 +175,10 @@ def _partial_buffers(abi, new, m, b, n, d, heads, ff0, nl, fused_attn):
     reduction fills it at the end of backward.  -> (part_f, part_a, tf, ta, wslot)"""
     rc = abi.rowlin_chunks(m)
     ra = abi.attn_block_bwd_blocks(b) if fused_attn else rc
-    tf = nl * ((ff0 * d + ff0) + (d * ff0 + d))
-    ta = nl * ((d * d + d) + (3 * d * d + 3 * d))
+    # ln_cols (LayerNorm on load): every layer's slot is followed by [dgamma | dbeta] of the LayerNorm whose backward
+    # the kernel applies on its gradient load (norm2 behind the feed-forward slot, norm1 behind the attention slot)
+    tf = nl * ((ff0 * d + ff0) + (d * ff0 + d) + (2 * d if ln_cols else 0))
+    ta = nl * ((d * d + d) + (3 * d * d + 3 * d) + (2 * d if ln_cols else 0))
     part_f, part_a = new(rc, tf), new(ra, ta)
     cur = {'f': 0, 'a': 0}
 
@@ -170,7 +189,14 @@ def _partial_buffers(abi, new, m, b, n, d, heads, ff0, nl, fused_attn):
         buf, base = (part_f, 0) if kind == 'f' else (part_a, tf)
         return buf.data_ptr() + 4 * off, base + off
 
+    def raw(kind, count):
+        """-> offset in dwdb_all of `count` further columns of this kind (they follow the previous slot in the row)"""
+        off = cur[kind]
+        cur[kind] += count
+        return (0 if kind == 'f' else tf) + off
+
     wslot.cur = cur
+    wslot.raw = raw
     return part_f, part_a, tf, ta, wslot
 
 
@@ -523,6 +549,10 @@ class FusedLayerNormStackFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         assert tail is None   # (LayerNorm is row-local: its output is materialised by feta_layernorm_fwd)
         ctx.pending = pending
+        ctx.on_load = (len(layers) > 0 and ln_on_load_supported(abi, layers, src.shape[0], src.shape[1], src.shape[2],
+                                                                 layers[0].self_attn.tie_qk))
+        if ctx.on_load:
+            return _ln_on_load_forward(ctx, abi, stream, src, pe, degree_rows, n_real, layers, need_attn, pending, params)
         if len(layers):
             STACK_FLAT_GRAD.pop(layers[0], None)
         n, b, d = src.shape
@@ -609,6 +639,8 @@ class FusedLayerNormStackFn(torch.autograd.Function):
         saved, params = ctx.saved_state, ctx.params
         if d_final is None and d_concat_last is None:
             return (None,) * (8 + len(params))      # (see FusedEncoderStackFn.backward)
+        if ctx.on_load:
+            return _ln_on_load_backward(ctx, d_final, d_concat_last)
         n, b, d, heads, dh, tie, scale, nl = ctx.meta
         pe_c, degree_rows, n_real = ctx.aux
         abi, stream = _lib.backend(saved[0]['qkv'])
@@ -719,6 +751,145 @@ class FusedLayerNormStackFn(torch.autograd.Function):
             if params[idx + 1] is not None:
                 grads[idx + 1] = dwdb_all[off + no * ki:off + no * ki + no]
         return (dcur.view(n, b, d), None, None, None, None, None, None, None) + tuple(grads)
+
+
+def _ln_on_load_forward(ctx, abi, stream, src, pe, degree_rows, n_real, layers, need_attn, pending, params):
+    """LayerNorm stack with the LayerNorm applied by the consumer of each pre-norm tensor (ABI 9).  Per layer, forward
+    (2 launches):
+        y1 = x0 + degree * out_proj(attention(in_proj(x0))),  x0 = LN2_prev(y2_prev) on load     feta_attn_block_fwd
+        y2 = x1 + linear2(relu(linear1(x1))),                 x1 = LN1(y1) on load               feta_ffn_fwd
+    and ONE feta_layernorm_fwd at the end of the stack (norm2 of the last layer: the output is handed out).  Backward
+    (2 launches per layer + one reduction): feta_ffn_bwd takes the gradient w.r.t. LN2(y2) and applies the LayerNorm
+    backward where it loads the gradient rows, feta_attn_block_bwd the same for LN1; [dgamma | dbeta] ride in the
+    kernels' split-K partial rows.  No normalised activation is written between the kernels."""
+    if len(layers):
+        STACK_FLAT_GRAD.pop(layers[0], None)
+    n, b, d = src.shape
+    m = n * b
+    nl = len(layers)
+    heads = layers[0].self_attn.num_heads
+    dh = d // heads
+    scale = float(dh) ** -0.5
+    dev = src.device
+    new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    dt = src.dtype
+    lowp = dt != torch.float32
+    newt = lambda *s: torch.empty(s, dtype=dt, device=dev)
+    if lowp and not lowp_stack_supported(abi, layers, n, b, d):
+        raise NotImplementedError('bf16 storage: the fused stack needs d_model = 64, 4 heads, N <= 64')
+    x_pre = src.contiguous().view(m, d)      # pre-norm input rows of the layer (layer 0: the stack input itself)
+    pe_c = None if pe is None else pe.contiguous()
+    saved = []
+    attn = out32 = None
+    ln_prev = {}
+    for li, layer in enumerate(layers):
+        (w_in, b_in, w_o, b_o, g1, be1, w1, bb1, w2, bb2, g2, be2) = params[li * PER_LAYER:(li + 1) * PER_LAYER]
+        ff = w1.shape[0]
+        attn = new(b, heads, n, n) if (need_attn and li == nl - 1) else None
+        ast = new(b, heads, n, 2)
+        qkv = newt(m, 3 * d)
+        out = torch.empty((n, b, heads, dh), dtype=dt, device=dev)
+        if lowp and li == nl - 1:
+            out32 = new(n, b, heads, dh)
+        y1 = newt(m, d)
+        abi.attn_block_fwd(b, n, scale, stream, x=x_pre, w_in=w_in, b_in=b_in, w_out=w_o, b_out=b_o, pe=pe_c, n_real=n_real,
+                           rowscale=degree_rows, qkv=qkv, out=out, attn_stats=ast, attn=attn, y=y1, y_stats=None,
+                           out_f32=(out32 if li == nl - 1 else None),
+                           sums=(pending.take_fwd() if (pending is not None and li == 0) else ()), **ln_prev)
+        h = newt(m, ff)
+        y2 = new(m, d) if li == nl - 1 else newt(m, d)    # (what leaves the stack is fp32 whatever the storage type)
+        abi.ffn_fwd(m, ff, stream, eps=float(layer.norm1.eps), x=y1, x_ln_gamma=g1, x_ln_beta=be1, w1=w1, b1=bb1, w2=w2,
+                    b2=bb2, h=h, y=y2, y_stats=None, coeff=_coeff_fwd_role(pending, li, nl, attn, n_real))
+        saved.append(dict(x0=x_pre, qkv=qkv, out=out, ast=ast, y1=y1, h=h, y2=y2))
+        x_pre = y2
+        ln_prev = dict(x_ln_gamma=g2, x_ln_beta=be2, eps=float(layer.norm2.eps))
+    # norm2 of the last layer: the only LayerNorm launch of the stack
+    last = layers[-1].norm2
+    final = new(m, d)
+    abi.layernorm_fwd(x_pre, params[(nl - 1) * PER_LAYER + 10], params[(nl - 1) * PER_LAYER + 11], float(last.eps), final,
+                      new(m, 2), stream)
+    ctx.saved_state = saved
+    ctx.meta = (n, b, d, heads, dh, False, scale, nl)
+    ctx.aux = (pe_c, degree_rows, n_real)
+    ctx.params = params
+    ctx.eps = [(float(l.norm1.eps), float(l.norm2.eps)) for l in layers]
+    ctx.owner = layers[0] if len(layers) else None
+    if attn is not None:
+        ctx.mark_non_differentiable(attn)
+    concat_last = (out32 if lowp else saved[-1]['out']).view(n, b, d)
+    return final.view(n, b, d), concat_last, attn
+
+
+def _ln_on_load_backward(ctx, d_final, d_concat_last):
+    saved, params = ctx.saved_state, ctx.params
+    n, b, d, heads, dh, tie, scale, nl = ctx.meta
+    pe_c, degree_rows, n_real = ctx.aux
+    abi, stream = _lib.backend(saved[0]['qkv'])
+    m = n * b
+    dev = saved[0]['qkv'].device
+    dt = saved[0]['qkv'].dtype
+    new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    newt = lambda *s: torch.empty(s, dtype=dt, device=dev)
+    grads = [None] * len(params)
+    ff0 = params[6].shape[0]
+    part_f, part_a, tf, ta, wslot = _partial_buffers(abi, new, m, b, n, d, heads, ff0, nl, True, ln_cols=True)
+    coeff_req = _coeff_bwd_request(ctx, abi, stream, d, params[(nl - 1) * PER_LAYER + 6].shape[0])
+    total = tf + ta
+    dwdb_all = new(total)      # [feed-forward slots | attention slots], each followed by its LayerNorm's [dgamma | dbeta]
+    slots, ln_slots = {}, {}
+    if d_final is None:
+        d_final = torch.zeros(n, b, d, dtype=torch.float32, device=dev)
+    if d_final.dtype != torch.float32:
+        d_final = d_final.float()      # (the stack's output is fp32: so is its gradient)
+    dcur, dcur_b = d_final.contiguous().view(m, d), None      # gradient w.r.t. LN2(y2) of the layer at hand
+    GB = abi.attn_block_bwd_blocks(b)
+    for li in range(nl - 1, -1, -1):
+        s = saved[li]
+        (w_in, b_in, w_o, b_o, g1, be1, w1, bb1, w2, bb2, g2, be2) = params[li * PER_LAYER:(li + 1) * PER_LAYER]
+        ff = w1.shape[0]
+        base = li * PER_LAYER
+        eps1, eps2 = ctx.eps[li]
+        pp, off = wslot('f', d, ff)
+        slots[base + 8] = (off, d, ff)
+        _, off1 = wslot('f', ff, d)
+        slots[base + 6] = (off1, ff, d)
+        ln_slots[base + 10] = wslot.raw('f', 2 * d)
+        dx1 = newt(m, d)
+        # linear2 + linear1 backward; LN2 backward on the gradient load, x1 = LN1(y1) on the operand load
+        abi.ffn_bwd(m, ff, stream, coeff=(coeff_req if li == nl - 1 else None), partial_ptr=pp, partial_ld=tf,
+                    dy=dcur, dy_b=dcur_b, g_y=s['y2'], g_ln_gamma=g2, ln_eps=eps2, h=s['h'], w2=w2, w1=w1, x=s['y1'],
+                    x_ln_gamma=g1, x_ln_beta=be1, dx=dx1)
+        ppo, offo = wslot('a', d, d)
+        slots[base + 2] = (offo, d, d)
+        _, offi = wslot('a', 3 * d, d)
+        slots[base + 0] = (offi, 3 * d, d)
+        ln_slots[base + 4] = wslot.raw('a', 2 * d)
+        d2 = d_concat_last if (li == nl - 1 and d_concat_last is not None) else None
+        # out_proj + attention + in_proj backward; LN1 backward on the gradient load, x0 = LN2_prev(y2_prev) on load.  The
+        # layer below takes its gradient in two parts (two workgroups per graph, one per pair of heads)
+        split = USE_ATTN_BLOCK_SPLIT and li > 0 and GB == b
+        dx0 = newt(m, d)
+        dx0b = newt(m, d) if split else None
+        ln0 = {}
+        if li > 0:
+            ln0 = dict(x0_ln_gamma=params[(li - 1) * PER_LAYER + 10], x0_ln_beta=params[(li - 1) * PER_LAYER + 11])
+        abi.attn_block_bwd(b, n, scale, stream, partial_ptr=ppo, partial_ld=ta, dy=dx1, y1=s['y1'], ln1_gamma=g1,
+                           ln_eps=eps1, dx_b=dx0b, rowscale=degree_rows, w_out=w_o, w_in=w_in, qkv=s['qkv'], out=s['out'],
+                           dout2=None if d2 is None else d2.contiguous().view(m, d), pe=pe_c, n_real=n_real,
+                           attn_stats=s['ast'], x0=s['x0'], dx=dx0, **ln0)
+        dcur, dcur_b = dx0, dx0b
+    assert dcur_b is None
+    assert wslot.cur == {'f': tf, 'a': ta}
+    abi.colsum_multi([(part_f, dwdb_all[:tf]), (part_a, dwdb_all[tf:total])] + _take_pending(ctx), stream)
+    if ctx.owner is not None:
+        STACK_FLAT_GRAD[ctx.owner] = dwdb_all
+    for idx, (off, no, ki) in slots.items():
+        grads[idx] = dwdb_all[off:off + no * ki].view(no, ki)
+        if params[idx + 1] is not None:
+            grads[idx + 1] = dwdb_all[off + no * ki:off + no * ki + no]
+    for idx, off in ln_slots.items():
+        grads[idx], grads[idx + 1] = dwdb_all[off:off + d], dwdb_all[off + d:off + 2 * d]
+    return (dcur.view(n, b, d), None, None, None, None, None, None, None) + tuple(grads)
 
 
 def _coeff_fwd_role(pending, li, nl, attn, n_real):

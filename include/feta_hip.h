@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FETA_ABI_VERSION 8
+#define FETA_ABI_VERSION 9
 
 #define FETA_OK 0
 #define FETA_E_ARG (-1)     /* bad shape / stride / alignment / unsupported size */
@@ -452,6 +452,13 @@ typedef struct feta_attn_block {
                            receives the shift */
   float* out_f32;      /* nullable: `out` once more, as fp32 [M,64] - the fp32 filter stage behind a bf16 stack reads it
                           (out_each_head of the last layer, transformer/models.py:179) without a cast launch */
+  const float* x_ln_gamma; /* nullable [64] (ABI 9): x is seen through a LAYERNORM - the rows of x are the PRE-norm rows
+                              (the previous layer's y2) and x_norm = (x - mean_row) * rstd_row * gamma + beta is computed
+                              per row when the row is staged (eps: the field above; biased variance, as F.layer_norm):
+                              LayerNorm is row-local, so its consumer applies it and no normalised tensor is ever
+                              written (norm2 of DiffTransformerEncoderLayer with batch_norm=False, the reference's
+                              default: experiments/run_transformer_gengcn_cv.py:56).  Excludes x_bn / x_stats. */
+  const float* x_ln_beta;  /* [64], with x_ln_gamma */
 } feta_attn_block;
 
 int feta_attn_block_supported(int N, int d_model, int heads);
@@ -525,6 +532,16 @@ typedef struct feta_attn_block_grad {
   int64_t row_sb, row_sn;
   int dtype;         /* FETA_F32 | FETA_BF16: storage type of dy, y1, qkv, out, dout2, pe, x0, dx, dx_b [T] (ABI 7) */
   int dout2_f32;     /* 1: dout2 is fp32 whatever dtype says (it comes from the fp32 filter stage) */
+  const float* ln1_gamma;   /* nullable [64] (ABI 9): dy is the gradient w.r.t. LN1(y1) = norm1's output, and
+                               g1 = LayerNorm backward of dy, computed per row when the gradient row is staged:
+                               xhat = (y1 - mean_row) rstd_row, g = dy * gamma, g1 = rstd_row (g - mean_row(g) -
+                               xhat mean_row(g xhat)); y1 = the pre-norm rows (bn1 / g_sum must be NULL).  The partial
+                               row gains [dgamma1 (64) | dbeta1 (64)] = per-workgroup sums of (dy xhat, dy) behind
+                               db_in (default pitch 4*64*64 + 4*64 + 128). */
+  const float* x0_ln_gamma; /* nullable [64]: x0 holds PRE-norm rows, the in_proj operand is LayerNorm(x0) * gamma +
+                               beta computed per row on load (feta_attn_block.x_ln_gamma); excludes bn0 */
+  const float* x0_ln_beta;
+  float ln_eps;
 } feta_attn_block_grad;
 
 int feta_attn_block_bwd_supported(int N, int d_model, int heads);
@@ -565,6 +582,9 @@ typedef struct feta_ffn {
                            feta_ffn_blocks(M) + 1 rows */
   int y_f32;        /* 1: y is written as fp32 whatever dtype says (last layer of a bf16 stack: its consumer, linear_cat
                        with the folded BatchNorm, transformer/models.py:223-224, is an fp32 kernel) */
+  const float* x_ln_gamma; /* nullable [64] (ABI 9): x = LayerNorm(x rows) * gamma + beta, computed per row on load
+                              (feta_attn_block.x_ln_gamma: norm1 with batch_norm=False); excludes x_bn / x_stats */
+  const float* x_ln_beta;
 } feta_ffn;
 
 int feta_ffn_supported(int d_model, int ff);
@@ -615,6 +635,14 @@ typedef struct feta_ffn_grad {
   int M, FF;
   int dtype;         /* FETA_F32 | FETA_BF16: storage type of dy, dy_b, g_y, h, x, dx [T] (ABI 7) */
   int g_f32;         /* 1: dy and g_y are fp32 whatever dtype says (last layer of a bf16 stack, see feta_ffn.y_f32) */
+  const float* g_ln_gamma; /* nullable [64] (ABI 9): dy is the gradient w.r.t. LN2(y2) = norm2's output and
+                              g2 = LayerNorm backward of dy per row, computed on load from g_y = y2 (pre-norm rows; g_bn /
+                              g_sum / g_fin must be NULL), as feta_attn_block_grad.ln1_gamma.  The partial rows gain
+                              [dgamma2 (64) | dbeta2 (64)] behind db1 (default pitch 2*64*FF + 64 + FF + 128). */
+  const float* x_ln_gamma; /* nullable [64]: x holds PRE-norm rows (y1), the operand is LayerNorm(x) * gamma + beta per
+                              row on load; excludes x_bn */
+  const float* x_ln_beta;
+  float ln_eps;
 } feta_ffn_grad;
 
 int feta_ffn_bwd_supported(int d_model, int ff);

@@ -1091,3 +1091,190 @@ def check_attn_block_bwd_lp(abi, dev, stream, bsz=5, n_pad=21, n_min=3, seed=0, 
     if with_bn:
         assert_close('lp block dgamma1', kw['dgamma'], gamma1.grad, tol=BF16_TOL)
         assert_close('lp block dbeta1', kw['dbeta'], beta1.grad, tol=BF16_TOL)
+
+
+# ---- LayerNorm "on load" in the fused layer-stack kernels (ABI 9, csrc/feta_ln.h) ---------------------------------------
+# norm1 / norm2 of DiffTransformerEncoderLayer with batch_norm=False (the reference's default for the TU / molhiv / SBM
+# scripts, experiments/run_transformer_gengcn_cv.py:56) are applied by the CONSUMER of a pre-norm tensor when it stages
+# the rows, forward and backward; checked against fp64 autograd of the sub-block with F.layer_norm.
+def _ln_tol(dtype):
+    return TOL if dtype == torch.float32 else BF16_TOL
+
+
+def _ln_rows(m, d, g, dtype):
+    """pre-norm rows with a row-dependent mean and spread (so that mean / rstd matter), representable in `dtype`"""
+    y = torch.randn(m, d, generator=g, dtype=torch.float64) * (0.5 + torch.rand(m, 1, generator=g, dtype=torch.float64) * 2.0)
+    y = y + torch.randn(m, 1, generator=g, dtype=torch.float64) * 1.5
+    return round_to(y, dtype)
+
+
+def _ln_affine(d, g):
+    return (torch.rand(d, generator=g, dtype=torch.float64) + 0.5).float().double(), \
+        (torch.randn(d, generator=g, dtype=torch.float64) * 0.3).float().double()
+
+
+def check_ffn_ln(abi, dev, stream, m=75, ff=128, seed=0, dtype=torch.float32):
+    """feta_ffn_fwd with x_ln_gamma: x = LayerNorm(y1) * gamma1 + beta1 per row on load, h = relu(x W1^T + b1),
+    y = x + h W2^T + b2"""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(seed)
+    d, tol = 64, _ln_tol(dtype)
+    y1 = _ln_rows(m, d, g, dtype)
+    gam, bet = _ln_affine(d, g)
+    w1, b1 = (torch.randn(ff, d, generator=g) / 8).double(), (torch.randn(ff, generator=g) * 0.1).double()
+    w2, b2 = (torch.randn(d, ff, generator=g) / 8).double(), (torch.randn(d, generator=g) * 0.1).double()
+    f32 = lambda t: t.float().contiguous().to(dev)
+    h = torch.full((m, ff), float('nan'), dtype=dtype, device=dev)
+    y = torch.full((m, d), float('nan'), dtype=dtype, device=dev)
+    abi.ffn_fwd(m, ff, stream, x=y1.to(dtype).to(dev), x_ln_gamma=f32(gam), x_ln_beta=f32(bet), w1=f32(w1), b1=f32(b1),
+                w2=f32(w2), b2=f32(b2), h=h, y=y, y_stats=None)
+    x = F.layer_norm(y1, (d,), gam, bet, 1e-5)
+    h_ref = torch.relu(x @ w1.t() + b1)
+    y_ref = x + h_ref @ w2.t() + b2
+    return {'h': assert_close('ln ffn h', h, h_ref, tol=tol), 'y': assert_close('ln ffn y2', y, y_ref, tol=tol)}
+
+
+def _ln_block_case(bsz, n_pad, n_min, seed, dtype, with_pe=True):
+    g = torch.Generator().manual_seed(seed)
+    d, heads = 64, 4
+    n_real = torch.randint(n_min, n_pad + 1, (bsz,), generator=g)
+    n_real[0] = n_pad
+    mask = torch.arange(n_pad)[None, :] >= n_real[:, None]                     # [B,N] True = pad
+    x0 = _ln_rows(n_pad * bsz, d, g, dtype).view(n_pad, bsz, d)                # pre-norm rows (padded rows: real values too)
+    pe = None
+    if with_pe:
+        pe = torch.rand(bsz, n_pad, n_pad, generator=g).double() + 0.1
+        pe = round_to(pe * (~mask).unsqueeze(1) * (~mask).unsqueeze(2), dtype)
+    degree = (torch.rand(bsz, n_pad, generator=g).double() * 0.5 + 0.5) * (~mask)
+    p = dict(w_in=torch.randn(3 * d, d, generator=g).double() / 8, b_in=torch.randn(3 * d, generator=g).double() * 0.1,
+             w_out=torch.randn(d, d, generator=g).double() / 8, b_out=torch.randn(d, generator=g).double() * 0.1)
+    p = {k: v.float().double() for k, v in p.items()}
+    gam0, bet0 = _ln_affine(d, g)
+    return g, d, heads, n_real.to(torch.int32), mask, x0, pe, degree, p, gam0, bet0
+
+
+def check_attn_block_ln(abi, dev, stream, bsz=5, n_pad=21, n_min=3, seed=0, dtype=torch.float32, with_pe=True, need_attn=True):
+    """feta_attn_block_fwd with x_ln_gamma: the layer input is LayerNorm(x0) * gamma + beta per row on load (the previous
+    layer's norm2), it is the in_proj operand AND the residual; y_stats = NULL (nobody needs column statistics)."""
+    import torch.nn.functional as F
+    g, d, heads, n_real, mask, x0, pe, degree, p, gam0, bet0 = _ln_block_case(bsz, n_pad, n_min, seed, dtype, with_pe)
+    m, tol = n_pad * bsz, _ln_tol(dtype)
+    f32 = lambda t: t.float().contiguous().to(dev)
+    st = lambda t: t.to(dtype).contiguous().to(dev)
+    new = lambda *s: torch.full(s, float('nan'), dtype=dtype, device=dev)
+    qkv, out, y = new(m, 3 * d), new(m, d), new(m, d)
+    ast = torch.full((bsz, heads, n_pad, 2), float('nan'), device=dev)
+    attn = torch.full((bsz, heads, n_pad, n_pad), float('nan'), device=dev) if need_attn else None
+    abi.attn_block_fwd(bsz, n_pad, float(d // heads) ** -0.5, stream, x=st(x0).view(m, d), x_ln_gamma=f32(gam0),
+                       x_ln_beta=f32(bet0), w_in=f32(p['w_in']), b_in=f32(p['b_in']), w_out=f32(p['w_out']),
+                       b_out=f32(p['b_out']), pe=None if pe is None else st(pe), n_real=n_real.to(dev),
+                       rowscale=f32(degree.t().reshape(m)), qkv=qkv, out=out, attn_stats=ast, attn=attn, y=y, y_stats=None)
+    x = F.layer_norm(x0, (d,), gam0, bet0, 1e-5)
+    qkv_ref = F.linear(x, p['w_in'], p['b_in'])
+    concat, a_ref, _ = O.attention_core(qkv_ref, pe, mask, heads)
+    y_ref = x + degree.t().unsqueeze(-1) * F.linear(concat, p['w_out'], p['b_out'])
+    real = (~mask).t().unsqueeze(-1)       # k / v rows of key tiles without a real node are never written
+    zero = torch.zeros((), dtype=torch.float64)
+    errs = {'qkv': assert_close('ln block qkv', torch.where(real, qkv.view(n_pad, bsz, 3 * d).cpu().double(), zero),
+                                torch.where(real, qkv_ref, zero), tol=tol)}
+    errs['out'] = assert_close('ln block out', out.view(n_pad, bsz, d), concat, tol=tol)
+    errs['y'] = assert_close('ln block y', y.view(n_pad, bsz, d), y_ref, tol=tol)
+    if need_attn:
+        errs['attn'] = assert_close('ln block attn', attn, a_ref, tol=tol)
+    return errs
+
+
+def check_ffn_bwd_ln(abi, dev, stream, m=150, ff=128, seed=0, dtype=torch.float32, two_parts=False):
+    """feta_ffn_bwd with g_ln_gamma / x_ln_gamma: dy is the gradient w.r.t. LN2(y2); g2 = its LayerNorm backward per row on
+    load, x = LN1(y1) per row on load; dx (w.r.t. x), the weight / bias partial rows and [dgamma2 | dbeta2] behind them
+    against fp64 autograd of x2 = LN2(x + linear2(relu(linear1(x))))."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(seed)
+    d, tol = 64, _ln_tol(dtype)
+    y1 = _ln_rows(m, d, g, dtype)
+    gam1, bet1 = _ln_affine(d, g)
+    gam2, bet2 = _ln_affine(d, g)
+    gam2.requires_grad_(True), bet2.requires_grad_(True)
+    w1 = (torch.randn(ff, d, generator=g) / 8).double().requires_grad_(True)
+    b1 = (torch.randn(ff, generator=g) * 0.1).double().requires_grad_(True)
+    w2 = (torch.randn(d, ff, generator=g) / 8).double().requires_grad_(True)
+    b2 = (torch.randn(d, generator=g) * 0.1).double().requires_grad_(True)
+    x = F.layer_norm(y1, (d,), gam1, bet1, 1e-5).detach().requires_grad_(True)
+    h_ref = torch.relu(x @ w1.t() + b1)
+    y2 = x + h_ref @ w2.t() + b2
+    dy = round_to(torch.randn(m, d, generator=g, dtype=torch.float64), dtype)
+    dy_a = round_to(dy * 0.25 + torch.randn(m, d, generator=g, dtype=torch.float64), dtype) if two_parts else dy
+    dy_b = round_to(dy - dy_a, dtype) if two_parts else None
+    dy_tot = dy_a + dy_b if two_parts else dy
+    (F.layer_norm(y2, (d,), gam2, bet2, 1e-5) * dy_tot).sum().backward()
+    f32 = lambda t: t.detach().float().contiguous().to(dev)
+    st = lambda t: t.detach().to(dtype).contiguous().to(dev)
+    rc = abi.rowlin_chunks(m)
+    ld = 2 * d * ff + d + ff + 2 * d
+    partial = torch.full((rc, ld), float('nan'), device=dev)
+    dx = torch.full((m, d), float('nan'), dtype=dtype, device=dev)
+    abi.ffn_bwd(m, ff, stream, partial=partial, dy=st(dy_a), dy_b=None if dy_b is None else st(dy_b), g_y=st(y2),
+                g_ln_gamma=f32(gam2), h=st(h_ref), w2=f32(w2), w1=f32(w1), x=st(y1), x_ln_gamma=f32(gam1), x_ln_beta=f32(bet1),
+                ln_eps=1e-5, dx=dx)
+    pw = partial.double().sum(0).cpu()
+    o = 0
+    errs = {'dx': assert_close('ln ffn dx', dx, x.grad, tol=tol)}
+    for name, ref in (('dW2', w2.grad), ('db2', b2.grad), ('dW1', w1.grad), ('db1', b1.grad), ('dgamma2', gam2.grad),
+                      ('dbeta2', bet2.grad)):
+        errs[name] = assert_close('ln ffn ' + name, pw[o:o + ref.numel()].view(ref.shape), ref, tol=tol)
+        o += ref.numel()
+    return errs
+
+
+def check_attn_block_bwd_ln(abi, dev, stream, bsz=5, n_pad=21, n_min=3, seed=0, dtype=torch.float32, with_pe=True, split=False,
+                            first_layer=False):
+    """feta_attn_block_bwd with ln1_gamma / x0_ln_gamma on the tensors its own forward (feta_attn_block_fwd with x_ln_gamma)
+    saved, against fp64 autograd of o1 = LN1(x + degree * out_proj(attention(in_proj(x)))), x = LN0(x0): dx (w.r.t. x),
+    both weight / bias gradients and [dgamma1 | dbeta1] from the per-graph partial rows.  first_layer: x0 is the layer
+    input itself (no LayerNorm in front of the first layer)."""
+    import torch.nn.functional as F
+    g, d, heads, n_real, mask, x0, pe, degree, p, gam0, bet0 = _ln_block_case(bsz, n_pad, n_min, seed, dtype, with_pe)
+    m, tol = n_pad * bsz, _ln_tol(dtype)
+    f32 = lambda t: t.detach().float().contiguous().to(dev)
+    st = lambda t: t.detach().to(dtype).contiguous().to(dev)
+    new = lambda *s: torch.full(s, float('nan'), dtype=dtype, device=dev)
+    qkv, out, y = new(m, 3 * d), new(m, d), new(m, d)
+    ast = torch.full((bsz, heads, n_pad, 2), float('nan'), device=dev)
+    rows = degree.t().reshape(m)
+    scale = float(d // heads) ** -0.5
+    pe_d = None if pe is None else st(pe)
+    ln0 = {} if first_layer else dict(x_ln_gamma=f32(gam0), x_ln_beta=f32(bet0))
+    abi.attn_block_fwd(bsz, n_pad, scale, stream, x=st(x0).view(m, d), w_in=f32(p['w_in']), b_in=f32(p['b_in']),
+                       w_out=f32(p['w_out']), b_out=f32(p['b_out']), pe=pe_d, n_real=n_real.to(dev), rowscale=f32(rows),
+                       qkv=qkv, out=out, attn_stats=ast, attn=None, y=y, y_stats=None, **ln0)
+    w = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    x = (x0 if first_layer else F.layer_norm(x0, (d,), gam0, bet0, 1e-5)).detach().requires_grad_(True)
+    qkv_ref = F.linear(x, w['w_in'], w['b_in'])
+    concat, _, _ = O.attention_core(qkv_ref, pe, mask, heads, detach_max=True)
+    y1 = x + degree.t().unsqueeze(-1) * F.linear(concat, w['w_out'], w['b_out'])
+    gam1, bet1 = _ln_affine(d, g)
+    gam1.requires_grad_(True), bet1.requires_grad_(True)
+    dy = round_to(torch.randn(n_pad, bsz, d, generator=g).double(), dtype)
+    dout2 = round_to(torch.randn(n_pad, bsz, d, generator=g).double() * (~mask).t().unsqueeze(-1), dtype)
+    ((F.layer_norm(y1, (d,), gam1, bet1, 1e-5) * dy).sum() + (concat * dout2).sum()).backward()
+    gb = abi.attn_block_bwd_blocks(bsz)
+    ld = 4 * d * d + 4 * d + 2 * d
+    partial = torch.full((gb, ld), float('nan'), device=dev)
+    dx = new(m, d)
+    dxb = new(m, d) if split else None
+    ln0b = {} if first_layer else dict(x0_ln_gamma=f32(gam0), x0_ln_beta=f32(bet0))
+    abi.attn_block_bwd(bsz, n_pad, scale, stream, partial=partial, dy=st(dy).view(m, d), y1=y, ln1_gamma=f32(gam1), ln_eps=1e-5,
+                       rowscale=f32(rows), w_out=f32(p['w_out']), w_in=f32(p['w_in']), qkv=qkv, out=out,
+                       dout2=st(dout2).view(m, d), pe=pe_d, n_real=n_real.to(dev), attn_stats=ast, x0=st(x0).view(m, d),
+                       dx=dx, dx_b=dxb, **ln0b)
+    got = dx.view(n_pad, bsz, d).float().cpu().double()
+    if split:
+        got = got + dxb.view(n_pad, bsz, d).float().cpu().double()
+    errs = {'dx': assert_close('ln block dx', got, x.grad, tol=tol)}
+    pw = partial.double().sum(0).cpu()
+    o = 0
+    for name, ref in (('dW_out', w['w_out'].grad), ('db_out', w['b_out'].grad), ('dW_in', w['w_in'].grad),
+                      ('db_in', w['b_in'].grad), ('dgamma1', gam1.grad), ('dbeta1', bet1.grad)):
+        errs[name] = assert_close('ln block ' + name, pw[o:o + ref.numel()].view(ref.shape), ref, tol=tol)
+        o += ref.numel()
+    return errs

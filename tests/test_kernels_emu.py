@@ -303,3 +303,43 @@ def test_attn_stab_clamp5(emu, bsz, n, h, dh, use_pe, dtype):
     """stab = clamp5 (witnesses LSPE/layers/graphit_gt_layer.py:39-43): exp(clamp(s, -5, 5)), forward and
     backward with zero gradient through clamped scores, fp32 and bf16 storage"""
     KC.check_attn(emu, CPU, None, bsz, n, h, dh, use_pe, dtype=dtype, clamp5=True)
+
+
+# ---- LayerNorm on load in the fused stack kernels (ABI 9) --------------------------------------------------------------
+F32, B16 = torch.float32, torch.bfloat16
+
+
+@pytest.mark.parametrize('kw', [dict(m=75, ff=128, dtype=F32), dict(m=40, ff=64, dtype=B16), dict(m=33, ff=256, dtype=F32)])
+def test_ffn_fwd_layernorm_on_load(emu, kw):
+    KC.check_ffn_ln(emu, CPU, None, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(bsz=3, n_pad=21, dtype=F32), dict(bsz=2, n_pad=37, n_min=9, dtype=B16),
+                                dict(bsz=2, n_pad=50, n_min=20, dtype=F32, with_pe=False, need_attn=False)])
+def test_attn_block_fwd_layernorm_on_load(emu, kw):
+    KC.check_attn_block_ln(emu, CPU, None, **kw)
+
+
+@pytest.mark.parametrize('env', [{}, {'FETA_BLOCK_FWD_WAVES': '4'}, {'FETA_BLOCK_MAX_GRID': '2'}])
+def test_attn_block_fwd_layernorm_on_load_forms(emu, monkeypatch, env):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    KC.check_attn_block_ln(emu, CPU, None, bsz=5, n_pad=33, n_min=5, dtype=F32)
+
+
+@pytest.mark.parametrize('kw', [dict(m=150, ff=128, dtype=F32), dict(m=70, ff=64, dtype=B16, two_parts=True),
+                                dict(m=100, ff=128, dtype=F32, two_parts=True)])
+def test_ffn_bwd_layernorm_on_load(emu, kw):
+    KC.check_ffn_bwd_ln(emu, CPU, None, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(bsz=3, n_pad=21, dtype=F32), dict(bsz=2, n_pad=37, n_min=9, dtype=B16, split=True),
+                                dict(bsz=2, n_pad=20, dtype=F32, split=True, first_layer=True),
+                                dict(bsz=2, n_pad=50, n_min=20, dtype=F32, with_pe=False)])
+def test_attn_block_bwd_layernorm_on_load(emu, kw):
+    KC.check_attn_block_bwd_ln(emu, CPU, None, **kw)
+
+
+def test_attn_block_bwd_layernorm_walks_several_graphs(emu, monkeypatch):
+    monkeypatch.setenv('FETA_BLOCK_BWD_MAX_GRID', '2')
+    KC.check_attn_block_bwd_ln(emu, CPU, None, bsz=5, n_pad=21, dtype=F32)

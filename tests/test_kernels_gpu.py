@@ -315,3 +315,44 @@ def test_attn_stab_clamp5(hip, bsz, n, h, dh, use_pe, dtype):
     """stab = clamp5 (witnesses LSPE/layers/graphit_gt_layer.py:39-43): exp(clamp(s, -5, 5)), forward and
     backward with zero gradient through clamped scores, fp32 and bf16 storage"""
     KC.check_attn(*hip, bsz, n, h, dh, use_pe, dtype=dtype, clamp5=True)
+
+
+# ---- LayerNorm on load in the fused stack kernels (ABI 9) --------------------------------------------------------------
+F32, B16 = torch.float32, torch.bfloat16
+
+
+@pytest.mark.parametrize('kw', [dict(m=4736, ff=128, dtype=F32), dict(m=4736, ff=128, dtype=B16), dict(m=75, ff=64, dtype=F32),
+                                dict(m=33, ff=256, dtype=B16), dict(m=65536, ff=128, dtype=F32)])
+def test_ffn_fwd_layernorm_on_load(hip, kw):
+    KC.check_ffn_ln(hip[0], hip[1], hip[2], **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(bsz=128, n_pad=37, n_min=9, dtype=F32), dict(bsz=128, n_pad=37, n_min=9, dtype=B16),
+                                dict(bsz=32, n_pad=28, n_min=10, dtype=F32, with_pe=False, need_attn=False),
+                                dict(bsz=300, n_pad=64, n_min=2, dtype=F32, with_pe=False),     # workgroups walk the batch
+                                dict(bsz=300, n_pad=64, n_min=2, dtype=B16), dict(bsz=3, n_pad=21, dtype=F32)])
+def test_attn_block_fwd_layernorm_on_load(hip, kw):
+    KC.check_attn_block_ln(hip[0], hip[1], hip[2], **kw)
+
+
+@pytest.mark.parametrize('env', [{'FETA_BLOCK_FWD_WAVES': '4'}, {'FETA_BLOCK_FWD_WGS': '1'}, {'FETA_BLOCK_FWD_WGS': '2'}])
+def test_attn_block_fwd_layernorm_on_load_forms(hip, monkeypatch, env):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    KC.check_attn_block_ln(hip[0], hip[1], hip[2], bsz=64, n_pad=37, n_min=5, dtype=F32)
+
+
+@pytest.mark.parametrize('kw', [dict(m=4736, ff=128, dtype=F32), dict(m=4736, ff=128, dtype=B16, two_parts=True),
+                                dict(m=150, ff=64, dtype=F32, two_parts=True), dict(m=65536, ff=128, dtype=F32),
+                                dict(m=19200, ff=128, dtype=B16)])
+def test_ffn_bwd_layernorm_on_load(hip, kw):
+    KC.check_ffn_bwd_ln(hip[0], hip[1], hip[2], **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(bsz=128, n_pad=37, n_min=9, dtype=F32), dict(bsz=128, n_pad=37, n_min=9, dtype=F32, split=True),
+                                dict(bsz=128, n_pad=37, n_min=9, dtype=B16, split=True),
+                                dict(bsz=32, n_pad=28, n_min=10, dtype=F32, with_pe=False, first_layer=True),
+                                dict(bsz=300, n_pad=64, n_min=2, dtype=F32, with_pe=False),     # the graph-walking form
+                                dict(bsz=300, n_pad=64, n_min=2, dtype=B16), dict(bsz=3, n_pad=21, dtype=F32)])
+def test_attn_block_bwd_layernorm_on_load(hip, kw):
+    KC.check_attn_block_bwd_ln(hip[0], hip[1], hip[2], **kw)

@@ -642,6 +642,61 @@ def test_layernorm_stack_equals_per_op(emu, monkeypatch, shape, n_min, n_max, d,
                                         d, heads, tie_qk, use_block=use_block)
 
 
+def check_layernorm_on_load_launches(dev, hook, abi, monkeypatch, bsz=4, layers=3):
+    """LayerNorm on load (ABI 9): a LayerNorm stack of L layers at the fused kernels' shape runs 2 L launches + ONE
+    feta_layernorm_fwd forward and 2 L launches + one reduction backward - no feta_layernorm_bwd at all - and agrees with
+    the round-3 form (a LayerNorm launch behind every sub-layer, FETA_LN_ON_LOAD=0) to rounding."""
+    from feta_tmlr_amd import fused_stack
+    torch.manual_seed(11)
+    model = DiffGraphTransformerGenGCN(9, 1, 64, 4, dim_feedforward=128, dropout=0.0, nb_layers=layers,
+                                       batch_norm=False, filter_order=2, heads_share_graph=True, filter_mode='spectral')
+    with torch.no_grad():
+        for l in model.encoder.layers:
+            l.norm1.weight.normal_(1.0, 0.2)
+            l.norm1.bias.normal_(0, 0.1)
+            l.norm2.weight.normal_(1.0, 0.2)
+            l.norm2.bias.normal_(0, 0.1)
+    ds = D.SyntheticGraphDataset('zinc', bsz, in_dim=9, seed=5, pos_enc=True, n_min=9, n_max=30)
+    n_pad = max(g.num_nodes for g in ds.samples)
+    batch9, cache = D.collate(ds.samples, k_eig=n_pad, device=dev)
+    model = model.to(dev)
+    calls = {}
+    names = ('layernorm_fwd', 'layernorm_bwd', 'attn_block_fwd', 'ffn_fwd', 'ffn_bwd', 'attn_block_bwd', 'colsum_multi')
+    orig = {k: getattr(abi, k) for k in names}
+
+    def counted(k):
+        def f(*a, **kw):
+            calls[k] = calls.get(k, 0) + 1
+            return orig[k](*a, **kw)
+        return f
+    for k in names:
+        setattr(abi, k, counted(k))
+    try:
+        monkeypatch.setattr(fused_stack, 'USE_LN_ON_LOAD', True)
+        a = _stack_run(model, batch9, cache, True, monkeypatch, hook)
+        on_load = dict(calls)
+        calls.clear()
+        monkeypatch.setattr(fused_stack, 'USE_LN_ON_LOAD', False)
+        b = _stack_run(model, batch9, cache, True, monkeypatch, hook)
+        unfused = dict(calls)
+    finally:
+        for k in names:
+            setattr(abi, k, orig[k])
+    assert on_load.get('layernorm_fwd') == 1 and 'layernorm_bwd' not in on_load, on_load
+    assert all(on_load[k] == layers for k in ('attn_block_fwd', 'ffn_fwd', 'ffn_bwd', 'attn_block_bwd')), on_load
+    assert unfused['layernorm_fwd'] == 2 * layers and unfused['layernorm_bwd'] == 2 * layers, unfused
+    KC.assert_close('output', a[0], b[0].double(), tol=2e-6)
+    KC.assert_close('coefficients', a[1], b[1].double(), tol=2e-6)
+    assert_close_up_to_relu_flips('dx', a[2], b[2].double(), tol=1e-5)
+    assert a[3].keys() == b[3].keys()
+    for k in a[3]:
+        KC.assert_close('grad ' + k, a[3][k], b[3][k].double(), tol=1e-5)
+
+
+def test_layernorm_on_load_launches(emu, monkeypatch):
+    check_layernorm_on_load_launches(CPU, lambda: _lib.override_for_tests(emu), emu, monkeypatch)
+
+
 def check_spectral_mode_without_eigenbasis(dev, hook, spectral_k=None):
     """filter_mode='spectral' fed only with the edge list: the encoder decomposes Lhat on the device
     (models._graph_cache -> position_encoding.device_spectrum) and agrees with the same model fed with

@@ -189,3 +189,10 @@ def test_linear_bf16_library_path_equals_tiled_kernels(monkeypatch):
     for name, t0, t1 in zip(('y', 'coeff', 'dpooled', 'dW', 'db', 'dbias'), a[:6], bb[:6]):
         scale = float(t0.abs().max())
         assert float((t0 - t1).abs().max()) <= 2e-5 * max(1.0, scale), name
+
+
+@pytest.mark.parametrize('bsz,layers', [(32, 3), (300, 2)])
+def test_layernorm_on_load_launches(hip, monkeypatch, bsz, layers):
+    import contextlib
+    from test_modules_emu import check_layernorm_on_load_launches
+    check_layernorm_on_load_launches(hip[1], contextlib.nullcontext, hip[0], monkeypatch, bsz=bsz, layers=layers)

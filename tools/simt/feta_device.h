@@ -148,6 +148,21 @@ inline float row16_sum(float v) {
   return v;
 }
 
+// sum over the 8 lanes that share lane >> 3, in the butterfly order of the device version (xor 1, xor 2, half-row mirror)
+inline float row8_sum(float v) {
+  simt::WaveScratch& s = simt::wave_scratch();
+  const int l = lane_id();
+  const int partner[3] = {l ^ 1, l ^ 2, (l & ~7) | (7 - (l & 7))};
+  for (int step = 0; step < 3; ++step) {
+    s.a[l] = v;
+    simt::wave_barrier();
+    const float o = s.a[partner[step]];
+    simt::wave_barrier();
+    v += o;
+  }
+  return v;
+}
+
 // orders this wave's LDS writes before its later LDS reads (other lanes' data)
 inline void wave_lds_sync() { simt::wave_barrier(); }
 
