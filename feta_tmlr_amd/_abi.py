@@ -54,6 +54,8 @@ SIGNATURES = {
     'feta_layernorm_fwd': ([_F, _F, _F, C.c_float, _F, _F, C.c_int, C.c_int, _S], C.c_int),
     'feta_layernorm_bwd': ([_F, _F, _F, _F, _F, _F, C.c_int, _F, C.c_int, C.c_int, _S], C.c_int),
     'feta_layernorm_fwd_ex': ([_F, _F, _F, C.c_float, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, _S], C.c_int),
+    'feta_layernorm_bwd_eps': ([_F, _F, _F, C.c_float, _F, _F, _F, C.c_int, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _S],
+                               C.c_int),
     'feta_layernorm_bwd_ex': ([_F, _F, _F, _F, _F, _F, C.c_int, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _S],
                               C.c_int),
     'feta_eigh_sym_supported': ([C.c_int], C.c_int),
@@ -723,13 +725,14 @@ class Abi:
         self._check(self.lib.feta_layernorm_fwd_ex(_p(y), _p(gamma), _p(beta), eps, _p(out), _p(stats), m, d,
                                                    self._dt(y), self._dt(out), stream), 'feta_layernorm_fwd')
 
-    def layernorm_bwd(self, dout, y, stats, gamma, dy, partial, dgdb, stream, partial_ld=0, partial_ptr=None):
+    def layernorm_bwd(self, dout, y, stats, gamma, dy, partial, dgdb, stream, partial_ld=0, partial_ptr=None, eps=1e-5):
         """partial_ptr / partial_ld: this LayerNorm's columns inside a shared [blocks, total] partial buffer
-        (dgdb None: the caller reduces it).  dout, y, dy: float32 or bfloat16 rows, independently."""
+        (dgdb None: the caller reduces it).  dout, y, dy: float32 or bfloat16 rows, independently.  stats None: the
+        forward saved none (LayerNorm on load) - recomputed from y with eps."""
         m, d = y.shape
         pp = _p(partial) if partial_ptr is None else C.c_void_p(partial_ptr)
-        self._check(self.lib.feta_layernorm_bwd_ex(_p(dout), _p(y), _p(stats), _p(gamma), _p(dy), pp, partial_ld,
-                                                   _p(dgdb), m, d, self._dt(dout), self._dt(y), self._dt(dy), stream),
+        self._check(self.lib.feta_layernorm_bwd_eps(_p(dout), _p(y), _p(stats), eps, _p(gamma), _p(dy), pp, partial_ld,
+                                                    _p(dgdb), m, d, self._dt(dout), self._dt(y), self._dt(dy), stream),
                     'feta_layernorm_bwd')
 
     def eigh_sym_supported(self, n):

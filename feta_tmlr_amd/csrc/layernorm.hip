@@ -117,15 +117,40 @@ __global__ __launch_bounds__(kLnThreads) void ln_bwd_kernel(LnArgs a) {
     const int row = blk * kLnRows + rg;
     const int rowc = min(row, a.M - 1);
     const bool rok = row < a.M;
-    const float mean = a.stats[2 * (int64_t)rowc], rstd = a.stats[2 * (int64_t)rowc + 1];
+    float4 yr[NV], dr[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int c = 64 * v + 4 * l;
+      yr[v] = ln_ld4(a.y, (int64_t)rowc * a.D + (c < a.D ? c : 0), a.y_bf16 != 0);
+      dr[v] = ln_ld4(a.dout, (int64_t)rowc * a.D + (c < a.D ? c : 0), a.dout_bf16 != 0);
+    }
+    float mean, rstd;
+    if (a.stats != nullptr) {
+      mean = a.stats[2 * (int64_t)rowc];
+      rstd = a.stats[2 * (int64_t)rowc + 1];
+    } else {
+      // no saved statistics (the forward applied this LayerNorm on load, csrc/feta_ln.h): the row is here - two more sums
+      float s0 = 0.0f, q0 = 0.0f;
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+        if (64 * v + 4 * l < a.D) s0 += (yr[v].x + yr[v].y) + (yr[v].z + yr[v].w);
+      mean = row16_sum(s0) * inv_d;
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+        if (64 * v + 4 * l < a.D) {
+          const float dx = yr[v].x - mean, dy_ = yr[v].y - mean, dz = yr[v].z - mean, dw = yr[v].w - mean;
+          q0 += (dx * dx + dy_ * dy_) + (dz * dz + dw * dw);
+        }
+      rstd = 1.0f / sqrtf(row16_sum(q0) * inv_d + a.eps);
+    }
     float4 xh[NV], g[NV];
     float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const int c = 64 * v + 4 * l;
       const bool ok = c < a.D && rok;
-      const float4 yv = ln_ld4(a.y, (int64_t)rowc * a.D + (c < a.D ? c : 0), a.y_bf16 != 0);
-      const float4 dv = ln_ld4(a.dout, (int64_t)rowc * a.D + (c < a.D ? c : 0), a.dout_bf16 != 0);
+      const float4 yv = yr[v];
+      const float4 dv = dr[v];
       const float m = ok ? 1.0f : 0.0f;
       xh[v].x = (yv.x - mean) * rstd * m;  xh[v].y = (yv.y - mean) * rstd * m;
       xh[v].z = (yv.z - mean) * rstd * m;  xh[v].w = (yv.w - mean) * rstd * m;
@@ -229,7 +254,14 @@ extern "C" int feta_layernorm_bwd(const float* dout, const float* y, const float
 extern "C" int feta_layernorm_bwd_ex(const void* dout, const void* y, const float* stats, const float* gamma,
                                      void* dy, float* partial, int partial_ld, float* dgamma_dbeta, int M, int D,
                                      int dout_dtype, int y_dtype, int dy_dtype, feta_stream_t stream) {
-  FETA_REQUIRE(dout && y && stats && gamma && dy && partial && M > 0, "layernorm_bwd: bad arguments");
+  return feta_layernorm_bwd_eps(dout, y, stats, 1e-5f, gamma, dy, partial, partial_ld, dgamma_dbeta, M, D, dout_dtype, y_dtype,
+                                dy_dtype, stream);
+}
+
+extern "C" int feta_layernorm_bwd_eps(const void* dout, const void* y, const float* stats, float eps, const float* gamma,
+                                      void* dy, float* partial, int partial_ld, float* dgamma_dbeta, int M, int D,
+                                      int dout_dtype, int y_dtype, int dy_dtype, feta_stream_t stream) {
+  FETA_REQUIRE(dout && y && gamma && dy && partial && M > 0, "layernorm_bwd: bad arguments");
   FETA_REQUIRE(partial_ld == 0 || partial_ld >= 2 * D, "layernorm_bwd: partial_ld = %d < 2 D", partial_ld);
   FETA_REQUIRE(dgamma_dbeta || partial_ld > 0, "layernorm_bwd: dgamma_dbeta may only be NULL with a caller-reduced partial_ld");
   FETA_REQUIRE(ln_dim_ok(D), "layernorm_bwd: D = %d (multiple of 4, <= 256)", D);
@@ -241,6 +273,7 @@ extern "C" int feta_layernorm_bwd_ex(const void* dout, const void* y, const floa
   a.y = static_cast<const float*>(y);
   a.gamma = gamma;
   a.stats = const_cast<float*>(stats);
+  a.eps = eps;
   a.dout = static_cast<const float*>(dout);
   a.dy = static_cast<float*>(dy);
   a.partial = partial;

@@ -167,7 +167,7 @@ def _cap_partials(abi, stream, st, new, shift_row=False):
     return tot, 1
 
 
-def _partial_buffers(abi, new, m, b, n, d, heads, ff0, nl, fused_attn, ln_cols=False):
+def _partial_buffers(abi, new, m, b, n, d, heads, ff0, nl, fused_attn, ln_cols=False, ln_f=None, ln_a=None):
     """Split-K partial buffers of a stack backward and the slot allocator.  Two buffers, because their row counts
     differ: 'f' (linear2 / linear1 of every layer) has one row per feta_rowlin_chunks(M) row chunk, 'a' (out_proj /
     in_proj) the same or - with the fused attention-block backward - one row per graph.  dwdb_all = [f columns |
@@ -177,8 +177,10 @@ def _partial_buffers(abi, new, m, b, n, d, heads, ff0, nl, fused_attn, ln_cols=F
     ra = abi.attn_block_bwd_blocks(b) if fused_attn else rc
     # ln_cols (LayerNorm on load): every layer's slot is followed by [dgamma | dbeta] of the LayerNorm whose backward
     # the kernel applies on its gradient load (norm2 behind the feed-forward slot, norm1 behind the attention slot)
-    tf = nl * ((ff0 * d + ff0) + (d * ff0 + d) + (2 * d if ln_cols else 0))
-    ta = nl * ((d * d + d) + (3 * d * d + 3 * d) + (2 * d if ln_cols else 0))
+    ln_f = ln_cols if ln_f is None else ln_f
+    ln_a = ln_cols if ln_a is None else ln_a
+    tf = nl * ((ff0 * d + ff0) + (d * ff0 + d) + (2 * d if ln_f else 0))
+    ta = nl * ((d * d + d) + (3 * d * d + 3 * d) + (2 * d if ln_a else 0))
     part_f, part_a = new(rc, tf), new(ra, ta)
     cur = {'f': 0, 'a': 0}
 
@@ -608,10 +610,21 @@ class FusedLayerNormStackFn(torch.autograd.Function):
                     dsc = abi.rowlin_ex(m, d, d, x=out.view(m, d), w=w_o, bias=b_o, rowscale=degree_rows,
                                         residual=x_in, y=y1)
                     abi.rowlin_fwd_ex(dsc, stream)
-            x1, lst1 = newt(m, d), new(m, 2)
-            abi.layernorm_fwd(y1, g1, be1, float(layer.norm1.eps), x1, lst1, stream)
             h, y2 = newt(m, ff), newt(m, d)
-            if USE_FFN_FUSED and abi.ffn_supported(d, ff):
+            # norm1 on load (ABI 9) where the feed-forward half runs as its two fused kernels: x1 is never written, the
+            # backward recomputes it from y1 and takes the LayerNorm backward of norm2 on its gradient load
+            ffn_on_load = (USE_LN_ON_LOAD and USE_FFN_FUSED and USE_FFN_BWD and abi.ffn_supported(d, ff)
+                           and abi.ffn_bwd_supported(d, ff))
+            x1 = lst1 = None
+            if ffn_on_load and li == nl - 1:
+                y2 = new(m, d)      # (its gradient arrives as fp32: feta_ffn_bwd wants dy and g_y of one type)
+            if not ffn_on_load:
+                x1, lst1 = newt(m, d), new(m, 2)
+                abi.layernorm_fwd(y1, g1, be1, float(layer.norm1.eps), x1, lst1, stream)
+            if ffn_on_load:
+                abi.ffn_fwd(m, ff, stream, eps=float(layer.norm1.eps), x=y1, x_ln_gamma=g1, x_ln_beta=be1, w1=w1, b1=bb1,
+                            w2=w2, b2=bb2, h=h, y=y2, coeff=_coeff_fwd_role(pending, li, nl, attn, n_real))
+            elif USE_FFN_FUSED and abi.ffn_supported(d, ff):
                 abi.ffn_fwd(m, ff, stream, x=x1, w1=w1, b1=bb1, w2=w2, b2=bb2, h=h, y=y2,
                             coeff=_coeff_fwd_role(pending, li, nl, attn, n_real))
             else:
@@ -621,9 +634,11 @@ class FusedLayerNormStackFn(torch.autograd.Function):
                 abi.rowlin_fwd_ex(dsc, stream)
             x2, lst2 = (new(m, d) if li == nl - 1 else newt(m, d)), new(m, 2)   # (the stack's output is fp32)
             abi.layernorm_fwd(y2, g2, be2, float(layer.norm2.eps), x2, lst2, stream)
-            saved.append(dict(x0=x_in, qkv=qkv, out=out, ast=ast, y1=y1, lst1=lst1, x1=x1, h=h, y2=y2, lst2=lst2))
+            saved.append(dict(x0=x_in, qkv=qkv, out=out, ast=ast, y1=y1, lst1=lst1, x1=x1, h=h, y2=y2, lst2=lst2,
+                              ffn_on_load=ffn_on_load))
             x_in = x2
         ctx.saved_state = saved
+        ctx.eps = [(float(l.norm1.eps), float(l.norm2.eps)) for l in layers]
         ctx.meta = (n, b, d, heads, dh, tie, scale, nl)
         ctx.aux = (pe_c, degree_rows, n_real)
         ctx.params = params
@@ -653,17 +668,22 @@ class FusedLayerNormStackFn(torch.autograd.Function):
         grads = [None] * len(params)
         ff0 = params[6].shape[0]
         fused_attn = _fused_attn_bwd(abi, b, n, d, heads, tie, dt)
-        part_f, part_a, tf, ta, wslot = _partial_buffers(abi, new, m, b, n, d, heads, ff0, nl, fused_attn)
+        # feed-forward half on its fused kernels with the LayerNorms on load (ABI 9): norm2's backward is taken on the
+        # gradient load of feta_ffn_bwd ([dgamma2 | dbeta2] in its partial rows, behind db1), x1 = LN1(y1) on its operand
+        # load; norm1's backward stays a launch (no saved statistics: recomputed from y1)
+        ffn_on_load = all(s_['ffn_on_load'] for s_ in saved)     # (one feed-forward width per stack: all or none)
+        part_f, part_a, tf, ta, wslot = _partial_buffers(abi, new, m, b, n, d, heads, ff0, nl, fused_attn, ln_f=ffn_on_load)
         coeff_req = _coeff_bwd_request(ctx, abi, stream, d, params[(nl - 1) * PER_LAYER + 6].shape[0])
         total = tf + ta
-        ln_part = new(GL, nl * 4 * d)
-        dwdb_all = new(total + nl * 4 * d)          # same layout as the BatchNorm stack's flat buffer
-        ln_tail = dwdb_all[total:].view(nl, 4, d)   # dgamma1, dbeta1, dgamma2, dbeta2 per layer
+        lnw = 2 if ffn_on_load else 4               # LayerNorm partial columns per layer that come from feta_layernorm_bwd
+        ln_part = new(GL, nl * lnw * d)
+        dwdb_all = new(total + nl * lnw * d)        # [feed-forward slots | attention slots | LayerNorm tail]
+        ln_tail = dwdb_all[total:].view(nl, lnw, d)   # dgamma1, dbeta1 (, dgamma2, dbeta2) per layer
 
-        def ln_bwd(dout, y, stats, gamma, li, which):
+        def ln_bwd(dout, y, stats, gamma, li, which, eps=1e-5):
             dy = newt(m, d)
-            abi.layernorm_bwd(dout, y, stats, gamma, dy, None, None, stream, partial_ld=nl * 4 * d,
-                              partial_ptr=ln_part.data_ptr() + 4 * (li * 4 + 2 * which) * d)
+            abi.layernorm_bwd(dout, y, stats, gamma, dy, None, None, stream, partial_ld=nl * lnw * d,
+                              partial_ptr=ln_part.data_ptr() + 4 * (li * lnw + 2 * which) * d, eps=eps)
             return dy
 
         slots = {}
@@ -677,14 +697,22 @@ class FusedLayerNormStackFn(torch.autograd.Function):
             (w_in, b_in, w_o, b_o, g1, be1, w1, bb1, w2, bb2, g2, be2) = params[li * PER_LAYER:(li + 1) * PER_LAYER]
             ff = w1.shape[0]
             base = li * PER_LAYER
-            dy2 = ln_bwd(dcur, s['y2'], s['lst2'], g2, li, 1)
-            grads[base + 10], grads[base + 11] = ln_tail[li, 2], ln_tail[li, 3]
+            eps1, eps2 = ctx.eps[li]
+            if not ffn_on_load:
+                dy2 = ln_bwd(dcur, s['y2'], s['lst2'], g2, li, 1, eps2)
+                grads[base + 10], grads[base + 11] = ln_tail[li, 2], ln_tail[li, 3]
             pp, off = wslot('f', d, ff)
             slots[base + 8] = (off, d, ff)
             pp1, off1 = wslot('f', ff, d)
             slots[base + 6] = (off1, ff, d)
             dx1 = newt(m, d)
-            if USE_FFN_BWD and abi.ffn_bwd_supported(d, ff):
+            if ffn_on_load:
+                offl = wslot.raw('f', 2 * d)
+                grads[base + 10], grads[base + 11] = dwdb_all[offl:offl + d], dwdb_all[offl + d:offl + 2 * d]
+                abi.ffn_bwd(m, ff, stream, coeff=(coeff_req if li == nl - 1 else None), partial_ptr=pp, partial_ld=tf,
+                            dy=dcur, g_y=s['y2'], g_ln_gamma=g2, ln_eps=eps2, h=s['h'], w2=w2, w1=w1, x=s['y1'],
+                            x_ln_gamma=g1, x_ln_beta=be1, dx=dx1)
+            elif USE_FFN_BWD and abi.ffn_bwd_supported(d, ff):
                 # linear2 + linear1 backward in one launch (csrc/ffn_bwd.hip), dx1 = dy2 + dh W1
                 abi.ffn_bwd(m, ff, stream, coeff=(coeff_req if li == nl - 1 else None), partial_ptr=pp, partial_ld=tf,
                             dy=dy2, h=s['h'], w2=w2, w1=w1, x=s['x1'],
@@ -697,7 +725,7 @@ class FusedLayerNormStackFn(torch.autograd.Function):
                 dsc = abi.rowlin_ex(m, d, ff, x=s['x1'], w=w1, dy=dh_, relu_y=s['h'], dx=dx1, partial_ptr=pp1,
                                     partial_ld=tf, add_plain=dy2)
                 abi.rowlin_bwd_ex(dsc, None, stream)
-            dy1 = ln_bwd(dx1, s['y1'], s['lst1'], g1, li, 0)
+            dy1 = ln_bwd(dx1, s['y1'], s['lst1'], g1, li, 0, eps1)     # (lst1 None: LayerNorm on load - recomputed)
             grads[base + 4], grads[base + 5] = ln_tail[li, 0], ln_tail[li, 1]
             ppo, offo = wslot('a', d, d)
             slots[base + 2] = (offo, d, d)

@@ -694,6 +694,11 @@ int feta_layernorm_fwd_ex(const void* y, const float* gamma, const float* beta, 
 int feta_layernorm_bwd_ex(const void* dout, const void* y, const float* stats, const float* gamma,
                           void* dy, float* partial, int partial_ld, float* dgamma_dbeta, int M, int D,
                           int dout_dtype, int y_dtype, int dy_dtype, feta_stream_t stream);
+/* ... with `stats` nullable (ABI 9): the forward applied this LayerNorm on load (feta_ffn.x_ln_gamma) and saved no
+ * statistics - mean / rstd are recomputed from the pre-norm rows y with `eps` (the row is in registers: two more sums). */
+int feta_layernorm_bwd_eps(const void* dout, const void* y, const float* stats, float eps, const float* gamma,
+                           void* dy, float* partial, int partial_ld, float* dgamma_dbeta, int M, int D,
+                           int dout_dtype, int y_dtype, int dy_dtype, feta_stream_t stream);
 
 /* ---- spectrum producer ------------------------------------------------
  * Batched symmetric eigendecomposition, one workgroup per graph, the matrix in LDS (N <= 192) or, for
