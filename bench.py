@@ -365,7 +365,7 @@ def _load_json(*names):
     return {}, None
 
 
-def roofline(args, gpu, dev, lowp=False):
+def roofline(args, gpu, dev, lowp=False, pmc_tag=None):
     """Times the hand-written kernels of one step in isolation, in exactly the variants the fused stack
     issues (feta_tmlr_amd/benchcases.py; HIP events on the stream they are launched on - torch's
     current stream), groups the variants by KERNEL SYMBOL (what rocprofv3 --stats reports: e.g. the two
@@ -458,7 +458,9 @@ def roofline(args, gpu, dev, lowp=False):
                      spec_bytes(b, n, h, dh, k_eig, p, sum_n, True)))
     r_ = h * b
     from feta_tmlr_amd import functional as FF
-    if abi.lin_supported(r_, c, c) and (r_ * c * c <= FF.LIN_OWN_GEMM_MAX_MACS or lowp):
+    if (abi.lin_supported(r_, c, c) and (r_ * c * c <= FF.LIN_OWN_GEMM_MAX_MACS or lowp)
+            and not (lowp and r_ >= FF.LIN_LIB_BF16_MIN_ROWS)):     # (functional.FilterFromPooledFn's policy: from that
+        # many rows the bf16 legs run library GEMMs too - the object lists what the step launches)
         # the C x C linear of the coefficient generator runs as csrc/lin.hip at this size (else: library GEMMs, which
         # are not candidates - the roofline object prices the hand-written kernels)
         lw, lb, lx, ldy = rnd(c, c) / c ** 0.5, rnd(c), rnd(r_, c), rnd(r_, c)
@@ -475,10 +477,13 @@ def roofline(args, gpu, dev, lowp=False):
               ('r03_end_traffic_b128.json', 'r03_traffic_b128.json', 'r02_traffic_b128.json'))
     mfiles = (('r03_end_pmc_mfma_b128_bf16.json', 'r03_pmc_mfma_b128_bf16.json') if lowp else
               ('r03_end_pmc_mfma_b128.json', 'r03_pmc_mfma_b128.json', 'r02_pmc_mfma_b128.json'))
-    if b != 128 or n != 37:      # (the committed PMC passes are of the BASELINE batch: other shapes carry no counters)
+    if b != 128 or n != 37:      # (the per-variant PMC passes are of the BASELINE batch)
         tfiles = mfiles = ()
     traffic, traffic_src = _load_json(*tfiles)
     mfma, mfma_src = _load_json(*mfiles)
+    # other shapes (extra_configs): counters of the STEP itself, per kernel symbol (tools/profile_config.sh -> tools/pmc_step.py:
+    # every launch of a symbol in an eager run of this configuration, FETCH_SIZE x2 + WRITE_SIZE, MFMA-pipe busy share)
+    step_pmc, step_src = _load_json('r04_%s_pmc.json' % pmc_tag) if pmc_tag else ({}, None)
     groups = {}
     for name, sym, cnt, fn, nbytes in cand:
         t = time_kernel(fn, args.kernel_iters)
@@ -500,17 +505,31 @@ def roofline(args, gpu, dev, lowp=False):
                 if base in key and ('bf16' in key) == lowp and val.get('mfma_busy_pct') is not None]
         if hits:
             busy = round(sum(hits) / len(hits), 2)      # mean over the instantiations of the source kernel
+        wait = None
+        if step_pmc:
+            # (the fused kernels of the stack and the filter stage, grouped by source kernel; row-wise symbols are not matched)
+            import re
+            pat = re.compile(r'feta::%s(8|_graph|_head|_dense)?_kernel' % re.escape(base))
+            ks = [(key, val) for key, val in step_pmc.items()
+                  if '<' not in sym and pat.search(key) and ('bf16' in key) == lowp and 'hbm_bytes' in val]
+            if ks:
+                wsum = sum(v_['launches'] for _, v_ in ks)
+                tr = int(sum(v_['launches'] * v_['hbm_bytes'] for _, v_ in ks) / wsum)
+                if all('mfma_busy_pct' in v_ for _, v_ in ks):
+                    busy = round(sum(v_['launches'] * v_['mfma_busy_pct'] for _, v_ in ks) / wsum, 2)
+                    wait = round(sum(v_['launches'] * v_['wait_any_pct_of_wave_cycles'] for _, v_ in ks) / wsum, 1)
         ach = bytes_step / t_step / 1e3       # bytes / us -> GB/s
         out_rows.append({'kernel': sym, 'launches_per_step': launches, 'launch_us': round(t_step / launches, 3),
                          'us_per_step': round(t_step, 2), 'algorithmic_bytes': int(bytes_step / launches),
                          'achieved': round(ach, 2), 'frac': round(ach / HBM_PEAK_GBS, 5), 'traffic': tr,
-                         'mfma_busy_pct': busy, 'variants': rows})
+                         'mfma_busy_pct': busy, 'wave_wait_pct': wait, 'variants': rows})
     dom = max(out_rows, key=lambda r: r['us_per_step'])
     res = {'kernel': dom['kernel'], 'bound': 'hbm', 'achieved': dom['achieved'], 'peak': HBM_PEAK_GBS,
            'unit': 'GB/s', 'frac': dom['frac'], 'traffic': dom['traffic'],
            'algorithmic_bytes': dom['algorithmic_bytes'], 'launch_us': dom['launch_us'],
            'launches_per_step': dom['launches_per_step'], 'us_per_step': dom['us_per_step'],
-           'mfma_busy_pct': dom['mfma_busy_pct'], 'traffic_source': traffic_src, 'mfma_busy_source': mfma_src,
+           'mfma_busy_pct': dom['mfma_busy_pct'], 'wave_wait_pct': dom['wave_wait_pct'],
+           'traffic_source': step_src or traffic_src, 'mfma_busy_source': step_src or mfma_src,
            'timing': 'HIP events in this run, launch stream', 'variants': dom['variants'],
            'other_kernels': [{k_: v_ for k_, v_ in r.items() if k_ != 'variants'} for r in out_rows if r is not dom]}
     return res
@@ -683,17 +702,17 @@ def main(argv=None):
         ref_default = dict(layer_norm=True, no_pe=True)    # what README.md:49,65,71 run: no --batch-norm, no --pos-enc
         for name, kw, with_roofline in (
                 ('config 4: PATTERN-shaped, B=64, N_pad=128, K=32, fp32',
-                 dict(shape='pattern', batch=64, n_pad=128, k_eig=32, dtype='f32'), True),
+                 dict(shape='pattern', batch=64, n_pad=128, k_eig=32, dtype='f32'), 'pattern'),
                 ('config 4 (reference defaults: LayerNorm, pe=None): PATTERN-shaped, B=64, N_pad=128, K=32, fp32',
-                 dict(shape='pattern', batch=64, n_pad=128, k_eig=32, dtype='f32', **ref_default), False),
+                 dict(shape='pattern', batch=64, n_pad=128, k_eig=32, dtype='f32', **ref_default), None),
                 ('config 5: molhiv-shaped, B=1024, N_pad=64 bucket, K=16, bf16 storage',
-                 dict(shape='molhiv', batch=1024, n_pad=64, k_eig=16, dtype='bf16'), True),
+                 dict(shape='molhiv', batch=1024, n_pad=64, k_eig=16, dtype='bf16'), 'molhiv_bf16'),
                 ('config 5 (reference defaults: LayerNorm, pe=None): molhiv-shaped, B=1024, N_pad=64 bucket, K=16, bf16 storage',
-                 dict(shape='molhiv', batch=1024, n_pad=64, k_eig=16, dtype='bf16', **ref_default), False),
+                 dict(shape='molhiv', batch=1024, n_pad=64, k_eig=16, dtype='bf16', **ref_default), None),
                 ('config 5 (reference defaults: LayerNorm, pe=None), fp32',
-                 dict(shape='molhiv', batch=1024, n_pad=64, k_eig=16, dtype='f32', **ref_default), False),
+                 dict(shape='molhiv', batch=1024, n_pad=64, k_eig=16, dtype='f32', **ref_default), None),
                 ('config 1 (reference defaults: LayerNorm, pe=None): MUTAG-shaped, B=32, N_pad=28, K=8, fp32',
-                 dict(shape='mutag', batch=32, n_pad=28, k_eig=8, dtype='f32', **ref_default), False)):
+                 dict(shape='mutag', batch=32, n_pad=28, k_eig=8, dtype='f32', **ref_default), None)):
             ax = copy.copy(args)
             for k_, v_ in kw.items():
                 setattr(ax, k_, v_)
@@ -711,8 +730,8 @@ def main(argv=None):
                 'flags': '--shape %s --batch %d --n-pad %d --k-eig %d --dtype %s%s%s' % (
                     ax.shape, ax.batch, ax.n_pad, ax.k_eig, ax.dtype, ' --layer-norm' if ax.layer_norm else '',
                     ' --no-pe' if ax.no_pe else '')}
-            if with_roofline:
-                row['roofline'] = roofline(ax, gpux, dev, lowp=ax.dtype == 'bf16')
+            if with_roofline:      # (= the tag of this configuration's committed counters, profiles/r04_<tag>_pmc.json)
+                row['roofline'] = roofline(ax, gpux, dev, lowp=ax.dtype == 'bf16', pmc_tag=with_roofline)
             extra['extra_configs'].append(row)
             del gpux, encx, stepx
 

@@ -546,16 +546,19 @@ __global__ __launch_bounds__(kBlk8Threads) void attn_block_fwd8_kernel(BlockArgs
   PartialBatchT<16> pb;   // (all 512 threads: 16 slices x 16 rows = every partial row of the BASELINE batch in one batch)
   partials_request_t<TH, 16>(a.x_stats != nullptr ? a.x_stats : a.w_in, a.x_stats != nullptr ? a.Gx : 0, D, pb);
   const bool has_pe = a.pe != nullptr;
+  // operands of the graph at hand as they arrive from memory (storage type: nothing depends on them until they are staged),
+  // requested while the graph before it is computed - a workgroup walks 4 graphs at config 5's batch, one workgroup per CU:
+  // nobody else hides the latency
   Vec xv[XI];
-  float pel[PEI];
-  float rsv[NQ];
-  int n = 0;
+  T pel[PEI];
+  float rsn[NQ], rsv[NQ];
+  int n = 0, n_req = 0;
   const int nn = a.N * a.N;
   // this workgroup's query rows [q0, q1) and their pe elements [q0 N, q1 N) - one contiguous stream
   const int q0 = WGS == 1 ? 0 : 32 * w, q1 = WGS == 1 ? a.N : min(a.N, 32 * w + 32);
   const int pe0 = q0 * a.N, pecnt = max(q1 - q0, 0) * a.N;
   auto request_graph = [&](int b) {
-    n = a.n_real[b];
+    n_req = a.n_real[b];
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
       const int idx = min(tid + TH * i, NR * RV - 1), node = idx / RV, q = idx % RV;
@@ -564,11 +567,11 @@ __global__ __launch_bounds__(kBlk8Threads) void attn_block_fwd8_kernel(BlockArgs
     }
 #pragma unroll
     for (int i = 0; i < PEI; ++i)
-      pel[i] = has_pe ? L::ld1(gpe + (int64_t)b * nn + pe0 + max(min(tid + TH * i, pecnt - 1), 0)) : 1.0f;
+      pel[i] = has_pe ? gpe[(int64_t)b * nn + pe0 + max(min(tid + TH * i, pecnt - 1), 0)] : L::one();
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
       const int qc = min(16 * (slot + S * i) + lq, a.N - 1);
-      rsv[i] = a.rowscale != nullptr ? a.rowscale[(int64_t)b * a.row_sb + (int64_t)qc * a.row_sn] : 1.0f;
+      rsn[i] = a.rowscale != nullptr ? a.rowscale[(int64_t)b * a.row_sb + (int64_t)qc * a.row_sn] : 1.0f;
     }
   };
   request_graph(b0);
@@ -632,17 +635,18 @@ __global__ __launch_bounds__(kBlk8Threads) void attn_block_fwd8_kernel(BlockArgs
   bool first = true;
   const int lane0 = lane;
   for (int b = b0; b < a.B; b += gp) {
-  if (!first) {
-    __syncthreads();   // the tiles of the previous graph have been consumed
-    request_graph(b);
-  }
+  // (LDS-only barriers from here on: the tiles of the previous graph have been consumed / xss is LDS data - the requests
+  // of the next graph stay in flight across them)
   first = false;
+  n = n_req;
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) rsv[i] = rsn[i];
   // (everything a lane derives from its id is invariant in the graph loop and would be hoisted and held across the whole
   // body - csrc/block_bwd.hip: the lane id is laundered once per graph)
   int lane_l = lane0;
   FETA_OPAQUE_LANE(lane_l);
   const int lane = lane_l, tid = (wv << 6) | lane, lq = lane & 15, g = lane >> 4;
-  __syncthreads();
+  lds_barrier();
 #pragma unroll
   for (int i = 0; i < XI; ++i) {
     const int idx = tid + TH * i, node = idx / RV, q = idx % RV;
@@ -670,10 +674,11 @@ __global__ __launch_bounds__(kBlk8Threads) void attn_block_fwd8_kernel(BlockArgs
     for (int i = 0; i < PEI; ++i) {
       const int idx = tid + TH * i, e = pe0 + idx;
       const int qq = (int)(((float)e + 0.5f) * rn), kk = e - qq * a.N;
-      if (idx < pecnt) Pe[qq * PEP + kk] = pel[i];
+      if (idx < pecnt) Pe[qq * PEP + kk] = L::to_f(pel[i]);
     }
   }
-  __syncthreads();
+  if (b + gp < a.B) request_graph(b + gp);   // (wave-uniform; xv / pel have been consumed)
+  lds_barrier();
   FETA_STAMP(1);
 
   // ---- in_proj: Q^T (scaled) of this wave's query tiles; K^T (p = 0) or V (p = 1) of every key tile -> LDS ----------

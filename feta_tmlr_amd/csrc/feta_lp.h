@@ -64,6 +64,8 @@ struct Lp<float> {
     return acc;
   }
   static __device__ __forceinline__ float ld1(const float* p) { return *p; }
+  static __device__ __forceinline__ float to_f(float v) { return v; }     // one stored element as it arrived -> fp32
+  static __device__ __forceinline__ float one() { return 1.0f; }
   static __device__ __forceinline__ void st1(float* p, float v) { *p = v; }
   static __device__ __forceinline__ void ld4(const float* p, float (&v)[4]) {
     const float4 x = *reinterpret_cast<const float4*>(p);
@@ -109,6 +111,8 @@ struct Lp<bf16_t> {
   }
   static __device__ __forceinline__ f32x4 mma(const Op& a, const Op& b, f32x4 acc) { return mfma16_bf16_pk(a, b, acc); }
   static __device__ __forceinline__ float ld1(const bf16_t* p) { return bf2f(*p); }
+  static __device__ __forceinline__ float to_f(bf16_t v) { return bf2f(v); }
+  static __device__ __forceinline__ bf16_t one() { return f2bf(1.0f); }
   static __device__ __forceinline__ void st1(bf16_t* p, float v) { *p = f2bf(v); }
   static __device__ __forceinline__ void ld4(const bf16_t* p, float (&v)[4]) {
     const Op x = ld(p);

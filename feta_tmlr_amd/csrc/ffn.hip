@@ -83,11 +83,14 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a, CoeffFw
 
   // ---- requests: the wave's first x rows, biases, then the weights ----------------------------------------
   float xr[4][4];   // the wave's x row chunks (features 16j + 4g ..), fp32: operand of the first product AND the residual
-  auto load_x = [&]() {
+  // ... as they arrive from memory (storage type): the rows of the NEXT row block are requested while the block at hand is
+  // computed (a workgroup walks 4 blocks at config 5's batch with one or two waves per SIMD: nobody else hides the latency)
+  Op xq[4];
+  auto request_x = [&](int rowc_) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) L::ld4(gx + (int64_t)rowc * D + 16 * j + 4 * g, xr[j]);
+    for (int j = 0; j < 4; ++j) xq[j] = L::ld(gx + (int64_t)rowc_ * D + 16 * j + 4 * g);
   };
-  load_x();
+  request_x(rowc);
   float4 b1v[HT], b2v[2], ksv[2];   // ksv: shift of the y statistics (feta_rowops.h) for this wave's two output tiles
 #pragma unroll
   for (int t = 0; t < HT; ++t)
@@ -176,12 +179,17 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a, CoeffFw
   FETA_OPAQUE_LANE(lane_l);
   const int lane = lane_l, tid = (wv << 6) | lane, lq = lane & 15, g = lane >> 4;
   if (blk != (int)blockIdx.x) {
-    __syncthreads();   // exchange / reduction scratch of the previous row block consumed
+    lds_barrier();   // exchange / reduction scratch of the previous row block consumed (LDS data only: loads stay in flight)
     row = blk * kFfnRows + 16 * rt + lq;
     rok = row < a.M;
     rowc = min(row, a.M - 1);
-    load_x();
   }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) xr[j][e] = L::get(xq[j], e);
+  if (blk + main_grid < nblk)   // (wave-uniform)
+    request_x(min((blk + main_grid) * kFfnRows + 16 * rt + lq, a.M - 1));
   RowOp<T, D> xf;
   if (x_ln) {
     // the row lq of this wave's tile is spread over the four lanes lq + 16 g (16 features each): mean and biased variance
@@ -255,7 +263,7 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a, CoeffFw
       for (int r = 0; r < 4; ++r)   // (selects, not a runtime index: that would put yp in private memory)
         mine[(t * 4 + r) * 64 + lane] = hh ? yp[t][r] : yp[2 + t][r];
   }
-  __syncthreads();
+  lds_barrier();   // (the partial tiles live in LDS; the next block's rows keep travelling)
   const float* theirs = xch + (wv ^ 1) * (2 * 4 * 64);
   float* red = scr;  // [2 row tiles][2][64] column sums, reduced below
 #pragma unroll
@@ -291,7 +299,7 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a, CoeffFw
     }
   }
   if (want_stats) {
-    __syncthreads();
+    lds_barrier();
     if (tid < 2 * D) tot1[0] += red[tid] + red[2 * D + tid];
   }
   FFN_STAMP(5);
