@@ -96,6 +96,11 @@ def parse(argv=None):
     ap.add_argument('--two-phase', action='store_true',
                     help='force the split backward (default for --gpus > 1: overlaps the all-reduce of the '
                          'filter-stage gradients with the backward of the encoder stack)')
+    ap.add_argument('--graph-collectives', action='store_true',
+                    help='split backward only: capture the gradient collectives INTO the step (RCCL collectives are '
+                         'capturable: the all-reduce of the head gradients becomes a branch of the hipGraph that joins '
+                         'behind the stack backward) - a rank\'s step is ONE replay instead of two replays with '
+                         'host-issued collectives between them.  Off by default: not exercised on more than one GPU yet')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=8)
     ap.add_argument('--kernel-iters', type=int, default=200)
@@ -259,6 +264,25 @@ def make_step(args, enc, gpu, world, dev):
 
     both()
     _sync(dev)
+    if use_graph and getattr(args, 'graph_collectives', False):
+        # ONE graph per step: phase 1, the head collectives (launched on RCCL's stream: a captured fork), the stack
+        # backward under them, the stack collective, and the joins (work.wait() inside the capture = an event wait of the
+        # capturing stream).  The communicators exist before the capture: the warm-up steps below run the collectives
+        # eagerly.  At world = 1 start() / finish() are no-ops and this is the single-pass step as one replay.
+        def whole():
+            phase1()
+            w1 = r_head.start()
+            enc.backward_stack()
+            w2 = r_stack.start()
+            r_head.finish(w1)
+            r_stack.finish(w2)
+
+        run = capture(whole)
+
+        def step():
+            run()
+        step.held = held
+        return step, two_phase, use_graph
     if use_graph:   # warm-up runs whole steps; the two graphs share one memory pool
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -767,7 +791,7 @@ def main(argv=None):
                        'norm': 'layer' if args.layer_norm else 'batch(per-rank stats)',
                        'heads_share_graph': share, 'hip_graph': bool(use_graph),
                        'backward': 'two-phase (head all-reduce under stack backward)' if two_phase else 'single',
-                       'two_phase': bool(two_phase),
+                       'two_phase': bool(two_phase), 'graph_collectives': bool(two_phase and args.graph_collectives),
                        'ranks': dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
                        'grad_bucket_bytes': grad_bucket_bytes(enc, two_phase, args.dtype),
                        'parallelism': 'dp%d' % world},

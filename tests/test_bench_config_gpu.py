@@ -45,6 +45,14 @@ def test_timed_extra_configurations_match_oracle(hip, argv):
     print('max abs errors:', {k: '%.2e' % v for k, v in errs.items()})
 
 
+def test_split_backward_with_captured_collectives_matches_oracle(hip):
+    """bench.py --two-phase --graph-collectives: the split backward and its (here: empty, world = 1) collectives as ONE
+    hipGraph per step - the same gradients as the two-replay form and the single pass (all against the oracle)"""
+    errs, used_graph = BC.check_bench_step(hip[1], contextlib.nullcontext, ['--graph-collectives'], replays=3, two_phase=True)
+    assert used_graph
+    print('max abs errors:', {k: '%.2e' % v for k, v in errs.items()})
+
+
 @pytest.mark.parametrize('argv', [[], ['--two-phase'],
                                   ['--shape', 'molhiv', '--batch', '96', '--n-pad', '64', '--k-eig', '32', '--layer-norm'],
                                   ['--shape', 'molhiv', '--batch', '300', '--n-pad', '64', '--k-eig', '32']])

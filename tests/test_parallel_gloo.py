@@ -193,13 +193,15 @@ def test_inplace_reducers_equal_packed_bucket_world2(emu, batch_norm):
     assert torch.allclose(ret[0][1], ret[1][1])
 
 
-def test_bf16_stack_split_backward_world2(emu):
+@pytest.mark.parametrize('batch_norm', [True, False])
+def test_bf16_stack_split_backward_world2(emu, batch_norm):
     """the bf16 storage stack (fused bf16 kernels, fp32 gradients) under the split backward of bench.py --gpus N:
-    in-place reducers == the packed bucket, identical on both ranks"""
-    port = 29500 + (os.getpid() % 400) + 23
+    in-place reducers == the packed bucket, identical on both ranks; batch_norm=False: the LayerNorm-on-load stack
+    (ABI 9), whose flat gradient buffer carries [dgamma | dbeta] inside the kernels' split-K slots"""
+    port = 29500 + (os.getpid() % 400) + 23 + (0 if batch_norm else 13)
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker_inplace, args=(2, port, ret, True, True), nprocs=2, join=True)
+    mp.spawn(_worker_inplace, args=(2, port, ret, batch_norm, True), nprocs=2, join=True)
     for rank in (0, 1):
         packed, inplace = ret[rank]
         assert torch.allclose(packed, inplace, rtol=1e-5, atol=1e-6), float((packed - inplace).abs().max())
