@@ -358,10 +358,20 @@ def _norm(x, w, b, batch_norm):
     return F.layer_norm(x, (x.shape[-1],), w, b, 1e-5)
 
 
+RELU_FORCED = 1e-6      # magnitude a forced pre-activation is set to (see encoder_layer: relu_force)
+
+
 def encoder_layer(src, pe, degree, key_padding_mask, p, prefix, num_heads,
-                  batch_norm=False, tie_qk=False, drop_scale=None):
+                  batch_norm=False, tie_qk=False, drop_scale=None, relu_capture=None, relu_force=None):
     """DiffTransformerEncoderLayer.forward(need_heads=True) -> (src', attn, out_each_head).
-    p: dict of tensors keyed like the product's state_dict, prefix e.g. 'layers.0.'."""
+    p: dict of tensors keyed like the product's state_dict, prefix e.g. 'layers.0.'.
+    relu_capture (a list): the pre-activations z of linear1 are appended (detached).
+    relu_force (a tensor like z with entries in {-1, 0, +1}): where it is non-zero, z is REPLACED by +-RELU_FORCED
+    (gradient: identity) before the relu.  The derivative of relu at a pre-activation that is zero to rounding is a
+    choice, not a value: an fp32 implementation and this fp64 restatement may land on different sides of it, and the
+    parameter gradients then differ by that node's whole contribution.  A test that finds such entries (|z| below fp32
+    resolution) evaluates the oracle for either choice (tests/bench_checks.py); the forward output moves by at most
+    RELU_FORCED * |linear2.weight|."""
     concat, attn, oh = diff_attention(src, pe, key_padding_mask,
                                       p[prefix + 'self_attn.in_proj_weight'],
                                       p.get(prefix + 'self_attn.in_proj_bias'),
@@ -372,8 +382,13 @@ def encoder_layer(src, pe, degree, key_padding_mask, p, prefix, num_heads,
         src2 = degree.transpose(0, 1).unsqueeze(-1) * src2
     src = src + src2
     src = _norm(src, p[prefix + 'norm1.weight'], p[prefix + 'norm1.bias'], batch_norm)
-    src2 = F.linear(F.relu(F.linear(src, p[prefix + 'linear1.weight'], p[prefix + 'linear1.bias'])),
-                    p[prefix + 'linear2.weight'], p[prefix + 'linear2.bias'])
+    z = F.linear(src, p[prefix + 'linear1.weight'], p[prefix + 'linear1.bias'])
+    if relu_capture is not None:
+        relu_capture.append(z.detach())
+    if relu_force is not None:
+        forced = relu_force.to(z.dtype) * RELU_FORCED
+        z = torch.where(relu_force != 0, z + (forced - z).detach(), z)
+    src2 = F.linear(F.relu(z), p[prefix + 'linear2.weight'], p[prefix + 'linear2.bias'])
     src = src + src2
     src = _norm(src, p[prefix + 'norm2.weight'], p[prefix + 'norm2.bias'], batch_norm)
     return src, attn, oh
@@ -437,7 +452,7 @@ def filter_stage_eigenbasis(out_each_head, coeff_all_heads, u, lam, key_padding_
 def encoder_gengcn(src, pe, edge_index, feature_indices, batch, degree, key_padding_mask,
                    p, num_layers, num_heads, order, batch_norm=False, tie_qk=False,
                    heads_share_graph=False, last_layer_filter=True, collapsed=False,
-                   prefix='', eig=None):
+                   prefix='', eig=None, relu_capture=None, relu_force=None):
     """DiffTransformerEncoderGenGCN.forward, transformer/models.py:155-238
     (gnn_type='ChebConvDynamic', use_skip_conn=True).
     ``eig=(u [B,N,K], lam [B,K])``: the filter stage runs in that (possibly truncated) eigenbasis
@@ -450,7 +465,9 @@ def encoder_gengcn(src, pe, edge_index, feature_indices, batch, degree, key_padd
     getc = get_filter_coefficients_collapsed if collapsed else get_filter_coefficients_faithful
     for li in range(num_layers):
         out, attn, oh = encoder_layer(out, pe, degree, key_padding_mask, p,
-                                      prefix + 'layers.%d.' % li, num_heads, batch_norm, tie_qk)
+                                      prefix + 'layers.%d.' % li, num_heads, batch_norm, tie_qk,
+                                      relu_capture=relu_capture,
+                                      relu_force=None if relu_force is None else relu_force.get(li))
         if last_layer_filter and li + 1 != num_layers:                       # :169-171
             continue
         c = getc(attn, key_padding_mask, p[prefix + 'gcn.weight'], p[prefix + 'gcn.bias'],

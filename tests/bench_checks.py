@@ -57,11 +57,57 @@ def check_bench_step(dev, run_ctx, argv, filter_mode=None, share=None, replays=2
     out = step.held['out'].detach().cpu()
     mode = enc.filter_mode
     eig = (cpu['cache'].u.double(), cpu['cache'].lam.double()) if mode == 'spectral' else None
-    ref, _, _ = O.encoder_gengcn(cpu['src'].double(), None if cpu['pe'] is None else cpu['pe'].double(), cpu['edge_index'], cpu['fi'],
-                                 cpu['batch'], cpu['degree'].double(), cpu['mask'], p64, args.layers, args.heads,
-                                 args.order, batch_norm=not args.layer_norm, heads_share_graph=enc.heads_share_graph,
-                                 collapsed=True, eig=eig)
-    (ref * cpu['dout'].double()).sum().backward()
+    def oracle_pass(relu_force=None, capture=None):
+        for v in p64.values():
+            v.grad = None
+        ref_, _, _ = O.encoder_gengcn(cpu['src'].double(), None if cpu['pe'] is None else cpu['pe'].double(),
+                                      cpu['edge_index'], cpu['fi'], cpu['batch'], cpu['degree'].double(), cpu['mask'], p64,
+                                      args.layers, args.heads, args.order, batch_norm=not args.layer_norm,
+                                      heads_share_graph=enc.heads_share_graph, collapsed=True, eig=eig,
+                                      relu_capture=capture, relu_force=relu_force)
+        (ref_ * cpu['dout'].double()).sum().backward()
+        return ref_.detach()
+
+    zs = []
+    ref = oracle_pass(capture=zs)
+    # pre-activations of REAL nodes that are zero to fp32 resolution: the relu derivative there is a choice (oracle.
+    # encoder_layer, relu_force) - the product may land on either side, and then differs from the reference by that
+    # node's whole contribution (seen on the MI355X at PATTERN B = 64: |z| = 8e-8 in the last layer moved dW1 of one
+    # hidden unit by 0.3 and every gradient below it by 1e-4).  The forward output and the tolerances are untouched: the
+    # gradients must meet `grad_tol` for ONE assignment of those (few) derivatives, each evaluated by the fp64 oracle.
+    real = (~cpu['mask']).t().unsqueeze(-1)
+    ambiguous = [(li, idx) for li, z in enumerate(zs) for idx in ((z.abs() < RELU_AMBIGUOUS) & real).nonzero().tolist()]
+    assert len(ambiguous) <= 4, 'too many ambiguous relu derivatives for an exhaustive check: %d' % len(ambiguous)
+    choices = [None]
+    if ambiguous and not lowp:
+        import itertools
+        choices = []
+        for signs in itertools.product((1, -1), repeat=len(ambiguous)):
+            force = {}
+            for (li, idx), sg in zip(ambiguous, signs):
+                force.setdefault(li, torch.zeros_like(zs[li]))[tuple(idx)] = sg
+            choices.append(force)
+    failures = []
+    for force in choices:
+        if force is not None:
+            oracle_pass(relu_force=force)
+        try:
+            errs = _compare_with_reference(args, enc, p64, cpu, out, ref, lowp, out_tol, grad_tol)
+            break
+        except AssertionError as e:     # (the next assignment of the ambiguous derivatives)
+            failures.append(str(e))
+    else:
+        raise AssertionError('no assignment of the %d ambiguous relu derivatives %s meets the tolerance: %s'
+                             % (len(ambiguous), ambiguous, failures))
+    if ambiguous and not lowp:
+        errs['relu_ambiguous'] = float(len(ambiguous))
+    return errs, used_graph
+
+
+RELU_AMBIGUOUS = 1e-6     # |z| below this is zero to fp32 resolution (z is a sum of 64 products of O(1) values)
+
+
+def _compare_with_reference(args, enc, p64, cpu, out, ref, lowp, out_tol, grad_tol):
     errs = {'out': KC.assert_close('encoder output', out, ref, tol=out_tol)}
     m_rows = cpu['src'].shape[0] * cpu['src'].shape[1]
     for name, p in enc.named_parameters():
@@ -89,4 +135,4 @@ def check_bench_step(dev, run_ctx, argv, filter_mode=None, share=None, replays=2
         bad = {k: '%.3e' % v for k, v in errs.items() if k != 'out' and v > bf16_grad_tol(k)}
         assert not bad, 'relative Frobenius error of parameter gradients above %.2g (%.2g behind the relu mask): %s (all: %s)' % (
             BF16_GRAD_FRO_TOL, BF16_GRAD_FRO_TOL_RELU, bad, {k: '%.2e' % v for k, v in errs.items()})
-    return errs, used_graph
+    return errs
