@@ -139,6 +139,10 @@ def stack_supported(layers, d_model):
     return True
 
 
+# TEST HOOK (tests/bench_checks.py): a list that receives the per-layer saved tensors of every fused-stack forward (the
+# relu output h among them - which side of a zero-to-rounding pre-activation the kernels took); None: off
+CAPTURE_SAVED = None
+
 # first layer of a stack -> the flat gradient buffer of its last backward (kept off the modules:
 # state_dict / deepcopy / pickle of a model must not see it)
 STACK_FLAT_GRAD = weakref.WeakKeyDictionary()
@@ -353,6 +357,8 @@ class FusedEncoderStackFn(torch.autograd.Function):
         ctx.pending = pending
         saved[-1]['prm2'] = prm2
         ctx.saved_state = saved
+        if CAPTURE_SAVED is not None:
+            CAPTURE_SAVED.append(saved)
         ctx.meta = (n, b, d, heads, dh, tie, scale, G, nl)
         ctx.aux = (pe_c, degree_rows, n_real)
         ctx.params = params
@@ -638,6 +644,8 @@ class FusedLayerNormStackFn(torch.autograd.Function):
                               ffn_on_load=ffn_on_load))
             x_in = x2
         ctx.saved_state = saved
+        if CAPTURE_SAVED is not None:
+            CAPTURE_SAVED.append(saved)
         ctx.eps = [(float(l.norm1.eps), float(l.norm2.eps)) for l in layers]
         ctx.meta = (n, b, d, heads, dh, tie, scale, nl)
         ctx.aux = (pe_c, degree_rows, n_real)
@@ -837,6 +845,8 @@ def _ln_on_load_forward(ctx, abi, stream, src, pe, degree_rows, n_real, layers, 
     abi.layernorm_fwd(x_pre, params[(nl - 1) * PER_LAYER + 10], params[(nl - 1) * PER_LAYER + 11], float(last.eps), final,
                       new(m, 2), stream)
     ctx.saved_state = saved
+    if CAPTURE_SAVED is not None:
+        CAPTURE_SAVED.append(saved)
     ctx.meta = (n, b, d, heads, dh, False, scale, nl)
     ctx.aux = (pe_c, degree_rows, n_real)
     ctx.params = params
