@@ -433,7 +433,7 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a, C
         delta += shfl_xor(delta, 16);
         delta += shfl_xor(delta, 32);
         const float m = ST[(h * NR + q) * 2], z = ST[(h * NR + q) * 2 + 1];
-        const float rinv = 1.0f / fmaxf(z, 1e-6f);
+        const float rinv = fast_rcp(fmaxf(z, 1e-6f));   // (v_rcp_f32, 1 ulp: a full-precision division is a dozen instructions)
         if (z < 1e-6f) delta = 0.0f;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(kBbThreads) void attn_block_bwd_kernel(BwdArgs a, C
           // a dozen instructions and this role is the one the other waves wait for
           const float z = ST[(h * NR + rr) * 2 + 1];
           mq[t][r] = ST[(h * NR + rr) * 2];
-          rz[t][r] = ok ? 1.0f / fmaxf(z, 1e-6f) : 0.0f;
+          rz[t][r] = ok ? fast_rcp(fmaxf(z, 1e-6f)) : 0.0f;
           if (z < 1e-6f) sd[t][r] = 0.0f;
         }
         qb4[t] = L::mk(qv4[0], qv4[1], qv4[2], qv4[3]);
