@@ -1053,8 +1053,13 @@ __global__ __launch_bounds__(512) void attn_bwd_head_kernel(AttnArgs a) {
       const float4 x = *reinterpret_cast<const float4*>(Ds + tid * P + c4), y = *reinterpret_cast<const float4*>(Os + tid * P + c4);
       d += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
     }
-    DL[tid] = d;
     if (tid < a.N) a.delta[(int64_t)bh * a.N + tid] = d;
+    // per query, once: the reciprocal of the clamped normaliser (v_rcp_f32, 1 ulp) in place of the row sum, and delta
+    // already zeroed where the clamp is active (the normaliser is a constant there) - the dk / dv waves used to divide
+    // and select per (query, key) pair
+    const float z = ST[2 * tid + 1];
+    ST[2 * tid + 1] = fast_rcp(fmaxf(z, 1e-6f));
+    DL[tid] = z < 1e-6f ? 0.0f : d;
   }
   lds_barrier();
 
@@ -1066,9 +1071,8 @@ __global__ __launch_bounds__(512) void attn_bwd_head_kernel(AttnArgs a) {
       Feat<DH> qf, dof;
       load_row<DH>(qf, Qs + q * P, g, a.scale);
       load_row<DH>(dof, Ds + q * P, g);
-      const float m = ST[2 * q], z = ST[2 * q + 1];
-      const float rinv = 1.0f / fmaxf(z, 1e-6f);
-      const float delta = z < 1e-6f ? 0.0f : DL[q];   // clamp active: the normaliser is a constant
+      const float m = ST[2 * q], rinv = ST[2 * q + 1];
+      const float delta = DL[q];
       f32x4 dq = zero4();
       float pnx[4] = {1.0f, 1.0f, 1.0f, 1.0f};
       const float* perow = has_pe ? peg + (int64_t)min(q, nm1) * a.N : nullptr;
@@ -1142,14 +1146,20 @@ __global__ __launch_bounds__(512) void attn_bwd_head_kernel(AttnArgs a) {
             for (int r = 0; r < 4; ++r) pv[r] = pnx[r];
             load_pe(min(qb + 1, NB - 1));
           }
+          // (row max, reciprocal normaliser) and delta of this lane's four queries: three 16-byte LDS reads
+          const float4 s01 = *reinterpret_cast<const float4*>(ST + 2 * (16 * qb + 4 * g));
+          const float4 s23 = *reinterpret_cast<const float4*>(ST + 2 * (16 * qb + 4 * g) + 4);
+          const float4 dl4 = *reinterpret_cast<const float4*>(DL + 16 * qb + 4 * g);
+          const float mq[4] = {s01.x, s01.z, s23.x, s23.z}, rq[4] = {s01.y, s01.w, s23.y, s23.w};
+          const float dq4[4] = {dl4.x, dl4.y, dl4.z, dl4.w};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int qq = 16 * qb + 4 * g + r;
-            const float m = ST[2 * qq], z = ST[2 * qq + 1];
+            const float m = mq[r], ri = rq[r];
             const bool ok = qq < a.N && kok;
             if (PE_LDS) pv[r] = PE[min(qq, nm1) * PEP + min(key, nm1)];
-            const float p = ok ? fast_exp(s[r] - m) * pv[r] * (1.0f / fmaxf(z, 1e-6f)) : 0.0f;
-            const float ds = p * (da[r] - (z < 1e-6f ? 0.0f : DL[qq]));
+            const float p = ok ? fast_exp(s[r] - m) * pv[r] * ri : 0.0f;
+            const float ds = p * (da[r] - dq4[r]);
             dv = mfma16(p, Ds[qq * P + lq], dv);              // (key 4g+r, c lq)
             dk = mfma16(ds, Qs[qq * P + lq] * a.scale, dk);
           }

@@ -632,12 +632,10 @@ __global__ __launch_bounds__(kBlk8Threads) void attn_block_fwd8_kernel(BlockArgs
   }
   const bool x_ln = a.x_ln_gamma != nullptr;
   FETA_STAMP(7);
-  bool first = true;
   const int lane0 = lane;
   for (int b = b0; b < a.B; b += gp) {
   // (LDS-only barriers from here on: the tiles of the previous graph have been consumed / xss is LDS data - the requests
   // of the next graph stay in flight across them)
-  first = false;
   n = n_req;
 #pragma unroll
   for (int i = 0; i < NQ; ++i) rsv[i] = rsn[i];
