@@ -497,10 +497,10 @@ def roofline(args, gpu, dev, lowp=False, pmc_tag=None):
                      4 * (3 * r_ * c + 2 * c * c + cat_part.numel())))
     # NOT measured in this run: committed products of separate rocprofv3 --pmc passes (tools/profile_round.sh), named in
     # the object so that nobody takes them for same-run counters
-    tfiles = (('r03_end_traffic_b128_bf16.json', 'r03_traffic_b128_bf16.json') if lowp else
-              ('r03_end_traffic_b128.json', 'r03_traffic_b128.json', 'r02_traffic_b128.json'))
-    mfiles = (('r03_end_pmc_mfma_b128_bf16.json', 'r03_pmc_mfma_b128_bf16.json') if lowp else
-              ('r03_end_pmc_mfma_b128.json', 'r03_pmc_mfma_b128.json', 'r02_pmc_mfma_b128.json'))
+    tfiles = (('r04_end_traffic_b128_bf16.json', 'r03_end_traffic_b128_bf16.json') if lowp else
+              ('r04_end_traffic_b128.json', 'r03_end_traffic_b128.json'))
+    mfiles = (('r04_end_pmc_mfma_b128_bf16.json', 'r03_end_pmc_mfma_b128_bf16.json') if lowp else
+              ('r04_end_pmc_mfma_b128.json', 'r03_end_pmc_mfma_b128.json'))
     if b != 128 or n != 37:      # (the per-variant PMC passes are of the BASELINE batch)
         tfiles = mfiles = ()
     traffic, traffic_src = _load_json(*tfiles)

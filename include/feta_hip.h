@@ -413,7 +413,8 @@ int feta_bn_bwd(const float* y, const float* dout, const float* mean_rstd, const
  * concatenated: out_each_head), attn_stats [B,4,N,2] (row max, un-clamped row sum), attn
  * [B,4,N,N] or NULL, y [M,64] = x_norm + rowscale * (out W_out^T + b_out), y_stats [G][2][64]
  * partial (sum, sum of squares) over the rows of y - padded rows included, as nn.BatchNorm1d over the
- * [N*B, d] view counts them.  G = feta_attn_block_stat_rows(B, N) (ABI 8): one row per WORKGROUP - a graph is one
+ * [N*B, d] view counts them; NULL (ABI 9): no statistics are taken (LayerNorm stack).
+ * G = feta_attn_block_stat_rows(B, N) (ABI 8): one row per WORKGROUP - a graph is one
  * workgroup of eight waves (head x query-tile parity), or two such workgroups (query tiles split between them, K and V
  * projected by both) where a graph has more than two 16-row tiles and 2 B workgroups still fit the chip; the shift row
  * (y_shift) is row G. */
