@@ -133,6 +133,22 @@ SIGNATURES.update({
 
 
 
+class SpecCat(C.Structure):
+    """struct feta_spec_cat (include/feta_hip.h) - field order must match the header."""
+    _fields_ = [
+        ('y2', _F), ('y2_sb', C.c_int64), ('y2_sn', C.c_int64), ('y2_bn', _F), ('y2_stats', _F), ('Gx', C.c_int),
+        ('gamma', _F), ('beta', _F), ('bn_out', _F), ('rmean', _F), ('rvar', _F), ('nbt', _I),
+        ('momentum', C.c_float), ('eps', C.c_float), ('M', C.c_int), ('w_cat', _F), ('b_cat', _F), ('out', _F),
+    ]
+
+
+SIGNATURES.update({
+    'feta_spec_cat_supported': ([C.c_int] * 6, C.c_int),
+    'feta_spec_filter_cat_fwd': ([_F, C.c_int64, C.c_int64, _F, _F, _F, _F, _I, _F, C.c_int64, C.c_int64,
+                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(SpecCat), _S], C.c_int),
+})
+
+
 class AttnBlock(C.Structure):
     """struct feta_attn_block (include/feta_hip.h) - field order must match the header."""
     _fields_ = [
@@ -228,7 +244,7 @@ SIGNATURES.update({
     'feta_ffn_bwd_coeff': ([C.POINTER(FfnGrad), C.POINTER(CoeffBwdRole), _S], C.c_int),
 })
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class FetaError(RuntimeError):
@@ -473,6 +489,31 @@ class Abi:
             fn, nm = self.lib.feta_spec_filter_fwd_bf16, 'feta_spec_filter_fwd_bf16'
         self._check(fn(_p(x), xsb, xsn, _p(u), _p(lam), _p(coeff), _p(bias), _p(n_real), _p(y), ysb, ysn,
                        b, n, h, dh, order, k, int(share), stream), nm)
+
+    def spec_cat_supported(self, n, h, dh, order, k, share):
+        return bool(self.lib.feta_spec_cat_supported(n, h, dh, order, k, int(share)))
+
+    def spec_filter_cat_fwd(self, x, u, lam, coeff, bias, n_real, y, order, share, stream, y2, w_cat, b_cat, out,
+                            y2_bn=None, y2_stats=None, Gx=0, gamma=None, beta=None, bn_out=None, rmean=None, rvar=None,
+                            nbt=None, momentum=0.1, eps=1e-5):
+        """feta_spec_filter_cat_fwd: the eigenbasis filter with linear_cat folded in.  y2 [N, B, 64] (or [B, N, 64]
+        batch-first like x) = the stack output, out like y."""
+        b, n, h, dh = x.shape
+        k = u.shape[2]
+        xsb, xsn = tok_strides(x)
+        ysb, ysn = tok_strides(y)
+        assert tok_strides(out) == (ysb, ysn)
+        c = SpecCat()
+        c.y2_sb, c.y2_sn = tok_strides(y2)
+        c.Gx, c.momentum, c.eps, c.M = Gx, momentum, eps, b * n
+        for name, t in (('y2', y2), ('y2_bn', y2_bn), ('y2_stats', y2_stats), ('gamma', gamma), ('beta', beta),
+                        ('bn_out', bn_out), ('rmean', rmean), ('rvar', rvar), ('nbt', nbt), ('w_cat', w_cat),
+                        ('b_cat', b_cat), ('out', out)):
+            if t is not None:
+                setattr(c, name, t.data_ptr())
+        self._check(self.lib.feta_spec_filter_cat_fwd(_p(x), xsb, xsn, _p(u), _p(lam), _p(coeff), _p(bias), _p(n_real), _p(y),
+                                                      ysb, ysn, b, n, h, dh, order, k, int(share), C.byref(c), stream),
+                    'feta_spec_filter_cat_fwd')
 
     def spec_filter_bwd(self, x, u, lam, coeff, n_real, dy, dx, dcoeff, dbias_part, order, share,
                         stream):

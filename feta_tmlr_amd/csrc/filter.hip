@@ -13,6 +13,7 @@
 // Tile conventions: feta_tiles.h.  "acc layout" of a [rows x cols] tile means register
 // r of lane (g, lq) holds element (row 4g + r, column lq).
 #include "feta_abi_common.h"
+#include "feta_rowops.h"
 #include "feta_tiles.h"
 
 namespace feta {
@@ -1360,6 +1361,252 @@ __global__ __launch_bounds__(256) void spec_bwd_graph_kernel(FilterArgs a) {
   }
 }
 
+// ---- linear_cat folded into the per-graph eigenbasis filter (round 4) --------------------------------------------
+// transformer/models.py:223-224: output = linear_cat(cat(output, allout_filtered)) - behind the last layer the stack
+// output and the filtered per-head outputs of a graph meet again, row by row.  With W_cat = [Wa | Wb]:
+//     out = xn Wa^T + filt Wb^T + b_cat,   filt = U Ytil + bias   =>   filt Wb^T = U (Ytil Wb^T) + bias Wb^T
+// i.e. the filter half of linear_cat is a [K x 64] x [64 x 64] product in the EIGEN domain (K = 16 rows instead of the
+// graph's N), and the stack half is the graph's own rows through a 64 x 64 product - both fit this kernel's workgroup.
+// One launch (feta_rowlin_fwd_ex over the virtual operand [xn | filt]) and one read of filt less per step; filt itself
+// is still written: the backward of linear_cat contracts it with dout (dW_cat).
+// xn = the stack output seen through its last BatchNorm: fresh statistics are finalized here (first consumer, the
+// fused_stack.StackTail contract: workgroup 0 publishes the parameter block and the running statistics), or a published
+// block, or the rows as they are (LayerNorm stack).  Rows of PADDED nodes (n_real <= node < N) take part: filt is zero there.
+struct CatArgs {
+  const float* y2;       // [N*B rows][64] stack output, row(b, i) = b * y2sb + i * y2sn (elements)
+  int64_t y2sb, y2sn;
+  const float* y2_bn;    // published [4][64] block, or NULL
+  const float* y2_stats; // fresh partial sums [Gx + 1][2][64], or NULL
+  int Gx;
+  const float* gamma; const float* beta;
+  float* bn_out; float* rmean; float* rvar; int64_t* nbt;
+  float momentum, eps;
+  int M;                 // rows the statistics run over (N * B)
+  const float* w_cat;    // [64][128]
+  const float* b_cat;    // [64] or NULL
+  float* out;            // [N*B rows][64], strides of y
+};
+
+constexpr int kCatD = 64;
+
+template <int NT_MAX, int ET_MAX>
+__host__ __device__ inline int spec_cat_fwd_lds_floats(int pp) {
+  constexpr int NR = 16 * NT_MAX, UP = 16 * ET_MAX + 4;
+  return 2 * NR * kGraphXP + NR * UP + 16 * ET_MAX + 4 * pp * 16 * kGraphWP + 16 * ET_MAX * (kCatD + 4) + 2 * kCatD +
+         reduce_scratch_floats(kCatD, 256);
+}
+
+template <int NT_MAX, int ET_MAX, int PP>
+__global__ __launch_bounds__(256) void spec_cat_fwd_graph_kernel(FilterArgs a, CatArgs c) {
+  constexpr int DH = 16, XP = kGraphXP, UP = 16 * ET_MAX + 4, WP = kGraphWP, NR = 16 * NT_MAX, D = kCatD, YP = D + 4;
+  const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6, lq = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x;
+  const int n = a.n_real[b], nm1 = max(n - 1, 0), Nm1 = a.N - 1;
+  float* Xs = feta_lds;               // [NR][XP] x rows (per-head outputs), later filt
+  float* Ys = Xs + NR * XP;           // [NR][XP] stack output rows, normalised; later out
+  float* Us = Ys + NR * XP;           // [NR][UP]
+  float* lams = Us + NR * UP;         // [16 ET_MAX]
+  float* Wsb = lams + 16 * ET_MAX;
+  float* Ws = Wsb + h * (PP * DH * WP);   // this head's [P * DH][WP]
+  float* YT = Wsb + 4 * PP * DH * WP;     // [16 ET_MAX][YP] Ytil of all heads
+  float* xss = YT + 16 * ET_MAX * YP;     // [2][64] scale | shift of the BatchNorm in front
+  float* scr = xss + 2 * D;               // finalize scratch
+  const float* U = a.u + (int64_t)b * a.N * a.K;
+  const float* w = a.coeff + ((int64_t)h * a.B + b) * PP * DH * DH;
+
+  // ---- requests: everything this workgroup reads, before the first value is consumed ---------------------------------
+  PartialBatchT<32> pb;
+  partials_request_t<256, 32>(c.y2_stats != nullptr ? c.y2_stats : c.w_cat, c.y2_stats != nullptr ? c.Gx : 0, D, pb);
+  float4 xv[NT_MAX], yv[NT_MAX];
+#pragma unroll
+  for (int i = 0; i < NT_MAX; ++i) {
+    const int idx = tid + 256 * i, node = idx >> 4, q = idx & 15;
+    const float4 v = *reinterpret_cast<const float4*>(tok_row(a.x, a.xsb, a.xsn, b, min(node, nm1), 0, DH) + 4 * q);
+    xv[i] = keep4(node < n, v);
+    yv[i] = *reinterpret_cast<const float4*>(c.y2 + (int64_t)b * c.y2sb + (int64_t)min(node, Nm1) * c.y2sn + 4 * q);
+  }
+  constexpr int UQ = 4 * ET_MAX, UI = (NR * UQ + 255) / 256;
+  float4 uv[UI];
+#pragma unroll
+  for (int i = 0; i < UI; ++i) {
+    const int idx = tid + 256 * i, node = idx / UQ, e = 4 * (idx % UQ);
+    const float4 v = *reinterpret_cast<const float4*>(U + (int64_t)min(node, nm1) * a.K + min(e, a.K - 4));
+    uv[i] = keep4(node < n && e < a.K, v);
+  }
+  {
+    float4 wv[PP];
+#pragma unroll
+    for (int i = 0; i < PP; ++i) wv[i] = reinterpret_cast<const float4*>(w)[lane + 64 * i];
+#pragma unroll
+    for (int i = 0; i < PP; ++i) {
+      const int idx = lane + 64 * i;
+      *reinterpret_cast<float4*>(Ws + (idx >> 2) * WP + 4 * (idx & 3)) = wv[i];
+    }
+  }
+  // this wave's 16 rows of W_cat (output columns 16 h + lq), both halves, as row operands (feta_tiles.h)
+  Feat<D> waf, wbf;
+  load_row<D>(waf, c.w_cat + (int64_t)(DH * h + lq) * 2 * D, g);
+  load_row<D>(wbf, c.w_cat + (int64_t)(DH * h + lq) * 2 * D + D, g);
+  const float bcat = c.b_cat != nullptr ? c.b_cat[DH * h + lq] : 0.0f;
+  const float lv = a.lam[(int64_t)b * a.K + min(tid, a.K - 1)];
+  const float bv = (a.bias != nullptr) ? a.bias[lq] : 0.0f;
+  float4 bs4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (a.bias != nullptr) bs4 = *reinterpret_cast<const float4*>(a.bias + 4 * g);
+  float xg = 1.0f, xb = 0.0f, xk = 0.0f;
+  if (c.y2_stats != nullptr && tid < D) {
+    xg = c.gamma[tid];
+    xb = c.beta[tid];
+    xk = partials_shift(c.y2_stats, c.Gx, D, tid);
+  }
+  // ---- the BatchNorm in front of linear_cat -----------------------------------------------------------------------------
+  if (c.y2_stats != nullptr) {
+    reduce_partials_finish_t<256, 32>(c.y2_stats, c.Gx, D, pb, scr + 2 * D, scr);
+    if (tid < D) {
+      float mean, var;
+      bn_moments_k(xk, D, c.M, scr, tid, mean, var);
+      const float rstd = rsqrtf(var + c.eps);
+      const float scale = xg * rstd, shift = xb - mean * scale;
+      xss[tid] = scale;
+      xss[D + tid] = shift;
+      if (blockIdx.x == 0) {
+        c.bn_out[tid] = scale;
+        c.bn_out[D + tid] = shift;
+        c.bn_out[2 * D + tid] = mean;
+        c.bn_out[3 * D + tid] = rstd;
+        if (c.rmean != nullptr) {
+          const float unbiased = c.M > 1 ? var * (float)c.M / (float)(c.M - 1) : var;
+          c.rmean[tid] = (1.0f - c.momentum) * c.rmean[tid] + c.momentum * mean;
+          c.rvar[tid] = (1.0f - c.momentum) * c.rvar[tid] + c.momentum * unbiased;
+        }
+        if (tid == 0 && c.nbt != nullptr) *c.nbt += 1;
+      }
+    }
+  } else if (tid < 2 * D) {
+    xss[tid] = c.y2_bn != nullptr ? c.y2_bn[tid] : (tid < D ? 1.0f : 0.0f);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NT_MAX; ++i) {
+    const int idx = tid + 256 * i, q = idx & 15;
+    *reinterpret_cast<float4*>(Xs + (idx >> 4) * XP + 4 * q) = xv[i];
+    const float4 sc = *reinterpret_cast<const float4*>(xss + 4 * q), sh = *reinterpret_cast<const float4*>(xss + D + 4 * q);
+    *reinterpret_cast<float4*>(Ys + (idx >> 4) * XP + 4 * q) =
+        make_float4(yv[i].x * sc.x + sh.x, yv[i].y * sc.y + sh.y, yv[i].z * sc.z + sh.z, yv[i].w * sc.w + sh.w);
+  }
+#pragma unroll
+  for (int i = 0; i < UI; ++i) {
+    const int idx = tid + 256 * i;
+    if (idx < NR * UQ) *reinterpret_cast<float4*>(Us + (idx / UQ) * UP + 4 * (idx % UQ)) = uv[i];
+  }
+  if (tid < 16 * ET_MAX) lams[tid] = tid < a.K ? lv : 0.0f;
+  __syncthreads();
+
+  // ---- (1) Xtil^T[c][e] = sum_node X[node][c] U[node][e] ----------------------------------------
+  f32x4 xtT[ET_MAX];
+#pragma unroll
+  for (int et = 0; et < ET_MAX; ++et) xtT[et] = zero4();
+#pragma unroll
+  for (int nt = 0; nt < NT_MAX; ++nt) {
+    if (16 * nt < n) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nd = 16 * nt + 4 * g + r;
+        const float xa = Xs[nd * XP + DH * h + lq];
+#pragma unroll
+        for (int et = 0; et < ET_MAX; ++et) xtT[et] = mfma16(xa, Us[nd * UP + 16 * et + lq], xtT[et]);
+      }
+    }
+  }
+  // ---- (2) Ytil[e][c'] = sum_k t_k(lam_e) sum_c Xtil[e][c] W_k[c][c'] ---------------------------
+  f32x4 yt[ET_MAX];
+#pragma unroll
+  for (int et = 0; et < ET_MAX; ++et) {
+    float tk[kMaxOrder];
+    cheb_poly(lams[16 * et + lq], PP, tk);
+    yt[et] = zero4();
+#pragma unroll
+    for (int k = 0; k < PP; ++k)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        yt[et] = mfma16(xtT[et][r] * tk[k], Ws[(k * DH + 4 * g + r) * WP + lq], yt[et]);
+    // every head's Ytil meets in LDS: the operand of the eigen-domain half of linear_cat
+#pragma unroll
+    for (int r = 0; r < 4; ++r) YT[(16 * et + 4 * g + r) * YP + DH * h + lq] = yt[et][r];
+  }
+  __syncthreads();
+  // ---- (2') YtilP[e][o] = sum_c Ytil[e][c] Wb[o][c], o = 16 h + lq: (row e = 4g + r, column o = lq) ---------------
+  f32x4 ytp[ET_MAX];
+#pragma unroll
+  for (int et = 0; et < ET_MAX; ++et) {
+    Feat<D> yf;
+    load_row<D>(yf, YT + (16 * et + lq) * YP, g);
+    ytp[et] = dot_rows<D>(yf, wbf, zero4());
+  }
+  // (bias Wb^T)[o]: the filter's bias is one [16] vector for every head; this lane holds Wb[o][16 j + 4 g + s]
+  float cbo = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    cbo += (wbf.f[j][0] * bs4.x + wbf.f[j][1] * bs4.y) + (wbf.f[j][2] * bs4.z + wbf.f[j][3] * bs4.w);
+  cbo += shfl_xor(cbo, 16);
+  cbo += shfl_xor(cbo, 32);
+  // ---- (3) filt = U Ytil + bias;  out = xn Wa^T + U YtilP + bias Wb^T + b_cat --------------------------------------
+  f32x4 y[NT_MAX], o[NT_MAX];
+#pragma unroll
+  for (int nt = 0; nt < NT_MAX; ++nt) {
+    y[nt] = zero4();
+    o[nt] = zero4();
+    if (16 * nt < a.N) {
+      Feat<D> xf;
+      load_row<D>(xf, Ys + (16 * nt + lq) * XP, g);
+      o[nt] = dot_rows<D>(xf, waf, zero4());   // (row node = 4g + r, column o = lq)
+    }
+    if (16 * nt < n) {
+#pragma unroll
+      for (int et = 0; et < ET_MAX; ++et) {
+        const float4 ub = *reinterpret_cast<const float4*>(Us + (16 * nt + lq) * UP + 16 * et + 4 * g);
+        y[nt] = mfma16(ub.x, yt[et][0], y[nt]);
+        y[nt] = mfma16(ub.y, yt[et][1], y[nt]);
+        y[nt] = mfma16(ub.z, yt[et][2], y[nt]);
+        y[nt] = mfma16(ub.w, yt[et][3], y[nt]);
+        o[nt] = mfma16(ub.x, ytp[et][0], o[nt]);
+        o[nt] = mfma16(ub.y, ytp[et][1], o[nt]);
+        o[nt] = mfma16(ub.z, ytp[et][2], o[nt]);
+        o[nt] = mfma16(ub.w, ytp[et][3], o[nt]);
+      }
+    }
+  }
+  __syncthreads();  // every wave has read its X / Y operands
+#pragma unroll
+  for (int nt = 0; nt < NT_MAX; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int nd = 16 * nt + 4 * g + r;
+      Xs[nd * XP + DH * h + lq] = nd < n ? y[nt][r] + bv : 0.0f;
+      Ys[nd * XP + DH * h + lq] = o[nt][r] + bcat + (nd < n ? cbo : 0.0f);
+    }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NT_MAX; ++i) {
+    const int idx = tid + 256 * i, node = idx >> 4, q = idx & 15;
+    if (node < a.N) {
+      *reinterpret_cast<float4*>(tok_row(a.y, a.ysb, a.ysn, b, node, 0, DH) + 4 * q) =
+          *reinterpret_cast<const float4*>(Xs + node * XP + 4 * q);
+      *reinterpret_cast<float4*>(tok_row(c.out, a.ysb, a.ysn, b, node, 0, DH) + 4 * q) =
+          *reinterpret_cast<const float4*>(Ys + node * XP + 4 * q);
+    }
+  }
+}
+
+template <int NT_MAX, int ET_MAX>
+int launch_spec_cat_fwd(const FilterArgs& a, const CatArgs& c, hipStream_t stream) {
+  const size_t lds = sizeof(float) * spec_cat_fwd_lds_floats<NT_MAX, ET_MAX>(4);
+  auto kern = spec_cat_fwd_graph_kernel<NT_MAX, ET_MAX, 4>;
+  static LdsSeen lds_seen;
+  allow_dynamic_lds(kern, lds, lds_seen);
+  hipLaunchKernelGGL(kern, dim3(a.B), dim3(256), lds, stream, a, c);
+  return check_launch("feta_spec_filter_cat_fwd");
+}
+
 template <int NT_MAX, int ET_MAX, int PP>
 int launch_spec_graph_p(const FilterArgs& a, bool bwd, hipStream_t stream) {
   constexpr int NR = 16 * NT_MAX, UP = 16 * ET_MAX + 4;
@@ -1550,4 +1797,41 @@ extern "C" int feta_spec_filter_bwd(const float* x, int64_t x_sb, int64_t x_sn, 
   int rcd = FETA_OK;
   if (try_spec_dense(a, dh, true, (hipStream_t)stream, &rcd)) return rcd;
   return dispatch<SpecBwd>(a, dh, (K + 15) / 16, (hipStream_t)stream);
+}
+
+extern "C" int feta_spec_cat_supported(int N, int H, int dh, int P, int K, int heads_share_graph) {
+  const int nt = (N + 15) / 16, et = (K + 15) / 16;
+  return (heads_share_graph && H == 4 && dh == 16 && P == 4 && nt >= 1 && nt <= 8 && et <= 2 && (K & 3) == 0 && K >= 4) ? 1 : 0;
+}
+
+extern "C" int feta_spec_filter_cat_fwd(const float* x, int64_t x_sb, int64_t x_sn, const float* u, const float* lam,
+                                        const float* coeff, const float* bias, const int32_t* n_real, float* y,
+                                        int64_t y_sb, int64_t y_sn, int B, int N, int H, int dh, int P, int K,
+                                        int heads_share_graph, const feta_spec_cat* cat, feta_stream_t stream) {
+  FilterArgs a{};
+  a.x = x; a.u = u; a.lam = lam; a.coeff = coeff; a.bias = bias; a.n_real = n_real; a.y = y;
+  a.xsb = x_sb; a.xsn = x_sn; a.ysb = y_sb; a.ysn = y_sn;
+  a.B = B; a.N = N; a.H = H; a.P = P; a.K = K; a.share = heads_share_graph; a.total = B * H;
+  FETA_REQUIRE(x && u && lam && coeff && n_real && y && cat, "spec_filter_cat_fwd: null pointer");
+  FETA_REQUIRE(feta_spec_cat_supported(N, H, dh, P, K, heads_share_graph),
+               "spec_filter_cat_fwd: needs 4 heads x 16, order 4, N <= 128, K <= 32 (multiple of 4), every head on the graph");
+  int rc = check_filter(a, dh, x, y);
+  if (rc != FETA_OK) return rc;
+  FETA_REQUIRE(cat->y2 && cat->w_cat && cat->out, "spec_filter_cat_fwd: y2, w_cat, out");
+  FETA_REQUIRE(!(cat->y2_bn && cat->y2_stats), "spec_filter_cat_fwd: y2_bn and y2_stats exclude each other");
+  FETA_REQUIRE(!cat->y2_stats || (cat->gamma && cat->beta && cat->bn_out && cat->Gx > 0 && cat->M > 0),
+               "spec_filter_cat_fwd: y2_stats needs gamma, beta, bn_out, Gx, M");
+  FETA_REQUIRE(aligned16(u) && aligned16(cat->y2) && aligned16(cat->w_cat) && aligned16(cat->out) && aligned16(cat->y2_stats) &&
+                   aligned16(bias) && (cat->y2_sb % 4) == 0 && (cat->y2_sn % 4) == 0,
+               "spec_filter_cat_fwd: 16-byte aligned tensors, strides multiples of 4 elements");
+  CatArgs c{};
+  c.y2 = cat->y2; c.y2sb = cat->y2_sb; c.y2sn = cat->y2_sn; c.y2_bn = cat->y2_bn; c.y2_stats = cat->y2_stats; c.Gx = cat->Gx;
+  c.gamma = cat->gamma; c.beta = cat->beta; c.bn_out = cat->bn_out; c.rmean = cat->rmean; c.rvar = cat->rvar;
+  c.nbt = cat->nbt; c.momentum = cat->momentum; c.eps = cat->eps; c.M = cat->M;
+  c.w_cat = cat->w_cat; c.b_cat = cat->b_cat; c.out = cat->out;
+  const int nt = (N + 15) / 16, et = (K + 15) / 16;
+  hipStream_t st = (hipStream_t)stream;
+  if (nt <= 3) return et <= 1 ? launch_spec_cat_fwd<3, 1>(a, c, st) : launch_spec_cat_fwd<3, 2>(a, c, st);
+  if (nt <= 4) return et <= 1 ? launch_spec_cat_fwd<4, 1>(a, c, st) : launch_spec_cat_fwd<4, 2>(a, c, st);
+  return et <= 1 ? launch_spec_cat_fwd<8, 1>(a, c, st) : launch_spec_cat_fwd<8, 2>(a, c, st);
 }

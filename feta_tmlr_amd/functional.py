@@ -350,6 +350,21 @@ class PendingSums:
                     p.grad.copy_(g.view_as(p.grad))
 
 
+USE_CAT_FOLD = _os.environ.get('FETA_CAT_FOLD', '1') != '0'
+
+
+class CatFold:
+    """linear_cat folded into the launch of the eigenbasis filter (feta_spec_filter_cat_fwd, ABI 10).  The encoder fills
+    in what linear_cat would read - the stack output `y2` ([N, B, d]; with `tail`: the pre-norm rows whose last BatchNorm the
+    consumer finalizes, fused_stack.StackTail), `w`, `bias` - and hands the object to filter_from_pooled; if the filter's
+    forward takes the fused kernel it leaves linear_cat's output in `out`, and row_linear_cat[_bn] then launches nothing
+    in forward (its backward is unchanged: it has everything it saves).  0: FETA_CAT_FOLD=0 (A/B timing)."""
+
+    def __init__(self, y2, w, bias, tail=None):
+        self.y2, self.w, self.bias, self.tail = y2, w, bias, tail
+        self.out = None
+
+
 class FilterFromPooledFn(torch.autograd.Function):
     """``self.linear`` of the coefficient generator (transformer/models.py:284) and the dynamic filter
     (transformer/models.py:346-360, transformer/ChebNetDynamic.py:132-189) as ONE autograd node:
@@ -360,7 +375,7 @@ class FilterFromPooledFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, pooled, lin_w, lin_b, bias, n_real, g0, g1, mode, order, share, batch_first, pending,
-                gemm_bf16=False):
+                gemm_bf16=False, cat=None):
         abi, stream = _lib.backend(x, pooled)
         ctx.gemm_bf16 = bool(gemm_bf16)
         b, n, h, dh = x.shape
@@ -396,7 +411,21 @@ class FilterFromPooledFn(torch.autograd.Function):
         # bf16 storage path: the per-block weights the filter kernel reads are bf16 copies of them
         cw = coeff if x.dtype == torch.float32 else coeff.to(x.dtype)
         y = _new_token(b, n, h, dh, batch_first, x)
-        if mode == 'cheb':
+        fold = (cat is not None and USE_CAT_FOLD and mode == 'spec' and x.dtype == torch.float32 and not batch_first
+                and cat.w.shape == (h * dh, 2 * h * dh) and abi.spec_cat_supported(n, h, dh, order, g0.shape[2], share))
+        if fold:
+            # linear_cat rides in this launch (CatFold): out = [xn | y] W_cat^T + b
+            out = _new_token(b, n, h, dh, batch_first, x)
+            y2v = cat.y2.detach().view(n, b, h, dh).permute(1, 0, 2, 3)
+            kw = {}
+            if cat.tail is not None:
+                t, nm = cat.tail, cat.tail.norm
+                kw = dict(y2_stats=t.st2, Gx=t.G2, gamma=t.gamma, beta=t.beta, bn_out=t.prm2, rmean=nm.running_mean,
+                          rvar=nm.running_var, nbt=nm.num_batches_tracked, momentum=float(nm.momentum), eps=float(nm.eps))
+            abi.spec_filter_cat_fwd(xs, g0, g1, cw, bias, n_real, y, order, share, stream, y2=y2v, w_cat=cat.w.detach().contiguous(),
+                                    b_cat=None if cat.bias is None else cat.bias.detach(), out=out, **kw)
+            cat.out = out.permute(1, 0, 2, 3).reshape(n * b, h * dh)      # (a view: [N, B, d] rows)
+        elif mode == 'cheb':
             abi.cheb_filter_fwd(xs, g0, cw, bias, n_real, y, order, share, stream)
         else:
             abi.spec_filter_fwd(xs, g0, g1, cw, bias, n_real, y, order, share, stream)
@@ -459,11 +488,11 @@ class FilterFromPooledFn(torch.autograd.Function):
                     dpooled, dw_lin = dcoeff.mm(lin_w), dcoeff.t().mm(pooled)
         if not has_bias:
             dbias = None
-        return (dx, dpooled, dw_lin, db_lin, dbias) + (None,) * 9
+        return (dx, dpooled, dw_lin, db_lin, dbias) + (None,) * 10
 
 
 def filter_from_pooled(x, pooled, lin_w, lin_b, bias, n_real, graph, mode, order, heads_share_graph=False,
-                       batch_first=False, pending=None, gemm_bf16=False):
+                       batch_first=False, pending=None, gemm_bf16=False, cat=None):
     """x [B,N,H,dh] view, pooled [H*B, C] -> (y, coeff [H*B, C]); graph = (lhat,) | (u, lam)."""
     g0 = graph[0].contiguous()
     g1 = graph[1].contiguous() if len(graph) > 1 else None
@@ -472,7 +501,7 @@ def filter_from_pooled(x, pooled, lin_w, lin_b, bias, n_real, graph, mode, order
             raise NotImplementedError("the bf16 storage path runs the eigenbasis filter (filter_mode='spectral')")
         g0 = g0.to(x.dtype)      # U travels as bf16; lambda and t_k(lambda) stay fp32
     return FilterFromPooledFn.apply(x, pooled, lin_w, lin_b, bias, n_real, g0, g1, mode, order,
-                                    bool(heads_share_graph), batch_first, pending, bool(gemm_bf16))
+                                    bool(heads_share_graph), batch_first, pending, bool(gemm_bf16), cat)
 
 
 class RowLinearFn(torch.autograd.Function):
@@ -529,16 +558,19 @@ class RowLinearCatFn(torch.autograd.Function):
     transformer/models.py:223-224); backward writes dx1 and dx2 directly."""
 
     @staticmethod
-    def forward(ctx, x1, x2, w, bias, pending=None):
+    def forward(ctx, x1, x2, w, bias, pending=None, done=None):
         abi, stream = _lib.backend(x1, x2, w)
         ctx.defer = pending if (pending is not None and pending.armed and x2.requires_grad) else None
         ctx.params = (w, bias)
         x1, x2, w = x1.contiguous(), x2.contiguous(), w.contiguous()
         m, k1 = x1.shape
         ki, no = k1 + x2.shape[1], w.shape[0]
-        y = torch.empty((m, no), dtype=torch.float32, device=x1.device)
-        d = abi.rowlin_ex(m, ki, no, x=x1, x2=x2, x_split=k1, w=w, bias=bias, y=y)
-        abi.rowlin_fwd_ex(d, stream)
+        if done is not None:     # the filter's launch computed it (CatFold)
+            y = done
+        else:
+            y = torch.empty((m, no), dtype=torch.float32, device=x1.device)
+            d = abi.rowlin_ex(m, ki, no, x=x1, x2=x2, x_split=k1, w=w, bias=bias, y=y)
+            abi.rowlin_fwd_ex(d, stream)
         ctx.save_for_backward(x1, x2, w)
         ctx.has_bias = bias is not None
         return y
@@ -563,7 +595,7 @@ class RowLinearCatFn(torch.autograd.Function):
                                                  (ctx.params[1], dwdb[no * ki:] if ctx.has_bias else None)])
         else:
             abi.rowlin_bwd_ex(d, dwdb, stream)
-        return dx1, dx2, dwdb[:no * ki].view(no, ki), (dwdb[no * ki:] if ctx.has_bias else None), None
+        return dx1, dx2, dwdb[:no * ki].view(no, ki), (dwdb[no * ki:] if ctx.has_bias else None), None, None
 
 
 class RowLinearCatBNFn(torch.autograd.Function):
@@ -573,20 +605,23 @@ class RowLinearCatBNFn(torch.autograd.Function):
     backward partial sums in tail.gs (fused_stack.StackTail contract)."""
 
     @staticmethod
-    def forward(ctx, y2, x2, w, bias, tail, pending=None):
+    def forward(ctx, y2, x2, w, bias, tail, pending=None, done=None):
         abi, stream = _lib.backend(y2, x2, w)
         ctx.defer = pending if (pending is not None and pending.armed and x2.requires_grad) else None
         ctx.params = (w, bias)
         y2, x2, w = y2.contiguous(), x2.contiguous(), w.contiguous()
         m, k1 = y2.shape
         ki, no = k1 + x2.shape[1], w.shape[0]
-        out = torch.empty((m, no), dtype=torch.float32, device=y2.device)
-        nm = tail.norm
-        d = abi.rowlin_ex(m, ki, no, x=y2, x2=x2, x_split=k1, w=w, bias=bias, y=out, x_stats=tail.st2, Gx=tail.G2,
-                          x_gamma=tail.gamma, x_beta=tail.beta, x_bn_out=tail.prm2, x_rmean=nm.running_mean,
-                          x_rvar=nm.running_var, x_nbt=nm.num_batches_tracked, momentum=float(nm.momentum),
-                          eps=float(nm.eps))
-        abi.rowlin_fwd_ex(d, stream)
+        if done is not None:     # the filter's launch computed it and finalized the BatchNorm (CatFold: tail.prm2 is published)
+            out = done
+        else:
+            out = torch.empty((m, no), dtype=torch.float32, device=y2.device)
+            nm = tail.norm
+            d = abi.rowlin_ex(m, ki, no, x=y2, x2=x2, x_split=k1, w=w, bias=bias, y=out, x_stats=tail.st2, Gx=tail.G2,
+                              x_gamma=tail.gamma, x_beta=tail.beta, x_bn_out=tail.prm2, x_rmean=nm.running_mean,
+                              x_rvar=nm.running_var, x_nbt=nm.num_batches_tracked, momentum=float(nm.momentum),
+                              eps=float(nm.eps))
+            abi.rowlin_fwd_ex(d, stream)
         ctx.save_for_backward(y2, x2, w, tail.prm2)
         ctx.tail = tail
         ctx.has_bias = bias is not None
@@ -614,11 +649,11 @@ class RowLinearCatBNFn(torch.autograd.Function):
         else:
             abi.rowlin_bwd_ex(d, dwdb, stream)
         ctx.tail.gs = gs
-        return dx1, dx2, dwdb[:no * ki].view(no, ki), (dwdb[no * ki:] if ctx.has_bias else None), None, None
+        return dx1, dx2, dwdb[:no * ki].view(no, ki), (dwdb[no * ki:] if ctx.has_bias else None), None, None, None
 
 
-def row_linear_cat_bn(y2, x2, w, bias, tail, pending=None):
-    return RowLinearCatBNFn.apply(y2, x2, w, bias, tail, pending)
+def row_linear_cat_bn(y2, x2, w, bias, tail, pending=None, done=None):
+    return RowLinearCatBNFn.apply(y2, x2, w, bias, tail, pending, done)
 
 
 class BatchNormTrainFn(torch.autograd.Function):
@@ -667,9 +702,9 @@ def row_linear(x, w, bias=None, rowscale=None, residual=None, relu=False, want_s
     return RowLinearFn.apply(x, w, bias, rowscale, residual, relu, want_stats, stats_shift)
 
 
-def row_linear_cat(x1, x2, w, bias=None, pending=None):
+def row_linear_cat(x1, x2, w, bias=None, pending=None, done=None):
     """[x1 | x2] W^T + b on [M, .] rows; needs x1.shape[1] % 16 == 0 and supported total dims."""
-    return RowLinearCatFn.apply(x1, x2, w, bias, pending)
+    return RowLinearCatFn.apply(x1, x2, w, bias, pending, done)
 
 
 def batch_norm_train(y, stats, gamma, beta, running_mean, running_var, momentum, eps, num_batches_tracked=None):

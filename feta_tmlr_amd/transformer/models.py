@@ -117,7 +117,7 @@ class DiffTransformerEncoderGenGCN(nn.Module):
         coeff = FF.dense_linear(pooled, self.linear.weight, self.linear.bias)    # :284
         return coeff.reshape(self.num_heads, attn_weights.shape[0], -1)          # :285
 
-    def _coefficients_and_filter(self, attn_weights, out_each_head, cache, pending=None):
+    def _coefficients_and_filter(self, attn_weights, out_each_head, cache, pending=None, cat=None):
         """get_filter_coefficients + filter of one layer (:173, :186-202) with ``self.linear`` folded into the
         filter's autograd node (functional.FilterFromPooledFn).  -> (coeff [H,B,C], out_filtered [N,B,d])"""
         bsz, n, h, dh = out_each_head.shape
@@ -133,7 +133,7 @@ class DiffTransformerEncoderGenGCN(nn.Module):
         y, coeff = FF.filter_from_pooled(out_each_head, pooled, self.linear.weight, self.linear.bias,
                                          self.spectral_gnns.bias, cache.n_real, graph, mode, self.order,
                                          self.heads_share_graph, pending=pending,
-                                         gemm_bf16=self.storage_dtype != torch.float32)
+                                         gemm_bf16=self.storage_dtype != torch.float32, cat=cat)
         return coeff.reshape(h, bsz, -1), y.permute(1, 0, 2, 3).reshape(n, bsz, h * dh)
 
     # -- A3 ---------------------------------------------------------------------------------
@@ -256,6 +256,7 @@ class DiffTransformerEncoderGenGCN(nn.Module):
             pending.fwd_sums = [(self.gcn.weight.detach(), pending.s)]
             # ... and the generator's forward kernel in the launch of the last layer's feed-forward half
             pending.coeff_fwd_req = self.gcn.bias
+        cat = None
         for layer_num, mod in enumerate(self.layers):
             last = layer_num + 1 == self.num_layers
             filt = last or not self.last_layer_filter                            # :169-171
@@ -286,7 +287,14 @@ class DiffTransformerEncoderGenGCN(nn.Module):
                                                                n_real=cache.n_real)   # :173
                 out_filtered = self.filter(coeff_all_heads, out_each_head, cache)     # :186-202
             else:
-                coeff_all_heads, out_filtered = self._coefficients_and_filter(attn, out_each_head, cache, pending)
+                # linear_cat (:223-224) can ride in the filter's launch when this is the one filter stage of the forward
+                # and its operands are the row-linear kernels' (functional.CatFold)
+                cat = None
+                if (last and self.last_layer_filter and self.use_skip_conn and not lowp and self.norm is None
+                        and output.dtype == torch.float32 and self.linear_cat.weight.shape[0] == output.shape[-1]
+                        and (tail is not None or not (fused and self.layers[0].batch_norm))):
+                    cat = FF.CatFold(output, self.linear_cat.weight, self.linear_cat.bias, tail)
+                coeff_all_heads, out_filtered = self._coefficients_and_filter(attn, out_each_head, cache, pending, cat)
             coefficients.append(coeff_all_heads)                                  # :198
             if self.use_skip_conn and allout_filtered is not None:
                 allout_filtered = allout_filtered + out_filtered                  # :209-213
@@ -297,17 +305,18 @@ class DiffTransformerEncoderGenGCN(nn.Module):
         if self.use_skip_conn and allout_filtered is not None:
             nn_, bb_, dd_ = output.shape
             wc = self.linear_cat.weight
+            done = cat.out if (cat is not None and cat.out is not None) else None    # (computed by the filter's launch)
             if lowp:    # plain library bf16 GEMM on bf16 copies of the master weights; the encoder hands back fp32
                 dt = self.storage_dtype
                 output = F.linear(torch.cat((output, allout_filtered.to(dt)), dim=-1), wc.to(dt),
                                   self.linear_cat.bias.to(dt)).float()
             elif tail is not None:
                 output = FF.row_linear_cat_bn(output.reshape(nn_ * bb_, dd_), allout_filtered.reshape(nn_ * bb_, dd_),
-                                              wc, self.linear_cat.bias, tail, pending).view(nn_, bb_, -1)
+                                              wc, self.linear_cat.bias, tail, pending, done=done).view(nn_, bb_, -1)
             elif (dd_ % 16 == 0 and FF.row_linear_supported(2 * dd_, wc.shape[0])):
                 # [output | allout_filtered] W^T + b without materialising the concatenation (:223-224)
                 output = FF.row_linear_cat(output.reshape(nn_ * bb_, dd_), allout_filtered.reshape(nn_ * bb_, dd_),
-                                           wc, self.linear_cat.bias, pending).view(nn_, bb_, -1)
+                                           wc, self.linear_cat.bias, pending, done=done).view(nn_, bb_, -1)
             else:
                 cat = torch.cat((output, allout_filtered), dim=-1)               # :223
                 output, _ = linear_rows(cat.reshape(nn_ * bb_, 2 * dd_), wc, self.linear_cat.bias)   # :224

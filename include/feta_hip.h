@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FETA_ABI_VERSION 9
+#define FETA_ABI_VERSION 10
 
 #define FETA_OK 0
 #define FETA_E_ARG (-1)     /* bad shape / stride / alignment / unsupported size */
@@ -201,6 +201,40 @@ int feta_spec_filter_bwd(const float* x, int64_t x_sb, int64_t x_sn,
                          float* dx, float* dcoeff, float* dbias_part,
                          int B, int N, int H, int dh, int P, int K, int heads_share_graph,
                          feta_stream_t stream);
+
+/* ---- linear_cat folded into the per-graph eigenbasis filter (ABI 10) -------------------------------------------
+ * transformer/models.py:223-224: output = linear_cat(cat(output, allout_filtered)).  With W_cat = [Wa | Wb] ([64][128]):
+ *   out = xn Wa^T + filt Wb^T + b_cat,  filt = U Ytil + bias  =>  filt Wb^T = U (Ytil Wb^T) + bias Wb^T
+ * - the filter half is a [K x 64] x [64 x 64] product in the eigen domain, the stack half the graph's own rows through a
+ * 64 x 64 product: both are done by the workgroup that filters the graph (feta_spec_cat_supported: 4 heads x 16, order 4,
+ * N <= 128, K <= 32, every head on the graph).  y (= filt) is still written (linear_cat's backward contracts it).
+ * y2: the stack output rows [N*B][64], row(b, i) = b*y2_sb + i*y2_sn elements; seen through its last BatchNorm when
+ * y2_stats (fresh partial sums [Gx + 1][2][64]: finalized here over M rows - workgroup 0 publishes bn_out [4][64] and
+ * updates rmean / rvar / nbt, as feta_rowlin_fwd_ex does for its x operand) or y2_bn (a published block) is given, else
+ * used as it is (LayerNorm stack).  Rows of padded nodes take part (filt is zero there).  out has y's strides. */
+typedef struct feta_spec_cat {
+  const float* y2;
+  int64_t y2_sb, y2_sn;
+  const float* y2_bn;
+  const float* y2_stats;
+  int Gx;
+  const float* gamma;
+  const float* beta;
+  float* bn_out;
+  float* rmean;
+  float* rvar;
+  int64_t* nbt;
+  float momentum, eps;
+  int M;
+  const float* w_cat;
+  const float* b_cat;
+  float* out;
+} feta_spec_cat;
+int feta_spec_cat_supported(int N, int H, int dh, int P, int K, int heads_share_graph);
+int feta_spec_filter_cat_fwd(const float* x, int64_t x_sb, int64_t x_sn, const float* u, const float* lam,
+                             const float* coeff, const float* bias, const int32_t* n_real, float* y,
+                             int64_t y_sb, int64_t y_sn, int B, int N, int H, int dh, int P, int K,
+                             int heads_share_graph, const feta_spec_cat* cat, feta_stream_t stream);
 
 /* ---- bf16 STORAGE variants of A1 and A3 (BASELINE configs 3 and 5) ----------------------------------
  * Same operators, same argument meaning as feta_attn_fwd/bwd and feta_spec_filter_fwd/bwd; `void*`

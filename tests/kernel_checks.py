@@ -1278,3 +1278,70 @@ def check_attn_block_bwd_ln(abi, dev, stream, bsz=5, n_pad=21, n_min=3, seed=0, 
         errs[name] = assert_close('ln block ' + name, pw[o:o + ref.numel()].view(ref.shape), ref, tol=tol)
         o += ref.numel()
     return errs
+
+
+# ---- linear_cat folded into the per-graph eigenbasis filter (ABI 10) ----------------------------------------------------
+def check_spec_cat(abi, dev, stream, bsz=5, shape='zinc', n_min=None, n_max=None, k_eig=16, seed=0, norm='bn_fresh'):
+    """feta_spec_filter_cat_fwd against the oracle: filt = the truncated-K eigenbasis filter (oracle.spec_filter_eig per
+    block), out = linear_cat([xn | filt]) (transformer/models.py:223-224) with xn = the stack output seen through a
+    BatchNorm (norm 'bn_fresh': statistics finalized by the kernel from partial sums, parameter block and running
+    statistics published; 'bn_block': a published block; 'plain': LayerNorm stack)."""
+    import torch.nn.functional as F
+    h, dh, order = 4, 16, 4
+    d = h * dh
+    x, coeff, bias, _, mask, _, _, _, cache, n = _filter_case(bsz, h, dh, order, seed, shape, n_min, n_max, k_eig)
+    g = torch.Generator().manual_seed(seed + 7)
+    m = n * bsz
+    y2 = torch.randn(n, bsz, d, generator=g, dtype=torch.float64) * 1.5 + 0.3
+    w_cat = (torch.randn(d, 2 * d, generator=g, dtype=torch.float64) / 8).float().double()
+    b_cat = (torch.randn(d, generator=g, dtype=torch.float64) * 0.1).float().double()
+    u, lam = cache.u.double(), cache.lam.double()
+    nb = cache.n_real.tolist()
+    filt = torch.zeros(n, bsz, d, dtype=torch.float64)
+    for hh in range(h):
+        for bb in range(bsz):
+            k = nb[bb]
+            yb = O.spec_filter_eig(x[bb, :k, hh], u[bb, :k], lam[bb], coeff[hh, bb].reshape(order, dh, dh), bias)
+            filt[:k, bb, hh * dh:(hh + 1) * dh] = yb
+    f32 = lambda t: t.float().contiguous().to(dev)
+    kw = {}
+    if norm == 'plain':
+        xn = y2
+    else:
+        gamma = (torch.rand(d, generator=g, dtype=torch.float64) + 0.5).float().double()
+        beta = (torch.randn(d, generator=g, dtype=torch.float64) * 0.2).float().double()
+        rows = y2.reshape(m, d)
+        mean, var = rows.mean(0), rows.var(0, unbiased=False)
+        rstd = (var + 1e-5).rsqrt()
+        xn = (y2 - mean) * rstd * gamma + beta
+        if norm == 'bn_block':
+            kw = dict(y2_bn=f32(torch.stack([gamma * rstd, beta - mean * gamma * rstd, mean, rstd])))
+        else:
+            # partial sums as a producer leaves them: G rows of (sum (y - K), sum (y - K)^2) and the shift row K
+            G = 5
+            shift = (mean + 0.05 * torch.randn(d, generator=g, dtype=torch.float64)).float().double()
+            parts = torch.zeros(G + 1, 2, d, dtype=torch.float64)
+            for i, chunk in enumerate(torch.chunk(rows - shift, G, dim=0)):
+                parts[i, 0], parts[i, 1] = chunk.sum(0), (chunk * chunk).sum(0)
+            parts[G, 0] = shift
+            rmean, rvar = torch.zeros(d, device=dev), torch.ones(d, device=dev)
+            nbt = torch.zeros((), dtype=torch.int64, device=dev)
+            kw = dict(y2_stats=f32(parts), Gx=G, gamma=f32(gamma), beta=f32(beta), bn_out=torch.full((4, d), float('nan'), device=dev),
+                      rmean=rmean, rvar=rvar, nbt=nbt)
+    out_ref = F.linear(torch.cat((xn, filt), dim=-1), w_cat, b_cat)
+    xv = to_view(x, True, dev)
+    yv = token_buffers(bsz, n, h, dh, True, dev)
+    ov = token_buffers(bsz, n, h, dh, True, dev)
+    y2v = to_view(y2.view(n, bsz, h, dh).permute(1, 0, 2, 3), True, dev)
+    abi.spec_filter_cat_fwd(xv, f32(u), f32(lam), f32(coeff.reshape(h * bsz, -1)), f32(bias), cache.n_real.to(dev), yv, order, 1,
+                            stream, y2=y2v, w_cat=f32(w_cat), b_cat=f32(b_cat), out=ov, **kw)
+    errs = {'filt': assert_close('spec_cat filt', yv.permute(1, 0, 2, 3).reshape(n, bsz, d), filt),
+            'out': assert_close('spec_cat out', ov.permute(1, 0, 2, 3).reshape(n, bsz, d), out_ref)}
+    if norm == 'bn_fresh':
+        errs['bn_out'] = assert_close('spec_cat bn block', kw['bn_out'],
+                                      torch.stack([gamma * rstd, beta - mean * gamma * rstd, mean, rstd]))
+        unb = var * m / (m - 1)
+        assert_close('spec_cat running mean', kw['rmean'], 0.1 * mean)
+        assert_close('spec_cat running var', kw['rvar'], 0.9 + 0.1 * unb)
+        assert int(kw['nbt']) == 1
+    return errs

@@ -69,7 +69,8 @@ def _header_structs():
 @pytest.mark.parametrize('cname,pyname', [('feta_attn_block', 'AttnBlock'), ('feta_ffn', 'Ffn'),
                                           ('feta_attn_block_grad', 'AttnBlockGrad'), ('feta_ffn_grad', 'FfnGrad'),
                                           ('feta_rowlin_ex', 'RowLinEx'), ('feta_colsum_seg', 'ColsumSeg'),
-                                          ('feta_coeff_fwd_role', 'CoeffFwdRole'), ('feta_coeff_bwd_role', 'CoeffBwdRole')])
+                                          ('feta_coeff_fwd_role', 'CoeffFwdRole'), ('feta_coeff_bwd_role', 'CoeffBwdRole'),
+                                          ('feta_spec_cat', 'SpecCat')])
 def test_descriptor_layouts_agree(cname, pyname):
     """Every descriptor struct of the header has the same fields, in the same order and of the same kind, as its ctypes
     mirror - a field added on one side only would shift every pointer behind it."""

@@ -343,3 +343,10 @@ def test_attn_block_bwd_layernorm_on_load(emu, kw):
 def test_attn_block_bwd_layernorm_walks_several_graphs(emu, monkeypatch):
     monkeypatch.setenv('FETA_BLOCK_BWD_MAX_GRID', '2')
     KC.check_attn_block_bwd_ln(emu, CPU, None, bsz=5, n_pad=21, dtype=F32)
+
+
+@pytest.mark.parametrize('kw', [dict(norm='bn_fresh'), dict(norm='bn_block', k_eig=8, bsz=3), dict(norm='plain', shape='mutag', k_eig=8),
+                                dict(norm='bn_fresh', shape='pattern', n_min=44, n_max=64, k_eig=32, bsz=2),
+                                dict(norm='plain', shape='pattern', n_min=70, n_max=100, k_eig=32, bsz=2)])
+def test_spec_filter_with_linear_cat(emu, kw):
+    KC.check_spec_cat(emu, CPU, None, **kw)

@@ -356,3 +356,12 @@ def test_ffn_bwd_layernorm_on_load(hip, kw):
                                 dict(bsz=300, n_pad=64, n_min=2, dtype=B16), dict(bsz=3, n_pad=21, dtype=F32)])
 def test_attn_block_bwd_layernorm_on_load(hip, kw):
     KC.check_attn_block_bwd_ln(hip[0], hip[1], hip[2], **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(norm='bn_fresh', bsz=128), dict(norm='bn_block', k_eig=8, bsz=32), dict(norm='plain', shape='mutag', k_eig=8, bsz=32),
+                                dict(norm='bn_fresh', shape='molhiv', n_max=64, k_eig=16, bsz=300),
+                                dict(norm='bn_fresh', shape='pattern', n_min=44, n_max=128, k_eig=32, bsz=64),
+                                dict(norm='plain', shape='pattern', n_min=70, n_max=100, k_eig=32, bsz=8)])
+def test_spec_filter_with_linear_cat(hip, kw):
+    """feta_spec_filter_cat_fwd (linear_cat folded into the per-graph eigenbasis filter) against the oracle"""
+    KC.check_spec_cat(hip[0], hip[1], hip[2], **kw)
