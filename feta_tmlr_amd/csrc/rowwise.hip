@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kRowThreads) void rowlin_fwd_kernel(RowLinArgs a, R
   if (a.x_stats != nullptr) {
     // first consumer of fresh statistics: finalize them (every block, redundantly and
     // deterministically); block 0 publishes the parameter block and the running statistics
-    reduce_partials(a.x_stats, a.Gx, DS, scr + 2 * DS, scr);
+    reduce_partials_t<kRowThreads, 32>(a.x_stats, a.Gx, DS, scr + 2 * DS, scr);   // (256 rows of 64 columns in ONE batch: feta_rowops.h)
     for (int c = threadIdx.x; c < DS; c += kRowThreads) {
       float mean, var;
       bn_moments(a.x_stats, a.Gx, DS, a.M, scr, c, mean, var);
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(kRowThreads) void rowlin_bwd_kernel(RowLinArgs a, R
     const int cpre = min((int)threadIdx.x, NO - 1);
     const float bn_scale = a.g_bn[cpre], bn_mean = a.g_bn[2 * NO + cpre], bn_rstd = a.g_bn[3 * NO + cpre];
     if (a.g_sum != nullptr) {
-      reduce_partials(a.g_sum, a.Gs, NO, scr + 2 * NO, scr);
+      reduce_partials_t<kRowThreads, 32>(a.g_sum, a.Gs, NO, scr + 2 * NO, scr);
       for (int c = threadIdx.x; c < NO; c += kRowThreads) {
         gv[3 * NO + c] = scr[c] / (float)a.M;
         gv[4 * NO + c] = scr[NO + c] / (float)a.M;
