@@ -176,7 +176,7 @@ int launch_colsum_multi(const feta_colsum_seg* segs, int nseg, hipStream_t strea
   }
   if (any_wide && !wide) {
     ColsumPlan p{};
-    const int tiles = plan_colsum(segs, nseg, p);
+    const int tiles = plan_colsum(segs, nseg, p, kColsumMixedThreads);
     auto kern = colsum_mixed_kernel;
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(kColsumMixedThreads),
                        colsum_role_lds_floats(kColsumMixedThreads) * sizeof(float), stream, p);

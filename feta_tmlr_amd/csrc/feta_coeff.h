@@ -203,11 +203,29 @@ __device__ __forceinline__ void coeff_fwd_body(
   const float inv_n = 1.0f / (float)n;
   const int cw = ((C + CS - 1) / CS + kCoeffThreads - 1) / kCoeffThreads * kCoeffThreads;   // channels per slice
   const int cend = min(C, (cs + 1) * cw);
-  for (int c = cs * cw + threadIdx.x; c < cend; c += kCoeffThreads) {
-    const float sc = s[c], bc = gbias[c];
-    float acc = 0.0f;
-    for (int i = 0; i < n; ++i) acc += fast_tanh(cjs[i] * sc + bc);
-    pooled[(int64_t)blk * C + c] = acc * inv_n;
+  // four channels of a thread advance together through the node loop: one tanh is a dependent chain of ~6 instructions
+  // (two of them transcendental) behind an LDS read - with one chain per iteration and two waves per SIMD (as a role the
+  // workgroup inherits its host kernel's 200 registers) the loop ran at the chain's LATENCY, not at the VALU's rate
+  for (int c0 = cs * cw + threadIdx.x; c0 < cend; c0 += 4 * kCoeffThreads) {
+    float sc[4], bc[4], acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = min(c0 + k * kCoeffThreads, C - 1);
+      sc[k] = s[c];
+      bc[k] = gbias[c];
+      acc[k] = 0.0f;
+    }
+#pragma unroll 2
+    for (int i = 0; i < n; ++i) {
+      const float ci = cjs[i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] += fast_tanh(ci * sc[k] + bc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = c0 + k * kCoeffThreads;
+      if (c < cend) pooled[(int64_t)blk * C + c] = acc[k] * inv_n;
+    }
   }
 }
 
@@ -243,17 +261,55 @@ __device__ __forceinline__ void coeff_bwd_body(
       cjs[i] = blk < total ? cj[(int64_t)blk * N + k] : 0.0f;
     }
     __syncthreads();
+    // independent tanh chains per iteration (see coeff_fwd_body).  Where the launch is latency-bound (few blocks: the
+    // BASELINE batch has 512) the blocks of a pass advance TOGETHER through the node loop - four chains, a block shorter
+    // than the longest contributes zeros behind its last node (0.2655 -> 0.262 ms per step); where it is throughput-bound
+    // (config 5: 4096 blocks) those zeros cost up to twice the tanh count (1.052 -> 1.060 ms), and four NODES of one block
+    // advance together instead (the last group masked)
+    int nmax = 0;
 #pragma unroll
-    for (int u = 0; u < kCoeffPass; ++u) {
-      const int n = nn[u];
-      if (n == 0) continue;
-      const float dpn = dp[u] / (float)n;
-      for (int i = 0; i < n; ++i) {
-        const float ci = cjs[u * N + i];
-        const float z = fast_tanh(ci * sc + bc);
-        const float t = dpn * (1.0f - z * z);
-        as += t * ci;
-        ab += t;
+    for (int u = 0; u < kCoeffPass; ++u) nmax = max(nmax, nn[u]);
+    if (total <= 2048) {
+      float dpn[kCoeffPass], as_[kCoeffPass], ab_[kCoeffPass];
+#pragma unroll
+      for (int u = 0; u < kCoeffPass; ++u) {
+        dpn[u] = nn[u] > 0 ? dp[u] / (float)nn[u] : 0.0f;
+        as_[u] = ab_[u] = 0.0f;
+      }
+      for (int i = 0; i < nmax; ++i) {
+#pragma unroll
+        for (int u = 0; u < kCoeffPass; ++u) {
+          const float ci = cjs[u * N + i];
+          const float z = fast_tanh(ci * sc + bc);
+          const float t = i < nn[u] ? dpn[u] * (1.0f - z * z) : 0.0f;
+          as_[u] += t * ci;
+          ab_[u] += t;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kCoeffPass; ++u) {
+        as += as_[u];
+        ab += ab_[u];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < kCoeffPass; ++u) {
+        const int n = nn[u];
+        if (n == 0) continue;
+        const float dpn = dp[u] / (float)n;
+        float a4[4] = {0.0f, 0.0f, 0.0f, 0.0f}, b4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int i = 0; i < n; i += 4) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float ci = cjs[u * N + min(i + k, N - 1)];
+            const float z = fast_tanh(ci * sc + bc);
+            const float t = i + k < n ? dpn * (1.0f - z * z) : 0.0f;
+            a4[k] += t * ci;
+            b4[k] += t;
+          }
+        }
+        as += (a4[0] + a4[1]) + (a4[2] + a4[3]);
+        ab += (b4[0] + b4[1]) + (b4[2] + b4[3]);
       }
     }
   }

@@ -31,16 +31,23 @@ inline bool colsum_seg_wide(const feta_colsum_seg& s, int min_cols) {
          s.bcast_out == nullptr;
 }
 
-// fills the plan, returns the number of tiles (= workgroups of the role); wide tiles are 256 float4 columns whatever
-// the workgroup size (larger workgroups split the rows)
-inline int plan_colsum(const feta_colsum_seg* segs, int nseg, ColsumPlan& p) {
+// float4 columns of a wide tile for a workgroup of `threads` threads: 256 (one thread per float4 column, larger
+// workgroups split the rows in 2) - but 64 for the 1024-thread launch of its own, whose segments are few rows x ~10^4
+// columns (the stack's split-K partials: 128 rows x 16 640 columns were 17 workgroups of 32 rows per thread, four dependent
+// batches; 65 workgroups of 8 rows per thread are one batch and fill a quarter of the chip instead of a sixteenth)
+constexpr int colsum_wide_q(int threads) { return threads >= 1024 ? 64 : 256; }
+
+// fills the plan, returns the number of tiles (= workgroups of the role); `threads`: the workgroup size the tiles will
+// be reduced with (colsum_role<THREADS>)
+inline int plan_colsum(const feta_colsum_seg* segs, int nseg, ColsumPlan& p, int threads = 256) {
   int tiles = 0;
+  const int wq = colsum_wide_q(threads);
   p.nseg = nseg;
   for (int i = 0; i < nseg; ++i) {
-    const bool wide = colsum_seg_wide(segs[i], 4096);   // (a wide tile is one workgroup per 1024 columns)
+    const bool wide = colsum_seg_wide(segs[i], 4096);
     p.seg[i] = segs[i];
     p.wide[i] = wide ? 1 : 0;
-    tiles += wide ? (segs[i].C / 4 + 255) / 256 : (segs[i].C + 15) / 16;
+    tiles += wide ? (segs[i].C / 4 + wq - 1) / wq : (segs[i].C + 15) / 16;
     p.tile_end[i] = tiles;
   }
   return tiles;
@@ -64,9 +71,9 @@ __device__ __forceinline__ void colsum_role(const ColsumPlan& sg, int tile_id) {
   const int ld = s.ld > 0 ? s.ld : s.C;
   const int tid = threadIdx.x;
   if (sg.wide[si]) {
-    // 256 float4 columns per tile; THREADS / 256 row slices, tree over the slices through LDS
-    constexpr int SLW = THREADS / 256;
-    const int c4 = tile * 256 + (tid & 255), slice = tid >> 8;
+    // WQ float4 columns per tile; THREADS / WQ row slices, tree over the slices through LDS
+    constexpr int WQ = colsum_wide_q(THREADS), SLW = THREADS / WQ;
+    const int c4 = tile * WQ + (tid % WQ), slice = tid / WQ;
     const bool ok = c4 < s.C / 4;
     const float* p = s.in + 4 * (int64_t)(ok ? c4 : 0);
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -80,14 +87,14 @@ __device__ __forceinline__ void colsum_role(const ColsumPlan& sg, int tile_id) {
     }
     for (; r < s.R; r += SLW) add4(acc, *reinterpret_cast<const float4*>(p + (int64_t)r * ld));
     if (SLW > 1) {
-      float4* red = reinterpret_cast<float4*>(feta_lds);   // [SLW][256]
+      float4* red = reinterpret_cast<float4*>(feta_lds);   // [SLW][WQ]
       red[tid] = acc;
       __syncthreads();
       for (int half = SLW / 2; half >= 1; half >>= 1) {
-        if (slice < half) add4(red[tid], red[tid + half * 256]);
+        if (slice < half) add4(red[tid], red[tid + half * WQ]);
         __syncthreads();
       }
-      acc = red[tid & 255];
+      acc = red[tid % WQ];
     }
     if (ok && slice == 0) *reinterpret_cast<float4*>(s.out + 4 * (int64_t)c4) = acc;
     return;
