@@ -206,6 +206,17 @@ __device__ __forceinline__ void coeff_fwd_body(
   // four channels of a thread advance together through the node loop: one tanh is a dependent chain of ~6 instructions
   // (two of them transcendental) behind an LDS read - with one chain per iteration and two waves per SIMD (as a role the
   // workgroup inherits its host kernel's 200 registers) the loop ran at the chain's LATENCY, not at the VALU's rate
+  if (cw < 4 * kCoeffThreads) {
+    // channel slices of large graphs (CS > 1, one channel per thread, thousands of workgroups): throughput-bound on the
+    // tanh, so the plain loop - the masked four-wide forms measured 23.5 -> 26.1 us on config 4
+    for (int c = cs * cw + threadIdx.x; c < cend; c += kCoeffThreads) {
+      const float sc = s[c], bc = gbias[c];
+      float acc = 0.0f;
+      for (int i = 0; i < n; ++i) acc += fast_tanh(cjs[i] * sc + bc);
+      pooled[(int64_t)blk * C + c] = acc * inv_n;
+    }
+    return;
+  }
   for (int c0 = cs * cw + threadIdx.x; c0 < cend; c0 += 4 * kCoeffThreads) {
     float sc[4], bc[4], acc[4];
 #pragma unroll
@@ -264,12 +275,14 @@ __device__ __forceinline__ void coeff_bwd_body(
     // independent tanh chains per iteration (see coeff_fwd_body).  Where the launch is latency-bound (few blocks: the
     // BASELINE batch has 512) the blocks of a pass advance TOGETHER through the node loop - four chains, a block shorter
     // than the longest contributes zeros behind its last node (0.2655 -> 0.262 ms per step); where it is throughput-bound
-    // (config 5: 4096 blocks) those zeros cost up to twice the tanh count (1.052 -> 1.060 ms), and four NODES of one block
-    // advance together instead (the last group masked)
+    // (config 5: 4096 blocks of <= 64 nodes; config 4: 512 blocks of 44..188 nodes) those zeros cost up to twice the tanh
+    // count (1.052 -> 1.060 ms on config 5, 32.4 -> 43.1 us for this role on config 4); a masked four-NODE form of one
+    // block measured 42.2 us there, so that regime keeps the plain loop.  The switch is the padded tanh count per channel,
+    // blocks x N (config 4 sits exactly AT 32768 = 256 x 128, hence the N bound as well).
     int nmax = 0;
 #pragma unroll
     for (int u = 0; u < kCoeffPass; ++u) nmax = max(nmax, nn[u]);
-    if (total <= 2048) {
+    if (N <= 64 && (int64_t)total * N <= 32768) {
       float dpn[kCoeffPass], as_[kCoeffPass], ab_[kCoeffPass];
 #pragma unroll
       for (int u = 0; u < kCoeffPass; ++u) {
@@ -297,19 +310,13 @@ __device__ __forceinline__ void coeff_bwd_body(
         const int n = nn[u];
         if (n == 0) continue;
         const float dpn = dp[u] / (float)n;
-        float a4[4] = {0.0f, 0.0f, 0.0f, 0.0f}, b4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int i = 0; i < n; i += 4) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float ci = cjs[u * N + min(i + k, N - 1)];
-            const float z = fast_tanh(ci * sc + bc);
-            const float t = i + k < n ? dpn * (1.0f - z * z) : 0.0f;
-            a4[k] += t * ci;
-            b4[k] += t;
-          }
+        for (int i = 0; i < n; ++i) {
+          const float ci = cjs[u * N + i];
+          const float z = fast_tanh(ci * sc + bc);
+          const float t = dpn * (1.0f - z * z);
+          as += t * ci;
+          ab += t;
         }
-        as += (a4[0] + a4[1]) + (a4[2] + a4[3]);
-        ab += (b4[0] + b4[1]) + (b4[2] + b4[3]);
       }
     }
   }
