@@ -12,6 +12,8 @@
 
 #include "feta_abi_common.h"
 #include <feta_device.h>
+#include <cstdlib>
+
 #include "feta_coeff.h"
 #include "feta_colsum.h"
 
@@ -23,6 +25,18 @@ __global__ __launch_bounds__(kCoeffThreads) void coeff_fwd_kernel(
     int N, int H, int C, int stage) {
   coeff_fwd_body(attn, n_real, s, gbias, cj_out, pooled, B, N, H, C, stage, (int)blockIdx.x, (int)blockIdx.y,
                  (int)gridDim.y);
+}
+
+// graphs beyond 64 nodes (config 4): ONE workgroup of 1024 threads per block.  The 256-thread form ran four channel-slice
+// workgroups per block, each staging the block's N x N attention rows again (two rounds of requests) and then walking the
+// nodes with two waves per SIMD: 23 us at B = 64, N = 128.  Here the rows arrive in one round (16 bytes x 4 per thread),
+// the column sweeps have 32 row slices, and every thread owns one of the 1024 channels with four waves per SIMD under the
+// tanh chain.
+__global__ __launch_bounds__(kCoeffWideThreads) void coeff_fwd_wide_kernel(
+    const float* __restrict__ attn, const int32_t* __restrict__ n_real, const float* __restrict__ s,
+    const float* __restrict__ gbias, float* __restrict__ cj_out, float* __restrict__ pooled, int B,
+    int N, int H, int C) {
+  coeff_fwd_body<kCoeffWideThreads>(attn, n_real, s, gbias, cj_out, pooled, B, N, H, C, 2, (int)blockIdx.x);
 }
 
 __global__ __launch_bounds__(kCoeffThreads) void coeff_bwd_kernel(
@@ -220,6 +234,18 @@ extern "C" int feta_coeff_fwd(const float* attn, const int32_t* n_real, const fl
   const int want = N > 64 ? 2 : 1;
   const int stage = sizeof(float) * (size_t)coeff_fwd_lds_floats_mode(N, want) <= 150 * 1024 ? want : 0;
   const size_t lds = sizeof(float) * (size_t)coeff_fwd_lds_floats_mode(N, stage);
+  if (N > 64) {
+    const size_t wide = sizeof(float) * (size_t)coeff_fwd_lds_floats_mode(N, 2, kCoeffWideThreads);
+    const char* e = getenv("FETA_COEFF_WIDE");
+    if (wide <= 160 * 1024 && !(e != nullptr && e[0] == '0')) {
+      auto kern = coeff_fwd_wide_kernel;
+      static LdsSeen wide_seen;
+      allow_dynamic_lds(kern, wide, wide_seen);
+      hipLaunchKernelGGL(kern, dim3(B * H), dim3(kCoeffWideThreads), wide, (hipStream_t)stream, attn, n_real, s, gcn_bias,
+                         cj, pooled, B, N, H, C);
+      return check_launch("feta_coeff_fwd");
+    }
+  }
   const int cs = (N > 64 && C >= 4 * kCoeffThreads) ? 4 : 1;
   const dim3 grid(B * H, cs), block(kCoeffThreads);
   auto kern = coeff_fwd_kernel;

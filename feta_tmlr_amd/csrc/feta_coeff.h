@@ -12,10 +12,13 @@
 namespace feta {
 
 constexpr int kCoeffThreads = 256;
+constexpr int kCoeffWideThreads = 1024;   // stand-alone forward launch of graphs beyond 64 nodes: one workgroup per block
 constexpr int kCoeffGroupsMax = 128;
 constexpr int kCoeffLdsTileMax = 12 * 1024;  // floats of attention staged per block (48 KB)
 
-// body of one (head, graph) block `blk` = h * B + b; 256 threads, dynamic LDS coeff_fwd_lds_floats(N, stage)
+// body of one (head, graph) block `blk` = h * B + b; TH threads (256 as a kernel of its own for N <= 64 and as a role,
+// kCoeffWideThreads for the stand-alone launch of larger graphs), dynamic LDS coeff_fwd_lds_floats_mode(N, stage, TH)
+template <int TH = 256>
 __device__ __forceinline__ void coeff_fwd_body(
     const float* __restrict__ attn, const int32_t* __restrict__ n_real, const float* __restrict__ s,
     const float* __restrict__ gbias, float* __restrict__ cj_out, float* __restrict__ pooled, int B,
@@ -39,12 +42,12 @@ __device__ __forceinline__ void coeff_fwd_body(
     float v[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-      const int idx = threadIdx.x + u * kCoeffThreads;
+      const int idx = threadIdx.x + u * TH;
       v[u] = a[idx < cnt ? idx : (cnt > 0 ? cnt - 1 : 0)];
     }
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-      const int idx = threadIdx.x + u * kCoeffThreads;
+      const int idx = threadIdx.x + u * TH;
       if (idx < cnt) tile[idx] = v[u];
     }
     __syncthreads();
@@ -84,41 +87,41 @@ __device__ __forceinline__ void coeff_fwd_body(
     // on all 256 threads over the staged rows (pitch NP = N rounded up to 4).  The diagonal rule (a zero self loop
     // counts 1: models.py:276,281 + add_remaining_self_loops) is a correction of the plain column sums:
     //   deg_j = sum_i a_ij + [a_jj == 0],   c_j = dis_j (sum_i dis_i a_ij + [a_jj == 0] dis_j)
-    const int NP = (N + 3) & ~3, NC4 = NP >> 2, SL = kCoeffThreads / NC4;
-    float* ps2 = feta_lds + 2 * N;     // [SL][NP] (<= 1024 floats)
-    float* tl = ps2 + 1024;            // [n][NP]
+    const int NP = (N + 3) & ~3, NC4 = NP >> 2, SL = TH / NC4;
+    float* ps2 = feta_lds + 2 * N;     // [SL][NP] (<= 4 TH floats)
+    float* tl = ps2 + 4 * TH;          // [n][NP]
     if ((N & 3) == 0) {
       const int cnt4 = n * NC4;
       const float4* a4 = reinterpret_cast<const float4*>(a);
-      for (int base = threadIdx.x; base < cnt4; base += 8 * kCoeffThreads) {
+      for (int base = threadIdx.x; base < cnt4; base += 8 * TH) {
         float4 v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const int idx = base + u * kCoeffThreads;
+          const int idx = base + u * TH;
           v[u] = a4[idx < cnt4 ? idx : cnt4 - 1];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const int idx = base + u * kCoeffThreads;
+          const int idx = base + u * TH;
           if (idx < cnt4) reinterpret_cast<float4*>(tl)[idx] = v[u];   // (NP == N: same linear index)
         }
       }
     } else {
       const int cnt = n * N;
-      for (int base = threadIdx.x; base < cnt; base += 8 * kCoeffThreads) {
+      for (int base = threadIdx.x; base < cnt; base += 8 * TH) {
         float v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const int idx = base + u * kCoeffThreads;
+          const int idx = base + u * TH;
           v[u] = a[idx < cnt ? idx : cnt - 1];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const int idx = base + u * kCoeffThreads;
+          const int idx = base + u * TH;
           if (idx < cnt) tl[(idx / N) * NP + idx % N] = v[u];
         }
       }
-      for (int i = threadIdx.x; i < n * (NP - N); i += kCoeffThreads) tl[(i / (NP - N)) * NP + N + i % (NP - N)] = 0.0f;
+      for (int i = threadIdx.x; i < n * (NP - N); i += TH) tl[(i / (NP - N)) * NP + N + i % (NP - N)] = 0.0f;
     }
     __syncthreads();
     const int cg = threadIdx.x % NC4, sl = threadIdx.x / NC4;
@@ -165,16 +168,16 @@ __device__ __forceinline__ void coeff_fwd_body(
     if (stage) {
       // eight requests in flight per thread (a plain copy loop pays one memory latency per 256 floats)
       const int cnt = n * N;
-      for (int base = threadIdx.x; base < cnt; base += 8 * kCoeffThreads) {
+      for (int base = threadIdx.x; base < cnt; base += 8 * TH) {
         float v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const int idx = base + u * kCoeffThreads;
+          const int idx = base + u * TH;
           v[u] = a[idx < cnt ? idx : cnt - 1];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const int idx = base + u * kCoeffThreads;
+          const int idx = base + u * TH;
           if (idx < cnt) tile[idx] = v[u];
         }
       }
@@ -201,15 +204,15 @@ __device__ __forceinline__ void coeff_fwd_body(
     __syncthreads();
   }
   const float inv_n = 1.0f / (float)n;
-  const int cw = ((C + CS - 1) / CS + kCoeffThreads - 1) / kCoeffThreads * kCoeffThreads;   // channels per slice
+  const int cw = ((C + CS - 1) / CS + TH - 1) / TH * TH;   // channels per slice
   const int cend = min(C, (cs + 1) * cw);
   // four channels of a thread advance together through the node loop: one tanh is a dependent chain of ~6 instructions
   // (two of them transcendental) behind an LDS read - with one chain per iteration and two waves per SIMD (as a role the
   // workgroup inherits its host kernel's 200 registers) the loop ran at the chain's LATENCY, not at the VALU's rate
-  if (cw < 4 * kCoeffThreads) {
+  if (cw < 4 * TH) {
     // channel slices of large graphs (CS > 1, one channel per thread, thousands of workgroups): throughput-bound on the
     // tanh, so the plain loop - the masked four-wide forms measured 23.5 -> 26.1 us on config 4
-    for (int c = cs * cw + threadIdx.x; c < cend; c += kCoeffThreads) {
+    for (int c = cs * cw + threadIdx.x; c < cend; c += TH) {
       const float sc = s[c], bc = gbias[c];
       float acc = 0.0f;
       for (int i = 0; i < n; ++i) acc += fast_tanh(cjs[i] * sc + bc);
@@ -217,11 +220,11 @@ __device__ __forceinline__ void coeff_fwd_body(
     }
     return;
   }
-  for (int c0 = cs * cw + threadIdx.x; c0 < cend; c0 += 4 * kCoeffThreads) {
+  for (int c0 = cs * cw + threadIdx.x; c0 < cend; c0 += 4 * TH) {
     float sc[4], bc[4], acc[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int c = min(c0 + k * kCoeffThreads, C - 1);
+      const int c = min(c0 + k * TH, C - 1);
       sc[k] = s[c];
       bc[k] = gbias[c];
       acc[k] = 0.0f;
@@ -234,7 +237,7 @@ __device__ __forceinline__ void coeff_fwd_body(
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int c = c0 + k * kCoeffThreads;
+      const int c = c0 + k * TH;
       if (c < cend) pooled[(int64_t)blk * C + c] = acc[k] * inv_n;
     }
   }
@@ -334,8 +337,8 @@ __host__ __device__ inline int coeff_fwd_stage(int N) {
   if (N <= 64) return 1;
   return N * ((N + 3) & ~3) <= kCoeffLdsTileMax ? 2 : 0;
 }
-__host__ __device__ inline int coeff_fwd_lds_floats_mode(int N, int stage) {
-  return 2 * N + (stage == 2 ? 1024 + N * ((N + 3) & ~3) : 4 * 64 + (stage == 1 ? N * N : 0));
+__host__ __device__ inline int coeff_fwd_lds_floats_mode(int N, int stage, int threads = kCoeffThreads) {
+  return 2 * N + (stage == 2 ? 4 * threads + N * ((N + 3) & ~3) : 4 * 64 + (stage == 1 ? N * N : 0));
 }
 __host__ __device__ inline int coeff_fwd_lds_floats(int N) { return coeff_fwd_lds_floats_mode(N, coeff_fwd_stage(N)); }
 

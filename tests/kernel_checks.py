@@ -374,11 +374,12 @@ def check_coeff(abi, dev, stream, bsz, n, h, c, seed=0, zero_diag=True, faithful
             abi.ffn_fwd(m, ff, stream, x=x, w1=w1, b1=b1, w2=w2, b2=b2, h=hbuf, y=y2,
                         coeff=(attn32, nbd, s, gb32, cj2, pooled2) if role else None)
             outs.append((hbuf, y2))
-        if n * ((n + 3) // 4 * 4) <= 12 * 1024:
+        if n <= 64:
             assert torch.equal(cj2, cj) and torch.equal(pooled2, pooled), 'coefficient generator forward as a role'
         else:
-            # (beyond the role's 48 KB tile budget the role sweeps global memory and the stand-alone launch its staged
-            # rows as column groups: same sums, another order.  The product takes the role at N <= 64 only.)
+            # (beyond 64 nodes the stand-alone launch is the 1024-thread kernel - 4x the row slices in its column sweeps - and
+            # beyond the role's 48 KB tile budget the role sweeps global memory: same sums, another order.  The product
+            # takes the role at N <= 64 only.)
             assert_close('role cj', cj2, cj.double(), tol=1e-6)
             assert_close('role pooled', pooled2, pooled.double(), tol=1e-6)
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
