@@ -258,6 +258,10 @@ extern "C" int feta_coeff_fwd(const float* attn, const int32_t* n_real, const fl
 
 extern "C" int feta_coeff_bwd_groups(int B, int H) {
   const int t = B * H;
+  // 128 groups x C / 256 channel tiles fill the chip twice at C = 1024 while a group walks a few blocks; from 2048 blocks on
+  // (config 5: 4096) a group of 128 walked 32 blocks with two waves per SIMD - 58.7 us stand-alone against a ~15 us tanh
+  // floor - so the groups grow with the batch (4 x the partial rows for the reduction launch)
+  if (t >= 2048) return 4 * kCoeffGroupsMax;
   return t < kCoeffGroupsMax ? t : kCoeffGroupsMax;
 }
 

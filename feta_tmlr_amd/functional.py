@@ -246,6 +246,13 @@ LIN_OWN_GEMM_MAX_MACS = int(_os.environ.get('FETA_LIN_OWN_MAX_MACS', str(1 << 27
 LIN_LIB_BF16_MIN_ROWS = int(_os.environ.get('FETA_LIN_LIB_BF16_MIN_ROWS', '2048'))
 
 
+# The coefficient generator's kernels ride as trailing workgroups of a feed-forward launch while the batch leaves CUs idle
+# there.  As a role they inherit the host kernel's two waves per SIMD; from this many (graph, head) blocks on, the stand-alone
+# launches (eight waves per SIMD) are the faster form even with their launch cost: config 5 (4096 blocks) 1.040 -> 1.022 ms
+# per step, the BASELINE batch (512 blocks) and config 4 (256 blocks of 128 nodes) the other way round.
+COEFF_ROLE_MAX_BLOCKS = int(_os.environ.get('FETA_COEFF_ROLE_MAX', 2048))
+
+
 class PendingSums:
     """Column sums (split-K partial buffer -> gradient) that one backward node of the filter stage leaves for a LATER
     node of the same backward pass which has a launch to carry them (trailing workgroups of feta_lin_bwd, or the
@@ -320,7 +327,9 @@ class PendingSums:
         if self.coeff_fwd_req is None or self.s is None or self.fwd_sums or attn is None:
             return None
         if attn.shape[-1] > 64:      # (beyond the role's LDS tile budget the stand-alone launch is the faster form:
-            return None              # csrc/feta_coeff.h - channel slices over 4 workgroups, staged rows)
+            return None              # csrc/feta_coeff.h - one 1024-thread workgroup per block, staged rows)
+        if attn.shape[0] * attn.shape[1] > COEFF_ROLE_MAX_BLOCKS:
+            return None
         gcn_bias, self.coeff_fwd_req = self.coeff_fwd_req, None
         b, h, n, _ = attn.shape
         cj = torch.empty((h * b, n), dtype=torch.float32, device=attn.device)

@@ -940,8 +940,10 @@ def _coeff_fwd_role(pending, li, nl, attn, n_real):
 def _coeff_bwd_request(ctx, abi, stream, d, ff_last):
     """The coefficient generator's backward kernel, left by its autograd node for the first launch of this backward
     (the last layer's fused FFN backward); run here on its own when that launch is not the fused kernel."""
+    from . import functional as F
     req = ctx.pending.take_coeff_bwd() if ctx.pending is not None else None
-    if req is not None and not (USE_FFN_BWD and abi.ffn_bwd_supported(d, ff_last)):
+    if req is not None and (not (USE_FFN_BWD and abi.ffn_bwd_supported(d, ff_last))
+                            or req[6] * req[8] > F.COEFF_ROLE_MAX_BLOCKS):
         cj, n_real, s, gb, dpooled, partial, b, n, h = req
         abi.coeff_bwd(cj, n_real, s, gb, dpooled, partial, None, None, b, n, h, stream)
         req = None
