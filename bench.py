@@ -486,9 +486,20 @@ def roofline(args, gpu, dev, lowp=False, pmc_tag=None):
         coeff, bias = rnd(h * b, c), rnd(dh)
         dcoeff, dbp = torch.empty_like(coeff), torch.empty(b * h, dh, device=dev)
         u, lam = gpu['cache'].u, gpu['cache'].lam
-        cand.append(('spec_filter_fwd', 'spec_fwd', 1,
-                     lambda: abi.spec_filter_fwd(xs, u, lam, coeff, bias, nr, ys, p, 1, st),
-                     spec_bytes(b, n, h, dh, k_eig, p, sum_n, False)))
+        from feta_tmlr_amd import functional as FF_
+        if FF_.USE_CAT_FOLD and not lowp and abi.spec_cat_supported(n, h, dh, p, k_eig, True):
+            # what the step launches since ABI 10: the filter with linear_cat folded in (+ the stack output rows in, the
+            # linear_cat output rows out, W_cat from L2)
+            y2c, wc, bc_, oc = rnd(n, b, d), rnd(d, 2 * d) / (2 * d) ** 0.5, rnd(d), torch.empty(n, b, d, device=dev)
+            cand.append(('spec_filter_cat_fwd', 'spec_cat_fwd', 1,
+                         lambda: abi.spec_filter_cat_fwd(xs, u, lam, coeff, bias, nr, ys, p, 1, st,
+                                                         y2c.view(n, b, h, dh).permute(1, 0, 2, 3), wc, bc_,
+                                                         oc.view(n, b, h, dh).permute(1, 0, 2, 3)),
+                         spec_bytes(b, n, h, dh, k_eig, p, sum_n, False) + 4 * (2 * sum_n * d + 2 * d * d + d)))
+        else:
+            cand.append(('spec_filter_fwd', 'spec_fwd', 1,
+                         lambda: abi.spec_filter_fwd(xs, u, lam, coeff, bias, nr, ys, p, 1, st),
+                         spec_bytes(b, n, h, dh, k_eig, p, sum_n, False)))
         cand.append(('spec_filter_bwd', 'spec_bwd', 1,
                      lambda: abi.spec_filter_bwd(xs, u, lam, coeff, nr, dys, dxs, dcoeff, dbp, p, 1, st),
                      spec_bytes(b, n, h, dh, k_eig, p, sum_n, True)))
@@ -741,6 +752,8 @@ def main(argv=None):
                  dict(shape='pattern', batch=64, n_pad=128, k_eig=32, dtype='f32'), 'pattern'),
                 ('config 4 (reference defaults: LayerNorm, pe=None): PATTERN-shaped, B=64, N_pad=128, K=32, fp32',
                  dict(shape='pattern', batch=64, n_pad=128, k_eig=32, dtype='f32', **ref_default), None),
+                ('config 4 at the largest PATTERN graph: B=64, N_pad=188, K=32, fp32',
+                 dict(shape='pattern', batch=64, n_pad=188, k_eig=32, dtype='f32'), None),
                 ('config 5: molhiv-shaped, B=1024, N_pad=64 bucket, K=16, bf16 storage',
                  dict(shape='molhiv', batch=1024, n_pad=64, k_eig=16, dtype='bf16'), 'molhiv_bf16'),
                 ('config 5 (reference defaults: LayerNorm, pe=None): molhiv-shaped, B=1024, N_pad=64 bucket, K=16, bf16 storage',
