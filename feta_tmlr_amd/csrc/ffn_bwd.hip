@@ -41,7 +41,8 @@ struct FfnBwdGeom {
   int xcd;  // 1: XCD-aware order of the workgroups (see ffn_bwd_kernel)
   int wxcd; // 1: XCD-aware order of the W-role workgroups of a capped grid
   int cxw;  // > 0: capped grid with the X role walking chunk-wise, cxw X walkers per chunk (wxcd is then not used)
-  int main_grid;   // workgroups of the two roles above; beyond: the coefficient generator's backward (feta_coeff.h)
+  int main_grid;   // workgroups of the two roles above
+  int role, role_lead;   // the coefficient generator's backward (feta_coeff.h): its workgroups, and how many grid slots lead the main ones (0: they trail)
 };
 
 inline int ffn_bwd_xblocks(int M) {
@@ -83,13 +84,20 @@ __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, Ffn
   typedef typename L::Op Op;
   typedef typename L::Vec Vec;
   constexpr int D = kFbD, NJ2 = FF / 16, VEC = L::VEC, RV = D / VEC;
-  if ((int)blockIdx.x >= ge.main_grid) {
-    // trailing workgroups: the backward of the coefficient generator (feta_coeff.h) - it depends on the filter stage
-    // only, and this is the first launch of the layer stack's backward
-    const int r = (int)blockIdx.x - ge.main_grid, nbx = (cb.C + kCoeffThreads - 1) / kCoeffThreads;
-    coeff_bwd_body(cb.cj, cb.n_real, cb.s, cb.gbias, cb.dpooled, cb.partial, cb.B, cb.N, cb.H, cb.C, cb.G, r % nbx, r / nbx);
+  // Extra workgroups: the backward of the coefficient generator (feta_coeff.h) - it depends on the filter stage only, and
+  // this is the first launch of the layer stack's backward.  They LEAD the grid (ge.role_lead, a multiple of 8 so that the
+  // XCD of every main workgroup stays what the orders below assume): the kernel's ~200 registers allow two workgroups per
+  // CU, 512 at a time - behind the main roles the generator's 512 short workgroups were a second round that started when the
+  // main ones (13 us) had finished; in front they are gone after ~3 us and the main workgroups move into their slots.
+  int bid = (int)blockIdx.x;
+  if (bid < ge.role_lead || bid >= ge.role_lead + ge.main_grid) {
+    const int r = bid < ge.role_lead ? bid : bid - ge.main_grid;
+    const int nbx = (cb.C + kCoeffThreads - 1) / kCoeffThreads;
+    if (r < ge.role)
+      coeff_bwd_body(cb.cj, cb.n_real, cb.s, cb.gbias, cb.dpooled, cb.partial, cb.B, cb.N, cb.H, cb.C, cb.G, r % nbx, r / nbx);
     return;
   }
+  bid -= ge.role_lead;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lq = lane & 15, g = lane >> 4;
   const T* gdy = reinterpret_cast<const T*>(a.dy);
   const T* gdyb = reinterpret_cast<const T*>(a.dy_b);
@@ -104,15 +112,15 @@ __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, Ffn
   // (chunk group, item, XCD): all six items of chunk 8 * group + XCD run on that XCD.
   int xblk, wbi;
   if (ge.xcd) {
-    const int xcd = (int)blockIdx.x & 7, v = (int)blockIdx.x >> 3, items = 2 + ge.NS;
+    const int xcd = bid & 7, v = bid >> 3, items = 2 + ge.NS;
     const int item = v % items, rc = (v / items) * 8 + xcd;
     if (rc >= ge.RC) return;
     xblk = item < 2 ? 2 * rc + item : -1;
     wbi = item < 2 ? -1 : rc * ge.NS + (item - 2);
     if (item < 2 && xblk >= ge.XB) return;
   } else {
-    xblk = (int)blockIdx.x < ge.XB ? (int)blockIdx.x : -1;
-    wbi = (int)blockIdx.x - ge.XB;
+    xblk = bid < ge.XB ? bid : -1;
+    wbi = bid - ge.XB;
     if (wbi >= 0 && ge.wxcd) {
       // capped grids (large batches): the NS hidden-unit slices of a row chunk read the same rows of dy, y2, x - in
       // launch order they sat on NS different XCDs and every one fetched the chunk from HBM (3.3x the algorithmic
@@ -129,7 +137,7 @@ __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, Ffn
   // i, i + cxw, ... - at the pace of the W slices, which pass over the same rows 64 at a time on the same XCD.
   int x_lo = xblk, x_hi = (a.M + kFbRows - 1) / kFbRows, x_step = ge.XB;
   if (ge.cxw > 0) {
-    const int xcd = (int)blockIdx.x & 7, v = (int)blockIdx.x >> 3, items = ge.cxw + ge.NS;
+    const int xcd = bid & 7, v = bid >> 3, items = ge.cxw + ge.NS;
     const int item = v % items, rc = (v / items) * 8 + xcd;
     if (rc >= ge.RC) return;
     if (item < ge.cxw) {
@@ -171,7 +179,7 @@ __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, Ffn
       for (int c = tid; c < D; c += kRowThreads) {
         gv[3 * D + c] = scr[c] / (float)a.M;
         gv[4 * D + c] = scr[D + c] / (float)a.M;
-        if (blockIdx.x == 0) {
+        if (bid == 0) {
           if (a.dbeta != nullptr) a.dbeta[c] = scr[c];
           if (a.dgamma != nullptr) a.dgamma[c] = scr[D + c];
           if (a.g_fin_out != nullptr) {
@@ -566,7 +574,10 @@ int launch_ffn_bwd(const FfnGradArgs& a, const CoeffBwdRole& cb, hipStream_t str
                  : ge.cxw > 0 ? 8 * ((ge.RC + 7) / 8) * (ge.cxw + ge.NS)
                               : ge.XB + (ge.wxcd ? 8 * ((ge.RC + 7) / 8) * ge.NS : ge.RC * ge.NS);
   ge.main_grid = grid;
-  hipLaunchKernelGGL(kern, dim3(grid + role), dim3(kRowThreads), lds, stream, a, ge, cb);
+  ge.role = role;
+  ge.role_lead = 8 * ((role + 7) / 8);
+  if (const char* e = getenv("FETA_COEFF_ROLE_FIRST")) if (atoi(e) == 0) ge.role_lead = 0;
+  hipLaunchKernelGGL(kern, dim3(grid + (ge.role_lead > 0 ? ge.role_lead : role)), dim3(kRowThreads), lds, stream, a, ge, cb);
   return check_launch("feta_ffn_bwd");
 }
 
