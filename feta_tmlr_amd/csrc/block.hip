@@ -633,6 +633,10 @@ __global__ __launch_bounds__(kBlk8Threads) void attn_block_fwd8_kernel(BlockArgs
   const bool x_ln = a.x_ln_gamma != nullptr;
   FETA_STAMP(7);
   const int lane0 = lane;
+  // column statistics of y: ONE partial row per workgroup - a workgroup that walks several graphs (B beyond the grid cap)
+  // keeps adding to these registers (the sums are relative to the same shift) and stores once behind the loop; a row per
+  // graph was 1024 rows at config 5, which the host then reduced with an extra launch per layer (fused_stack._cap_partials)
+  float s1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   for (int b = b0; b < a.B; b += gp) {
   // (LDS-only barriers from here on: the tiles of the previous graph have been consumed / xss is LDS data - the requests
   // of the next graph stay in flight across them)
@@ -888,7 +892,6 @@ __global__ __launch_bounds__(kBlk8Threads) void attn_block_fwd8_kernel(BlockArgs
     RowOp<T, D> wf;
     load_row_op<T, D>(wf, Wo + (DH * h + lq) * P, g);
     const int o0 = DH * h + 4 * g;
-    float s1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     float4 ks = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (a.y_shift != nullptr) ks = *reinterpret_cast<const float4*>(a.y_shift + o0);
     const float kv[4] = {ks.x, ks.y, ks.z, ks.w};
@@ -917,8 +920,11 @@ __global__ __launch_bounds__(kBlk8Threads) void attn_block_fwd8_kernel(BlockArgs
         }
       }
     }
-    if (a.y_stats == nullptr) continue;
+  }
+  }  // graphs of this workgroup
+  if (a.y_stats != nullptr) {
     // the two parities of a head hold sums over different rows of the same columns: odd hands over, even adds and stores
+    const int o0 = DH * h + 4 * g;
     if (p == 1 && lq == 0) {
       float* e = sx + (4 * h + g) * 8;
       *reinterpret_cast<float4*>(e) = make_float4(s1[0], s1[1], s1[2], s1[3]);
@@ -928,13 +934,16 @@ __global__ __launch_bounds__(kBlk8Threads) void attn_block_fwd8_kernel(BlockArgs
     if (p == 0 && lq == 0) {
       const float* e = sx + (4 * h + g) * 8;
       const float4 t1 = *reinterpret_cast<const float4*>(e), t2 = *reinterpret_cast<const float4*>(e + 4);
-      float* st = a.y_stats + ((int64_t)b * WGS + w) * 2 * D;
+      float* st = a.y_stats + ((int64_t)b0 * WGS + w) * 2 * D;
       *reinterpret_cast<float4*>(st + o0) = make_float4(s1[0] + t1.x, s1[1] + t1.y, s1[2] + t1.z, s1[3] + t1.w);
       *reinterpret_cast<float4*>(st + D + o0) = make_float4(s2[0] + t2.x, s2[1] + t2.y, s2[2] + t2.z, s2[3] + t2.w);
-      if (b == 0 && w == 0) *reinterpret_cast<float4*>(a.y_stats + (int64_t)a.B * WGS * 2 * D + o0) = ks;   // the shift row
+      if (b0 == 0 && w == 0) {   // the shift row, behind the gp * WGS partial rows
+        float4 ks = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (a.y_shift != nullptr) ks = *reinterpret_cast<const float4*>(a.y_shift + o0);
+        *reinterpret_cast<float4*>(a.y_stats + (int64_t)gp * WGS * 2 * D + o0) = ks;
+      }
     }
   }
-  }  // graphs of this workgroup
   FETA_STAMP(5);
   FETA_RT_LAUNCH_DONE(feta_block_launch);
 }
@@ -1034,7 +1043,11 @@ extern "C" int feta_attn_block_supported(int N, int d_model, int heads) {
 
 extern "C" int feta_attn_block_stat_rows(int B, int N) {
   if (B < 1 || N < 1 || N > 64) return 0;
-  return B * block_fwd_form(B, N).wgs;
+  const BlockFwdForm f = block_fwd_form(B, N);
+  if (f.waves == 4) return B;                    // the four-wave kernel: a row per graph
+  int gp = f.cap / f.wgs;                        // (launch_block_fwd8: graphs in flight)
+  if (gp < 1) gp = 1;
+  return (B < gp ? B : gp) * f.wgs;              // one row per workgroup
 }
 
 extern "C" int feta_attn_block_fwd(const feta_attn_block* d, feta_stream_t stream) {

@@ -438,7 +438,11 @@ def check_attn_block_equals_three_launches(dev, hook, monkeypatch, shape, n_min,
     b = _stack_run(model, batch9, cache, False, monkeypatch, hook)
     KC.assert_close('output', a[0], b[0].double(), tol=2e-6)
     KC.assert_close('coefficients', a[1], b[1].double(), tol=2e-6)
-    assert_close_up_to_relu_flips('dx', a[2], b[2].double(), tol=1e-5)
+    # beyond the grid cap (256 graphs) a workgroup of the one-launch form adds the statistics of the graphs it walks into one
+    # partial row: another summation order than the three-launch sequence's per-block rows - at 300 graphs ONE node row
+    # of dx takes the other branch of a relu (1.4e-5 against the 1e-5 bar, MI355X; everything else at 2e-8).  Two rows are
+    # tolerated there and nowhere else.
+    assert_close_up_to_relu_flips('dx', a[2], b[2].double(), tol=1e-5, max_rows=2 if bsz > 256 else 0)
     assert a[3].keys() == b[3].keys()
     for k in a[3]:
         KC.assert_close('grad ' + k, a[3][k], b[3][k].double(), tol=1e-5)
