@@ -142,7 +142,20 @@ class SpecCat(C.Structure):
     ]
 
 
+class SpecCatGrad(C.Structure):
+    """struct feta_spec_cat_grad (include/feta_hip.h) - field order must match the header."""
+    _fields_ = [
+        ('dout', _F), ('y2', _F), ('y2_sb', C.c_int64), ('y2_sn', C.c_int64), ('y2_bn', _F), ('filt', _F), ('w_cat', _F),
+        ('dxn', _F), ('gs', _F), ('partial', _F), ('partial_ld', C.c_int64),
+    ]
+
+
 SIGNATURES.update({
+    'feta_spec_cat_bwd_supported': ([C.c_int] * 6, C.c_int),
+    'feta_spec_cat_bwd_rows': ([C.c_int], C.c_int),
+    'feta_spec_filter_cat_bwd': ([_F, C.c_int64, C.c_int64, _F, _F, _F, _I, C.c_int64, C.c_int64, _F, _F, _F,
+                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(SpecCatGrad), _S],
+                                 C.c_int),
     'feta_spec_cat_supported': ([C.c_int] * 6, C.c_int),
     'feta_spec_filter_cat_fwd': ([_F, C.c_int64, C.c_int64, _F, _F, _F, _F, _I, _F, C.c_int64, C.c_int64,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(SpecCat), _S], C.c_int),
@@ -244,7 +257,7 @@ SIGNATURES.update({
     'feta_ffn_bwd_coeff': ([C.POINTER(FfnGrad), C.POINTER(CoeffBwdRole), _S], C.c_int),
 })
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class FetaError(RuntimeError):
@@ -514,6 +527,36 @@ class Abi:
         self._check(self.lib.feta_spec_filter_cat_fwd(_p(x), xsb, xsn, _p(u), _p(lam), _p(coeff), _p(bias), _p(n_real), _p(y),
                                                       ysb, ysn, b, n, h, dh, order, k, int(share), C.byref(c), stream),
                     'feta_spec_filter_cat_fwd')
+
+    def spec_cat_bwd_supported(self, n, h, dh, order, k, share):
+        return bool(self.lib.feta_spec_cat_bwd_supported(n, h, dh, order, k, int(share)))
+
+    def spec_cat_bwd_rows(self, b):
+        return int(self.lib.feta_spec_cat_bwd_rows(b))
+
+    def spec_filter_cat_bwd(self, x, u, lam, coeff, n_real, filt, dx, dcoeff, dbias_part, order, share, stream, dout, y2,
+                            w_cat, dxn, partial, y2_bn=None, gs=None):
+        """feta_spec_filter_cat_bwd: the eigenbasis filter's backward with the backward of linear_cat folded in.
+        x / filt / dx: [B, N, H, dh] token views; dout / y2 / dxn: [B, N, H, dh] views of [N, B, 64] row tensors (same
+        strides); partial [B, >= 64 * 128 + 64]; gs [B, 2, 64] with y2_bn."""
+        b, n, h, dh = x.shape
+        k = u.shape[2]
+        xsb, xsn = tok_strides(x)
+        assert tok_strides(dx) == (xsb, xsn)
+        ysb, ysn = tok_strides(filt)
+        c = SpecCatGrad()
+        c.y2_sb, c.y2_sn = tok_strides(y2)
+        assert tok_strides(dout) == (c.y2_sb, c.y2_sn) and tok_strides(dxn) == (c.y2_sb, c.y2_sn)
+        assert partial.shape[0] == self.spec_cat_bwd_rows(b) and partial.stride(1) == 1
+        assert gs is None or gs.shape[0] == partial.shape[0]
+        c.partial_ld = partial.stride(0)
+        for name, t in (('dout', dout), ('y2', y2), ('y2_bn', y2_bn), ('filt', filt), ('w_cat', w_cat), ('dxn', dxn),
+                        ('gs', gs), ('partial', partial)):
+            if t is not None:
+                setattr(c, name, t.data_ptr())
+        self._check(self.lib.feta_spec_filter_cat_bwd(_p(x), xsb, xsn, _p(u), _p(lam), _p(coeff), _p(n_real), ysb, ysn,
+                                                      _p(dx), _p(dcoeff), _p(dbias_part), b, n, h, dh, order, k, int(share),
+                                                      C.byref(c), stream), 'feta_spec_filter_cat_bwd')
 
     def spec_filter_bwd(self, x, u, lam, coeff, n_real, dy, dx, dcoeff, dbias_part, order, share,
                         stream):

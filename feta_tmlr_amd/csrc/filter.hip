@@ -1607,6 +1607,357 @@ int launch_spec_cat_fwd(const FilterArgs& a, const CatArgs& c, hipStream_t strea
   return check_launch("feta_spec_filter_cat_fwd");
 }
 
+// ---- backward of the filter stage with linear_cat folded in (round 4, ABI 11) ------------------------------------------
+// What feta_rowlin_bwd_ex (linear_cat: dx_n, dfilt, dW_cat, db_cat, BatchNorm-backward sums) and feta_spec_filter_bwd did in
+// two launches, per graph in one.  dout = the gradient of linear_cat's output, W_cat = [Wa | Wb]:
+//     dfilt = dout Wb  =>  U^T dfilt = (U^T dout) Wb = Dt Wb           (a [K x 64] x [64 x 64] product, never N rows)
+//     dbias_filter     = (sum_{node < n} dout) Wb
+//     dW_b = sum_node dout^T filt,  dW_a = sum_node dout^T xn,  db_cat = sum_node dout      (per-graph partial row)
+//     dxn  = dout Wa,  gs = (sum dxn, sum dxn xhat)                     (fused_stack.StackTail contract, one row per graph)
+// Wave h owns columns 16 h .. 16 h + 15 of every 64-wide quantity (its head's columns of filt / x, its 16 outputs of Dt).
+// Rows of padded nodes (n_real <= node < N) take part in everything but the eigen-domain terms: filt is zero there, U too.
+constexpr int kCatBwdMaxGrid = 512;   // workgroups of a backward launch = rows of its partial / gs outputs
+inline int spec_cat_bwd_rows(int B) { return B < kCatBwdMaxGrid ? B : kCatBwdMaxGrid; }
+
+struct CatGradArgs {
+  const float* dout;     // [rows][64], row(b, i) = b * y2sb + i * y2sn (the strides of y2: both are [N, B, 64] tensors)
+  const float* y2;       // stack output rows (pre-norm if y2_bn)
+  int64_t y2sb, y2sn;
+  const float* y2_bn;    // published [4][64] block (scale, shift, mean, rstd) or NULL: xn = y2
+  const float* filt;     // the forward's filter output (strides ysb, ysn of the call)
+  const float* w_cat;    // [64][128]
+  float* dxn;            // [rows][64], strides of y2
+  float* gs;             // [B][2][64] or NULL
+  float* partial;        // [B][partial_ld]: dW_cat [64][128] | db_cat [64]
+  int64_t partial_ld;
+};
+
+template <int NT_MAX, int ET_MAX>
+__host__ __device__ inline int spec_cat_bwd_lds_floats() {
+  constexpr int NR = 16 * NT_MAX, UP = 16 * ET_MAX + 4;
+  return 2 * NR * kGraphXP + NR * UP + 16 * ET_MAX + 16 * ET_MAX * (kCatD + 4) + 2 * kCatD;
+}
+
+template <int NT_MAX, int ET_MAX, int PP>
+__global__ __launch_bounds__(256) void spec_cat_bwd_graph_kernel(FilterArgs a, CatGradArgs c) {
+  constexpr int DH = 16, XP = kGraphXP, UP = 16 * ET_MAX + 4, NR = 16 * NT_MAX, D = kCatD, DP = D + 4;
+  const int h = threadIdx.x >> 6, lane0 = threadIdx.x & 63;
+  const int Nm1 = a.N - 1;
+  const int col = DH * h + (lane0 & 15);   // this lane's column of the 64-wide rows
+  float* Xs = feta_lds;               // [NR][XP] x rows (per-head outputs), later dx
+  float* Ds = Xs + NR * XP;           // [NR][XP] dout rows (all N of them), later dxn
+  float* Us = Ds + NR * XP;           // [NR][UP]
+  float* lams = Us + NR * UP;         // [16 ET_MAX]
+  float* DT = lams + 16 * ET_MAX;     // [16 ET_MAX][DP]  Dt = U^T dout
+  float* SR = DT + 16 * ET_MAX * DP;  // [2][64] column sums of dout: real nodes | all N rows
+  // W_cat[o = 16 j + 4 g + s][this lane's column], both halves: the k-slot g of step (j, s) stands for output o
+  float wa[16], wb[16];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+      const float* row = c.w_cat + (int64_t)(16 * j + 4 * (lane0 >> 4) + s_) * 2 * D;
+      wa[4 * j + s_] = row[col];
+      wb[4 * j + s_] = row[D + col];
+    }
+  float bsc = 1.0f, bsh = 0.0f, bmean = 0.0f, brstd = 0.0f;
+  if (c.y2_bn != nullptr) {
+    bsc = c.y2_bn[col];
+    bsh = c.y2_bn[D + col];
+    bmean = c.y2_bn[2 * D + col];
+    brstd = c.y2_bn[3 * D + col];
+  }
+  // what a workgroup leaves per LAUNCH, not per graph: its row of the dW_cat / db_cat partials and of the BatchNorm-backward
+  // sums.  A batch beyond the grid (launch_spec_cat_bwd: 512 workgroups) is walked, and these stay in registers across the
+  // graphs - one row per graph was 1024 rows of 33 KB at config 5 for the reduction launch and for feta_ffn_bwd's prologue
+  f32x4 gaw[4], gbw[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    gaw[t] = zero4();
+    gbw[t] = zero4();
+  }
+  float sall_w = 0.0f, g1 = 0.0f, g2 = 0.0f;
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+  if (b != (int)blockIdx.x) __syncthreads();   // the previous graph's tiles have been written out
+  // (what a lane derives from its id is invariant in the graph loop and would be hoisted and held across the whole body -
+  // 256 + 111 registers; the lane id is laundered once per graph: csrc/block_bwd.hip)
+  int lane_l = lane0;
+  FETA_OPAQUE_LANE(lane_l);
+  const int lane = lane_l, tid = (h << 6) | lane, lq = lane & 15, g = lane >> 4;
+  const int item = b * a.H + h;
+  const int n = a.n_real[b], nm1 = max(n - 1, 0);
+  const float* U = a.u + (int64_t)b * a.N * a.K;
+  const int64_t blk = (int64_t)h * a.B + b;
+  const float* w = a.coeff + blk * PP * DH * DH;
+  float* dw = a.dcoeff + blk * PP * DH * DH;
+  const int64_t rb = (int64_t)b * c.y2sb;
+
+  // ---- requests ------------------------------------------------------------------------------------------------------
+  float4 xv[NT_MAX], dv[NT_MAX];
+#pragma unroll
+  for (int i = 0; i < NT_MAX; ++i) {
+    const int idx = tid + 256 * i, node = idx >> 4, q = idx & 15;
+    const float4 v1 = *reinterpret_cast<const float4*>(tok_row(a.x, a.xsb, a.xsn, b, min(node, nm1), 0, DH) + 4 * q);
+    const float4 v2 = *reinterpret_cast<const float4*>(c.dout + rb + (int64_t)min(node, Nm1) * c.y2sn + 4 * q);
+    xv[i] = keep4(node < n, v1);
+    dv[i] = keep4(node < a.N, v2);
+  }
+  constexpr int UQ = 4 * ET_MAX, UI = (NR * UQ + 255) / 256;
+  float4 uv[UI];
+#pragma unroll
+  for (int i = 0; i < UI; ++i) {
+    const int idx = tid + 256 * i, node = idx / UQ, e = 4 * (idx % UQ);
+    const float4 v = *reinterpret_cast<const float4*>(U + (int64_t)min(node, nm1) * a.K + min(e, a.K - 4));
+    uv[i] = keep4(node < n && e < a.K, v);
+  }
+  float4 wr[PP];  // W_k[c = lq][c' = 4g .. 4g+3]
+#pragma unroll
+  for (int k = 0; k < PP; ++k) wr[k] = *reinterpret_cast<const float4*>(w + (k * DH + lq) * DH + 4 * g);
+  const float lv = a.lam[(int64_t)b * a.K + min(tid, a.K - 1)];
+  // this lane's column of the stack-output and filter-output rows node = 16 nt + 4 g + r (k-slot g of step (nt, r))
+  float xn[NT_MAX][4], fl[NT_MAX][4], xh[NT_MAX][4];
+#pragma unroll
+  for (int nt = 0; nt < NT_MAX; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int node = 16 * nt + 4 * g + r, nc = min(node, Nm1);
+      const float yv = c.y2[rb + (int64_t)nc * c.y2sn + col];
+      const float fv = tok_row(c.filt, a.ysb, a.ysn, b, nc, h, DH)[lq];
+      const bool ok = node < a.N;
+      xn[nt][r] = ok ? yv * bsc + bsh : 0.0f;
+      xh[nt][r] = ok ? (yv - bmean) * brstd : 0.0f;
+      fl[nt][r] = ok ? fv : 0.0f;
+    }
+#pragma unroll
+  for (int i = 0; i < NT_MAX; ++i) {
+    const int idx = tid + 256 * i, off = (idx >> 4) * XP + 4 * (idx & 15);
+    *reinterpret_cast<float4*>(Xs + off) = xv[i];
+    *reinterpret_cast<float4*>(Ds + off) = dv[i];
+  }
+#pragma unroll
+  for (int i = 0; i < UI; ++i) {
+    const int idx = tid + 256 * i;
+    if (idx < NR * UQ) *reinterpret_cast<float4*>(Us + (idx / UQ) * UP + 4 * (idx % UQ)) = uv[i];
+  }
+  if (tid < 16 * ET_MAX) lams[tid] = tid < a.K ? lv : 0.0f;
+  __syncthreads();
+
+  // ---- (1) Xtil = U^T X; Dt[e][o = 16 h + lq] = sum_{node < n} U[node][e] dout[node][o]; column sums of dout ----------
+  f32x4 xt[ET_MAX], dt[ET_MAX];
+#pragma unroll
+  for (int et = 0; et < ET_MAX; ++et) {
+    xt[et] = zero4();
+    dt[et] = zero4();
+  }
+  float sreal = 0.0f, sall = 0.0f;
+#pragma unroll
+  for (int nt = 0; nt < NT_MAX; ++nt) {
+    if (16 * nt < a.N) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nd = 16 * nt + 4 * g + r;
+        const float db = Ds[nd * XP + col];
+        sall += db;
+        if (16 * nt < n) {
+          const float xb = Xs[nd * XP + col];
+          sreal += nd < n ? db : 0.0f;
+#pragma unroll
+          for (int et = 0; et < ET_MAX; ++et) {
+            const float ua = Us[nd * UP + 16 * et + lq];   // (zero for node >= n)
+            xt[et] = mfma16(ua, xb, xt[et]);
+            dt[et] = mfma16(ua, db, dt[et]);
+          }
+        }
+      }
+    }
+  }
+  sreal += shfl_xor(sreal, 16);
+  sreal += shfl_xor(sreal, 32);
+  sall += shfl_xor(sall, 16);
+  sall += shfl_xor(sall, 32);
+  if (g == 0) {
+    SR[col] = sreal;
+    SR[D + col] = sall;
+  }
+#pragma unroll
+  for (int et = 0; et < ET_MAX; ++et)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) DT[(16 * et + 4 * g + r) * DP + col] = dt[et][r];
+  __syncthreads();
+
+  // ---- (1') dYtil = Dt Wb ([e][c'] and its transpose), dbias_filter = (sum_real dout) Wb --------------------------------
+  f32x4 dyt[ET_MAX], dytT[ET_MAX];
+#pragma unroll
+  for (int et = 0; et < ET_MAX; ++et) {
+    dyt[et] = zero4();
+    dytT[et] = zero4();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 d4 = *reinterpret_cast<const float4*>(DT + (16 * et + lq) * DP + 16 * j + 4 * g);   // Dt[e = lq][o]
+      dyt[et] = mfma16(d4.x, wb[4 * j], dyt[et]);           // (row e = 4g + r, column c' = lq)
+      dyt[et] = mfma16(d4.y, wb[4 * j + 1], dyt[et]);
+      dyt[et] = mfma16(d4.z, wb[4 * j + 2], dyt[et]);
+      dyt[et] = mfma16(d4.w, wb[4 * j + 3], dyt[et]);
+      dytT[et] = mfma16(wb[4 * j], d4.x, dytT[et]);         // (row c' = 4g + r, column e = lq)
+      dytT[et] = mfma16(wb[4 * j + 1], d4.y, dytT[et]);
+      dytT[et] = mfma16(wb[4 * j + 2], d4.z, dytT[et]);
+      dytT[et] = mfma16(wb[4 * j + 3], d4.w, dytT[et]);
+    }
+  }
+  {
+    float dbs = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 s4 = *reinterpret_cast<const float4*>(SR + 16 * j + 4 * g);
+      dbs += (s4.x * wb[4 * j] + s4.y * wb[4 * j + 1]) + (s4.z * wb[4 * j + 2] + s4.w * wb[4 * j + 3]);
+    }
+    dbs += shfl_xor(dbs, 16);
+    dbs += shfl_xor(dbs, 32);
+    if (g == 0) a.dbias_part[(int64_t)item * DH + lq] = dbs;
+  }
+
+  // ---- (2) dW_k[c][c'] = sum_e t_k(lam_e) Xtil[e][c] dYtil[e][c'] --------------------------------
+  f32x4 dwa[PP];
+#pragma unroll
+  for (int k = 0; k < PP; ++k) dwa[k] = zero4();
+#pragma unroll
+  for (int et = 0; et < ET_MAX; ++et) {
+    const float4 l4 = *reinterpret_cast<const float4*>(lams + 16 * et + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float tk[kMaxOrder];
+      cheb_poly(f4(l4, r), PP, tk);
+#pragma unroll
+      for (int k = 0; k < PP; ++k) dwa[k] = mfma16(xt[et][r] * tk[k], dyt[et][r], dwa[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < PP; ++k)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dw[(k * DH + 4 * g + r) * DH + lq] = dwa[k][r];
+
+  // ---- (3) dXtil[e][c] = sum_k t_k(lam_e) sum_c' dYtil[e][c'] W_k[c][c'] -------------------------
+  f32x4 dxt[ET_MAX];
+#pragma unroll
+  for (int et = 0; et < ET_MAX; ++et) {
+    float tk[kMaxOrder];
+    cheb_poly(lams[16 * et + lq], PP, tk);
+    dxt[et] = zero4();
+#pragma unroll
+    for (int k = 0; k < PP; ++k) {
+      dxt[et] = mfma16(dytT[et][0] * tk[k], wr[k].x, dxt[et]);
+      dxt[et] = mfma16(dytT[et][1] * tk[k], wr[k].y, dxt[et]);
+      dxt[et] = mfma16(dytT[et][2] * tk[k], wr[k].z, dxt[et]);
+      dxt[et] = mfma16(dytT[et][3] * tk[k], wr[k].w, dxt[et]);
+    }
+  }
+
+  // ---- (4) dX = U dXtil (rows >= n_real come out zero) -------------------------------------------
+  f32x4 dx[NT_MAX];
+#pragma unroll
+  for (int nt = 0; nt < NT_MAX; ++nt) {
+    dx[nt] = zero4();
+    if (16 * nt < n) {
+#pragma unroll
+      for (int et = 0; et < ET_MAX; ++et) {
+        const float4 ub = *reinterpret_cast<const float4*>(Us + (16 * nt + lq) * UP + 16 * et + 4 * g);
+        dx[nt] = mfma16(ub.x, dxt[et][0], dx[nt]);
+        dx[nt] = mfma16(ub.y, dxt[et][1], dx[nt]);
+        dx[nt] = mfma16(ub.z, dxt[et][2], dx[nt]);
+        dx[nt] = mfma16(ub.w, dxt[et][3], dx[nt]);
+      }
+    }
+  }
+
+  // ---- (5) linear_cat: dW_a / dW_b tiles (rows o = 16 t + 4g + r, this lane's column), dxn = dout Wa ----------------------
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+#pragma unroll
+    for (int nt = 0; nt < NT_MAX; ++nt) {
+      if (16 * nt < a.N) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float da = Ds[(16 * nt + 4 * g + r) * XP + 16 * t + lq];   // dout[node][o = 16 t + lq]
+          gaw[t] = mfma16(da, xn[nt][r], gaw[t]);
+          gbw[t] = mfma16(da, fl[nt][r], gbw[t]);
+        }
+      }
+    }
+  }
+  sall_w += sall;
+  f32x4 dn[NT_MAX];
+#pragma unroll
+  for (int nt = 0; nt < NT_MAX; ++nt) {
+    dn[nt] = zero4();
+    if (16 * nt < a.N) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 d4 = *reinterpret_cast<const float4*>(Ds + (16 * nt + lq) * XP + 16 * j + 4 * g);   // dout[node = lq][o]
+        dn[nt] = mfma16(d4.x, wa[4 * j], dn[nt]);           // (row node = 4g + r, this lane's column)
+        dn[nt] = mfma16(d4.y, wa[4 * j + 1], dn[nt]);
+        dn[nt] = mfma16(d4.z, wa[4 * j + 2], dn[nt]);
+        dn[nt] = mfma16(d4.w, wa[4 * j + 3], dn[nt]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = 16 * nt + 4 * g + r < a.N ? dn[nt][r] : 0.0f;
+        g1 += v;
+        g2 += v * xh[nt][r];
+      }
+    }
+  }
+  __syncthreads();  // every wave has read its X / dout operands
+#pragma unroll
+  for (int nt = 0; nt < NT_MAX; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      Xs[(16 * nt + 4 * g + r) * XP + col] = dx[nt][r];
+      Ds[(16 * nt + 4 * g + r) * XP + col] = dn[nt][r];
+    }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NT_MAX; ++i) {
+    const int idx = tid + 256 * i, node = idx >> 4, q = idx & 15;
+    if (node < a.N) {
+      *reinterpret_cast<float4*>(tok_row(a.dx, a.xsb, a.xsn, b, node, 0, DH) + 4 * q) =
+          *reinterpret_cast<const float4*>(Xs + node * XP + 4 * q);
+      *reinterpret_cast<float4*>(c.dxn + rb + (int64_t)node * c.y2sn + 4 * q) =
+          *reinterpret_cast<const float4*>(Ds + node * XP + 4 * q);
+    }
+  }
+  }  // graphs of this workgroup
+  const int g = lane0 >> 4;
+  float* prow = c.partial + (int64_t)blockIdx.x * c.partial_ld;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      prow[(int64_t)(16 * t + 4 * g + r) * 2 * D + col] = gaw[t][r];
+      prow[(int64_t)(16 * t + 4 * g + r) * 2 * D + D + col] = gbw[t][r];
+    }
+  if (g == 0) prow[(int64_t)D * 2 * D + col] = sall_w;   // db_cat
+  if (c.gs != nullptr) {
+    g1 += shfl_xor(g1, 16);
+    g1 += shfl_xor(g1, 32);
+    g2 += shfl_xor(g2, 16);
+    g2 += shfl_xor(g2, 32);
+    if (g == 0) {
+      c.gs[(int64_t)blockIdx.x * 2 * D + col] = g1;
+      c.gs[(int64_t)blockIdx.x * 2 * D + D + col] = g2;
+    }
+  }
+}
+
+template <int NT_MAX, int ET_MAX>
+int launch_spec_cat_bwd(const FilterArgs& a, const CatGradArgs& c, hipStream_t stream) {
+  const size_t lds = sizeof(float) * spec_cat_bwd_lds_floats<NT_MAX, ET_MAX>();
+  auto kern = spec_cat_bwd_graph_kernel<NT_MAX, ET_MAX, 4>;
+  static LdsSeen lds_seen;
+  allow_dynamic_lds(kern, lds, lds_seen);
+  hipLaunchKernelGGL(kern, dim3(spec_cat_bwd_rows(a.B)), dim3(256), lds, stream, a, c);
+  return check_launch("feta_spec_filter_cat_bwd");
+}
+
 template <int NT_MAX, int ET_MAX, int PP>
 int launch_spec_graph_p(const FilterArgs& a, bool bwd, hipStream_t stream) {
   constexpr int NR = 16 * NT_MAX, UP = 16 * ET_MAX + 4;
@@ -1802,6 +2153,42 @@ extern "C" int feta_spec_filter_bwd(const float* x, int64_t x_sb, int64_t x_sn, 
 extern "C" int feta_spec_cat_supported(int N, int H, int dh, int P, int K, int heads_share_graph) {
   const int nt = (N + 15) / 16, et = (K + 15) / 16;
   return (heads_share_graph && H == 4 && dh == 16 && P == 4 && nt >= 1 && nt <= 8 && et <= 2 && (K & 3) == 0 && K >= 4) ? 1 : 0;
+}
+
+extern "C" int feta_spec_cat_bwd_supported(int N, int H, int dh, int P, int K, int heads_share_graph) {
+  const int nt = (N + 15) / 16, et = (K + 15) / 16;
+  return (heads_share_graph && H == 4 && dh == 16 && P == 4 && nt >= 1 && nt <= 4 && et <= 2 && (K & 3) == 0 && K >= 4) ? 1 : 0;
+}
+
+extern "C" int feta_spec_cat_bwd_rows(int B) { return B < 1 ? 0 : spec_cat_bwd_rows(B); }
+
+extern "C" int feta_spec_filter_cat_bwd(const float* x, int64_t x_sb, int64_t x_sn, const float* u, const float* lam,
+                                        const float* coeff, const int32_t* n_real, int64_t y_sb, int64_t y_sn, float* dx,
+                                        float* dcoeff, float* dbias_part, int B, int N, int H, int dh, int P, int K,
+                                        int heads_share_graph, const feta_spec_cat_grad* cat, feta_stream_t stream) {
+  FilterArgs a{};
+  a.x = x; a.u = u; a.lam = lam; a.coeff = coeff; a.n_real = n_real; a.dx = dx; a.dcoeff = dcoeff; a.dbias_part = dbias_part;
+  a.xsb = x_sb; a.xsn = x_sn; a.ysb = y_sb; a.ysn = y_sn;
+  a.B = B; a.N = N; a.H = H; a.P = P; a.K = K; a.share = heads_share_graph; a.total = B * H;
+  FETA_REQUIRE(x && u && lam && coeff && n_real && dx && dcoeff && dbias_part && cat, "spec_filter_cat_bwd: null pointer");
+  FETA_REQUIRE(feta_spec_cat_bwd_supported(N, H, dh, P, K, heads_share_graph),
+               "spec_filter_cat_bwd: needs 4 heads x 16, order 4, N <= 64, K <= 32 (multiple of 4), every head on the graph");
+  int rc = check_filter(a, dh, x, dx);
+  if (rc != FETA_OK) return rc;
+  FETA_REQUIRE(cat->dout && cat->y2 && cat->filt && cat->w_cat && cat->dxn && cat->partial,
+               "spec_filter_cat_bwd: dout, y2, filt, w_cat, dxn, partial");
+  FETA_REQUIRE(cat->partial_ld >= 64 * 128 + 64, "spec_filter_cat_bwd: partial_ld %lld < 64 * 128 + 64", (long long)cat->partial_ld);
+  FETA_REQUIRE(!cat->gs || cat->y2_bn, "spec_filter_cat_bwd: gs (BatchNorm-backward sums) needs the published block y2_bn");
+  FETA_REQUIRE(aligned16(u) && aligned16(cat->dout) && aligned16(cat->dxn) && aligned16(cat->filt) && (cat->y2_sb % 4) == 0 &&
+                   (cat->y2_sn % 4) == 0 && (y_sb % 4) == 0 && (y_sn % 4) == 0,
+               "spec_filter_cat_bwd: 16-byte aligned tensors, strides multiples of 4 elements");
+  CatGradArgs c{};
+  c.dout = cat->dout; c.y2 = cat->y2; c.y2sb = cat->y2_sb; c.y2sn = cat->y2_sn; c.y2_bn = cat->y2_bn; c.filt = cat->filt;
+  c.w_cat = cat->w_cat; c.dxn = cat->dxn; c.gs = cat->gs; c.partial = cat->partial; c.partial_ld = cat->partial_ld;
+  const int nt = (N + 15) / 16, et = (K + 15) / 16;
+  hipStream_t st = (hipStream_t)stream;
+  if (nt <= 3) return et <= 1 ? launch_spec_cat_bwd<3, 1>(a, c, st) : launch_spec_cat_bwd<3, 2>(a, c, st);
+  return et <= 1 ? launch_spec_cat_bwd<4, 1>(a, c, st) : launch_spec_cat_bwd<4, 2>(a, c, st);
 }
 
 extern "C" int feta_spec_filter_cat_fwd(const float* x, int64_t x_sb, int64_t x_sn, const float* u, const float* lam,

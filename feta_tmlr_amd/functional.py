@@ -367,11 +367,39 @@ class CatFold:
     in what linear_cat would read - the stack output `y2` ([N, B, d]; with `tail`: the pre-norm rows whose last BatchNorm the
     consumer finalizes, fused_stack.StackTail), `w`, `bias` - and hands the object to filter_from_pooled; if the filter's
     forward takes the fused kernel it leaves linear_cat's output in `out`, and row_linear_cat[_bn] then launches nothing
-    in forward (its backward is unchanged: it has everything it saves).  0: FETA_CAT_FOLD=0 (A/B timing)."""
+    in forward.  0: FETA_CAT_FOLD=0 (A/B timing).
+    Backward (feta_spec_filter_cat_bwd, ABI 11; FETA_CAT_FOLD_BWD=0: off): linear_cat's autograd node runs first - it
+    launches nothing either, allocates its outputs (dxn, the BatchNorm-backward sums of the StackTail contract, one partial row
+    per graph for dW_cat) and leaves them with dout in `bwd`; the filter's node, which autograd runs next (its incoming
+    gradient is linear_cat's dx2, a placeholder nobody reads), fills them in its one launch.  Only when the partial rows
+    have a reduction launch to ride in (PendingSums armed) - else linear_cat's own backward kernel runs as before."""
 
     def __init__(self, y2, w, bias, tail=None):
-        self.y2, self.w, self.bias, self.tail = y2, w, bias, tail
+        self.y2, self.w, self.bias, self.tail = y2.detach(), w, bias, tail
         self.out = None
+        self.y = None          # the filter's output (token view), saved by the fused forward for the fused backward
+        self.bwd_ok = False    # the backward fold is possible for this shape
+        self.bwd = None        # linear_cat's backward -> the filter's backward: dict(dout, dxn, partial, gs, prm)
+
+    def defer_backward(self, dy, y2, x2, w, prm, pending, owners_of, has_bias):
+        """Called by linear_cat's backward: -> (dx1, dx2, dW view, db view, gs) with nothing launched, or None if the
+        backward fold does not apply."""
+        if not (self.bwd_ok and USE_CAT_FOLD_BWD and pending is not None and self.bwd is None and self.y is not None):
+            return None
+        m, k1 = y2.shape
+        ki, no = k1 + x2.shape[1], w.shape[0]
+        nb = _lib.backend(y2)[0].spec_cat_bwd_rows(self.y.shape[0])       # one row per graph, or per workgroup of a walked batch
+        dx1, dx2 = torch.empty_like(y2), torch.empty_like(x2)    # dx2: a placeholder (the filter's node ignores it)
+        partial = torch.empty((nb, no * ki + no), dtype=torch.float32, device=y2.device)
+        dwdb = torch.empty(no * ki + no, dtype=torch.float32, device=y2.device)
+        gs = torch.empty((nb, 2, k1), dtype=torch.float32, device=y2.device) if prm is not None else None
+        self.bwd = dict(dout=dy, dxn=dx1, partial=partial, gs=gs, prm=prm)
+        pending.add(partial, dwdb, owners=[(owners_of[0], dwdb[:no * ki].view(no, ki)),
+                                           (owners_of[1], dwdb[no * ki:] if has_bias else None)])
+        return dx1, dx2, dwdb[:no * ki].view(no, ki), (dwdb[no * ki:] if has_bias else None), gs
+
+
+USE_CAT_FOLD_BWD = _os.environ.get('FETA_CAT_FOLD_BWD', '1') != '0'
 
 
 class FilterFromPooledFn(torch.autograd.Function):
@@ -434,12 +462,15 @@ class FilterFromPooledFn(torch.autograd.Function):
             abi.spec_filter_cat_fwd(xs, g0, g1, cw, bias, n_real, y, order, share, stream, y2=y2v, w_cat=cat.w.detach().contiguous(),
                                     b_cat=None if cat.bias is None else cat.bias.detach(), out=out, **kw)
             cat.out = out.permute(1, 0, 2, 3).reshape(n * b, h * dh)      # (a view: [N, B, d] rows)
+            cat.y = y.detach()      # (another tensor object: the returned y gets this node as grad_fn - kept in ctx.cat it would be a cycle)
+            cat.bwd_ok = bool(abi.spec_cat_bwd_supported(n, h, dh, order, g0.shape[2], share))
         elif mode == 'cheb':
             abi.cheb_filter_fwd(xs, g0, cw, bias, n_real, y, order, share, stream)
         else:
             abi.spec_filter_fwd(xs, g0, g1, cw, bias, n_real, y, order, share, stream)
         ctx.save_for_backward(xs, cw, pooled, lin_w, n_real, g0, g1)
         ctx.cfg = (mode, order, share, batch_first, bias is not None)
+        ctx.cat = cat if fold else None
         ctx.set_materialize_grads(False)
         return y, coeff
 
@@ -456,11 +487,24 @@ class FilterFromPooledFn(torch.autograd.Function):
             dcoeff = dcoeff_ext.contiguous()
             db_lin = torch.empty(dcoeff.shape[1], dtype=torch.float32, device=xs.device)
         else:
-            dys = _dense_like(dy.to(xs.dtype), batch_first)
+            st = None
+            if ctx.cat is not None and ctx.cat.bwd is not None:
+                st, ctx.cat.bwd = ctx.cat.bwd, None
             dx = _new_token(b, n, h, dh, batch_first, xs)
             dcoeff = torch.empty_like(coeff)
             dbp = torch.empty((b * h, dh), dtype=torch.float32, device=xs.device)
-            if mode == 'cheb':
+            if st is not None:
+                # linear_cat's backward rides in this launch (CatFold): dy is its placeholder - the kernel starts from dout
+                cat = ctx.cat
+                tv = lambda t: t.view(n, b, h, dh).permute(1, 0, 2, 3)
+                abi.spec_filter_cat_bwd(xs, g0, g1, coeff, n_real, cat.y, dx, dcoeff, dbp, order, share, stream,
+                                        dout=tv(st['dout']), y2=tv(cat.y2.detach()), w_cat=cat.w.detach().contiguous(),
+                                        dxn=tv(st['dxn']), partial=st['partial'], y2_bn=st['prm'], gs=st['gs'])
+            else:
+                dys = _dense_like(dy.to(xs.dtype), batch_first)
+            if st is not None:
+                pass
+            elif mode == 'cheb':
                 abi.cheb_filter_bwd(xs, g0, coeff, n_real, dys, dx, dcoeff, dbp, order, share, stream)
             else:
                 abi.spec_filter_bwd(xs, g0, g1, coeff, n_real, dys, dx, dcoeff, dbp, order, share, stream)
@@ -567,9 +611,10 @@ class RowLinearCatFn(torch.autograd.Function):
     transformer/models.py:223-224); backward writes dx1 and dx2 directly."""
 
     @staticmethod
-    def forward(ctx, x1, x2, w, bias, pending=None, done=None):
+    def forward(ctx, x1, x2, w, bias, pending=None, done=None, fold=None):
         abi, stream = _lib.backend(x1, x2, w)
         ctx.defer = pending if (pending is not None and pending.armed and x2.requires_grad) else None
+        ctx.fold = fold if done is not None else None
         ctx.params = (w, bias)
         x1, x2, w = x1.contiguous(), x2.contiguous(), w.contiguous()
         m, k1 = x1.shape
@@ -593,6 +638,10 @@ class RowLinearCatFn(torch.autograd.Function):
         dy = dy.contiguous()
         if ctx.defer is not None and not PendingSums.untouched(*ctx.params):
             ctx.defer = None
+        if ctx.fold is not None and ctx.defer is not None:
+            r = ctx.fold.defer_backward(dy, x1, x2, w, None, ctx.defer, ctx.params, ctx.has_bias)
+            if r is not None:
+                return r[0], r[1], r[2], r[3], None, None, None
         dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
         partial = torch.empty((abi.rowlin_chunks(m), no * ki + no), dtype=torch.float32, device=x1.device)
         dwdb = torch.empty(no * ki + no, dtype=torch.float32, device=x1.device)
@@ -604,7 +653,7 @@ class RowLinearCatFn(torch.autograd.Function):
                                                  (ctx.params[1], dwdb[no * ki:] if ctx.has_bias else None)])
         else:
             abi.rowlin_bwd_ex(d, dwdb, stream)
-        return dx1, dx2, dwdb[:no * ki].view(no, ki), (dwdb[no * ki:] if ctx.has_bias else None), None, None
+        return dx1, dx2, dwdb[:no * ki].view(no, ki), (dwdb[no * ki:] if ctx.has_bias else None), None, None, None
 
 
 class RowLinearCatBNFn(torch.autograd.Function):
@@ -614,9 +663,10 @@ class RowLinearCatBNFn(torch.autograd.Function):
     backward partial sums in tail.gs (fused_stack.StackTail contract)."""
 
     @staticmethod
-    def forward(ctx, y2, x2, w, bias, tail, pending=None, done=None):
+    def forward(ctx, y2, x2, w, bias, tail, pending=None, done=None, fold=None):
         abi, stream = _lib.backend(y2, x2, w)
         ctx.defer = pending if (pending is not None and pending.armed and x2.requires_grad) else None
+        ctx.fold = fold if done is not None else None
         ctx.params = (w, bias)
         y2, x2, w = y2.contiguous(), x2.contiguous(), w.contiguous()
         m, k1 = y2.shape
@@ -645,6 +695,11 @@ class RowLinearCatBNFn(torch.autograd.Function):
         dy = dy.contiguous()
         if ctx.defer is not None and not PendingSums.untouched(*ctx.params):
             ctx.defer = None
+        if ctx.fold is not None and ctx.defer is not None:
+            r = ctx.fold.defer_backward(dy, y2, x2, w, prm2, ctx.defer, ctx.params, ctx.has_bias)
+            if r is not None:
+                ctx.tail.gs = r[4]      # (one row per graph, filled by the filter's launch: the stack's node runs behind it)
+                return r[0], r[1], r[2], r[3], None, None, None, None
         dx1, dx2 = torch.empty_like(y2), torch.empty_like(x2)
         partial = torch.empty((abi.rowlin_chunks(m), no * ki + no), dtype=torch.float32, device=y2.device)
         dwdb = torch.empty(no * ki + no, dtype=torch.float32, device=y2.device)
@@ -658,11 +713,11 @@ class RowLinearCatBNFn(torch.autograd.Function):
         else:
             abi.rowlin_bwd_ex(d, dwdb, stream)
         ctx.tail.gs = gs
-        return dx1, dx2, dwdb[:no * ki].view(no, ki), (dwdb[no * ki:] if ctx.has_bias else None), None, None, None
+        return dx1, dx2, dwdb[:no * ki].view(no, ki), (dwdb[no * ki:] if ctx.has_bias else None), None, None, None, None
 
 
-def row_linear_cat_bn(y2, x2, w, bias, tail, pending=None, done=None):
-    return RowLinearCatBNFn.apply(y2, x2, w, bias, tail, pending, done)
+def row_linear_cat_bn(y2, x2, w, bias, tail, pending=None, done=None, fold=None):
+    return RowLinearCatBNFn.apply(y2, x2, w, bias, tail, pending, done, fold)
 
 
 class BatchNormTrainFn(torch.autograd.Function):
@@ -711,9 +766,9 @@ def row_linear(x, w, bias=None, rowscale=None, residual=None, relu=False, want_s
     return RowLinearFn.apply(x, w, bias, rowscale, residual, relu, want_stats, stats_shift)
 
 
-def row_linear_cat(x1, x2, w, bias=None, pending=None, done=None):
+def row_linear_cat(x1, x2, w, bias=None, pending=None, done=None, fold=None):
     """[x1 | x2] W^T + b on [M, .] rows; needs x1.shape[1] % 16 == 0 and supported total dims."""
-    return RowLinearCatFn.apply(x1, x2, w, bias, pending, done)
+    return RowLinearCatFn.apply(x1, x2, w, bias, pending, done, fold)
 
 
 def batch_norm_train(y, stats, gamma, beta, running_mean, running_var, momentum, eps, num_batches_tracked=None):

@@ -406,7 +406,8 @@ class FusedEncoderStackFn(torch.autograd.Function):
         dcur, dcur_b = d_final.contiguous().view(m, d), None
         if ctx.tail is not None:
             # (StackTail contract) d_final is the gradient w.r.t. BN2(y2); its partial sums came with it
-            gs, Gs_cur = ctx.tail.gs, G
+            gs = ctx.tail.gs
+            Gs_cur = G if gs is None else gs.shape[0]     # (row blocks of linear_cat's backward, or one row per graph: CatFold)
             ctx.tail.gs = None
             if gs is None:
                 raise RuntimeError('fused stack: the consumer of the un-normalised output did not leave the '

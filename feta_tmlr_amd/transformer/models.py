@@ -312,11 +312,11 @@ class DiffTransformerEncoderGenGCN(nn.Module):
                                   self.linear_cat.bias.to(dt)).float()
             elif tail is not None:
                 output = FF.row_linear_cat_bn(output.reshape(nn_ * bb_, dd_), allout_filtered.reshape(nn_ * bb_, dd_),
-                                              wc, self.linear_cat.bias, tail, pending, done=done).view(nn_, bb_, -1)
+                                              wc, self.linear_cat.bias, tail, pending, done=done, fold=cat).view(nn_, bb_, -1)
             elif (dd_ % 16 == 0 and FF.row_linear_supported(2 * dd_, wc.shape[0])):
                 # [output | allout_filtered] W^T + b without materialising the concatenation (:223-224)
                 output = FF.row_linear_cat(output.reshape(nn_ * bb_, dd_), allout_filtered.reshape(nn_ * bb_, dd_),
-                                           wc, self.linear_cat.bias, pending, done=done).view(nn_, bb_, -1)
+                                           wc, self.linear_cat.bias, pending, done=done, fold=cat).view(nn_, bb_, -1)
             else:
                 cat = torch.cat((output, allout_filtered), dim=-1)               # :223
                 output, _ = linear_rows(cat.reshape(nn_ * bb_, 2 * dd_), wc, self.linear_cat.bias)   # :224

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FETA_ABI_VERSION 10
+#define FETA_ABI_VERSION 11
 
 #define FETA_OK 0
 #define FETA_E_ARG (-1)     /* bad shape / stride / alignment / unsupported size */
@@ -235,6 +235,34 @@ int feta_spec_filter_cat_fwd(const float* x, int64_t x_sb, int64_t x_sn, const f
                              const float* coeff, const float* bias, const int32_t* n_real, float* y,
                              int64_t y_sb, int64_t y_sn, int B, int N, int H, int dh, int P, int K,
                              int heads_share_graph, const feta_spec_cat* cat, feta_stream_t stream);
+
+/* Backward of the same fold (ABI 11): feta_spec_filter_bwd with the backward of linear_cat inside - replaces
+ * feta_rowlin_bwd_ex over [x_n | filt] (functional.RowLinearCat[BN]Fn.backward, transformer/models.py:223-224 under
+ * autograd) + feta_spec_filter_bwd.  dout [N*B rows][64] = gradient w.r.t. linear_cat's output, rows addressed with the
+ * strides of y2; filt = the forward's y (strides y_sb, y_sn); y2_bn = the block the forward published (or NULL: x_n = y2).
+ * Outputs: dx / dcoeff / dbias_part as feta_spec_filter_bwd; dxn [rows][64] = dout W_a (gradient w.r.t. the NORMALISED
+ * stack output); gs [R][2][64] = per-workgroup (sum dxn, sum dxn * xhat) for the BatchNorm backward of the stack's last norm
+ * (NULL without y2_bn); partial [R][partial_ld] = [dW_cat 64 x 128 | db_cat 64] per workgroup, reduced by the caller's
+ * feta_colsum_multi.  R = feta_spec_cat_bwd_rows(B) rows in gs and partial: one per graph up to 512 graphs, beyond that a
+ * workgroup walks graphs blockIdx, blockIdx + 512, ... and leaves their sum.  P = 4, 4 heads x 16, N <= 64, K <= 32, fp32, every head on the graph (feta_spec_cat_bwd_supported). */
+typedef struct feta_spec_cat_grad {
+  const float* dout;
+  const float* y2;
+  int64_t y2_sb, y2_sn;
+  const float* y2_bn;
+  const float* filt;
+  const float* w_cat;
+  float* dxn;
+  float* gs;
+  float* partial;
+  int64_t partial_ld;
+} feta_spec_cat_grad;
+int feta_spec_cat_bwd_supported(int N, int H, int dh, int P, int K, int heads_share_graph);
+int feta_spec_cat_bwd_rows(int B);
+int feta_spec_filter_cat_bwd(const float* x, int64_t x_sb, int64_t x_sn, const float* u, const float* lam,
+                             const float* coeff, const int32_t* n_real, int64_t y_sb, int64_t y_sn, float* dx,
+                             float* dcoeff, float* dbias_part, int B, int N, int H, int dh, int P, int K,
+                             int heads_share_graph, const feta_spec_cat_grad* cat, feta_stream_t stream);
 
 /* ---- bf16 STORAGE variants of A1 and A3 (BASELINE configs 3 and 5) ----------------------------------
  * Same operators, same argument meaning as feta_attn_fwd/bwd and feta_spec_filter_fwd/bwd; `void*`

@@ -1346,3 +1346,83 @@ def check_spec_cat(abi, dev, stream, bsz=5, shape='zinc', n_min=None, n_max=None
         assert_close('spec_cat running var', kw['rvar'], 0.9 + 0.1 * unb)
         assert int(kw['nbt']) == 1
     return errs
+
+
+def check_spec_cat_bwd(abi, dev, stream, bsz=5, shape='zinc', n_min=None, n_max=None, k_eig=16, seed=0, norm='bn_block'):
+    """feta_spec_filter_cat_bwd against fp64 autograd of the oracle's formulas: loss = <dout, linear_cat([xn | filt])> with
+    filt = the truncated-K eigenbasis filter (oracle.spec_filter_eig per block) and xn = the stack output seen through a
+    published BatchNorm block (norm 'bn_block') or as it is ('plain').  Checked: dx, dcoeff, the filter's bias gradient
+    (sum of dbias_part), dxn (gradient w.r.t. the NORMALISED stack output), the per-graph partial rows summed = dW_cat /
+    db_cat, and gs = per-graph (sum dxn, sum dxn * xhat)."""
+    import torch.nn.functional as F
+    h, dh, order = 4, 16, 4
+    d = h * dh
+    x, coeff, bias, _, mask, _, _, _, cache, n = _filter_case(bsz, h, dh, order, seed, shape, n_min, n_max, k_eig)
+    g = torch.Generator().manual_seed(seed + 11)
+    m = n * bsz
+    y2 = torch.randn(n, bsz, d, generator=g, dtype=torch.float64) * 1.5 + 0.3
+    dout = torch.randn(n, bsz, d, generator=g, dtype=torch.float64)
+    w_cat = (torch.randn(d, 2 * d, generator=g, dtype=torch.float64) / 8).float().double().requires_grad_(True)
+    b_cat = (torch.randn(d, generator=g, dtype=torch.float64) * 0.1).float().double().requires_grad_(True)
+    u, lam = cache.u.double(), cache.lam.double()
+    nb = cache.n_real.tolist()
+    xr = x.clone().requires_grad_(True)
+    cr = coeff.clone().requires_grad_(True)
+    br = bias.clone().requires_grad_(True)
+    blocks = [[None] * bsz for _ in range(h)]
+    filt = torch.zeros(n, bsz, d, dtype=torch.float64)
+    cols = []
+    for hh in range(h):
+        col = []
+        for bb in range(bsz):
+            k = nb[bb]
+            yb = O.spec_filter_eig(xr[bb, :k, hh], u[bb, :k], lam[bb], cr[hh, bb].reshape(order, dh, dh), br)
+            col.append(torch.cat([yb, torch.zeros(n - k, dh, dtype=torch.float64)], 0))     # [n, dh]
+        cols.append(torch.stack(col, 1))       # [n, bsz, dh]
+    filt = torch.cat(cols, -1)                 # [n, bsz, d]
+    f32 = lambda t: t.detach().float().contiguous().to(dev)
+    prm = None
+    if norm == 'plain':
+        xn = y2.clone().requires_grad_(True)
+        xhat = torch.zeros_like(y2)
+    else:
+        gamma = (torch.rand(d, generator=g, dtype=torch.float64) + 0.5).float().double()
+        beta = (torch.randn(d, generator=g, dtype=torch.float64) * 0.2).float().double()
+        rows = y2.reshape(m, d)
+        mean, var = rows.mean(0), rows.var(0, unbiased=False)
+        rstd = (var + 1e-5).rsqrt()
+        prm = torch.stack([gamma * rstd, beta - mean * gamma * rstd, mean, rstd]).float().double()   # what the kernel reads
+        xhat = (y2 - prm[2]) * prm[3]
+        xn = (y2 * prm[0] + prm[1]).detach().requires_grad_(True)
+    out = F.linear(torch.cat((xn, filt), dim=-1), w_cat, b_cat)
+    (out * dout).sum().backward()
+    gs_ref = torch.stack([xn.grad.sum(0), (xn.grad * xhat).sum(0)], 1)     # [bsz, 2, d]
+
+    xv = to_view(x, True, dev)
+    fv = to_view(filt.detach().view(n, bsz, h, dh).permute(1, 0, 2, 3), True, dev)
+    y2v = to_view(y2.view(n, bsz, h, dh).permute(1, 0, 2, 3), True, dev)
+    dov = to_view(dout.view(n, bsz, h, dh).permute(1, 0, 2, 3), True, dev)
+    dxv = token_buffers(bsz, n, h, dh, True, dev)
+    dxnv = token_buffers(bsz, n, h, dh, True, dev)
+    dcoeff = torch.full((h * bsz, order * dh * dh), float('nan'), device=dev)
+    dbp = torch.full((bsz * h, dh), float('nan'), device=dev)
+    ld = d * 2 * d + d + 8      # (a pitch beyond the row: the kernel must respect partial_ld)
+    rows = abi.spec_cat_bwd_rows(bsz)
+    partial = torch.full((rows, ld), float('nan'), device=dev)
+    gs = torch.full((rows, 2, d), float('nan'), device=dev) if prm is not None else None
+    abi.spec_filter_cat_bwd(xv, f32(u), f32(lam), f32(coeff.reshape(h * bsz, -1)), cache.n_real.to(dev), fv, dxv, dcoeff, dbp,
+                            order, 1, stream, dout=dov, y2=y2v, w_cat=f32(w_cat), dxn=dxnv, partial=partial,
+                            y2_bn=None if prm is None else f32(prm), gs=gs)
+    errs = {'dx': assert_close('spec_cat_bwd dx', dxv, xr.grad),
+            'dcoeff': assert_close('spec_cat_bwd dcoeff', dcoeff, cr.grad.reshape(h * bsz, -1)),
+            'dbias': assert_close('spec_cat_bwd dbias', dbp.sum(0), br.grad),
+            'dxn': assert_close('spec_cat_bwd dxn', dxnv.permute(1, 0, 2, 3).reshape(n, bsz, d), xn.grad),
+            'dW_cat': assert_close('spec_cat_bwd dW_cat', partial[:, :d * 2 * d].sum(0).view(d, 2 * d), w_cat.grad),
+            'db_cat': assert_close('spec_cat_bwd db_cat', partial[:, d * 2 * d:d * 2 * d + d].sum(0), b_cat.grad)}
+    assert bool(torch.isnan(partial[:, d * 2 * d + d:]).all()), 'spec_cat_bwd wrote beyond its partial row'
+    if gs is not None:
+        if rows == bsz:
+            errs['gs'] = assert_close('spec_cat_bwd gs', gs, gs_ref)
+        else:     # a walked batch: workgroup i holds the sum over graphs i, i + rows, ...
+            errs['gs'] = assert_close('spec_cat_bwd gs', gs.sum(0), gs_ref.sum(0))
+    return errs

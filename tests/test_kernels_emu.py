@@ -350,3 +350,10 @@ def test_attn_block_bwd_layernorm_walks_several_graphs(emu, monkeypatch):
                                 dict(norm='plain', shape='pattern', n_min=70, n_max=100, k_eig=32, bsz=2)])
 def test_spec_filter_with_linear_cat(emu, kw):
     KC.check_spec_cat(emu, CPU, None, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(norm='bn_block'), dict(norm='plain', k_eig=8, bsz=3), dict(norm='bn_block', shape='mutag', k_eig=8),
+                                dict(norm='bn_block', shape='pattern', n_min=44, n_max=64, k_eig=32, bsz=2),
+                                dict(norm='plain', shape='molhiv', n_min=2, n_max=50, k_eig=16, bsz=4)])
+def test_spec_filter_with_linear_cat_backward(emu, kw):
+    KC.check_spec_cat_bwd(emu, CPU, None, **kw)

@@ -365,3 +365,11 @@ def test_attn_block_bwd_layernorm_on_load(hip, kw):
 def test_spec_filter_with_linear_cat(hip, kw):
     """feta_spec_filter_cat_fwd (linear_cat folded into the per-graph eigenbasis filter) against the oracle"""
     KC.check_spec_cat(hip[0], hip[1], hip[2], **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(norm='bn_block', bsz=128), dict(norm='plain', k_eig=8, bsz=32), dict(norm='bn_block', shape='mutag', k_eig=8, bsz=32),
+                                dict(norm='bn_block', shape='molhiv', n_max=64, k_eig=16, bsz=300),
+                                dict(norm='bn_block', shape='pattern', n_min=44, n_max=64, k_eig=32, bsz=16)])
+def test_spec_filter_with_linear_cat_backward(hip, kw):
+    """feta_spec_filter_cat_bwd (the filter's backward with linear_cat's backward inside) against fp64 autograd"""
+    KC.check_spec_cat_bwd(hip[0], hip[1], hip[2], **kw)
