@@ -426,6 +426,10 @@ def roofline(args, gpu, dev, lowp=False, pmc_tag=None):
                   and abi.ffn_bwd_supported(d, 2 * d) and abi.attn_block_bwd_supported(n, d, h)
                   and abi.attn_block_bwd_blocks(b) > 0)
     coeff_roles = args.filter_mode in ('spectral', 'cheb') and not args.two_phase and args.gpus == 1 and p == 4
+    from feta_tmlr_amd import functional as FF0
+    cat_fold = (FF0.USE_CAT_FOLD and not lowp and args.filter_mode == 'spectral' and not args.no_share_graph
+                and abi.spec_cat_supported(n, h, dh, p, k_eig, True))
+    cat_bwd_fold = cat_fold and FF0.USE_CAT_FOLD_BWD and abi.spec_cat_bwd_supported(n, h, dh, p, k_eig, True)
     for name, per_layer, fn, nbytes, syms in stack_layer_cases(abi, st, dev, b, n, d, h, 2 * d, gpu['pe'], nr,
                                                                dtype=torch.bfloat16 if lowp else torch.float32):
         if name == 'attn_block_fwd (no attn write)':
@@ -433,7 +437,7 @@ def roofline(args, gpu, dev, lowp=False, pmc_tag=None):
         elif name == 'attn_block_fwd (+attn write)':
             cnt = 1
         elif 'linear_cat' in name:
-            cnt = 1
+            cnt = 0 if cat_bwd_fold else 1      # (ABI 11: linear_cat's backward rides in the filter's backward launch)
         elif name in ('ffn_bwd (gradient in two parts)', 'attn_block_bwd (two workgroups per graph)'):
             cnt = L - 1      # fused_stack.py: every layer but the first hands its input gradient to a fused FFN backward
         elif name == 'attn_block_bwd' and split_form:
@@ -486,8 +490,7 @@ def roofline(args, gpu, dev, lowp=False, pmc_tag=None):
         coeff, bias = rnd(h * b, c), rnd(dh)
         dcoeff, dbp = torch.empty_like(coeff), torch.empty(b * h, dh, device=dev)
         u, lam = gpu['cache'].u, gpu['cache'].lam
-        from feta_tmlr_amd import functional as FF_
-        if FF_.USE_CAT_FOLD and not lowp and abi.spec_cat_supported(n, h, dh, p, k_eig, True):
+        if cat_fold:
             # what the step launches since ABI 10: the filter with linear_cat folded in (+ the stack output rows in, the
             # linear_cat output rows out, W_cat from L2)
             y2c, wc, bc_, oc = rnd(n, b, d), rnd(d, 2 * d) / (2 * d) ** 0.5, rnd(d), torch.empty(n, b, d, device=dev)
@@ -500,9 +503,22 @@ def roofline(args, gpu, dev, lowp=False, pmc_tag=None):
             cand.append(('spec_filter_fwd', 'spec_fwd', 1,
                          lambda: abi.spec_filter_fwd(xs, u, lam, coeff, bias, nr, ys, p, 1, st),
                          spec_bytes(b, n, h, dh, k_eig, p, sum_n, False)))
-        cand.append(('spec_filter_bwd', 'spec_bwd', 1,
-                     lambda: abi.spec_filter_bwd(xs, u, lam, coeff, nr, dys, dxs, dcoeff, dbp, p, 1, st),
-                     spec_bytes(b, n, h, dh, k_eig, p, sum_n, True)))
+        if cat_bwd_fold:
+            # what the step launches since ABI 11: the filter's backward with linear_cat's backward inside (+ dout, y2 and
+            # filt rows in, dxn rows out, one [64 x 128 + 64] partial row per workgroup)
+            rows_ = abi.spec_cat_bwd_rows(b)
+            tv_ = lambda t: t.view(n, b, h, dh).permute(1, 0, 2, 3)
+            dob, y2b, dxnb = rnd(n, b, d), rnd(n, b, d), torch.empty(n, b, d, device=dev)
+            wcb = rnd(d, 2 * d) / (2 * d) ** 0.5
+            partb = torch.empty(rows_, d * 2 * d + d, device=dev)
+            cand.append(('spec_filter_cat_bwd', 'spec_cat_bwd', 1,
+                         lambda: abi.spec_filter_cat_bwd(xs, u, lam, coeff, nr, ys, dxs, dcoeff, dbp, p, 1, st, dout=tv_(dob),
+                                                         y2=tv_(y2b), w_cat=wcb, dxn=tv_(dxnb), partial=partb),
+                         spec_bytes(b, n, h, dh, k_eig, p, sum_n, True) + 4 * (4 * sum_n * d + 2 * d * d + rows_ * (2 * d * d + d))))
+        else:
+            cand.append(('spec_filter_bwd', 'spec_bwd', 1,
+                         lambda: abi.spec_filter_bwd(xs, u, lam, coeff, nr, dys, dxs, dcoeff, dbp, p, 1, st),
+                         spec_bytes(b, n, h, dh, k_eig, p, sum_n, True)))
     r_ = h * b
     from feta_tmlr_amd import functional as FF
     if (abi.lin_supported(r_, c, c) and (r_ * c * c <= FF.LIN_OWN_GEMM_MAX_MACS or lowp)

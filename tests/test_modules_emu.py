@@ -445,7 +445,11 @@ def check_attn_block_equals_three_launches(dev, hook, monkeypatch, shape, n_min,
     assert_close_up_to_relu_flips('dx', a[2], b[2].double(), tol=1e-5, max_rows=2 if bsz > 256 else 0)
     assert a[3].keys() == b[3].keys()
     for k in a[3]:
-        KC.assert_close('grad ' + k, a[3][k], b[3][k].double(), tol=1e-5)
+        if bsz > 256:   # (the same flip, seen from the parameters: one row of dW1 / one element of db1 of that layer - 8e-5 on
+            # the MI355X - and 1e-6 .. 7e-6 in everything below it)
+            assert_close_up_to_relu_flips('grad ' + k, a[3][k], b[3][k].double(), tol=1e-5, max_rows=2)
+        else:
+            KC.assert_close('grad ' + k, a[3][k], b[3][k].double(), tol=1e-5)
 
 
 @pytest.mark.parametrize('shape,n_min,n_max,tie_qk,pe_on,split', [
