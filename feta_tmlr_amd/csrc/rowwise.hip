@@ -814,14 +814,29 @@ int tg_env(const char* name, int dflt) {
   const int v = e ? atoi(e) : 0;
   return (v >= 1 && v <= 4) ? v : dflt;
 }
-int tiles_fwd(int KI) {  // LDS: 16 tg (KI + 4) floats
-  int tg = tg_env("FETA_ROWLIN_TG", 2);
+// Output tiles per workgroup of the forward kernel.  Its ~230 registers allow two workgroups per CU - 512 at a time on the
+// MI355X - so a grid just above that runs a second, mostly empty round: in_proj at config 4 (M = 8192, 192 outputs) was
+// 128 row blocks x 6 groups of two tiles = 768 workgroups, 15 us; as 4 groups of three tiles it is 512, one round (PATTERN
+// B = 64, N_pad = 128: 0.4216 -> 0.4115 ms per step).  Two tiles otherwise (more workgroups in flight for small M).
+int tiles_fwd(int KI, int NO, int G) {  // LDS: 16 tg (KI + 4) floats
+  const int n_ot = NO / 16;
+  int tg = tg_env("FETA_ROWLIN_TG", 0);
+  if (tg <= 0) {
+    tg = 2;
+    if (G * ((n_ot + 1) / 2) > 512)
+      for (int cand = 3; cand <= 4; ++cand)
+        if (G * ((n_ot + cand - 1) / cand) <= 512) {
+          tg = cand;
+          break;
+        }
+  }
   while (tg > 1 && 16 * tg * (KI + 4) * 4 > 48 * 1024) --tg;
   return tg;
 }
-int tiles_dx(int NO) {   // LDS: NO (16 tg + 4) floats
+int tiles_dx(int NO) {   // LDS: NO (16 tg + 4) floats (two workgroups per CU: up to 64 KB each - four tiles at NO = 192, where
+  // three made the in_proj backward 256 + 384 = 640 workgroups, a second round; four: 128 + 384 = 512)
   int tg = tg_env("FETA_ROWLIN_TG_DX", 4);
-  while (tg > 1 && NO * (16 * tg + 4) * 4 > 48 * 1024) --tg;
+  while (tg > 1 && NO * (16 * tg + 4) * 4 > 64 * 1024) --tg;
   return tg;
 }
 
@@ -870,7 +885,7 @@ extern "C" int feta_rowlin_fwd_ex(const feta_rowlin_ex* d, feta_stream_t stream)
                "rowlin_fwd: x2 needs 0 < x_split < KI, x_split %% 16 == 0 (an input BatchNorm covers the x part)");
   RowLinGeom ge{};
   ge.G = row_blocks(a.M);
-  ge.TG = tiles_fwd(a.KI);
+  ge.TG = tiles_fwd(a.KI, a.NO, ge.G);
   const int n_og = (a.NO / 16 + ge.TG - 1) / ge.TG;
   const size_t lds = sizeof(float) * (16 * ge.TG * (a.KI + 4) + kRowWaves * 2 * 16 * ge.TG + 2 * a.KI +
                                       (a.x_stats ? reduce_scratch_floats(a.x2 ? a.x_split : a.KI) : 0));
