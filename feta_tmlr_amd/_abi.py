@@ -253,6 +253,7 @@ class FfnGrad(C.Structure):
 SIGNATURES.update({
     'feta_ffn_bwd_supported': ([C.c_int, C.c_int], C.c_int),
     'feta_ffn_bwd_blocks': ([C.c_int], C.c_int),
+    'feta_ffn_bwd_chunks': ([C.c_int, C.c_int], C.c_int),
     'feta_ffn_bwd': ([C.POINTER(FfnGrad), _S], C.c_int),
     'feta_ffn_bwd_coeff': ([C.POINTER(FfnGrad), C.POINTER(CoeffBwdRole), _S], C.c_int),
 })
@@ -741,6 +742,9 @@ class Abi:
 
     def ffn_bwd_blocks(self, m):
         return int(self.lib.feta_ffn_bwd_blocks(m))
+
+    def ffn_bwd_chunks(self, m, ff):
+        return int(self.lib.feta_ffn_bwd_chunks(m, ff))
 
     def ffn_bwd_desc(self, m, ff, Gs=0, partial_ld=0, partial_ptr=None, ln_eps=1e-5, **ptrs):
         d = FfnGrad()

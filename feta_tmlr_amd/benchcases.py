@@ -104,20 +104,21 @@ def stack_layer_cases(abi, st, dev, b, n, d, heads, ff, pe, n_real, last_layer_a
         w2, w1 = rnd(d, ff) / ff ** 0.5, rnd(ff, d) / d ** 0.5
         cols = 2 * d * ff + d + ff
         part = new(RC, cols)
+        RCF = abi.ffn_bwd_chunks(m, ff)      # partial rows this kernel writes (feta_ffn_bwd_chunks)
         xb = abi.ffn_bwd_blocks(m)
         kw = dict(dy=dy, g_y=y2, g_bn=prm_of(d), g_sum=rnd(G, 2, d), g_fin_out=new(2, d), dgamma=new(d), dbeta=new(d),
                   h=hh, w2=w2, w1=w1, x=y1, x_bn=prm_of(d), dx=dx, sum_out=new(xb, 2, d))
         fdsc = abi.ffn_bwd_desc(m, ff, Gs=G, partial_ld=cols, partial_ptr=part.data_ptr(), **kw)
         keep_f = (kw, part)
         cases.append(('ffn_bwd', 1.0, lambda: (abi.ffn_bwd_launch(fdsc, st), keep_f)[0],
-                      ft * (4 * m * d + m * ff) + f4 * (2 * d * ff + RC * cols), ['ffn_bwd']))
+                      ft * (4 * m * d + m * ff) + f4 * (2 * d * ff + RCF * cols), ['ffn_bwd']))
         # the last layer's launch (the first of the stack's backward) carries the coefficient generator's backward
         # kernel in trailing workgroups (feta_ffn_bwd_coeff)
         cgen = 4 * (d // heads) ** 2
         cgrp = abi.coeff_bwd_groups(b, heads)
         brole = (rnd(heads * b, n), n_real, rnd(cgen), rnd(cgen), rnd(heads * b, cgen), new(cgrp, 2, cgen), b, n, heads)
         cases.append(('ffn_bwd (+ coefficient generator)', 1.0, lambda: (abi.ffn_bwd_launch(fdsc, st, brole), keep_f)[0],
-                      ft * (4 * m * d + m * ff) + f4 * (2 * d * ff + RC * cols + b * (heads * cgen + heads * n) + cgrp * 2 * cgen),
+                      ft * (4 * m * d + m * ff) + f4 * (2 * d * ff + RCF * cols + b * (heads * cgen + heads * n) + cgrp * 2 * cgen),
                       ['ffn_bwd']))
         if fused_a:
             # ... below a layer whose attention backward ran as two workgroups per graph: the gradient in two parts
@@ -128,7 +129,7 @@ def stack_layer_cases(abi, st, dev, b, n, d, heads, ff, pe, n_real, last_layer_a
             fdsc2 = abi.ffn_bwd_desc(m, ff, Gs=gs2, partial_ld=cols, partial_ptr=part.data_ptr(), **kw2)
             keep_f2 = (kw2, part)
             cases.append(('ffn_bwd (gradient in two parts)', 1.0, lambda: (abi.ffn_bwd_launch(fdsc2, st), keep_f2)[0],
-                          ft * (5 * m * d + m * ff) + f4 * (2 * d * ff + RC * cols), ['ffn_bwd']))
+                          ft * (5 * m * d + m * ff) + f4 * (2 * d * ff + RCF * cols), ['ffn_bwd']))
     else:
         bwd_case('rowlin_bwd linear2 (stack: BN-backward gradient)', ff, d, 'g')
         bwd_case('rowlin_bwd linear1 (stack: relu, add, sums)', d, ff, 'ras')

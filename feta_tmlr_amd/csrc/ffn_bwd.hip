@@ -541,11 +541,31 @@ __global__ __launch_bounds__(kRowThreads) void ffn_bwd_kernel(FfnGradArgs a, Ffn
 
 extern int row_chunks(int M);   // rowwise.hip
 
+// Workgroups of the two main roles for RC split-K chunks of M rows (the same arithmetic as launch_ffn_bwd below).
+static int ffn_bwd_main_grid(int M, int RC, int NS) {
+  const int XB = ffn_bwd_xblocks(M), nblk = (M + kFbRows - 1) / kFbRows, nrb16 = (M + 15) / 16;
+  const int per = (nrb16 + RC - 1) / RC;
+  const bool xcd = XB == nblk && per == 4;
+  return xcd ? 8 * ((RC + 7) / 8) * (2 + NS) : XB + 8 * ((RC + 7) / 8) * NS;
+}
+// Split-K chunks (= partial rows) of a launch: the 64-row chunks of the row-wise kernels - unless that makes the grid
+// just exceed one round of resident workgroups (the kernel's ~200 registers allow two per CU, 512) and chunks of twice the
+// rows fit: config 4 (M = 8192) was 256 X blocks + 128 x 4 W slices = 768 workgroups, 21.7 us; with 64 chunks of 128 rows it
+// is 512, 17.5 us (PATTERN B = 64, N_pad = 128: 0.405 -> 0.398 ms).  FETA_FFN_BWD_RC_HALF=0: off (A/B).
+static int ffn_bwd_chunks_for(int M, int ff) {
+  const int rc = row_chunks(M), ns = ff / kFbSlice;
+  if (const char* e = getenv("FETA_FFN_BWD_RC_HALF"))
+    if (atoi(e) == 0) return rc;
+  const int half = (rc + 1) / 2;
+  if (rc >= 2 && ffn_bwd_main_grid(M, rc, ns) > 512 && ffn_bwd_main_grid(M, half, ns) <= 512) return half;
+  return rc;
+}
+
 template <class T, int FF>
 int launch_ffn_bwd(const FfnGradArgs& a, const CoeffBwdRole& cb, hipStream_t stream) {
   FfnBwdGeom ge{};
   ge.XB = ffn_bwd_xblocks(a.M);
-  ge.RC = row_chunks(a.M);
+  ge.RC = ffn_bwd_chunks_for(a.M, FF);
   const int nrb16 = (a.M + 15) / 16;
   ge.per = (nrb16 + ge.RC - 1) / ge.RC;
   ge.NS = FF / kFbSlice;
@@ -588,6 +608,7 @@ using namespace feta;
 extern "C" int feta_ffn_bwd_supported(int d_model, int ff) { return (d_model == kFbD && (ff == 64 || ff == 128)) ? 1 : 0; }
 
 extern "C" int feta_ffn_bwd_blocks(int M) { return ffn_bwd_xblocks(M); }
+extern "C" int feta_ffn_bwd_chunks(int M, int ff) { return (M < 1 || !feta_ffn_bwd_supported(kFbD, ff)) ? 0 : ffn_bwd_chunks_for(M, ff); }
 
 extern "C" int feta_ffn_bwd(const feta_ffn_grad* d, feta_stream_t stream) { return feta_ffn_bwd_coeff(d, nullptr, stream); }
 

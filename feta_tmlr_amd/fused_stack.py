@@ -171,7 +171,7 @@ def _cap_partials(abi, stream, st, new, shift_row=False):
     return tot, 1
 
 
-def _partial_buffers(abi, new, m, b, n, d, heads, ff0, nl, fused_attn, ln_cols=False, ln_f=None, ln_a=None):
+def _partial_buffers(abi, new, m, b, n, d, heads, ff0, nl, fused_attn, ln_cols=False, ln_f=None, ln_a=None, ffn_fused=None):
     """Split-K partial buffers of a stack backward and the slot allocator.  Two buffers, because their row counts
     differ: 'f' (linear2 / linear1 of every layer) has one row per feta_rowlin_chunks(M) row chunk, 'a' (out_proj /
     in_proj) the same or - with the fused attention-block backward - one row per graph.  dwdb_all = [f columns |
@@ -179,6 +179,12 @@ def _partial_buffers(abi, new, m, b, n, d, heads, ff0, nl, fused_attn, ln_cols=F
     reduction fills it at the end of backward.  -> (part_f, part_a, tf, ta, wslot)"""
     rc = abi.rowlin_chunks(m)
     ra = abi.attn_block_bwd_blocks(b) if fused_attn else rc
+    # the fused feed-forward backward chooses its own split-K chunk count (feta_ffn_bwd_chunks: the row-wise kernels' chunks
+    # or, where that keeps its grid within one round of resident workgroups, half as many)
+    if ffn_fused is None:
+        ffn_fused = USE_FFN_BWD and abi.ffn_bwd_supported(d, ff0)
+    if ffn_fused:
+        rc = abi.ffn_bwd_chunks(m, ff0)
     # ln_cols (LayerNorm on load): every layer's slot is followed by [dgamma | dbeta] of the LayerNorm whose backward
     # the kernel applies on its gradient load (norm2 behind the feed-forward slot, norm1 behind the attention slot)
     ln_f = ln_cols if ln_f is None else ln_f
@@ -681,7 +687,9 @@ class FusedLayerNormStackFn(torch.autograd.Function):
         # gradient load of feta_ffn_bwd ([dgamma2 | dbeta2] in its partial rows, behind db1), x1 = LN1(y1) on its operand
         # load; norm1's backward stays a launch (no saved statistics: recomputed from y1)
         ffn_on_load = all(s_['ffn_on_load'] for s_ in saved)     # (one feed-forward width per stack: all or none)
-        part_f, part_a, tf, ta, wslot = _partial_buffers(abi, new, m, b, n, d, heads, ff0, nl, fused_attn, ln_f=ffn_on_load)
+        part_f, part_a, tf, ta, wslot = _partial_buffers(
+            abi, new, m, b, n, d, heads, ff0, nl, fused_attn, ln_f=ffn_on_load,
+            ffn_fused=bool(ffn_on_load or (USE_FFN_BWD and abi.ffn_bwd_supported(d, ff0))))
         coeff_req = _coeff_bwd_request(ctx, abi, stream, d, params[(nl - 1) * PER_LAYER + 6].shape[0])
         total = tf + ta
         lnw = 2 if ffn_on_load else 4               # LayerNorm partial columns per layer that come from feta_layernorm_bwd
@@ -871,7 +879,7 @@ def _ln_on_load_backward(ctx, d_final, d_concat_last):
     newt = lambda *s: torch.empty(s, dtype=dt, device=dev)
     grads = [None] * len(params)
     ff0 = params[6].shape[0]
-    part_f, part_a, tf, ta, wslot = _partial_buffers(abi, new, m, b, n, d, heads, ff0, nl, True, ln_cols=True)
+    part_f, part_a, tf, ta, wslot = _partial_buffers(abi, new, m, b, n, d, heads, ff0, nl, True, ln_cols=True, ffn_fused=True)
     coeff_req = _coeff_bwd_request(ctx, abi, stream, d, params[(nl - 1) * PER_LAYER + 6].shape[0])
     total = tf + ta
     dwdb_all = new(total)      # [feed-forward slots | attention slots], each followed by its LayerNorm's [dgamma | dbeta]

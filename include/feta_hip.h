@@ -672,7 +672,7 @@ int feta_ffn_fwd_coeff(const feta_ffn* d, const feta_coeff_fwd_role* c, feta_str
  *   dh = (g2 W2) * [h > 0] (never written to memory);  dx = g2 + dh W1;
  *   sum_out (nullable) [feta_ffn_bwd_blocks(M)][2][64]: partial (sum dx, sum dx * xhat) with xhat from x = y1
  *        (pre-norm) and x_bn [4][64], for the BatchNorm-1 backward;
- *   partial: one row per feta_rowlin_chunks(M) chunk, pitch partial_ld (0: 2*64*FF + 64 + FF), columns
+ *   partial: one row per chunk - feta_ffn_bwd_chunks(M, FF) rows (ABI 11; feta_rowlin_chunks(M) or half of it) -, pitch partial_ld (0: 2*64*FF + 64 + FF), columns
  *        [dW2 (64 x FF) | db2 (64) | dW1 (FF x 64) | db1 (FF)], reduced by the caller (feta_colsum).
  * x is seen through x_bn (scale, shift rows) when given, else used as it is. */
 typedef struct feta_ffn_grad {
@@ -710,6 +710,7 @@ typedef struct feta_ffn_grad {
 
 int feta_ffn_bwd_supported(int d_model, int ff);
 int feta_ffn_bwd_blocks(int M);
+int feta_ffn_bwd_chunks(int M, int ff);   /* split-K chunks = rows of `partial` a launch writes */
 int feta_ffn_bwd(const feta_ffn_grad* d, feta_stream_t stream);
 /* ... and the BACKWARD kernel of the coefficient generator (feta_coeff_bwd with ds = NULL: partial [G, 2, C] is left
  * for the caller's feta_colsum_multi) in trailing workgroups of the first launch of the layer stack's backward. */

@@ -384,7 +384,7 @@ def check_coeff(abi, dev, stream, bsz, n, h, c, seed=0, zero_diag=True, faithful
             assert_close('role pooled', pooled2, pooled.double(), tol=1e-6)
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
         dy, dpd = rnd(m, d), dp.float().to(dev)
-        rc = abi.rowlin_chunks(m)
+        rc = abi.ffn_bwd_chunks(m, ff)
         cols = 2 * d * ff + d + ff
         res = []
         for role in (False, True):
@@ -986,7 +986,7 @@ def check_ffn_bwd_lp(abi, dev, stream, m=150, ff=128, seed=0, with_bn=True):
     hs = round_to(h_ref.detach(), BF16)
     f32 = lambda t: t.float().to(dev).contiguous()
     b16 = lambda t: t.to(BF16).to(dev).contiguous()
-    rc = abi.rowlin_chunks(m)
+    rc = abi.ffn_bwd_chunks(m, ff)
     ld = 2 * d * ff + d + ff
     partial = torch.full((rc, ld), float('nan'), device=dev)
     dx = torch.full((m, d), float('nan'), dtype=BF16, device=dev)
@@ -1210,7 +1210,7 @@ def check_ffn_bwd_ln(abi, dev, stream, m=150, ff=128, seed=0, dtype=torch.float3
     (F.layer_norm(y2, (d,), gam2, bet2, 1e-5) * dy_tot).sum().backward()
     f32 = lambda t: t.detach().float().contiguous().to(dev)
     st = lambda t: t.detach().to(dtype).contiguous().to(dev)
-    rc = abi.rowlin_chunks(m)
+    rc = abi.ffn_bwd_chunks(m, ff)
     ld = 2 * d * ff + d + ff + 2 * d
     partial = torch.full((rc, ld), float('nan'), device=dev)
     dx = torch.full((m, d), float('nan'), dtype=dtype, device=dev)
