@@ -822,13 +822,17 @@ int tiles_fwd(int KI, int NO, int G) {  // LDS: 16 tg (KI + 4) floats
   const int n_ot = NO / 16;
   int tg = tg_env("FETA_ROWLIN_TG", 0);
   if (tg <= 0) {
+    // the fewest tiles per workgroup among {2, 3, 4} that reach the fewest whole rounds (N_pad = 188, M = 12032: 1128
+    // workgroups = 3 rounds with two tiles, 752 = 2 rounds with three)
     tg = 2;
-    if (G * ((n_ot + 1) / 2) > 512)
-      for (int cand = 3; cand <= 4; ++cand)
-        if (G * ((n_ot + cand - 1) / cand) <= 512) {
-          tg = cand;
-          break;
-        }
+    int best = (G * ((n_ot + 1) / 2) + 511) / 512;
+    for (int cand = 3; cand <= 4; ++cand) {
+      const int rounds = (G * ((n_ot + cand - 1) / cand) + 511) / 512;
+      if (rounds < best) {
+        best = rounds;
+        tg = cand;
+      }
+    }
   }
   while (tg > 1 && 16 * tg * (KI + 4) * 4 > 48 * 1024) --tg;
   return tg;
