@@ -210,6 +210,7 @@ class Ffn(C.Structure):
         ('w1', _F), ('b1', _F), ('w2', _F), ('b2', _F), ('h', _F), ('y', _F), ('y_stats', _F),
         ('M', C.c_int), ('FF', C.c_int), ('dtype', C.c_int), ('y_shift', _F), ('y_f32', C.c_int),
         ('x_ln_gamma', _F), ('x_ln_beta', _F),
+        ('y_ln_out', _F), ('y_ln_gamma', _F), ('y_ln_beta', _F), ('y_ln_eps', C.c_float), ('y_ln_f32', C.c_int),
     ]
 
 
@@ -711,16 +712,18 @@ class Abi:
     def ffn_blocks(self, m):
         return int(self.lib.feta_ffn_blocks(m))
 
-    def ffn_fwd(self, m, ff, stream, momentum=0.1, eps=1e-5, Gx=0, coeff=None, **ptrs):
+    def ffn_fwd(self, m, ff, stream, momentum=0.1, eps=1e-5, Gx=0, coeff=None, y_ln_eps=1e-5, **ptrs):
         """feta_ffn_fwd; tensor-valued keyword arguments become the descriptor's pointers.  coeff (optional): the
         arguments of coeff_fwd as a tuple - the coefficient generator's forward rides in trailing workgroups."""
-        self.ffn_launch(self.ffn_desc(m, ff, momentum, eps, Gx, **ptrs), stream, coeff)
+        self.ffn_launch(self.ffn_desc(m, ff, momentum, eps, Gx, y_ln_eps=y_ln_eps, **ptrs), stream, coeff)
 
-    def ffn_desc(self, m, ff, momentum=0.1, eps=1e-5, Gx=0, **ptrs):
+    def ffn_desc(self, m, ff, momentum=0.1, eps=1e-5, Gx=0, y_ln_eps=1e-5, **ptrs):
         d = Ffn()
-        d.M, d.FF, d.momentum, d.eps, d.Gx = m, ff, momentum, eps, Gx
-        d.dtype = _stack_dtype(ptrs, ('x', 'h', 'y'), f32_ok=('y',))
+        d.M, d.FF, d.momentum, d.eps, d.Gx, d.y_ln_eps = m, ff, momentum, eps, Gx, y_ln_eps
+        d.dtype = _stack_dtype(ptrs, ('x', 'h', 'y', 'y_ln_out'), f32_ok=('y', 'y_ln_out'))
         d.y_f32 = int(ptrs['y'].dtype == torch.float32)
+        if ptrs.get('y_ln_out') is not None:
+            d.y_ln_f32 = int(ptrs['y_ln_out'].dtype == torch.float32)
         for k, t in ptrs.items():
             if t is not None:
                 setattr(d, k, t.data_ptr())

@@ -104,6 +104,15 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a, CoeffFw
                  ? *reinterpret_cast<const float4*>(a.y_shift + 16 * (2 * hh + t) + 4 * g)
                  : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
+  // LayerNorm of the OUTPUT rows in the epilogue (y_ln_out: norm2 of a LayerNorm stack whose consumer is not one of the
+  // on-load kernels - graphs beyond 64 nodes, or the end of the stack): gamma / beta of this wave's two output tiles
+  const bool y_ln = a.y_ln_out != nullptr;
+  float4 lgv[2], lbv[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    lgv[t] = y_ln ? *reinterpret_cast<const float4*>(a.y_ln_gamma + 16 * (2 * hh + t) + 4 * g) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    lbv[t] = y_ln ? *reinterpret_cast<const float4*>(a.y_ln_beta + 16 * (2 * hh + t) + 4 * g) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  }
   // gamma, beta and the shift of the input BatchNorm travel with the first requests (three floats for each of the first D
   // threads): read after the reduction they were one more dependent round trip in the middle of the prologue
   float xg = 1.0f, xb = 0.0f, xk = 0.0f;
@@ -266,11 +275,12 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a, CoeffFw
   lds_barrier();   // (the partial tiles live in LDS; the next block's rows keep travelling)
   const float* theirs = xch + (wv ^ 1) * (2 * 4 * 64);
   float* red = scr;  // [2 row tiles][2][64] column sums, reduced below
+  float vv[2][4];    // this wave's 32 columns of row lq (kept for the LayerNorm epilogue)
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int t2 = 2 * hh + t, o2 = 16 * t2 + 4 * g;
     const float bb[4] = {b2v[t].x, b2v[t].y, b2v[t].z, b2v[t].w};
-    float v[4];
+    float* v = vv[t];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float own = hh ? yp[2 + t][r] : yp[t][r];
@@ -301,6 +311,41 @@ __global__ __launch_bounds__(kRowThreads) void ffn_fwd_kernel(FfnArgs a, CoeffFw
   if (want_stats) {
     lds_barrier();
     if (tid < 2 * D) tot1[0] += red[tid] + red[2 * D + tid];
+  }
+  if (y_ln) {
+    // out = LayerNorm(y row) * gamma + beta: the row lq of tile rt is spread over the four lane groups of this wave (32
+    // columns) and of its partner (the other 32) - two passes (mean, centred squares) as F.layer_norm, each one shuffle
+    // pair and one hand-over through LDS (scr: no column statistics in a LayerNorm stack)
+    float* lnx = scr;   // [2 passes][4 waves][16 rows]
+    float s1 = ((vv[0][0] + vv[0][1]) + (vv[0][2] + vv[0][3])) + ((vv[1][0] + vv[1][1]) + (vv[1][2] + vv[1][3]));
+    s1 += shfl_xor(s1, 16);
+    s1 += shfl_xor(s1, 32);
+    if (g == 0) lnx[wv * 16 + lq] = s1;
+    lds_barrier();
+    const float mean = (s1 + lnx[(wv ^ 1) * 16 + lq]) * (1.0f / (float)D);
+    float s2 = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        vv[t][r] -= mean;
+        s2 += vv[t][r] * vv[t][r];
+      }
+    s2 += shfl_xor(s2, 16);
+    s2 += shfl_xor(s2, 32);
+    if (g == 0) lnx[64 + wv * 16 + lq] = s2;
+    lds_barrier();
+    const float rstd = rsqrtf((s2 + lnx[64 + (wv ^ 1) * 16 + lq]) * (1.0f / (float)D) + a.y_ln_eps);
+    if (rok) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int o2 = 16 * (2 * hh + t) + 4 * g;
+        const float o0 = vv[t][0] * rstd * lgv[t].x + lbv[t].x, o1 = vv[t][1] * rstd * lgv[t].y + lbv[t].y;
+        const float o2v = vv[t][2] * rstd * lgv[t].z + lbv[t].z, o3 = vv[t][3] * rstd * lgv[t].w + lbv[t].w;
+        if (a.y_ln_f32) *reinterpret_cast<float4*>(a.y_ln_out + (int64_t)row * D + o2) = make_float4(o0, o1, o2v, o3);
+        else L::st4(reinterpret_cast<T*>(a.y_ln_out) + (int64_t)row * D + o2, o0, o1, o2v, o3);
+      }
+    }
   }
   FFN_STAMP(5);
   }  // row blocks of this workgroup
@@ -368,6 +413,8 @@ extern "C" int feta_ffn_fwd_coeff(const feta_ffn* d, const feta_coeff_fwd_role* 
   FETA_REQUIRE(aligned16(a.x) && aligned16(a.w1) && aligned16(a.w2) && aligned16(a.h) && aligned16(a.y) &&
                    aligned16(a.b1) && aligned16(a.b2) && aligned16(a.x_stats) && aligned16(a.y_stats),
                "ffn_fwd: tensors must be 16-byte aligned");
+  FETA_REQUIRE(a.y_ln_out == nullptr || (a.y_ln_gamma && a.y_ln_beta && a.y_stats == nullptr && aligned16(a.y_ln_out)),
+               "ffn_fwd: y_ln_out needs y_ln_gamma, y_ln_beta and excludes y_stats");
   FETA_REQUIRE(a.dtype == FETA_F32 || a.dtype == FETA_BF16, "ffn_fwd: dtype %d", a.dtype);
   if (a.dtype == FETA_BF16) return dispatch_ffn_fwd<bf16_t>(a, cf, (hipStream_t)stream);
   return dispatch_ffn_fwd<float>(a, cf, (hipStream_t)stream);

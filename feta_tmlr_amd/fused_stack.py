@@ -40,6 +40,9 @@ USE_FFN_FUSED = os.environ.get('FETA_FFN_FUSED', '1') != '0'
 # graphs beyond the one-launch block (64 < N <= 256, config 4): attention core + out_proj + degree + residual + statistics
 # as one launch behind the in_proj launch (csrc/attnout.hip); 0: feta_attn_fwd -> feta_rowlin_fwd_ex
 USE_ATTN_OUT = os.environ.get('FETA_ATTN_OUT', '1') != '0'
+# LayerNorm of the feed-forward kernel's OUTPUT rows in its epilogue (feta_ffn.y_ln_out) where nobody downstream applies it
+# on load; 0: feta_layernorm_fwd launches (A/B timing)
+USE_LN_EPILOGUE = os.environ.get('FETA_LN_EPILOGUE', '1') != '0'
 # backward of the FFN half (linear2 + linear1) in one launch (csrc/ffn_bwd.hip); 0: two feta_rowlin_bwd_ex launches
 USE_FFN_BWD = os.environ.get('FETA_FFN_BWD', '1') != '0'
 # backward of the attention sub-block (out_proj + attention + in_proj) in one launch per layer (csrc/block_bwd.hip,
@@ -634,9 +637,16 @@ class FusedLayerNormStackFn(torch.autograd.Function):
             if not ffn_on_load:
                 x1, lst1 = newt(m, d), new(m, 2)
                 abi.layernorm_fwd(y1, g1, be1, float(layer.norm1.eps), x1, lst1, stream)
+            x2 = lst2 = None
             if ffn_on_load:
+                ln_out = {}
+                if USE_LN_EPILOGUE:
+                    # x2 = LN2(y2) from the same launch (feta_ffn.y_ln_out): its consumers here - in_proj, the residual of
+                    # feta_attn_out_fwd - are not on-load kernels, so it is materialised, but not by a launch of its own
+                    x2 = new(m, d) if li == nl - 1 else newt(m, d)
+                    ln_out = dict(y_ln_out=x2, y_ln_gamma=g2, y_ln_beta=be2, y_ln_eps=float(layer.norm2.eps))
                 abi.ffn_fwd(m, ff, stream, eps=float(layer.norm1.eps), x=y1, x_ln_gamma=g1, x_ln_beta=be1, w1=w1, b1=bb1,
-                            w2=w2, b2=bb2, h=h, y=y2, coeff=_coeff_fwd_role(pending, li, nl, attn, n_real))
+                            w2=w2, b2=bb2, h=h, y=y2, coeff=_coeff_fwd_role(pending, li, nl, attn, n_real), **ln_out)
             elif USE_FFN_FUSED and abi.ffn_supported(d, ff):
                 abi.ffn_fwd(m, ff, stream, x=x1, w1=w1, b1=bb1, w2=w2, b2=bb2, h=h, y=y2,
                             coeff=_coeff_fwd_role(pending, li, nl, attn, n_real))
@@ -645,8 +655,9 @@ class FusedLayerNormStackFn(torch.autograd.Function):
                 abi.rowlin_fwd_ex(dsc, stream)
                 dsc = abi.rowlin_ex(m, ff, d, x=h, w=w2, bias=bb2, residual=x1, y=y2)
                 abi.rowlin_fwd_ex(dsc, stream)
-            x2, lst2 = (new(m, d) if li == nl - 1 else newt(m, d)), new(m, 2)   # (the stack's output is fp32)
-            abi.layernorm_fwd(y2, g2, be2, float(layer.norm2.eps), x2, lst2, stream)
+            if x2 is None:
+                x2, lst2 = (new(m, d) if li == nl - 1 else newt(m, d)), new(m, 2)   # (the stack's output is fp32)
+                abi.layernorm_fwd(y2, g2, be2, float(layer.norm2.eps), x2, lst2, stream)
             saved.append(dict(x0=x_in, qkv=qkv, out=out, ast=ast, y1=y1, lst1=lst1, x1=x1, h=h, y2=y2, lst2=lst2,
                               ffn_on_load=ffn_on_load))
             x_in = x2
@@ -843,16 +854,23 @@ def _ln_on_load_forward(ctx, abi, stream, src, pe, degree_rows, n_real, layers, 
                            sums=(pending.take_fwd() if (pending is not None and li == 0) else ()), **ln_prev)
         h = newt(m, ff)
         y2 = new(m, d) if li == nl - 1 else newt(m, d)    # (what leaves the stack is fp32 whatever the storage type)
+        # norm2 of the LAST layer is what the stack hands out: the feed-forward kernel writes it beside y2 from its epilogue
+        # (feta_ffn.y_ln_out) - the stack launches no LayerNorm kernel at all
+        ln_out = {}
+        if li == nl - 1 and USE_LN_EPILOGUE:
+            final = new(m, d)
+            ln_out = dict(y_ln_out=final, y_ln_gamma=g2, y_ln_beta=be2, y_ln_eps=float(layer.norm2.eps))
         abi.ffn_fwd(m, ff, stream, eps=float(layer.norm1.eps), x=y1, x_ln_gamma=g1, x_ln_beta=be1, w1=w1, b1=bb1, w2=w2,
-                    b2=bb2, h=h, y=y2, y_stats=None, coeff=_coeff_fwd_role(pending, li, nl, attn, n_real))
+                    b2=bb2, h=h, y=y2, y_stats=None, coeff=_coeff_fwd_role(pending, li, nl, attn, n_real), **ln_out)
         saved.append(dict(x0=x_pre, qkv=qkv, out=out, ast=ast, y1=y1, h=h, y2=y2))
         x_pre = y2
         ln_prev = dict(x_ln_gamma=g2, x_ln_beta=be2, eps=float(layer.norm2.eps))
-    # norm2 of the last layer: the only LayerNorm launch of the stack
-    last = layers[-1].norm2
-    final = new(m, d)
-    abi.layernorm_fwd(x_pre, params[(nl - 1) * PER_LAYER + 10], params[(nl - 1) * PER_LAYER + 11], float(last.eps), final,
-                      new(m, 2), stream)
+    if not USE_LN_EPILOGUE:
+        # norm2 of the last layer as a launch of its own (FETA_LN_EPILOGUE=0: A/B timing)
+        last = layers[-1].norm2
+        final = new(m, d)
+        abi.layernorm_fwd(x_pre, params[(nl - 1) * PER_LAYER + 10], params[(nl - 1) * PER_LAYER + 11], float(last.eps), final,
+                          new(m, 2), stream)
     ctx.saved_state = saved
     if CAPTURE_SAVED is not None:
         CAPTURE_SAVED.append(saved)

@@ -648,6 +648,11 @@ typedef struct feta_ffn {
   const float* x_ln_gamma; /* nullable [64] (ABI 9): x = LayerNorm(x rows) * gamma + beta, computed per row on load
                               (feta_attn_block.x_ln_gamma: norm1 with batch_norm=False); excludes x_bn / x_stats */
   const float* x_ln_beta;
+  float* y_ln_out;          /* nullable [M,64] [T, or fp32 with y_ln_f32] (ABI 11): LayerNorm(y rows) * y_ln_gamma + y_ln_beta, */
+  const float* y_ln_gamma;  /*   written beside y by the epilogue - norm2 of a LayerNorm stack where its consumer is not an */
+  const float* y_ln_beta;   /*   on-load kernel (graphs beyond 64 nodes; the end of the stack).  Excludes y_stats. */
+  float y_ln_eps;
+  int y_ln_f32;
 } feta_ffn;
 
 int feta_ffn_supported(int d_model, int ff);

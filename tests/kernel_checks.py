@@ -1132,7 +1132,20 @@ def check_ffn_ln(abi, dev, stream, m=75, ff=128, seed=0, dtype=torch.float32):
     x = F.layer_norm(y1, (d,), gam, bet, 1e-5)
     h_ref = torch.relu(x @ w1.t() + b1)
     y_ref = x + h_ref @ w2.t() + b2
-    return {'h': assert_close('ln ffn h', h, h_ref, tol=tol), 'y': assert_close('ln ffn y2', y, y_ref, tol=tol)}
+    errs = {'h': assert_close('ln ffn h', h, h_ref, tol=tol), 'y': assert_close('ln ffn y2', y, y_ref, tol=tol)}
+    # ... and with the LayerNorm of the OUTPUT rows in the epilogue (y_ln_out: norm2 where its consumer is not an on-load
+    # kernel), in the storage type and as fp32 (the end of a stack); h and y unchanged
+    gam2, bet2 = _ln_affine(d, g)
+    for odt in {dtype, torch.float32}:
+        h2 = torch.full((m, ff), float('nan'), dtype=dtype, device=dev)
+        y2 = torch.full((m, d), float('nan'), dtype=dtype, device=dev)
+        xo = torch.full((m, d), float('nan'), dtype=odt, device=dev)
+        abi.ffn_fwd(m, ff, stream, x=y1.to(dtype).to(dev), x_ln_gamma=f32(gam), x_ln_beta=f32(bet), w1=f32(w1), b1=f32(b1),
+                    w2=f32(w2), b2=f32(b2), h=h2, y=y2, y_stats=None, y_ln_out=xo, y_ln_gamma=f32(gam2), y_ln_beta=f32(bet2),
+                    y_ln_eps=1e-5)
+        assert torch.equal(h2, h) and torch.equal(y2, y)
+        errs['x2 %s' % str(odt)[6:]] = assert_close('ln ffn x2 = LN2(y2)', xo, F.layer_norm(y_ref, (d,), gam2, bet2, 1e-5), tol=tol)
+    return errs
 
 
 def _ln_block_case(bsz, n_pad, n_min, seed, dtype, with_pe=True):
