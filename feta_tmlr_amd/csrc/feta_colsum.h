@@ -6,6 +6,8 @@
 //          columns per workgroup, larger workgroups split the rows), eight rows requested before the first add
 // Deterministic: the order of the adds depends on the segment's shape and the workgroup size only.
 #pragma once
+#include <cstdlib>
+
 #include "feta_abi_common.h"
 #include <feta_device.h>
 
@@ -19,6 +21,7 @@ struct ColsumPlan {
   int tile_end[FETA_COLSUM_MAX_SEGS];   // exclusive prefix end of each segment's tiles
   int wide[FETA_COLSUM_MAX_SEGS];
   int nseg;
+  int wq;   // float4 columns of a wide tile (plan_colsum)
 };
 
 inline bool colsum_seg_ok(const feta_colsum_seg& s) {
@@ -36,21 +39,31 @@ inline bool colsum_seg_wide(const feta_colsum_seg& s, int min_cols) {
 // columns (the stack's split-K partials: 128 rows x 16 640 columns were 17 workgroups of 32 rows per thread, four dependent
 // batches; 65 workgroups of 8 rows per thread are one batch and fill a quarter of the chip instead of a sixteenth)
 constexpr int colsum_wide_q(int threads) { return threads >= 1024 ? 64 : 256; }
+inline int colsum_wide_adapt() {   // FETA_COLSUM_ADAPT=0: always the tile width above (A/B timing)
+  const char* e = getenv("FETA_COLSUM_ADAPT");
+  return (e != nullptr && e[0] == '0') ? 0 : 1;
+}
 
 // fills the plan, returns the number of tiles (= workgroups of the role); `threads`: the workgroup size the tiles will
 // be reduced with (colsum_role<THREADS>)
 inline int plan_colsum(const feta_colsum_seg* segs, int nseg, ColsumPlan& p, int threads = 256) {
-  int tiles = 0;
-  const int wq = colsum_wide_q(threads);
+  int wq = colsum_wide_q(threads);
   p.nseg = nseg;
-  for (int i = 0; i < nseg; ++i) {
-    const bool wide = colsum_seg_wide(segs[i], 4096);
-    p.seg[i] = segs[i];
-    p.wide[i] = wide ? 1 : 0;
-    tiles += wide ? (segs[i].C / 4 + wq - 1) / wq : (segs[i].C + 15) / 16;
-    p.tile_end[i] = tiles;
+  for (;;) {
+    int tiles = 0;
+    for (int i = 0; i < nseg; ++i) {
+      const bool wide = colsum_seg_wide(segs[i], 4096);
+      p.seg[i] = segs[i];
+      p.wide[i] = wide ? 1 : 0;
+      tiles += wide ? (segs[i].C / 4 + wq - 1) / wq : (segs[i].C + 15) / 16;
+      p.tile_end[i] = tiles;
+    }
+    p.wq = wq;
+    // the 1024-thread launch holds two workgroups per CU (512 at a time): where 64-column tiles are more than that - the
+    // partials of configs 4 / 5: 616 - 641 tiles, a second round for a fifth of them - tiles of twice the columns
+    if (threads < 1024 || tiles <= 512 || wq >= 256 || colsum_wide_adapt() == 0) return tiles;
+    wq *= 2;
   }
-  return tiles;
 }
 
 // dynamic LDS floats the role needs in a workgroup of THREADS threads
@@ -72,7 +85,7 @@ __device__ __forceinline__ void colsum_role(const ColsumPlan& sg, int tile_id) {
   const int tid = threadIdx.x;
   if (sg.wide[si]) {
     // WQ float4 columns per tile; THREADS / WQ row slices, tree over the slices through LDS
-    constexpr int WQ = colsum_wide_q(THREADS), SLW = THREADS / WQ;
+    const int WQ = sg.wq, SLW = THREADS / WQ;
     const int c4 = tile * WQ + (tid % WQ), slice = tid / WQ;
     const bool ok = c4 < s.C / 4;
     const float* p = s.in + 4 * (int64_t)(ok ? c4 : 0);
